@@ -1,0 +1,193 @@
+/*
+ * mfa.h -- C ABI of the MI355X-native FlashAttention kernel suite.
+ *
+ * This is the drop-in boundary for ONE path of philipturner/metal-flash-attention:
+ *     AttentionDescriptor -> AttentionKernelDescriptor -> AttentionKernel -> dispatch
+ * The reference has no FFI: its boundary is the public Swift API plus the Metal calls its
+ * callers make (compile source, bind buffers 0-9, set threadgroup memory, dispatch).  Each
+ * entry point below names the reference interface it replaces (paths relative to
+ * /root/reference).  The reference-side binding a maintainer would add is in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only (no torch / HIP types in signatures; a stream is
+ * passed as void* = hipStream_t).  Every function returns an mfa_status; nothing aborts the
+ * process (the reference uses fatalError).  The library never allocates device memory and
+ * keeps no hidden workspace: the caller owns all ten operand buffers, as in the reference.
+ */
+#ifndef MFA_H
+#define MFA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFA_ABI_VERSION 1
+
+/* ---- status codes (replace fatalError, e.g. AttentionKernel.swift:33,
+ *      AttentionDescriptor.swift:45/72/90/97, AttentionParameterRow.swift:50/57/100) -------- */
+typedef enum mfa_status {
+  MFA_OK = 0,
+  MFA_ERR_INCOMPLETE_DESCRIPTOR = 1, /* "Descriptor was incomplete." */
+  MFA_ERR_INVALID_ARGUMENT = 2,      /* bad enum, null pointer, unexpected cached operand ... */
+  MFA_ERR_UNSUPPORTED = 3,           /* valid request this build has no kernel for */
+  MFA_ERR_HIP = 4,                   /* HIP runtime error; see mfa_last_error_string() */
+  MFA_ERR_PARSE = 5                  /* malformed parameter table text */
+} mfa_status;
+
+/* ---- GEMMOperandPrecision (Sources/FlashAttention/GEMM/GEMMOperandPrecision.swift:33-60) */
+typedef enum mfa_precision { MFA_FP32 = 0, MFA_FP16 = 1, MFA_BF16 = 2 } mfa_precision;
+const char *mfa_precision_name(int precision); /* "float" / "half" / "bfloat" (:39-48) */
+int mfa_precision_size(int precision);          /* 4 / 2 / 2               (:51-59) */
+
+/* ---- AttentionKernelType (Sources/FlashAttention/Attention/AttentionKernelType.swift:10-23) */
+typedef enum mfa_kernel_type {
+  MFA_FORWARD = 0,           /* computes O and L */
+  MFA_BACKWARD_QUERY = 1,    /* computes D and dQ; depends on L */
+  MFA_BACKWARD_KEY_VALUE = 2 /* computes dK and dV; depends on L and D */
+} mfa_kernel_type;
+
+/* ---- AttentionOperand (Sources/FlashAttention/Attention/AttentionOperand.swift:9-71) ---- */
+typedef enum mfa_operand {
+  MFA_Q = 0, MFA_K, MFA_S, MFA_P, MFA_V, MFA_O, MFA_L, MFA_D,
+  MFA_dO, MFA_dV, MFA_dP, MFA_dS, MFA_dK, MFA_dQ,
+  MFA_OPERAND_COUNT
+} mfa_operand;
+const char *mfa_operand_name(int operand);   /* AttentionOperand.description (:30-50) */
+/* AttentionOperand.bufferBinding (:52-71): Q0 K1 V2 O3 L4 D5 dO6 dV7 dK8 dQ9, -1 if none */
+int mfa_operand_buffer_binding(int operand);
+#define MFA_BUFFER_SLOTS 10
+
+/* ---- AttentionDescriptor (Attention/AttentionDescriptor/AttentionDescriptor.swift:10-27) -- */
+typedef struct mfa_attention_descriptor {
+  uint8_t lowPrecisionInputs;        /* Q, K, V, dO          (:12) */
+  uint8_t lowPrecisionIntermediates; /* S, P, L, D, dP, dS   (:15) */
+  uint8_t hasMatrixDimensions;       /* Swift optional tuple (:20) */
+  uint8_t hasTransposeState;         /* Swift optional tuple (:22) */
+  uint32_t row, column;              /* matrixDimensions.row / .column */
+  uint16_t head;                     /* matrixDimensions.head */
+  uint8_t transposeQ, transposeK, transposeV, transposeO;
+  /* Extension (not in the reference): 16-bit storage type used when lowPrecisionInputs is set.
+   * MFA_FP16 reproduces +Precisions.swift:13-17 exactly (Q,K,V FP16; dO BF16).
+   * MFA_BF16 stores Q,K,V,dO all as BF16 (what BASELINE.json's bf16 configs use). */
+  uint8_t lowPrecisionInputType;
+  uint8_t reserved[3];
+} mfa_attention_descriptor;
+void mfa_attention_descriptor_init(mfa_attention_descriptor *desc); /* AttentionDescriptor() */
+
+/* ---- AttentionKernelDescriptor (Attention/AttentionKernelDescriptor.swift:8-49) ----------
+ * Dictionaries keyed by AttentionOperand become arrays indexed by mfa_operand; -1 = absent. */
+typedef struct mfa_attention_kernel_descriptor {
+  uint8_t hasBlockDimensions;
+  uint8_t hasHeadDimension;
+  uint16_t parallelization, traversal, headBlock; /* blockDimensions (:9-10) */
+  uint16_t headDimension;                         /* (:16) */
+  int8_t cacheState[MFA_OPERAND_COUNT];           /* (:13)  -1 / 0 / 1 */
+  int8_t memoryPrecisions[MFA_OPERAND_COUNT];     /* (:18)  -1 or mfa_precision */
+  int8_t registerPrecisions[MFA_OPERAND_COUNT];   /* (:26) */
+  int8_t transposeState[MFA_OPERAND_COUNT];       /* (:42)  -1 / 0 / 1 */
+  int8_t preferAsyncCache;                        /* (:21)  -1 / 0 / 1 */
+  int8_t preferAsyncLoad;                         /* (:24) */
+  int8_t type;                                    /* (:44)  -1 or mfa_kernel_type */
+  int8_t reserved;
+} mfa_attention_kernel_descriptor;
+void mfa_attention_kernel_descriptor_init(mfa_attention_kernel_descriptor *kdesc);
+
+/* AttentionDescriptor.memoryPrecisions / .registerPrecisions
+ * (AttentionDescriptor+Precisions.swift:10-146, :149-215).  out[MFA_OPERAND_COUNT], -1 = absent. */
+mfa_status mfa_attention_descriptor_memory_precisions(const mfa_attention_descriptor *desc, int8_t *out);
+mfa_status mfa_attention_descriptor_register_precisions(const mfa_attention_descriptor *desc, int8_t *out);
+
+/* AttentionDescriptor.kernelDescriptor(type:) (AttentionDescriptor.swift:33-130): parameter
+ * table lookup by head dimension, head-block clamp to pad8(D), cache-state validation,
+ * gradient transposes inherited from the primal operands, precision maps. */
+mfa_status mfa_attention_descriptor_kernel_descriptor(const mfa_attention_descriptor *desc,
+                                                      int type,
+                                                      mfa_attention_kernel_descriptor *out);
+
+/* ---- parameter tables (AttentionDescriptor+Parameters.swift:13-66, :77-285;
+ *      text format of AttentionParameterRow.parseTable, AttentionParameterRow.swift:22-74):
+ *      "| max D | parallelization | traversal | head | cached operands |" one row per line.
+ *      `mixed` selects the table used when BOTH low-precision flags are set (+Parameters.swift:16). */
+mfa_status mfa_parameter_table_get(int type, int mixed, char *out, size_t capacity);
+mfa_status mfa_parameter_table_set(int type, int mixed, const char *text); /* validates, then installs */
+mfa_status mfa_parameter_table_reset(void);                                /* back to built-in gfx950 tables */
+typedef struct mfa_parameter_row {
+  uint16_t maximumHeadDimension;
+  uint16_t parallelization, traversal, head;
+  int8_t cached[MFA_OPERAND_COUNT]; /* 1 if listed */
+} mfa_parameter_row;
+/* parseTable + row(table:) in one call (AttentionParameterRow.swift:22-74, +Parameters.swift:41-66) */
+mfa_status mfa_parameter_table_select(const char *text, uint16_t headDimension, mfa_parameter_row *out);
+
+/* ---- AttentionKernel (Attention/AttentionKernel/AttentionKernel.swift:10-51) --------------
+ * In the reference this object generates Metal source (createSource, +Source.swift:11-55)
+ * which the CALLER compiles and dispatches.  Here it resolves to a pre-compiled gfx950 code
+ * object; mfa_attention_kernel_launch replaces createSource + makeLibrary + pipeline +
+ * setBuffer x10 + setThreadgroupMemoryLength + dispatchThreadgroups
+ * (Tests/.../SquareAttentionTest.swift:244-260, :319-368). */
+typedef struct mfa_attention_kernel mfa_attention_kernel;
+mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kdesc,
+                                       mfa_attention_kernel **out);
+void mfa_attention_kernel_destroy(mfa_attention_kernel *kernel);
+/* AttentionKernel.blockDimensions (:22-23) -- the dimensions the selected code object really uses */
+mfa_status mfa_attention_kernel_block_dimensions(const mfa_attention_kernel *kernel,
+                                                 uint16_t *parallelization, uint16_t *traversal,
+                                                 uint16_t *headBlock);
+/* AttentionKernel.threadgroupSize (:268-270): work-items per workgroup (64 x waves) */
+uint32_t mfa_attention_kernel_threadgroup_size(const mfa_attention_kernel *kernel);
+/* AttentionKernel.threadgroupMemoryAllocation (:25, :272-363): LDS bytes per workgroup */
+uint32_t mfa_attention_kernel_threadgroup_memory_allocation(const mfa_attention_kernel *kernel);
+/* name of the selected HIP kernel variant, e.g. "attn_fwd_bf16_d128_r256" (diagnostics) */
+const char *mfa_attention_kernel_variant(const mfa_attention_kernel *kernel);
+/* The descriptor as the selected code object really executes it: the Swift struct lets callers
+ * request any block dimensions / cache state (AttentionKernelDescriptor.swift:9-13); a
+ * pre-compiled suite honours the nearest compiled variant and reports it here. */
+mfa_status mfa_attention_kernel_effective_descriptor(const mfa_attention_kernel *kernel,
+                                                     mfa_attention_kernel_descriptor *out);
+
+/* ---- launch ---------------------------------------------------------------------------------
+ * row/column replace AttentionDescriptor.setFunctionConstants (AttentionDescriptor.swift:139-148).
+ * heads/batches + strides are this library's multi-head extension of the recipe in
+ * AttentionKernelDescriptor.swift:37-41 (leading dimension D -> D*H): grid = (blocks, heads,
+ * batches); operand X of head h, batch b starts at X + h*headStride[slot] + b*batchStride[slot]
+ * (element units).  leadingDimension[slot] == 0 means the reference default
+ * (AttentionKernel.swift:189-204): D if not transposed, the sequence length if transposed.
+ * L and D are vectors: leadingDimension is ignored for slots 4 and 5. */
+typedef struct mfa_launch_params {
+  uint32_t row, column;
+  uint32_t heads, batches;                    /* 0 is treated as 1 */
+  int64_t leadingDimension[MFA_BUFFER_SLOTS];
+  int64_t headStride[MFA_BUFFER_SLOTS];
+  int64_t batchStride[MFA_BUFFER_SLOTS];
+} mfa_launch_params;
+void mfa_launch_params_init(mfa_launch_params *params);
+
+/* buffers[slot] = device pointer bound at AttentionOperand.bufferBinding `slot`; slots the
+ * kernel type does not use may be NULL (forward: 0-4; backwardQuery: 0-6,9;
+ * backwardKeyValue: 0-2,4-8; +Source.swift:72-103).  Asynchronous on `stream`. */
+mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel,
+                                       void *const buffers[MFA_BUFFER_SLOTS],
+                                       const mfa_launch_params *params, void *stream);
+
+/* Timing helper: `warmup` untimed launches, then `iterations` back-to-back launches bracketed by
+ * HIP events recorded on `stream` (the harness of SquareAttentionTest.swift:733-761 uses
+ * gpuEndTime-gpuStartTime around 5 dispatches).  *milliseconds = total for all iterations. */
+mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel,
+                                     void *const buffers[MFA_BUFFER_SLOTS],
+                                     const mfa_launch_params *params, void *stream,
+                                     int warmup, int iterations, float *milliseconds);
+
+/* ---- device context (replaces MTLContext.global, Utilities/MTLContext.swift:10-20) -------- */
+mfa_status mfa_device_count(int *count);
+mfa_status mfa_device_name(int device, char *out, size_t capacity); /* gcnArchName, e.g. gfx950 */
+
+/* thread-local description of the last non-OK status returned on this thread */
+const char *mfa_last_error_string(void);
+int mfa_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFA_H */

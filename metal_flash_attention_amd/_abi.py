@@ -1,0 +1,155 @@
+"""ctypes declarations for include/mfa.h (the C-ABI drop-in boundary).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU or PyTorch
+fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfa_hip.so")
+
+MFA_OPERAND_COUNT = 14
+MFA_BUFFER_SLOTS = 10
+
+MFA_OK = 0
+STATUS_NAMES = {
+    0: "MFA_OK",
+    1: "MFA_ERR_INCOMPLETE_DESCRIPTOR",
+    2: "MFA_ERR_INVALID_ARGUMENT",
+    3: "MFA_ERR_UNSUPPORTED",
+    4: "MFA_ERR_HIP",
+    5: "MFA_ERR_PARSE",
+}
+
+
+class mfa_attention_descriptor(ctypes.Structure):
+    _fields_ = [
+        ("lowPrecisionInputs", ctypes.c_uint8),
+        ("lowPrecisionIntermediates", ctypes.c_uint8),
+        ("hasMatrixDimensions", ctypes.c_uint8),
+        ("hasTransposeState", ctypes.c_uint8),
+        ("row", ctypes.c_uint32),
+        ("column", ctypes.c_uint32),
+        ("head", ctypes.c_uint16),
+        ("transposeQ", ctypes.c_uint8),
+        ("transposeK", ctypes.c_uint8),
+        ("transposeV", ctypes.c_uint8),
+        ("transposeO", ctypes.c_uint8),
+        ("lowPrecisionInputType", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8 * 3),
+    ]
+
+
+class mfa_attention_kernel_descriptor(ctypes.Structure):
+    _fields_ = [
+        ("hasBlockDimensions", ctypes.c_uint8),
+        ("hasHeadDimension", ctypes.c_uint8),
+        ("parallelization", ctypes.c_uint16),
+        ("traversal", ctypes.c_uint16),
+        ("headBlock", ctypes.c_uint16),
+        ("headDimension", ctypes.c_uint16),
+        ("cacheState", ctypes.c_int8 * MFA_OPERAND_COUNT),
+        ("memoryPrecisions", ctypes.c_int8 * MFA_OPERAND_COUNT),
+        ("registerPrecisions", ctypes.c_int8 * MFA_OPERAND_COUNT),
+        ("transposeState", ctypes.c_int8 * MFA_OPERAND_COUNT),
+        ("preferAsyncCache", ctypes.c_int8),
+        ("preferAsyncLoad", ctypes.c_int8),
+        ("type", ctypes.c_int8),
+        ("reserved", ctypes.c_int8),
+    ]
+
+
+class mfa_parameter_row(ctypes.Structure):
+    _fields_ = [
+        ("maximumHeadDimension", ctypes.c_uint16),
+        ("parallelization", ctypes.c_uint16),
+        ("traversal", ctypes.c_uint16),
+        ("head", ctypes.c_uint16),
+        ("cached", ctypes.c_int8 * MFA_OPERAND_COUNT),
+    ]
+
+
+class mfa_launch_params(ctypes.Structure):
+    _fields_ = [
+        ("row", ctypes.c_uint32),
+        ("column", ctypes.c_uint32),
+        ("heads", ctypes.c_uint32),
+        ("batches", ctypes.c_uint32),
+        ("leadingDimension", ctypes.c_int64 * MFA_BUFFER_SLOTS),
+        ("headStride", ctypes.c_int64 * MFA_BUFFER_SLOTS),
+        ("batchStride", ctypes.c_int64 * MFA_BUFFER_SLOTS),
+    ]
+
+
+# every symbol include/mfa.h declares: (name, restype, argtypes)
+_P = ctypes.POINTER
+_KERNEL = ctypes.c_void_p
+_BUFS = ctypes.c_void_p * MFA_BUFFER_SLOTS
+SYMBOLS = [
+    ("mfa_precision_name", ctypes.c_char_p, [ctypes.c_int]),
+    ("mfa_precision_size", ctypes.c_int, [ctypes.c_int]),
+    ("mfa_operand_name", ctypes.c_char_p, [ctypes.c_int]),
+    ("mfa_operand_buffer_binding", ctypes.c_int, [ctypes.c_int]),
+    ("mfa_attention_descriptor_init", None, [_P(mfa_attention_descriptor)]),
+    ("mfa_attention_kernel_descriptor_init", None, [_P(mfa_attention_kernel_descriptor)]),
+    ("mfa_attention_descriptor_memory_precisions", ctypes.c_int,
+     [_P(mfa_attention_descriptor), _P(ctypes.c_int8)]),
+    ("mfa_attention_descriptor_register_precisions", ctypes.c_int,
+     [_P(mfa_attention_descriptor), _P(ctypes.c_int8)]),
+    ("mfa_attention_descriptor_kernel_descriptor", ctypes.c_int,
+     [_P(mfa_attention_descriptor), ctypes.c_int, _P(mfa_attention_kernel_descriptor)]),
+    ("mfa_parameter_table_get", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
+    ("mfa_parameter_table_set", ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    ("mfa_parameter_table_reset", ctypes.c_int, []),
+    ("mfa_parameter_table_select", ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint16, _P(mfa_parameter_row)]),
+    ("mfa_attention_kernel_create", ctypes.c_int, [_P(mfa_attention_kernel_descriptor), _P(_KERNEL)]),
+    ("mfa_attention_kernel_destroy", None, [_KERNEL]),
+    ("mfa_attention_kernel_block_dimensions", ctypes.c_int,
+     [_KERNEL, _P(ctypes.c_uint16), _P(ctypes.c_uint16), _P(ctypes.c_uint16)]),
+    ("mfa_attention_kernel_threadgroup_size", ctypes.c_uint32, [_KERNEL]),
+    ("mfa_attention_kernel_threadgroup_memory_allocation", ctypes.c_uint32, [_KERNEL]),
+    ("mfa_attention_kernel_variant", ctypes.c_char_p, [_KERNEL]),
+    ("mfa_attention_kernel_effective_descriptor", ctypes.c_int, [_KERNEL, _P(mfa_attention_kernel_descriptor)]),
+    ("mfa_launch_params_init", None, [_P(mfa_launch_params)]),
+    ("mfa_attention_kernel_launch", ctypes.c_int, [_KERNEL, _P(_BUFS), _P(mfa_launch_params), ctypes.c_void_p]),
+    ("mfa_attention_kernel_time", ctypes.c_int,
+     [_KERNEL, _P(_BUFS), _P(mfa_launch_params), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _P(ctypes.c_float)]),
+    ("mfa_device_count", ctypes.c_int, [_P(ctypes.c_int)]),
+    ("mfa_device_name", ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]),
+    ("mfa_last_error_string", ctypes.c_char_p, []),
+    ("mfa_abi_version", ctypes.c_int, []),
+]
+
+_lib = None
+
+
+class MFAError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+def lib() -> ctypes.CDLL:
+    """Load libmfa_hip.so.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C metal_flash_attention_amd/csrc`. There is no fallback path.")
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return handle
+
+
+def check(status: int) -> None:
+    if status != MFA_OK:
+        raise MFAError(status, lib().mfa_last_error_string().decode())

@@ -1,0 +1,36 @@
+// attn_generic_dkv.hip -- instantiations of the generic (fp32-MFMA) dkv kernel for gfx950.
+#include "attn_generic.h"
+#include "launchers.h"
+
+namespace mfa {
+
+template <int DP, int NW, bool CACHE>
+static void launch_dkv(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
+  hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE>), grid, dim3(NW * 64), lds, stream, args);
+}
+
+template <int DP, int NW, bool CACHE>
+static void fill(VariantInfo *v, const char *name) {
+  v->func = reinterpret_cast<const void *>(&attn_generic_dkv<DP, NW, CACHE>);
+  v->name = name;
+  v->parallelization = NW * 32;
+  v->traversal = 32;
+  v->headBlock = DP;
+  v->threads = NW * 64;
+  v->ldsBytes = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
+  v->cacheLeft = CACHE;
+  v->launch = &launch_dkv<DP, NW, CACHE>;
+}
+
+bool generic_dkv_variant(int DP, VariantInfo *out) {
+  switch (DP) {
+    case 32:  fill<32, 4, true>(out, "attn_generic_dkv_f32mfma_d32_w4_cached"); return true;
+    case 64:  fill<64, 4, true>(out, "attn_generic_dkv_f32mfma_d64_w4_cached"); return true;
+    case 128: fill<128, 4, true>(out, "attn_generic_dkv_f32mfma_d128_w4_cached"); return true;
+    case 256: fill<256, 1, false>(out, "attn_generic_dkv_f32mfma_d256_w1_lds"); return true;
+    default: return false;
+  }
+}
+
+} // namespace mfa

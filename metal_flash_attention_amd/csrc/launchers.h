@@ -1,0 +1,24 @@
+// launchers.h -- host-side entry points of each kernel translation unit (internal, C++).
+#pragma once
+#include "attn_common.h"
+
+namespace mfa {
+
+struct VariantInfo {
+  const void *func = nullptr;   // __global__ function address (for hipFuncSetAttribute)
+  const char *name = "";
+  uint16_t parallelization = 0; // rows (fwd, dQ) or columns (dK/dV) per workgroup
+  uint16_t traversal = 0;       // columns (fwd, dQ) or rows (dK/dV) per main-loop step
+  uint16_t headBlock = 0;       // padded head dimension the code object is unrolled for
+  uint32_t threads = 0;         // work-items per workgroup
+  uint32_t ldsBytes = 0;        // dynamic LDS
+  bool cacheLeft = false;       // left-hand operands cached in VGPRs (Q / Q,dO / K,V)
+  void (*launch)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
+};
+
+// generic (fp32-MFMA) family: returns false if (DP) is not compiled
+bool generic_fwd_variant(int DP, VariantInfo *out);
+bool generic_dq_variant(int DP, VariantInfo *out);
+bool generic_dkv_variant(int DP, VariantInfo *out);
+
+} // namespace mfa

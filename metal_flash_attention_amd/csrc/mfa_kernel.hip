@@ -1,0 +1,262 @@
+// mfa_kernel.hip -- AttentionKernel object, variant selection and launch (C ABI of include/mfa.h).
+//
+// Replaces, for gfx950, the reference's AttentionKernel(descriptor:) + createSource() and the
+// Metal calls its callers make (Sources/FlashAttention/Attention/AttentionKernel/
+// AttentionKernel.swift:27-50, :268-363; AttentionKernel+Source.swift:11-55;
+// Tests/FlashAttentionTests/Attention/SquareAttentionTest.swift:244-260, :319-368): instead of
+// emitting shader source for a JIT, the descriptor selects one of the pre-compiled code objects.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "launchers.h"
+#include "mfa_internal.h"
+
+using namespace mfa;
+
+struct mfa_attention_kernel {
+  mfa_attention_kernel_descriptor desc;  // as requested
+  mfa_attention_kernel_descriptor effective; // what the selected code object really does
+  VariantInfo variant;
+  std::mutex attrMutex;
+  uint64_t attrDeviceMask = 0; // devices on which the LDS attribute has been raised
+};
+
+static mfa_status hip_fail(hipError_t err, const char *what) {
+  return fail(MFA_ERR_HIP, std::string(what) + ": " + hipGetErrorName(err) + " (" + hipGetErrorString(err) + ")");
+}
+
+static int slot_operand(int slot) {
+  static const int ops[MFA_BUFFER_SLOTS] = {MFA_Q, MFA_K, MFA_V, MFA_O, MFA_L, MFA_D, MFA_dO, MFA_dV, MFA_dK, MFA_dQ};
+  return ops[slot];
+}
+
+// operands each kernel type touches (+Source.swift:72-103)
+static bool slot_used(int type, int slot) {
+  switch (type) {
+    case MFA_FORWARD: return slot <= 4;
+    case MFA_BACKWARD_QUERY: return slot <= 6 || slot == 9;
+    default: return slot <= 2 || (slot >= 4 && slot <= 8);
+  }
+}
+
+static int generic_bucket(int D) {
+  static const int buckets[] = {32, 64, 128, 256};
+  for (int b : buckets)
+    if (D <= b) return b;
+  return -1;
+}
+
+extern "C" {
+
+mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kdesc, mfa_attention_kernel **out) {
+  if (!kdesc || !out) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  // AttentionKernel.init guard (AttentionKernel.swift:28-34)
+  if (!kdesc->hasBlockDimensions || !kdesc->hasHeadDimension || kdesc->preferAsyncCache < 0 ||
+      kdesc->preferAsyncLoad < 0 || kdesc->type < 0)
+    return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, "Descriptor was incomplete.");
+  const int type = kdesc->type;
+  if (type > 2) return fail(MFA_ERR_INVALID_ARGUMENT, "unknown kernel type");
+  if (kdesc->headDimension == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "headDimension must be non-zero");
+  for (int slot = 0; slot < MFA_BUFFER_SLOTS; ++slot) {
+    if (!slot_used(type, slot)) continue;
+    const int op = slot_operand(slot);
+    const int prec = kdesc->memoryPrecisions[op];
+    if (prec < 0)  // AttentionKernel.swift:56-58 "Memory precision of X was not specified."
+      return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, std::string("Memory precision of ") + mfa_operand_name(op) + " was not specified.");
+    if (prec > MFA_BF16) return fail(MFA_ERR_INVALID_ARGUMENT, "unknown precision");
+    if (op != MFA_L && op != MFA_D && kdesc->transposeState[op] < 0)
+      return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, std::string("Transpose state of ") + mfa_operand_name(op) + " was not specified.");
+  }
+
+  VariantInfo variant;
+  bool found = false;
+  const int D = kdesc->headDimension;
+  const int bucket = generic_bucket(D);
+  if (!found && bucket > 0) {
+    switch (type) {
+      case MFA_FORWARD: found = generic_fwd_variant(bucket, &variant); break;
+      case MFA_BACKWARD_QUERY: found = generic_dq_variant(bucket, &variant); break;
+      default: found = generic_dkv_variant(bucket, &variant); break;
+    }
+  }
+  if (!found)
+    return fail(MFA_ERR_UNSUPPORTED, "no gfx950 code object for head dimension " + std::to_string(D) +
+                                         " (this build supports D <= 256)");
+
+  mfa_attention_kernel *kernel = new mfa_attention_kernel();
+  kernel->desc = *kdesc;
+  kernel->variant = variant;
+  kernel->effective = *kdesc;
+  kernel->effective.parallelization = variant.parallelization;
+  kernel->effective.traversal = variant.traversal;
+  kernel->effective.headBlock = variant.headBlock;
+  // accumulators always live in registers on gfx950; left-hand operands per variant
+  switch (type) {
+    case MFA_FORWARD:
+      kernel->effective.cacheState[MFA_Q] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_O] = 1;
+      break;
+    case MFA_BACKWARD_QUERY:
+      kernel->effective.cacheState[MFA_Q] = kernel->effective.cacheState[MFA_dO] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_dQ] = 1;
+      break;
+    default:
+      kernel->effective.cacheState[MFA_K] = kernel->effective.cacheState[MFA_V] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_dK] = kernel->effective.cacheState[MFA_dV] = 1;
+      break;
+  }
+  *out = kernel;
+  return MFA_OK;
+}
+
+void mfa_attention_kernel_destroy(mfa_attention_kernel *kernel) { delete kernel; }
+
+mfa_status mfa_attention_kernel_block_dimensions(const mfa_attention_kernel *kernel, uint16_t *parallelization,
+                                                 uint16_t *traversal, uint16_t *headBlock) {
+  if (!kernel) return fail(MFA_ERR_INVALID_ARGUMENT, "null kernel");
+  if (parallelization) *parallelization = kernel->variant.parallelization;
+  if (traversal) *traversal = kernel->variant.traversal;
+  if (headBlock) *headBlock = kernel->variant.headBlock;
+  return MFA_OK;
+}
+
+uint32_t mfa_attention_kernel_threadgroup_size(const mfa_attention_kernel *kernel) {
+  return kernel ? kernel->variant.threads : 0;
+}
+uint32_t mfa_attention_kernel_threadgroup_memory_allocation(const mfa_attention_kernel *kernel) {
+  return kernel ? kernel->variant.ldsBytes : 0;
+}
+const char *mfa_attention_kernel_variant(const mfa_attention_kernel *kernel) {
+  return kernel ? kernel->variant.name : "";
+}
+mfa_status mfa_attention_kernel_effective_descriptor(const mfa_attention_kernel *kernel,
+                                                     mfa_attention_kernel_descriptor *out) {
+  if (!kernel || !out) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = kernel->effective;
+  return MFA_OK;
+}
+
+static mfa_status prepare_args(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
+                               const mfa_launch_params *p, KernelArgs *args, dim3 *grid) {
+  if (!kernel || !buffers || !p) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  if (p->row == 0 || p->column == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "row and column must be non-zero");
+  const int type = kernel->desc.type;
+  const uint32_t D = kernel->desc.headDimension;
+  std::memset(args, 0, sizeof(*args));
+  for (int slot = 0; slot < MFA_BUFFER_SLOTS; ++slot) {
+    if (!slot_used(type, slot)) continue;
+    const int op = slot_operand(slot);
+    if (!buffers[slot])
+      return fail(MFA_ERR_INVALID_ARGUMENT, std::string("buffer for operand ") + mfa_operand_name(op) + " is null");
+    OperandView &v = args->op[slot];
+    v.ptr = buffers[slot];
+    v.precision = kernel->desc.memoryPrecisions[op];
+    const bool vector = (op == MFA_L || op == MFA_D);
+    v.transposed = vector ? 0 : kernel->desc.transposeState[op];
+    // sequence length of the operand (AttentionKernel.swift:157-187)
+    const bool rowOperand = (op == MFA_Q || op == MFA_O || op == MFA_dO || op == MFA_dQ || vector);
+    const int64_t seq = rowOperand ? p->row : p->column;
+    int64_t ld = p->leadingDimension[slot];
+    if (ld == 0) ld = v.transposed ? seq : (int64_t)D;  // AttentionKernel.swift:189-204
+    if (!vector) {
+      if (!v.transposed && ld < (int64_t)D) return fail(MFA_ERR_INVALID_ARGUMENT, "leading dimension smaller than head dimension");
+      if (v.transposed && ld < seq) return fail(MFA_ERR_INVALID_ARGUMENT, "leading dimension smaller than sequence length");
+    }
+    v.ld = vector ? 1 : ld;
+    v.headStride = p->headStride[slot];
+    v.batchStride = p->batchStride[slot];
+  }
+  args->R = p->row;
+  args->C = p->column;
+  args->D = D;
+  args->scale = 1.0f / std::sqrt((float)D);
+  args->scale2 = 1.44269504089f / std::sqrt((float)D);
+  const uint32_t heads = p->heads ? p->heads : 1, batches = p->batches ? p->batches : 1;
+  if (heads > 65535 || batches > 65535) return fail(MFA_ERR_INVALID_ARGUMENT, "heads and batches must be <= 65535");
+  // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
+  // (SquareAttentionTest.swift:355-367)
+  const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? p->column : p->row;
+  const uint32_t blocks = (par + kernel->variant.parallelization - 1) / kernel->variant.parallelization;
+  *grid = dim3(blocks, heads, batches);
+  return MFA_OK;
+}
+
+static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel) {
+  if (kernel->variant.ldsBytes <= 64 * 1024) return MFA_OK;
+  int device = 0;
+  hipError_t err = hipGetDevice(&device);
+  if (err != hipSuccess) return hip_fail(err, "hipGetDevice");
+  std::lock_guard<std::mutex> lock(kernel->attrMutex);
+  if (device < 64 && (kernel->attrDeviceMask >> device) & 1ull) return MFA_OK;
+  err = hipFuncSetAttribute(kernel->variant.func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kernel->variant.ldsBytes);
+  if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (device < 64) kernel->attrDeviceMask |= 1ull << device;
+  return MFA_OK;
+}
+
+mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
+                                       const mfa_launch_params *params, void *stream) {
+  KernelArgs args;
+  dim3 grid;
+  mfa_status st = prepare_args(kernel, buffers, params, &args, &grid);
+  if (st != MFA_OK) return st;
+  st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel));
+  if (st != MFA_OK) return st;
+  kernel->variant.launch(grid, (hipStream_t)stream, args);
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return hip_fail(err, kernel->variant.name);
+  return MFA_OK;
+}
+
+mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
+                                     const mfa_launch_params *params, void *stream, int warmup, int iterations,
+                                     float *milliseconds) {
+  if (!milliseconds || iterations <= 0 || warmup < 0) return fail(MFA_ERR_INVALID_ARGUMENT, "bad timing arguments");
+  KernelArgs args;
+  dim3 grid;
+  mfa_status st = prepare_args(kernel, buffers, params, &args, &grid);
+  if (st != MFA_OK) return st;
+  st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel));
+  if (st != MFA_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t start, stop;
+  hipError_t err = hipEventCreate(&start);
+  if (err != hipSuccess) return hip_fail(err, "hipEventCreate");
+  err = hipEventCreate(&stop);
+  if (err != hipSuccess) { hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
+  for (int i = 0; i < warmup; ++i) kernel->variant.launch(grid, s, args);
+  hipEventRecord(start, s);
+  for (int i = 0; i < iterations; ++i) kernel->variant.launch(grid, s, args);
+  hipEventRecord(stop, s);
+  err = hipEventSynchronize(stop);
+  if (err == hipSuccess) err = hipGetLastError();
+  if (err == hipSuccess) err = hipEventElapsedTime(milliseconds, start, stop);
+  hipEventDestroy(start);
+  hipEventDestroy(stop);
+  if (err != hipSuccess) return hip_fail(err, kernel->variant.name);
+  return MFA_OK;
+}
+
+mfa_status mfa_device_count(int *count) {
+  if (!count) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  hipError_t err = hipGetDeviceCount(count);
+  if (err != hipSuccess) { *count = 0; return hip_fail(err, "hipGetDeviceCount"); }
+  return MFA_OK;
+}
+
+mfa_status mfa_device_name(int device, char *out, size_t capacity) {
+  if (!out || capacity == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  hipDeviceProp_t prop;
+  hipError_t err = hipGetDeviceProperties(&prop, device);
+  if (err != hipSuccess) return hip_fail(err, "hipGetDeviceProperties");
+  std::strncpy(out, prop.gcnArchName, capacity - 1);
+  out[capacity - 1] = '\0';
+  return MFA_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,24 @@
+"""Independent numpy fp64 restatement of the reference Network formulas
+(Network.swift:134-402) -- TEST INFRASTRUCTURE ONLY.  Written in matrix form on
+purpose (different code shape from network.c) so that it can catch a mistake in
+the C restatement."""
+import numpy as np
+
+
+def attention_f64(Q, K, V, dO=None):
+    Q, K, V = (np.asarray(a, np.float64) for a in (Q, K, V))
+    D = Q.shape[-1]
+    scale = 1.0 / np.sqrt(np.float64(D))
+    S = (Q @ K.T) * scale                                   # Network.swift:134-149, :153
+    m = S.max(axis=1, keepdims=True)                        # :156-160
+    lse = m + np.log(np.exp(S - m).sum(axis=1, keepdims=True))   # :163-171
+    P = np.exp(S - lse)                                     # :172-176
+    out = {"O": P @ V, "L": lse[:, 0]}                      # :286-311, :181-203
+    if dO is None:
+        return out
+    dO = np.asarray(dO, np.float64)
+    Dt = (out["O"] * dO).sum(axis=1)                        # :259-281
+    dP = dO @ V.T                                           # :205-218
+    dS = P * (dP - Dt[:, None]) * scale                     # :245-255
+    out.update(D=Dt, dV=P.T @ dO, dK=dS.T @ Q, dQ=dS @ K)   # :329-402
+    return out

@@ -1,0 +1,156 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP kernels, called through the C ABI,
+against the CPU oracle on the same seeded inputs.  Shapes, dtype packing, canaries and tolerances
+follow the reference's tests (SquareAttentionTest.swift:5-26, :397-554;
+RectangularAttentionTest.swift:7-35, :451-472); unlike the reference these tests ASSERT."""
+import numpy as np
+import pytest
+
+import harness
+from harness import TOL_FP32, TOL_MIXED, TOL_MIXED_SHORT
+from metal_flash_attention_amd import (
+    AttentionDescriptor, AttentionKernel, AttentionKernelType, AttentionOperand, GEMMOperandPrecision,
+)
+from oracle import Network, NetworkDescriptor
+
+pytestmark = pytest.mark.gpu
+P = GEMMOperandPrecision
+Op = AttentionOperand
+
+
+def make_desc(R, C, D, low_in=False, low_mid=False, tr=(False,) * 4, in_type=P.FP16):
+    d = AttentionDescriptor()
+    d.lowPrecisionInputs, d.lowPrecisionIntermediates = low_in, low_mid
+    d.matrixDimensions = (R, C, D)
+    d.transposeState = tuple(tr)
+    d.lowPrecisionInputType = in_type
+    return d
+
+
+def run_case(R, C, D, seed=0, tolerances=None, **kw):
+    net = Network(NetworkDescriptor(R, C, D), seed=seed)
+    desc = make_desc(R, C, D, **kw)
+    run = harness.DeviceRun(desc, net, seed=seed + 1000)
+    got = run.execute()
+    ref = net.run()
+    low = desc.lowPrecisionInputs or desc.lowPrecisionIntermediates
+    if tolerances is None:
+        tolerances = (TOL_MIXED_SHORT if C <= 20 else TOL_MIXED) if low else TOL_FP32
+    failures, report = harness.compare(ref, got, tolerances)
+    variants = [k.variant for k in run.kernels.values()]
+    assert not failures, (failures, variants)
+    assert all(run.tails_ok.values()), f"out-of-bounds write: {run.tails_ok} {variants}"
+    assert not np.isnan(got["O"]).any(), "NaN poison in O[0] was not overwritten"
+    return report, run
+
+
+@pytest.mark.parametrize("N,D", harness.SQUARE_SHAPES)
+def test_square_fp32(N, D):
+    """SquareAttentionTest.testCorrectness: 20 fixed (N, D), FP32, all six outputs within 2e-5."""
+    run_case(N, N, D, seed=N * 1000 + D)
+
+
+@pytest.mark.parametrize("index,case", list(enumerate(harness.rectangular_cases(15, seed=0))))
+def test_rectangular_random(index, case):
+    """RectangularAttentionTest.testCorrectness: R != C, random D, transposes and precision flags."""
+    run_case(case["row"], case["column"], case["head"], seed=index,
+             low_in=case["lowPrecisionInputs"], low_mid=case["lowPrecisionIntermediates"],
+             tr=case["transposeState"])
+
+
+@pytest.mark.parametrize("index,case", list(enumerate(harness.rectangular_cases(12, seed=1))))
+def test_rectangular_random_bf16_inputs(index, case):
+    """Same generator with this project's BF16 input extension (Q, K, V, dO all BF16)."""
+    run_case(case["row"], case["column"], case["head"], seed=100 + index, low_in=True,
+             low_mid=case["lowPrecisionIntermediates"], tr=case["transposeState"], in_type=P.BF16)
+
+
+@pytest.mark.parametrize("tr", [(True, True, True, True), (True, False, False, True), (False, True, True, False)])
+@pytest.mark.parametrize("shape", [(130, 67, 72), (33, 200, 128), (257, 129, 200)])
+def test_transposes_fp32(shape, tr):
+    run_case(*shape, seed=3, tr=tr)
+
+
+def test_rounded_inputs_tight_bf16_and_fp16():
+    """Feeding the oracle the ROUNDED inputs removes the input-quantisation term, so the generic
+    (fp32-compute) path must then agree to fp32 accuracy even with 16-bit storage."""
+    R, C, D = 150, 170, 64
+    for in_type in (P.FP16, P.BF16):
+        net = Network(NetworkDescriptor(R, C, D), seed=9)
+        desc = make_desc(R, C, D, low_in=True, in_type=in_type)
+        prec = desc.memoryPrecisions
+        run = harness.DeviceRun(desc, net)
+        got = run.execute()
+        from oracle import round_trip
+        net.Q, net.K, net.V = (round_trip(a, int(prec[o])) for a, o in ((net.Q, Op.Q), (net.K, Op.K), (net.V, Op.V)))
+        net.dO = round_trip(net.dO, int(prec[Op.dO]))
+        ref = net.run()
+        failures, report = harness.compare(ref, got, {k: 5e-5 for k in TOL_FP32})
+        assert not failures, (in_type, failures)
+
+
+def test_multi_head_strides_match_per_head_runs():
+    """Multi-head recipe of AttentionKernelDescriptor.swift:37-41: heads interleaved along the row,
+    leading dimension D*H; and contiguous [B, H, N, D] via head/batch strides."""
+    import torch
+    R, C, D, H, B = 70, 90, 48, 3, 2
+    nets = [[Network(NetworkDescriptor(R, C, D), seed=50 + b * H + h) for h in range(H)] for b in range(B)]
+    desc = make_desc(R, C, D)
+    kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in AttentionKernelType}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def gather(name, interleaved):
+        a = np.stack([np.stack([getattr(nets[b][h], name) for h in range(H)]) for b in range(B)])  # [B,H,N,D]
+        return np.ascontiguousarray(a.transpose(0, 2, 1, 3)) if interleaved else a              # [B,N,H,D]
+
+    for interleaved in (False, True):
+        bufs, ld, hs, bs = {}, {}, {}, {}
+        for op, name, seq in ((Op.Q, "Q", R), (Op.K, "K", C), (Op.V, "V", C), (Op.dO, "dO", R)):
+            bufs[op] = torch.from_numpy(gather(name, interleaved)).cuda()
+        for op, seq in ((Op.O, R), (Op.dQ, R), (Op.dK, C), (Op.dV, C)):
+            bufs[op] = torch.full((B, seq, H, D) if interleaved else (B, H, seq, D), float("nan"), device="cuda")
+        for op in (Op.L, Op.D):
+            bufs[op] = torch.zeros((B, H, R), device="cuda")
+            hs[op], bs[op] = R, H * R
+        for op, seq in ((Op.Q, R), (Op.K, C), (Op.V, C), (Op.dO, R), (Op.O, R), (Op.dQ, R), (Op.dK, C), (Op.dV, C)):
+            if interleaved:
+                ld[op], hs[op], bs[op] = D * H, D, seq * H * D
+            else:
+                ld[op], hs[op], bs[op] = D, seq * D, H * seq * D
+        for t in AttentionKernelType:
+            kernels[t].dispatch(bufs, row=R, column=C, heads=H, batches=B, leadingDimensions=ld,
+                                headStrides=hs, batchStrides=bs, stream=stream)
+        torch.cuda.synchronize()
+        for b in range(B):
+            for h in range(H):
+                ref = nets[b][h].run()
+                for op, name in ((Op.O, "O"), (Op.dQ, "dQ"), (Op.dK, "dK"), (Op.dV, "dV")):
+                    t = bufs[op].cpu().numpy()
+                    got = t[b, :, h, :] if interleaved else t[b, h]
+                    assert np.abs(got - ref[name]).max() < 2e-5, (interleaved, b, h, name)
+                Lgot = bufs[Op.L].cpu().numpy()[b, h] / np.float32(harness.LOG2E)
+                assert np.abs(Lgot - ref["L"]).max() < 2e-5
+
+
+def test_determinism_run_to_run():
+    R, C, D = 300, 300, 96
+    net = Network(NetworkDescriptor(R, C, D), seed=4)
+    a = harness.DeviceRun(make_desc(R, C, D), net).execute()
+    b = harness.DeviceRun(make_desc(R, C, D), net).execute()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_softmax_extremes_do_not_overflow():
+    """Large-magnitude logits: the running max / correction path must stay finite
+    (AttentionKernel+Softmax.swift:290-301)."""
+    R, C, D = 64, 200, 32
+    net = Network(NetworkDescriptor(R, C, D), seed=8)
+    net.Q *= 30.0
+    net.K[150] *= 40.0  # one key dominates late in the traversal: forces a big rescale
+    net.invalidate()
+    desc = make_desc(R, C, D)
+    got = harness.DeviceRun(desc, net).execute()
+    ref = net.run()
+    assert np.isfinite(got["O"]).all() and np.isfinite(got["L"]).all()
+    assert np.abs(got["O"] - ref["O"]).max() < 1e-4
+    assert np.abs(got["L"] - ref["L"]).max() / np.abs(ref["L"]).max() < 1e-5

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline benchmark on MI355X.
+
+Metric (BASELINE.json): GINSTR/s + achieved MFMA TFLOPS vs peak, forward, N=4096, D=128, bf16.
+GINSTR = (2D+5) N^2 per head per dispatch (reference: README.md:108-124,
+Tests/FlashAttentionTests/Attention/SquareAttentionTest.swift:742-756).
+
+A "step" is one forward dispatch over this rank's shard of batch x head (synthetic Q/K/V already
+resident in HBM).  The reference benchmarks a single head and raises N until the GPU is full
+(SquareAttentionTest.swift:159-165); a single N=4096 head is 16 workgroups on a 256-CU chip, so
+the throughput number is taken with a batch x head grid (B=8, H=32 per GPU), the sharding axis of
+BASELINE config 5.  Multi-GPU: one process per GPU, heads sharded, NO data-path collective
+(attention heads are independent); torch.distributed is used only for the barrier and the
+max-over-ranks of the elapsed time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fwd_bf16_d128|...]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (kernel types, N, D, dtype, batch, heads)
+    "fwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",)),   # headline
+    "fwd_bf16_d64": dict(N=4096, D=64, dtype="bf16", batch=8, heads=32, types=("forward",)),     # config 2, batched
+    "fwd_bf16_d64_1head": dict(N=4096, D=64, dtype="bf16", batch=1, heads=1, types=("forward",)),  # config 2 as written
+    "fwd_bf16_d256": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",)),   # config 4, batched
+    "fwdbwd_f32_d128": dict(N=4096, D=128, dtype="f32", batch=2, heads=16,
+                            types=("forward", "backwardQuery", "backwardKeyValue")),             # config 3, batched
+    "fwd_bf16_d128_n16k": dict(N=16384, D=128, dtype="bf16", batch=1, heads=32, types=("forward",)),  # config 5 shard
+}
+OPS_PER_N2 = {"forward": lambda D: 2 * D + 5, "backwardQuery": lambda D: 3 * D + 5,
+              "backwardKeyValue": lambda D: 4 * D + 5}       # README.md:108-124
+FLOPS_PER_N2 = {"forward": lambda D: 4 * D, "backwardQuery": lambda D: 6 * D,
+                "backwardKeyValue": lambda D: 8 * D}         # MFMA flops: 2, 3, 4 GEMMs of 2 N^2 D
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="fwd_bf16_d128", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
+                                           AttentionOperand as Op, GEMMOperandPrecision as P)
+
+    w = WORKLOADS[args.workload]
+    N, D, B, H = w["N"], w["D"], w["batch"], w["heads"]
+    low = w["dtype"] != "f32"
+    desc = AttentionDescriptor()
+    desc.lowPrecisionInputs = low
+    desc.lowPrecisionIntermediates = False
+    desc.lowPrecisionInputType = P.BF16 if w["dtype"] == "bf16" else P.FP16
+    desc.matrixDimensions = (N, N, D)
+    desc.transposeState = (False, False, False, False)
+    types = [AttentionKernelType[t] for t in w["types"]]
+    kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in types}
+
+    # synthetic inputs: i.i.d. N(0,1) (Network.swift:96-129 distribution), this rank's shard of heads
+    tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[w["dtype"]]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234 + rank)
+    shape = (B, H, N, D)
+    bufs = {}
+    for op in (Op.Q, Op.K, Op.V):
+        bufs[op] = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32).to(tdtype)
+    bufs[Op.O] = torch.empty(shape, device="cuda", dtype=torch.float32)
+    bufs[Op.L] = torch.empty((B, H, N), device="cuda", dtype=torch.float32)
+    backward = len(types) > 1
+    if backward:
+        # the reference stores dO as BF16 in low-precision mode (+Precisions.swift:17)
+        bufs[Op.dO] = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32).to(
+            torch.bfloat16 if low else torch.float32)
+        bufs[Op.D] = torch.empty((B, H, N), device="cuda", dtype=torch.float32)
+        for op in (Op.dQ, Op.dK, Op.dV):
+            bufs[op] = torch.empty(shape, device="cuda", dtype=torch.float32)
+    hs = {op: (N if op in (Op.L, Op.D) else N * D) for op in bufs}
+    bs = {op: v * H for op, v in hs.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        for t in types:
+            kernels[t].dispatch(bufs, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                                stream=stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                      # HIP events on the stream the kernels are launched on
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    device_ms = ev0.elapsed_time(ev1)
+    if dist is not None:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        dist.barrier()
+
+    heads_total = B * H * world
+    ops_step = sum(OPS_PER_N2[t.name](D) for t in types) * N * N * heads_total
+    ginstrs = ops_step * args.steps / elapsed / 1e9
+    # roofline of the dominant kernel, per launch on this rank, from the HIP-event time
+    flops_launch_rank = sum(FLOPS_PER_N2[t.name](D) for t in types) * N * N * B * H
+    launch_ms = device_ms / args.steps
+    achieved_tflops = flops_launch_rank / (launch_ms * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[w["dtype"]]
+
+    out = {
+        "metric": "GINSTR/s forward attention N=4096 D=128 bf16" if args.workload == "fwd_bf16_d128"
+        else f"GINSTR/s {args.workload}",
+        "value": round(ginstrs, 2),
+        "unit": "GINSTR/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": w["dtype"],
+        "data": "synthetic",
+        "config": {"workload": f"attention {'+'.join(w['types'])} N={N} D={D} {w['dtype']} Q/K/V, fp32 O/L; "
+                               f"B={B} H={H} heads per GPU, batch x head sharded across GPUs, no collectives",
+                   "kernel_variants": [kernels[t].variant for t in types]},
+        "mfma_tflops": round(achieved_tflops * world, 2),
+        "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved_tflops / peak, 4), "traffic": None,
+                     "kernel": kernels[types[0]].variant, "launch_ms": round(launch_ms, 4)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(np, torch, w, bufs, Op, args.cpu_seconds, backward)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(np, torch, w, bufs, Op, target_seconds, backward):
+    """Times the oracle (C restatement of the reference's naive CPU Network) on the host cores for a
+    bounded sample of the SAME workload -- whole heads taken from the GPU buffers -- and checks the
+    GPU result of those heads against it."""
+    from oracle import Network, NetworkDescriptor, max_threads
+
+    N, D = w["N"], w["D"]
+    ops_head = (OPS_PER_N2["forward"](D) + (OPS_PER_N2["backwardQuery"](D) + OPS_PER_N2["backwardKeyValue"](D)
+                                            if backward else 0)) * N * N
+    threads = max_threads()
+    heads_done, cpu_time, max_err = 0, 0.0, 0.0
+    flat = {op: t.reshape(-1, *t.shape[2:]) for op, t in bufs.items()}
+    nheads = flat[Op.Q].shape[0]
+    while heads_done < nheads and heads_done < 64:
+        net = Network(NetworkDescriptor(N, N, D), seed=0)
+        net.Q = flat[Op.Q][heads_done].float().cpu().numpy()
+        net.K = flat[Op.K][heads_done].float().cpu().numpy()
+        net.V = flat[Op.V][heads_done].float().cpu().numpy()
+        if backward:
+            net.dO = flat[Op.dO][heads_done].float().cpu().numpy()
+        t0 = time.perf_counter()
+        ref = net.run(backward=backward)
+        cpu_time += time.perf_counter() - t0
+        got = flat[Op.O][heads_done].cpu().numpy()
+        max_err = max(max_err, float(np.abs(got - ref["O"]).max()))
+        heads_done += 1
+        if cpu_time >= target_seconds:
+            break
+    return {"value": round(ops_head * heads_done / cpu_time / 1e9, 3), "unit": "GINSTR/s", "cores": threads,
+            "kind": "port",
+            "sample": f"{heads_done} of {nheads} heads of the same workload (same Q/K/V as the GPU run), "
+                      f"{cpu_time:.2f} s of oracle time, OpenMP over rows",
+            "gpu_vs_oracle_max_abs_err_O": max_err}
+
+
+if __name__ == "__main__":
+    main()

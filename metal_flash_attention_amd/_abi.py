@@ -141,6 +141,14 @@ def lib() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C metal_flash_attention_amd/csrc`. There is no fallback path.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; when a process uses both, torch's copy must be
+    # the one that is resident (loading /opt/rocm's first leaves torch with a runtime that reports
+    # hipErrorNoDevice).  torch is only plumbing here (device memory, streams): import it first if
+    # it is installed, so the C-ABI library binds to the same HIP runtime instance.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     handle = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(handle, name)  # AttributeError if the ABI is incomplete

@@ -21,4 +21,7 @@ bool generic_fwd_variant(int DP, VariantInfo *out);
 bool generic_dq_variant(int DP, VariantInfo *out);
 bool generic_dkv_variant(int DP, VariantInfo *out);
 
+// 16-bit MFMA forward family (Q, K, V in one 16-bit type, row-major, D % 8 == 0)
+bool fwd16_variant(int precision, int D, VariantInfo *out);
+
 } // namespace mfa

@@ -20,9 +20,12 @@ using namespace mfa;
 struct mfa_attention_kernel {
   mfa_attention_kernel_descriptor desc;  // as requested
   mfa_attention_kernel_descriptor effective; // what the selected code object really does
-  VariantInfo variant;
+  VariantInfo variant;            // preferred code object
+  VariantInfo fallback;           // general code object, used when a launch does not meet the
+  bool hasFallback = false;       // preferred variant's alignment requirements
   std::mutex attrMutex;
-  uint64_t attrDeviceMask = 0; // devices on which the LDS attribute has been raised
+  uint64_t attrDeviceMask = 0;    // devices on which the LDS attribute has been raised (variant)
+  uint64_t attrDeviceMaskFallback = 0;
 };
 
 static mfa_status hip_fail(hipError_t err, const char *what) {
@@ -73,17 +76,28 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, std::string("Transpose state of ") + mfa_operand_name(op) + " was not specified.");
   }
 
-  VariantInfo variant;
-  bool found = false;
+  VariantInfo variant, general;
+  bool found = false, fast = false;
   const int D = kdesc->headDimension;
   const int bucket = generic_bucket(D);
-  if (!found && bucket > 0) {
+  if (bucket > 0) {
     switch (type) {
-      case MFA_FORWARD: found = generic_fwd_variant(bucket, &variant); break;
-      case MFA_BACKWARD_QUERY: found = generic_dq_variant(bucket, &variant); break;
-      default: found = generic_dkv_variant(bucket, &variant); break;
+      case MFA_FORWARD: found = generic_fwd_variant(bucket, &general); break;
+      case MFA_BACKWARD_QUERY: found = generic_dq_variant(bucket, &general); break;
+      default: found = generic_dkv_variant(bucket, &general); break;
     }
   }
+  // 16-bit matrix-core path: Q, K, V stored in ONE 16-bit type, nothing transposed, O in FP32,
+  // head dimension a multiple of 8 (16-byte chunks).
+  if (found && type == MFA_FORWARD) {
+    const int pq = kdesc->memoryPrecisions[MFA_Q];
+    const bool same = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
+    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
+                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
+    if (same && rowMajor && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 && (D % 8) == 0)
+      fast = fwd16_variant(pq, bucket, &variant);
+  }
+  if (found && !fast) variant = general;
   if (!found)
     return fail(MFA_ERR_UNSUPPORTED, "no gfx950 code object for head dimension " + std::to_string(D) +
                                          " (this build supports D <= 256)");
@@ -91,6 +105,8 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   mfa_attention_kernel *kernel = new mfa_attention_kernel();
   kernel->desc = *kdesc;
   kernel->variant = variant;
+  kernel->fallback = general;
+  kernel->hasFallback = fast;
   kernel->effective = *kdesc;
   kernel->effective.parallelization = variant.parallelization;
   kernel->effective.traversal = variant.traversal;
@@ -141,10 +157,31 @@ mfa_status mfa_attention_kernel_effective_descriptor(const mfa_attention_kernel 
   return MFA_OK;
 }
 
-static mfa_status prepare_args(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
-                               const mfa_launch_params *p, KernelArgs *args, dim3 *grid) {
+// true if this launch satisfies the 16-byte-chunk requirements of the 16-bit MFMA kernels
+static bool meets_fast_requirements(const mfa_attention_kernel *kernel, const KernelArgs &args) {
+  const int type = kernel->desc.type;
+  for (int slot = 0; slot < MFA_BUFFER_SLOTS; ++slot) {
+    if (!slot_used(type, slot) || slot == SLOT_L || slot == SLOT_D) continue;
+    const OperandView &v = args.op[slot];
+    const int64_t per16 = 16 / (v.precision == PREC_FP32 ? 4 : 2);  // elements per 16 bytes
+    if ((reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
+    if (v.ld % per16 || v.headStride % per16 || v.batchStride % per16) return false;
+  }
+  return true;
+}
+
+struct LaunchPlan {
+  KernelArgs args;
+  dim3 grid;
+  const VariantInfo *variant;
+  bool useFallback;
+};
+
+static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
+                                 const mfa_launch_params *p, LaunchPlan *plan) {
   if (!kernel || !buffers || !p) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
   if (p->row == 0 || p->column == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "row and column must be non-zero");
+  KernelArgs *args = &plan->args;
   const int type = kernel->desc.type;
   const uint32_t D = kernel->desc.headDimension;
   std::memset(args, 0, sizeof(*args));
@@ -178,38 +215,41 @@ static mfa_status prepare_args(const mfa_attention_kernel *kernel, void *const b
   args->scale2 = 1.44269504089f / std::sqrt((float)D);
   const uint32_t heads = p->heads ? p->heads : 1, batches = p->batches ? p->batches : 1;
   if (heads > 65535 || batches > 65535) return fail(MFA_ERR_INVALID_ARGUMENT, "heads and batches must be <= 65535");
+  plan->useFallback = kernel->hasFallback && !meets_fast_requirements(kernel, *args);
+  plan->variant = plan->useFallback ? &kernel->fallback : &kernel->variant;
   // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
   // (SquareAttentionTest.swift:355-367)
   const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? p->column : p->row;
-  const uint32_t blocks = (par + kernel->variant.parallelization - 1) / kernel->variant.parallelization;
-  *grid = dim3(blocks, heads, batches);
+  const uint32_t blocks = (par + plan->variant->parallelization - 1) / plan->variant->parallelization;
+  if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
+  plan->grid = dim3(blocks, heads, batches);
   return MFA_OK;
 }
 
-static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel) {
-  if (kernel->variant.ldsBytes <= 64 * 1024) return MFA_OK;
+static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const LaunchPlan &plan) {
+  if (plan.variant->ldsBytes <= 64 * 1024) return MFA_OK;
   int device = 0;
   hipError_t err = hipGetDevice(&device);
   if (err != hipSuccess) return hip_fail(err, "hipGetDevice");
   std::lock_guard<std::mutex> lock(kernel->attrMutex);
-  if (device < 64 && (kernel->attrDeviceMask >> device) & 1ull) return MFA_OK;
-  err = hipFuncSetAttribute(kernel->variant.func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kernel->variant.ldsBytes);
+  uint64_t &mask = plan.useFallback ? kernel->attrDeviceMaskFallback : kernel->attrDeviceMask;
+  if (device < 64 && (mask >> device) & 1ull) return MFA_OK;
+  err = hipFuncSetAttribute(plan.variant->func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
   if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-  if (device < 64) kernel->attrDeviceMask |= 1ull << device;
+  if (device < 64) mask |= 1ull << device;
   return MFA_OK;
 }
 
 mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
                                        const mfa_launch_params *params, void *stream) {
-  KernelArgs args;
-  dim3 grid;
-  mfa_status st = prepare_args(kernel, buffers, params, &args, &grid);
+  LaunchPlan plan;
+  mfa_status st = prepare_launch(kernel, buffers, params, &plan);
   if (st != MFA_OK) return st;
-  st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel));
+  st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
-  kernel->variant.launch(grid, (hipStream_t)stream, args);
+  plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
   hipError_t err = hipGetLastError();
-  if (err != hipSuccess) return hip_fail(err, kernel->variant.name);
+  if (err != hipSuccess) return hip_fail(err, plan.variant->name);
   return MFA_OK;
 }
 
@@ -217,28 +257,27 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
                                      const mfa_launch_params *params, void *stream, int warmup, int iterations,
                                      float *milliseconds) {
   if (!milliseconds || iterations <= 0 || warmup < 0) return fail(MFA_ERR_INVALID_ARGUMENT, "bad timing arguments");
-  KernelArgs args;
-  dim3 grid;
-  mfa_status st = prepare_args(kernel, buffers, params, &args, &grid);
+  LaunchPlan plan;
+  mfa_status st = prepare_launch(kernel, buffers, params, &plan);
   if (st != MFA_OK) return st;
-  st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel));
+  st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t start, stop;
   hipError_t err = hipEventCreate(&start);
   if (err != hipSuccess) return hip_fail(err, "hipEventCreate");
   err = hipEventCreate(&stop);
-  if (err != hipSuccess) { hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
-  for (int i = 0; i < warmup; ++i) kernel->variant.launch(grid, s, args);
-  hipEventRecord(start, s);
-  for (int i = 0; i < iterations; ++i) kernel->variant.launch(grid, s, args);
-  hipEventRecord(stop, s);
+  if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
+  for (int i = 0; i < warmup; ++i) plan.variant->launch(plan.grid, s, plan.args);
+  (void)hipEventRecord(start, s);
+  for (int i = 0; i < iterations; ++i) plan.variant->launch(plan.grid, s, plan.args);
+  (void)hipEventRecord(stop, s);
   err = hipEventSynchronize(stop);
   if (err == hipSuccess) err = hipGetLastError();
   if (err == hipSuccess) err = hipEventElapsedTime(milliseconds, start, stop);
-  hipEventDestroy(start);
-  hipEventDestroy(stop);
-  if (err != hipSuccess) return hip_fail(err, kernel->variant.name);
+  (void)hipEventDestroy(start);
+  (void)hipEventDestroy(stop);
+  if (err != hipSuccess) return hip_fail(err, plan.variant->name);
   return MFA_OK;
 }
 

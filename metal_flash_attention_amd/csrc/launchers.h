@@ -23,5 +23,7 @@ bool generic_dkv_variant(int DP, VariantInfo *out);
 
 // 16-bit MFMA forward family (Q, K, V in one 16-bit type, row-major, D % 8 == 0)
 bool fwd16_variant(int precision, int D, VariantInfo *out);
+// software-pipelined version; impl selects an experimental schedule (see attn_fwd16_v2.hip)
+bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 
 } // namespace mfa

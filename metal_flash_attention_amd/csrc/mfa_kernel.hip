@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -94,8 +95,17 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const bool same = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
-    if (same && rowMajor && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 && (D % 8) == 0)
-      fast = fwd16_variant(pq, bucket, &variant);
+    if (same && rowMajor && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 && (D % 8) == 0) {
+      // MFA_FWD16_IMPL (developer knob for A/B runs): "v1" = unpipelined kernel, "v2:<n>" = pipelined
+      // kernel schedule n.  Default: pipelined schedule 0 where compiled, else v1.
+      const char *knob = std::getenv("MFA_FWD16_IMPL");
+      int impl = 0;
+      bool wantV1 = false;
+      if (knob && std::strcmp(knob, "v1") == 0) wantV1 = true;
+      if (knob && std::strncmp(knob, "v2:", 3) == 0) impl = std::atoi(knob + 3);
+      if (!wantV1) fast = fwd16_v2_variant(pq, bucket, impl, &variant);
+      if (!fast) fast = fwd16_variant(pq, bucket, &variant);
+    }
   }
   if (found && !fast) variant = general;
   if (!found)

@@ -254,3 +254,26 @@ def test_forward_16bit_unaligned_launch_falls_back_to_general_kernel():
     round_inputs(net, desc)
     ref = net.run(backward=False)
     assert np.abs(bufs[Op.O].cpu().numpy() - ref["O"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("impl", ["v1", "v2:0", "v2:1"])
+def test_forward_16bit_forced_rescale(impl, monkeypatch):
+    """The deferred-rescale branch of the pipelined kernel is rare on random data, so force it
+    (guide rule: a rare data-dependent branch needs its own test): one key far along the traversal
+    dominates some rows by much more than the threshold, another grows the maximum only slightly.
+    All schedules -- THR=0 (the reference's rule), THR=8 and the unpipelined kernel -- must agree
+    with the full-tensor oracle."""
+    monkeypatch.setenv("MFA_FWD16_IMPL", impl)
+    R, C, D = 128, 640, 64
+    net = Network(NetworkDescriptor(R, C, D), seed=21)
+    net.K[300] = net.Q[5] * 6.0      # huge score for row 5 (and large for correlated rows) at tile 4
+    net.K[500] = net.Q[70] * 1.5     # moderate growth for row 70 at tile 7
+    net.invalidate()
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net, run_backward=False)
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(backward=False)
+    assert np.isfinite(got["O"]).all()
+    assert np.abs(got["O"] - ref["O"]).max() < 2e-2, run.kernels[AttentionKernelType.forward].variant
+    assert np.abs(got["L"] - ref["L"]).max() < 2e-3

@@ -189,7 +189,7 @@ def test_forward_16bit_mfma(shape, in_type):
     net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
     desc = make_desc(R, C, D, low_in=True, in_type=in_type)
     run = harness.DeviceRun(desc, net, run_backward=False)
-    assert run.kernels[AttentionKernelType.forward].variant.startswith("attn_fwd16_"), run.kernels[AttentionKernelType.forward].variant
+    assert run.kernels[AttentionKernelType.forward].variant.startswith("attn_fwd16"), run.kernels[AttentionKernelType.forward].variant
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run(backward=False)

@@ -17,6 +17,9 @@
 //     raised -- and O, l multiplied by exp2(m_old - m_new) -- when some row's block maximum exceeds
 //     m by more than THR; otherwise P = exp2(S*scale2 - m) simply runs up to 2^THR.  THR = 0 is the
 //     reference's rule (+Softmax.swift:290-301) exactly.  L = m + log2(l) is unaffected.
+//   * the row sum l = sum_c P runs on the matrix pipe too (an all-ones A operand times P^T), which
+//     also makes it the sum of the ROUNDED P, the reference's rule (+Softmax.swift:308-321); the
+//     VALU keeps ~4.3 instructions per score: fma, exp2, 1/2 cvt_pk, 1/2 max3, moves.
 //   * the epilogue transposes O through LDS so that every store instruction writes whole rows.
 #pragma once
 #include "attn_fwd16.h"
@@ -51,7 +54,7 @@ __device__ __forceinline__ float half_swap_add(float x) {
   return a + b;
 }
 
-template <typename T, int D, int NW, int RB, int THR>
+template <typename T, int D, int NW, int RB, int THR, bool MSUM>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -94,7 +97,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
   }
 
   // ---- K/V staging: thread handles chunks id = tid + i*NT (row = id / CPR, c = id % CPR)
-  uint32_t koff[NCH], voff[NCH], kinc[NCH], vinc[NCH], klds[NCH], vlds[NCH];
+  // A chunk past the runtime head dimension must read as zero in EVERY tile: its offset is parked
+  // just below 2^32 and the per-tile stride is applied with a saturating add, so it can never
+  // wrap back into the buffer.
+  uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
+  const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;   // wave-uniform (SGPRs)
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int id = tid + i * NT;
@@ -102,8 +109,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
     const bool valid = c * 8 < Dr;
     koff[i] = valid ? row * ldk2 + c * 16 : OOB;
     voff[i] = valid ? row * ldv2 + c * 16 : OOB;
-    kinc[i] = valid ? BC * ldk2 : 0;
-    vinc[i] = valid ? BC * ldv2 : 0;
     klds[i] = row * ROWB + kswz<D>(row, c) * 16;
     vlds[i] = TILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;   // V image [D/32][64 keys][32 d]
   }
@@ -113,8 +118,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
     for (int i = 0; i < NCH; ++i) {
       kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
       vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
-      koff[i] += kinc[i];
-      voff[i] += vinc[i];
+      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
     }
   };
   auto write_tiles = [&](int stage) {
@@ -163,6 +168,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
       for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
   }
 
+  f32x16 lsum[MSUM ? RB : 1];
+  v8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
+  if constexpr (MSUM) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lsum[b][r] = 0.f;
+  }
+
   // ---- online softmax, split in three so that the only branch of the loop sits at its top ------
   // (+Softmax.swift:228-324, :406-417)
   auto mask_edge = [&](f32x16 (&s)[RB][2], int c0) {   // maskAttentionMatrixEdge
@@ -179,9 +195,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
     for (int b = 0; b < RB; ++b) {
       float mx0 = fmaxf(s[b][0][0], s[b][0][1]), mx1 = fmaxf(s[b][1][0], s[b][1][1]);
 #pragma unroll
-      for (int r = 2; r < 16; r += 2) {
-        mx0 = fmaxf(mx0, fmaxf(s[b][0][r], s[b][0][r + 1]));
-        mx1 = fmaxf(mx1, fmaxf(s[b][1][r], s[b][1][r + 1]));
+      for (int r = 2; r < 16; r += 2) {   // fmaxf(fmaxf(a, b), c) -> one v_max3_f32
+        mx0 = fmaxf(fmaxf(mx0, s[b][0][r]), s[b][0][r + 1]);
+        mx1 = fmaxf(fmaxf(mx1, s[b][1][r]), s[b][1][r + 1]);
       }
       m_new[b] = half_swap_max(fmaxf(mx0, mx1)) * a.scale2;
     }
@@ -197,6 +213,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
         const float corr = fast_exp2(m[b] - m_up);
         m[b] = m_up;
         l[b] *= corr;
+        if constexpr (MSUM) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lsum[b][r] *= corr;
+        }
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -215,9 +235,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
         for (int r = 0; r < 16; ++r) {
           const float p = fast_exp2(s[b][kb][r] * a.scale2 - mb);
           s[b][kb][r] = p;
-          ps[r & 3] += p;
+          if constexpr (!MSUM) ps[r & 3] += p;
         }
-      l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      if constexpr (!MSUM) l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {   // MFMA step u uses registers 8*(u&1)..+7 of key block u>>1
         v8 pk;
@@ -241,6 +261,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
 #pragma unroll
         for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf, pf[b][u], o[b][db]);
       }
+    if constexpr (MSUM) {   // onlineReduceSum on the matrix pipe: l = sum_k 1 * P (every output row equal)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int b = 0; b < RB; ++b) lsum[b] = F::mfma(ones, pf[b][u], lsum[b]);
+    }
   };
 
   // ---- prologue: tile 0 -> stage 0, loads of tile 1 in flight, S(0) and its block maximum
@@ -258,8 +284,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
   block_max(s_cur, m_new);
 
   int st_cur = 0, st_next = 1;
-  // one iteration: [rare rescale] | write tile j+1, barrier | S(j+1) on the matrix pipe while the
-  // VALU exponentiates tile j | O += P(j) V(j) while the VALU reduces the maximum of tile j+1
   auto iteration = [&](int j, bool last) {
     rescale_if_needed(m_new);
     write_tiles(st_next);        // tile j+1 (replaces tile j-2)
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
   };
   int j = 0;
   for (; j + 2 < ntiles; ++j) iteration(j, false);
-  if (j + 1 < ntiles) iteration(j, true);   // produces the (possibly ragged) last tile's scores
+  if (j + 1 < ntiles) iteration(j, true);
   rescale_if_needed(m_new);
   exponentiate(s_cur, pf);
   pv(st_cur, pf);
@@ -291,7 +315,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
   char *lbase = operand_base(a.op[SLOT_L], head, batch);
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
-    const float l_tot = half_swap_add(l[b]) + 1.401298464e-45f;
+    const float l_tot = (MSUM ? lsum[b][0] : half_swap_add(l[b])) + 1.401298464e-45f;
     const float inv = 1.0f / l_tot;
     float *orow = Os + (b * 32 + q) * OLD;
 #pragma unroll

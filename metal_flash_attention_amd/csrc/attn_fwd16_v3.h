@@ -1,0 +1,287 @@
+// attn_fwd16_v3.h -- forward attention, 16-bit matrix cores, ONE wave per SIMD owning 64 query rows.
+//
+// Same math / fragment maps / LDS images as attn_fwd16.h and the same ring, loads, deferred rescale
+// and epilogue as attn_fwd16_v2.h.  What is re-derived here is the register blocking, for gfx950's
+// 512-register lanes (the reference blocks for Apple's ~208 B/thread,
+// AttentionDescriptor+Parameters.swift:77-285):
+//   * a wave owns RB = 2 blocks of 32 query rows: every K fragment (ds_read_b128) and every V^T
+//     fragment (2 x ds_read_b64_tr_b16) read from LDS feeds TWO MFMAs, halving LDS traffic per flop;
+//     4 waves per workgroup = one wave per SIMD, each with the whole 512-entry register file
+//     (O accumulators 128, Q fragments 64, two live half score tiles 64, staging 32, ...).
+//   * the pipeline step is HALF a K/V tile (32 keys): S^T of the next 32 keys is produced by the
+//     matrix pipe while the VALU exponentiates the current 32, then O^T += V^T P^T for the current
+//     32 while the VALU reduces the next block's maximum.  The two half score tiles swap roles every
+//     step, so no register copies are needed, and only 64 score registers are live.
+//   * per step and wave: 32 MFMAs against 8 + 16 LDS reads and ~110 VALU instructions.
+#pragma once
+#include "attn_fwd16_v2.h"
+
+namespace mfa {
+
+template <typename T, int D, int NW, int RB, int THR>
+__global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
+  typedef Frag16<T> F;
+  typedef typename F::v8 v8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BC = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
+  constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 2 * TILE;
+  constexpr int CPR = D / 8, NCH = BC * CPR / NT;
+  static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
+  uint32_t rblk, head, batch;
+  fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  const int R = a.R, C = a.C, Dr = a.D;
+  const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
+  const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
+                 ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
+
+  const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
+      operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)R * ldq2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(
+      operand_base(a.op[SLOT_K], head, batch), 0, (uint32_t)C * ldk2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
+      operand_base(a.op[SLOT_V], head, batch), 0, (uint32_t)C * ldv2, 0x00020000);
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+
+  // ---- Q fragments (B operand of S^T = K Q^T), cached in registers for the whole kernel
+  v8 qf[RB][NKS];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const uint32_t rowoff = (uint32_t)(r0 + b * 32 + q) * ldq2;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const int d0 = 16 * s + 8 * hi;
+      const uint32_t off = (d0 < Dr && r0 + b * 32 + q < R) ? rowoff + d0 * 2 : OOB;
+      qf[b][s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(qres, off, 0, 0));
+    }
+  }
+
+  // ---- K/V staging (identical to v2)
+  uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
+  const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = tid + i * NT;
+    const int row = id / CPR, c = id % CPR;
+    const bool valid = c * 8 < Dr;
+    koff[i] = valid ? row * ldk2 + c * 16 : OOB;
+    voff[i] = valid ? row * ldv2 + c * 16 : OOB;
+    klds[i] = row * ROWB + kswz<D>(row, c) * 16;
+    vlds[i] = TILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+  }
+  u32x4 kreg[NCH], vreg[NCH];
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+    }
+  };
+  auto write_tiles = [&](int stage) {
+    char *base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+    }
+  };
+
+  const int n16 = lane & 15;
+  const int vtr_off = TILE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
+  int kread[NKS];
+#pragma unroll
+  for (int t = 0; t < NKS; ++t) kread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
+
+  // S^T for the 32 keys of half `kb` of the tile in `stage`: one K fragment feeds RB MFMAs
+  auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
+    const char *Ks = smem + stage * STAGE + kb * 32 * ROWB;
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) {
+      const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[t]);
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        if (t == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+        }
+        s[b] = F::mfma(kf, qf[b][t], s[b]);
+      }
+    }
+  };
+
+  f32x16 o[RB][NDB];
+  float m[RB], l[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    m[b] = -3.402823466e+38f;   // +Caching.swift:310
+    l[b] = 0.f;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
+  }
+
+  auto mask_edge = [&](f32x16 (&s)[RB], int c0) {   // maskAttentionMatrixEdge (+Softmax.swift:228-260)
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (c0 + crow(r, hi) >= C) s[b][r] = mask_value();
+  };
+  auto block_max = [&](const f32x16 (&s)[RB], float (&m_new)[RB]) {   // onlineReduceMaximum
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      float mx0 = fmaxf(s[b][0], s[b][1]), mx1 = fmaxf(s[b][2], s[b][3]);
+#pragma unroll
+      for (int r = 4; r < 16; r += 4) {
+        mx0 = fmaxf(fmaxf(mx0, s[b][r]), s[b][r + 1]);
+        mx1 = fmaxf(fmaxf(mx1, s[b][r + 2]), s[b][r + 3]);
+      }
+      m_new[b] = half_swap_max(fmaxf(mx0, mx1)) * a.scale2;
+    }
+  };
+  auto rescale_if_needed = [&](const float (&m_new)[RB]) {   // onlineCorrectO, deferred by THR
+    bool need = false;
+#pragma unroll
+    for (int b = 0; b < RB; ++b) need |= (m_new[b] > m[b] + (float)THR);
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        const float m_up = fmaxf(m[b], m_new[b]);
+        const float corr = fast_exp2(m[b] - m_up);
+        m[b] = m_up;
+        l[b] *= corr;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[b][db][r] *= corr;
+      }
+    }
+  };
+  auto exponentiate = [&](f32x16 (&s)[RB], v8 (&pf)[RB][2]) {   // softmax + onlineReduceSum
+#pragma unroll
+    for (int b = 0; b < RB; ++b) {
+      const float mb = m[b];
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[b][r] * a.scale2 - mb);
+        s[b][r] = p;
+        ps[r & 3] += p;
+      }
+      l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {   // MFMA step u (16 keys) uses registers 8u .. 8u+7
+        v8 pk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk[i] = (T)s[b][8 * u + i];
+        pf[b][u] = pk;
+      }
+    }
+  };
+  // O^T += V^T P^T for the 32 keys of half `kb`: one V^T fragment feeds RB MFMAs
+  auto pv = [&](int stage, int kb, const v8 (&pf)[RB][2]) {
+    const char *Vs = smem + stage * STAGE + vtr_off + kb * 32 * 64;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const char *vp = Vs + (db * BC + 16 * u) * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
+        const v8 vf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf, pf[b][u], o[b][db]);
+      }
+  };
+
+  // ---- prologue
+  const int ntiles = (C + BC - 1) / BC;
+  const bool ragged = (C & (BC - 1)) != 0;
+  issue_loads();
+  write_tiles(0);
+  issue_loads();
+  __syncthreads();
+  f32x16 s0[RB], s1[RB];   // half score tiles (keys 0-31 / 32-63 of a tile); roles alternate
+  v8 pf[RB][2];
+  float m_new[RB];
+  qk(0, 0, s0);
+  if (ntiles == 1 && ragged) mask_edge(s0, 0);
+  block_max(s0, m_new);
+
+  int st_cur = 0, st_next = 1;
+  // iteration j: s0 = S(tile j, keys 0-31) and its block maximum are ready on entry
+  auto iteration = [&](int j, bool next_is_last) {
+    rescale_if_needed(m_new);
+    write_tiles(st_next);          // tile j+1 (replaces tile j-2)
+    issue_loads();                 // tile j+2 (reads as zero past the end)
+    __syncthreads();
+    // step A: matrix pipe S(j, keys 32-63) | VALU exp(s0); then PV(keys 0-31) | VALU max(s1)
+    qk(st_cur, 1, s1);
+    exponentiate(s0, pf);
+    pv(st_cur, 0, pf);
+    block_max(s1, m_new);
+    rescale_if_needed(m_new);
+    // step B: matrix pipe S(j+1, keys 0-31) | VALU exp(s1); then PV(keys 32-63) | VALU max(s0)
+    qk(st_next, 0, s0);
+    exponentiate(s1, pf);
+    pv(st_cur, 1, pf);
+    if (next_is_last && ragged) mask_edge(s0, (j + 1) * BC);
+    block_max(s0, m_new);
+    st_cur = st_next;
+    st_next = (st_next == 2) ? 0 : st_next + 1;
+  };
+  int j = 0;
+  for (; j + 2 < ntiles; ++j) iteration(j, false);
+  if (j + 1 < ntiles) { iteration(j, true); ++j; }
+  // last tile (j = ntiles-1): both halves, no successor
+  rescale_if_needed(m_new);
+  qk(st_cur, 1, s1);
+  exponentiate(s0, pf);
+  pv(st_cur, 0, pf);
+  if (ragged) mask_edge(s1, j * BC + 32);
+  block_max(s1, m_new);
+  rescale_if_needed(m_new);
+  exponentiate(s1, pf);
+  pv(st_cur, 1, pf);
+
+  // ---- epilogue: O /= l (+Source.swift:165-171), L = m + log2(l) (+Caching.swift:373-377)
+  __syncthreads();   // every wave is done with the ring
+  constexpr int OLD = D + 4;
+  float *Os = reinterpret_cast<float *>(smem) + wave * (RB * 32 * OLD);
+  char *lbase = operand_base(a.op[SLOT_L], head, batch);
+#pragma unroll
+  for (int b = 0; b < RB; ++b) {
+    const float l_tot = half_swap_add(l[b]) + 1.401298464e-45f;
+    const float inv = 1.0f / l_tot;
+    float *orow = Os + (b * 32 + q) * OLD;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
+            make_float4(o[b][db][4 * g] * inv, o[b][db][4 * g + 1] * inv, o[b][db][4 * g + 2] * inv, o[b][db][4 * g + 3] * inv);
+    const int64_t row = r0 + b * 32 + q;
+    if (hi == 0 && row < R) store_elem(lbase, row, a.op[SLOT_L].precision, m[b] + log2f(l_tot));
+  }
+  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
+      operand_base(a.op[SLOT_O], head, batch), 0, (uint32_t)R * (uint32_t)a.op[SLOT_O].ld * 4u, 0x00020000);
+  const uint32_t ldo4 = (uint32_t)a.op[SLOT_O].ld * 4;
+  constexpr int CPRO = D / 4;
+#pragma unroll
+  for (int i = 0; i < RB * 32 * CPRO / 64; ++i) {
+    const int id = lane + i * 64;
+    const int rr = id / CPRO, c = id % CPRO;
+    const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
+    const int64_t row = r0 + rr;
+    const uint32_t off = (row < R && c * 4 < Dr) ? (uint32_t)row * ldo4 + c * 16 : OOB;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ores, off, 0, 0);
+  }
+}
+
+} // namespace mfa

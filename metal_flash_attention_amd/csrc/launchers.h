@@ -25,5 +25,7 @@ bool generic_dkv_variant(int DP, VariantInfo *out);
 bool fwd16_variant(int precision, int D, VariantInfo *out);
 // software-pipelined version; impl selects an experimental schedule (see attn_fwd16_v2.hip)
 bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
+// one wave per SIMD, 64 query rows per wave, half-tile pipeline (see attn_fwd16_v3.h)
+bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
 
 } // namespace mfa

@@ -103,7 +103,8 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       bool wantV1 = false;
       if (knob && std::strcmp(knob, "v1") == 0) wantV1 = true;
       if (knob && std::strncmp(knob, "v2:", 3) == 0) impl = std::atoi(knob + 3);
-      if (!wantV1) fast = fwd16_v2_variant(pq, bucket, impl, &variant);
+      if (knob && std::strncmp(knob, "v3:", 3) == 0) fast = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &variant);
+      if (!fast && !wantV1) fast = fwd16_v2_variant(pq, bucket, impl, &variant);
       if (!fast) fast = fwd16_variant(pq, bucket, &variant);
     }
   }

@@ -18,7 +18,7 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR>
+template <typename T, int D, int NW, int RB, int THR, int PRE>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -200,6 +200,58 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       }
   };
 
+  v8 pf[RB][2];
+  // One pipeline step with the LDS fragment reads issued up front (PRE >= 1): all K fragments of
+  // the NEXT 32 keys (and with PRE == 2 the first half of the V^T fragments of the current 32) are
+  // requested before the VALU starts exponentiating, so their LDS latency is covered by that work
+  // instead of being exposed in front of every MFMA (hipcc otherwise issues each ds_read one MFMA
+  // ahead of its consumer).  sched_barrier(0) pins the reads above the arithmetic.
+  auto step = [&](f32x16 (&s_cur)[RB], f32x16 (&s_next)[RB], int k_stage, int k_kb, int v_stage, int v_kb,
+                  bool do_qk) {
+    const char *Ks = smem + k_stage * STAGE + k_kb * 32 * ROWB;
+    const char *Vs = smem + v_stage * STAGE + vtr_off + v_kb * 32 * 64;
+    v8 kf[NKS];
+    if (do_qk) {
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) kf[t] = *reinterpret_cast<const v8 *>(Ks + kread[t]);
+    }
+    auto load_v = [&](int u, v8 (&vf)[NDB]) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const char *vp = Vs + (db * BC + 16 * u) * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
+        vf[db] = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    v8 vf0[NDB], vf1[NDB];
+    if constexpr (PRE == 2) load_v(0, vf0);
+    __builtin_amdgcn_sched_barrier(0);
+    exponentiate(s_cur, pf);
+    if (do_qk) {
+#pragma unroll
+      for (int t = 0; t < NKS; ++t)
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          if (t == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_next[b][r] = 0.f;
+          }
+          s_next[b] = F::mfma(kf[t], qf[b][t], s_next[b]);
+        }
+    }
+    if constexpr (PRE != 2) load_v(0, vf0);
+    load_v(1, vf1);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf0[db], pf[b][0], o[b][db]);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf1[db], pf[b][1], o[b][db]);
+  };
+
   // ---- prologue
   const int ntiles = (C + BC - 1) / BC;
   const bool ragged = (C & (BC - 1)) != 0;
@@ -208,7 +260,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   issue_loads();
   __syncthreads();
   f32x16 s0[RB], s1[RB];   // half score tiles (keys 0-31 / 32-63 of a tile); roles alternate
-  v8 pf[RB][2];
   float m_new[RB];
   qk(0, 0, s0);
   if (ntiles == 1 && ragged) mask_edge(s0, 0);
@@ -222,15 +273,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     issue_loads();                 // tile j+2 (reads as zero past the end)
     __syncthreads();
     // step A: matrix pipe S(j, keys 32-63) | VALU exp(s0); then PV(keys 0-31) | VALU max(s1)
-    qk(st_cur, 1, s1);
-    exponentiate(s0, pf);
-    pv(st_cur, 0, pf);
+    if constexpr (PRE == 0) {
+      qk(st_cur, 1, s1);
+      exponentiate(s0, pf);
+      pv(st_cur, 0, pf);
+    } else {
+      step(s0, s1, st_cur, 1, st_cur, 0, true);
+    }
     block_max(s1, m_new);
     rescale_if_needed(m_new);
     // step B: matrix pipe S(j+1, keys 0-31) | VALU exp(s1); then PV(keys 32-63) | VALU max(s0)
-    qk(st_next, 0, s0);
-    exponentiate(s1, pf);
-    pv(st_cur, 1, pf);
+    if constexpr (PRE == 0) {
+      qk(st_next, 0, s0);
+      exponentiate(s1, pf);
+      pv(st_cur, 1, pf);
+    } else {
+      step(s1, s0, st_next, 0, st_cur, 1, true);
+    }
     if (next_is_last && ragged) mask_edge(s0, (j + 1) * BC);
     block_max(s0, m_new);
     st_cur = st_next;

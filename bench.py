@@ -70,9 +70,14 @@ def main():
 
     from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
                                            AttentionOperand as Op, GEMMOperandPrecision as P)
+    from metal_flash_attention_amd.sharding import max_over_ranks, shard_range
 
     w = WORKLOADS[args.workload]
     N, D, B, H = w["N"], w["D"], w["batch"], w["heads"]
+    # weak scaling: the job has B*H heads per GPU; this rank owns a contiguous range of the
+    # flattened batch x head axis (no data-path collective, heads are independent)
+    unit_begin, unit_end = shard_range(B * H * world, world, rank)
+    assert unit_end - unit_begin == B * H
     low = w["dtype"] != "f32"
     desc = AttentionDescriptor()
     desc.lowPrecisionInputs = low
@@ -86,7 +91,7 @@ def main():
     # synthetic inputs: i.i.d. N(0,1) (Network.swift:96-129 distribution), this rank's shard of heads
     tdtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[w["dtype"]]
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234 + rank)
+    gen.manual_seed(1234 + unit_begin)
     shape = (B, H, N, D)
     bufs = {}
     for op in (Op.Q, Op.K, Op.V):
@@ -129,10 +134,8 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     device_ms = ev0.elapsed_time(ev1)
+    elapsed = max_over_ranks(elapsed, dist, device="cuda")
     if dist is not None:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         dist.barrier()
 
     heads_total = B * H * world

@@ -18,7 +18,7 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR, int PRE>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const char *Ks = smem + stage * STAGE + kb * 32 * ROWB;
 #pragma unroll
     for (int t = 0; t < NKS; ++t) {
-      const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[t]);
+      const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
         if (t == 0) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = fast_exp2(s[b][r] * a.scale2 - mb);
+        const float p = (ABL == 2) ? s[b][r] * a.scale2 - mb : fast_exp2(s[b][r] * a.scale2 - mb);
         s[b][r] = p;
         ps[r & 3] += p;
       }
@@ -252,6 +252,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf1[db], pf[b][1], o[b][db]);
   };
 
+  if constexpr (ABL == 1) {   // static priority for the second-dispatched half (T5 static form)
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+  }
   // ---- prologue
   const int ntiles = (C + BC - 1) / BC;
   const bool ragged = (C & (BC - 1)) != 0;
@@ -267,11 +270,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 
   int st_cur = 0, st_next = 1;
   // iteration j: s0 = S(tile j, keys 0-31) and its block maximum are ready on entry
+  // RING == 3: tile j+1 replaces tile j-2, whose last reader finished before the barrier of the
+  // previous iteration, so one barrier per tile suffices.  RING == 2 (head dimensions whose three
+  // stages would not fit the 160 KiB LDS): tile j+1 replaces tile j-1, still being read by slower
+  // waves until they reach this iteration's first barrier -- write after it, and publish the tile
+  // with a second barrier before step B reads it.
   auto iteration = [&](int j, bool next_is_last) {
     rescale_if_needed(m_new);
-    write_tiles(st_next);          // tile j+1 (replaces tile j-2)
-    issue_loads();                 // tile j+2 (reads as zero past the end)
-    __syncthreads();
+    if constexpr (RING == 3) {
+      write_tiles(st_next);          // tile j+1 (replaces tile j-2)
+      issue_loads();                 // tile j+2 (reads as zero past the end)
+      __syncthreads();
+    } else {
+      __syncthreads();
+      write_tiles(st_next);
+      issue_loads();
+    }
     // step A: matrix pipe S(j, keys 32-63) | VALU exp(s0); then PV(keys 0-31) | VALU max(s1)
     if constexpr (PRE == 0) {
       qk(st_cur, 1, s1);
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     }
     block_max(s1, m_new);
     rescale_if_needed(m_new);
+    if constexpr (RING == 2) __syncthreads();
     // step B: matrix pipe S(j+1, keys 0-31) | VALU exp(s1); then PV(keys 32-63) | VALU max(s0)
     if constexpr (PRE == 0) {
       qk(st_next, 0, s0);
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     if (next_is_last && ragged) mask_edge(s0, (j + 1) * BC);
     block_max(s0, m_new);
     st_cur = st_next;
-    st_next = (st_next == 2) ? 0 : st_next + 1;
+    st_next = (st_next == RING - 1) ? 0 : st_next + 1;
   };
   int j = 0;
   for (; j + 2 < ntiles; ++j) iteration(j, false);

@@ -96,15 +96,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
     if (same && rowMajor && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 && (D % 8) == 0) {
-      // MFA_FWD16_IMPL (developer knob for A/B runs): "v1" = unpipelined kernel, "v2:<n>" = pipelined
-      // kernel schedule n.  Default: pipelined schedule 0 where compiled, else v1.
+      // MFA_FWD16_IMPL (developer knob for A/B runs): "v1" = unpipelined kernel, "v2:<n>" = full-tile
+      // pipeline schedule n, "v3:<n>" = half-tile pipeline schedule n.  Default: v3 schedule 0.
       const char *knob = std::getenv("MFA_FWD16_IMPL");
-      int impl = 0;
-      bool wantV1 = false;
-      if (knob && std::strcmp(knob, "v1") == 0) wantV1 = true;
-      if (knob && std::strncmp(knob, "v2:", 3) == 0) impl = std::atoi(knob + 3);
-      if (knob && std::strncmp(knob, "v3:", 3) == 0) fast = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &variant);
-      if (!fast && !wantV1) fast = fwd16_v2_variant(pq, bucket, impl, &variant);
+      bool wantV1 = knob && std::strcmp(knob, "v1") == 0;
+      if (knob && std::strncmp(knob, "v2:", 3) == 0) fast = fwd16_v2_variant(pq, bucket, std::atoi(knob + 3), &variant);
+      else if (knob && std::strncmp(knob, "v3:", 3) == 0) fast = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &variant);
+      else if (!wantV1) fast = fwd16_v3_variant(pq, bucket, 0, &variant);
       if (!fast) fast = fwd16_variant(pq, bucket, &variant);
     }
   }

@@ -277,3 +277,80 @@ def test_forward_16bit_forced_rescale(impl, monkeypatch):
     assert np.isfinite(got["O"]).all()
     assert np.abs(got["O"] - ref["O"]).max() < 2e-2, run.kernels[AttentionKernelType.forward].variant
     assert np.abs(got["L"] - ref["L"]).max() < 2e-3
+
+
+# ---- BASELINE.json configurations at FULL size ------------------------------------------------
+def _full_size(R, D, low, in_type=P.BF16, backward=False, seed=0):
+    net = Network(NetworkDescriptor(R, R, D), seed=seed)
+    desc = make_desc(R, R, D, low_in=low, in_type=in_type)
+    run = harness.DeviceRun(desc, net, run_backward=backward)
+    got = run.execute()
+    if low:
+        round_inputs(net, desc)
+    ref = net.run(backward=backward)
+    return ref, got, run
+
+
+def test_config2_forward_n4096_d64_bf16_single_head():
+    ref, got, run = _full_size(4096, 64, True)
+    assert np.abs(got["O"] - ref["O"]).max() < 5e-3 and np.abs(got["L"] - ref["L"]).max() < 1e-3
+    assert all(run.tails_ok.values())
+
+
+def test_config3_forward_backward_n4096_d128_fp32():
+    """FP32 at N=4096: the reference's 2e-5 tolerance was set on N <= 777 (SquareAttentionTest.swift:6-25);
+    fp32 summation-order noise grows with N, so the full-size check states its own bound: 2e-5 for
+    O/L/D, 1e-4 for the gradients (each a 4096-term fp32 sum in a different order from the oracle)."""
+    ref, got, run = _full_size(4096, 128, False, backward=True)
+    for name, tol in (("O", 2e-5), ("L", 2e-5), ("D", 2e-5), ("dV", 1e-4), ("dK", 1e-4), ("dQ", 1e-4)):
+        err = np.abs(got[name] - ref[name]).max()
+        assert err < tol, (name, err)
+    assert all(run.tails_ok.values())
+
+
+def test_config4_forward_n8192_d256_bf16():
+    ref, got, run = _full_size(8192, 256, True)
+    assert run.kernels[AttentionKernelType.forward].variant.startswith("attn_fwd16")
+    assert np.abs(got["O"] - ref["O"]).max() < 5e-3 and np.abs(got["L"] - ref["L"]).max() < 1e-3
+
+
+def test_config5_shard_forward_n16384_d128_bf16_two_heads():
+    """Config 5 is B=8 H=32 N=16384 D=128 sharded over 8 GPUs; the oracle checks a sample of heads at
+    full sequence length (the GPU kernel treats every head identically)."""
+    for seed in (0, 1):
+        ref, got, run = _full_size(16384, 128, True, seed=seed)
+        assert np.abs(got["O"] - ref["O"]).max() < 5e-3 and np.abs(got["L"] - ref["L"]).max() < 1e-3
+
+
+def test_size_independent_properties_at_full_size():
+    """Properties that need no oracle: (i) V = 1 gives O = 1 exactly up to rounding (rows of P sum to
+    one); (ii) permuting the keys (rows of K and V together) leaves O and L unchanged up to
+    summation order -- this exercises tile boundaries at N=4096; (iii) O is linear in V."""
+    import torch
+    N, D = 4096, 128
+    desc = make_desc(N, N, D, low_in=True, in_type=P.BF16)
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    q, k, v1, v2 = (torch.randn((N, D), generator=g, device="cuda").to(torch.bfloat16) for _ in range(4))
+
+    def fwd(k_, v_):
+        o = torch.full((N, D), float("nan"), device="cuda")
+        l = torch.zeros(N, device="cuda")
+        kernel.dispatch({Op.Q: q, Op.K: k_, Op.V: v_, Op.O: o, Op.L: l}, row=N, column=N,
+                        stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return o, l
+
+    ones = torch.ones((N, D), device="cuda", dtype=torch.bfloat16)
+    o, l = fwd(k, ones)
+    assert (o - 1).abs().max().item() < 4e-3       # P is rounded to bf16 before the sum
+    o1, l1 = fwd(k, v1)
+    perm = torch.randperm(N, generator=g, device="cuda")
+    op, lp = fwd(k[perm].contiguous(), v1[perm].contiguous())
+    assert (op - o1).abs().max().item() < 3e-3 and (lp - l1).abs().max().item() < 1e-4
+    # linearity: V1 + V2 rounded to bf16 once; compare against the same rounded sum
+    vs = (v1.float() + v2.float()).to(torch.bfloat16)
+    o2, _ = fwd(k, v2)
+    os_, _ = fwd(k, vs)
+    resid = (vs.float() - v1.float() - v2.float()).abs().max().item()
+    assert (os_ - o1 - o2).abs().max().item() < resid + 5e-3

@@ -24,8 +24,9 @@ static void fill(VariantInfo *v, const char *name) {
   v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING>;
 }
 
-// impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring; D = 256: 4 waves x 32 rows
-// (one per SIMD, 512 registers), 2-stage ring.  1: K fragments hoisted; 2: K + first V fragments
+// impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring (two waves per SIMD hide the
+// LDS latency: hoisting fragment reads measured +-0); D = 256: 4 waves x 32 rows (one per SIMD, 512
+// registers), 2-stage ring, K fragments hoisted (+11 % measured: nothing else hides the latency).  1: K fragments hoisted; 2: K + first V fragments
 // hoisted; 3: 4 waves x 64 rows (K hoisted); >= 10: developer ablations.
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
@@ -39,14 +40,14 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 64 && impl == 0) { fill<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }
     if (D == 64 && impl == 2) { fill<__bf16, 64, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_prekv"); return true; }
     if (D == 32 && impl == 0) { fill<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
-    if (D == 256 && impl == 0) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
-    if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
+    if (D == 256 && impl == 0) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
+    if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
   }
   if (precision == PREC_FP16) {
     if (D == 128 && impl == 0) { fill<_Float16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8"); return true; }
     if (D == 64 && impl == 0) { fill<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
     if (D == 32 && impl == 0) { fill<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
-    if (D == 256 && impl == 0) { fill<_Float16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2"); return true; }
+    if (D == 256 && impl == 0) { fill<_Float16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_prek"); return true; }
   }
   return false;
 }

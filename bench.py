@@ -34,6 +34,8 @@ WORKLOADS = {
     "fwd_bf16_d256": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",)),   # config 4, batched
     "fwdbwd_f32_d128": dict(N=4096, D=128, dtype="f32", batch=2, heads=16,
                             types=("forward", "backwardQuery", "backwardKeyValue")),             # config 3, batched
+    "fwdbwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16,
+                             types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_n16k": dict(N=16384, D=128, dtype="bf16", batch=1, heads=32, types=("forward",)),  # config 5 shard
 }
 OPS_PER_N2 = {"forward": lambda D: 2 * D + 5, "backwardQuery": lambda D: 3 * D + 5,

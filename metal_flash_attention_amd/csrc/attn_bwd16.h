@@ -1,0 +1,404 @@
+// attn_bwd16.h -- backward attention on the 16-bit matrix cores of gfx950 (BF16 or FP16 Q, K, V, dO).
+//
+//   backwardQuery    : D = rowsum(dO o O)/sqrt(D);  dQ = sum_c dS K      (+Source.swift:202-242)
+//   backwardKeyValue : dV = sum_r P^T dO;  dK = sum_r dS^T Q             (+Source.swift:244-293)
+//   with  P = exp2(S*scale2 - L),  dS = P o (dP/sqrt(D) - D)             (+Softmax.swift:406-427)
+// reference: Sources/FlashAttention/Attention/AttentionKernel/AttentionKernel+Source.swift,
+//            +OuterProduct.swift, +Accumulate.swift, +Softmax.swift:32-221, +Caching.swift:333-413.
+//
+// The two kernels stay separate and each recomputes S and P from L, exactly as the reference does to
+// avoid FP32 atomics (README.md:11, :39-46): 7 GEMMs instead of 5.
+//
+// Building blocks are those of attn_fwd16.h: v_mfma_f32_32x32x16, the first product of each pair is
+// oriented so that a lane owns one reduction row (dQ: S^T = K Q^T, lane = query; dK/dV: S = Q K^T,
+// lane = key, which is the orientation the reference uses too, +Source.swift:245-249), and the
+// contraction index of the second product is permuted so the C/D registers of the first ARE its B
+// operand.  An operand that is needed both as a row fragment (A of a "outer product") and transposed
+// (A of an "accumulate") gets two LDS images: row-major with the 16-byte XOR swizzle (ds_read_b128)
+// and [D/32][rows][32] (ds_read_b64_tr_b16).  That is K in backwardQuery and Q, dO in
+// backwardKeyValue; each staged chunk is simply written twice.
+#pragma once
+#include "attn_fwd16_v2.h"
+
+namespace mfa {
+
+// ------------------------------------------------------------------------------------------------
+// backwardQuery.  Workgroup = NW waves x 32 query rows; traversal over 64-key tiles.
+// LDS stage = K row-major | K transposable | V row-major.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NW> constexpr int dq16_lds_bytes() {
+  constexpr int ring = 2 * 3 * 64 * D * 2;
+  constexpr int epi = NW * 32 * (D + 4) * 4;
+  return ring > epi ? ring : epi;
+}
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const Fwd16Grid grid) {
+  typedef Frag16<T> F;
+  typedef typename F::v8 v8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BC = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
+  constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 3 * TILE;
+  constexpr int CPR = D / 8, NCH = BC * CPR / NT;
+  static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
+  uint32_t rblk, head, batch;
+  fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  const int R = a.R, C = a.C, Dr = a.D;
+  const int64_t r0 = (int64_t)rblk * (NW * 32) + wave * 32;
+  const int64_t row = r0 + q;
+  const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
+                 ldv2 = (uint32_t)a.op[SLOT_V].ld * 2, ldg2 = (uint32_t)a.op[SLOT_dO].ld * 2,
+                 ldo4 = (uint32_t)a.op[SLOT_O].ld * 4;
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+  const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)R * ldq2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_dO], head, batch), 0, (uint32_t)R * ldg2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_O], head, batch), 0, (uint32_t)R * ldo4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_K], head, batch), 0, (uint32_t)C * ldk2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_V], head, batch), 0, (uint32_t)C * ldv2, 0x00020000);
+
+  // ---- cached left-hand operands: Q and dO fragments (B operands), +Caching.swift:316-346
+  v8 qf[NKS], gf[NKS];
+  float dterm = 0.f;
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const int d0 = 16 * s + 8 * hi;
+    const bool ok = d0 < Dr && row < R;
+    qf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(qres, ok ? (uint32_t)row * ldq2 + d0 * 2 : OOB, 0, 0));
+    gf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(gres, ok ? (uint32_t)row * ldg2 + d0 * 2 : OOB, 0, 0));
+    // computeD (+Softmax.swift:32-221): D = sum_d dO*O, the two half-waves split the head dimension
+    const uint32_t ooff = ok ? (uint32_t)row * ldo4 + d0 * 4 : OOB;
+    const f32x4 o0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ooff, 0, 0));
+    const f32x4 o1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ok ? ooff + 16 : OOB, 0, 0));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dterm += (float)gf[s][i] * o0[i] + (float)gf[s][4 + i] * o1[i];
+  }
+  dterm = half_swap_add(dterm) * a.scale;
+  float Lrow = 0.f;
+  if (row < R) Lrow = load_elem(operand_base(a.op[SLOT_L], head, batch), row, a.op[SLOT_L].precision);
+
+  // ---- K/V staging
+  uint32_t koff[NCH], voff[NCH], klds[NCH], ktlds[NCH], vlds[NCH];
+  const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = tid + i * NT;
+    const int rr = id / CPR, c = id % CPR;
+    const bool valid = c * 8 < Dr;
+    koff[i] = valid ? rr * ldk2 + c * 16 : OOB;
+    voff[i] = valid ? rr * ldv2 + c * 16 : OOB;
+    klds[i] = rr * ROWB + kswz<D>(rr, c) * 16;                        // K row-major (swizzled)
+    ktlds[i] = TILE + ((c >> 2) * BC + rr) * 64 + (c & 3) * 16;       // K transposable [D/32][64][32]
+    vlds[i] = 2 * TILE + rr * ROWB + kswz<D>(rr, c) * 16;             // V row-major (swizzled)
+  }
+  u32x4 kreg[NCH], vreg[NCH];
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+    }
+  };
+  auto write_tiles = [&](int stage) {
+    char *base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+      *reinterpret_cast<u32x4 *>(base + ktlds[i]) = kreg[i];
+      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+    }
+  };
+  const int n16 = lane & 15;
+  const int tr_off = ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
+  int fread[NKS];   // row-fragment offsets (row q of a 32-row block; same swizzle for rows q and q+32)
+#pragma unroll
+  for (int t = 0; t < NKS; ++t) fread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
+
+  f32x16 dq[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+
+  const int ntiles = (C + BC - 1) / BC;
+  issue_loads();
+  write_tiles(0);
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    const char *st = smem + (j & 1) * STAGE;
+    if (j + 1 < ntiles) issue_loads();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      // S^T = K Q^T and dP^T = V dO^T for 32 keys: lane = query row, registers = keys crow(r, hi)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) {
+        const v8 kf = *reinterpret_cast<const v8 *>(st + kb * 32 * ROWB + fread[t]);
+        s = F::mfma(kf, qf[t], s);
+      }
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) {
+        const v8 vf = *reinterpret_cast<const v8 *>(st + 2 * TILE + kb * 32 * ROWB + fread[t]);
+        dp = F::mfma(vf, gf[t], dp);
+      }
+      // P = exp2(S*scale2 - L); dS = P (dP*scale - D).  Keys past C have zero K and V rows, so their
+      // dS multiplies zero K rows below: no mask needed (as in the reference, +Accumulate.swift:330-346).
+      v8 dsf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        v8 pk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int r = 8 * u + i;
+          const float p = fast_exp2(s[r] * a.scale2 - Lrow);
+          pk[i] = (T)(p * (dp[r] * a.scale - dterm));
+        }
+        dsf[u] = pk;
+      }
+      // dQ^T += K^T dS^T (K transposed by the LDS read; key index permuted as in forward)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const char *kp = st + TILE + tr_off + (db * BC + 32 * kb + 16 * u) * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + 8 * 64));
+          const v8 ktf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+          dq[db] = F::mfma(ktf, dsf[u], dq[db]);
+        }
+    }
+    if (j + 1 < ntiles) write_tiles((j + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: dQ through LDS (whole-row stores); D written pre-scaled (+Caching.swift:381-413)
+  constexpr int OLD = D + 4;
+  float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
+  float *orow = Os + q * OLD;
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
+          make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
+  if (hi == 0 && row < R) store_elem(operand_base(a.op[SLOT_D], head, batch), row, a.op[SLOT_D].precision, dterm);
+  const __amdgpu_buffer_rsrc_t dqres = __builtin_amdgcn_make_buffer_rsrc(
+      operand_base(a.op[SLOT_dQ], head, batch), 0, (uint32_t)R * (uint32_t)a.op[SLOT_dQ].ld * 4u, 0x00020000);
+  const uint32_t lddq4 = (uint32_t)a.op[SLOT_dQ].ld * 4;
+  constexpr int CPRO = D / 4;
+#pragma unroll
+  for (int i = 0; i < 32 * CPRO / 64; ++i) {
+    const int id = lane + i * 64;
+    const int rr = id / CPRO, c = id % CPRO;
+    const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
+    const uint32_t off = (r0 + rr < R && c * 4 < Dr) ? (uint32_t)(r0 + rr) * lddq4 + c * 16 : OOB;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), dqres, off, 0, 0);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backwardKeyValue.  Workgroup = NW waves x 32 key columns; traversal over 64-row tiles of Q / dO.
+// LDS stage = Q row-major | Q transposable | dO row-major | dO transposable | L[64] | D[64].
+// ------------------------------------------------------------------------------------------------
+template <int D, int NW> constexpr int dkv16_lds_bytes() {
+  constexpr int ring = 2 * (4 * 64 * D * 2 + 512);
+  constexpr int epi = NW * 32 * (D + 4) * 4;
+  return ring > epi ? ring : epi;
+}
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const Fwd16Grid grid) {
+  typedef Frag16<T> F;
+  typedef typename F::v8 v8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BR = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
+  constexpr int ROWB = D * 2, TILE = BR * D * 2, STAGE = 4 * TILE + 512;
+  constexpr int CPR = D / 8, NCH = BR * CPR / NT;
+  static_assert(BR * CPR % NT == 0, "tile must divide evenly over the workgroup");
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, kc = lane & 31, hi = lane >> 5;
+  uint32_t cblk, head, batch;
+  fwd16_decode_block(grid, blockIdx.x, &cblk, &head, &batch);
+  const int R = a.R, C = a.C, Dr = a.D;
+  const int64_t c0 = (int64_t)cblk * (NW * 32) + wave * 32;
+  const int64_t col = c0 + kc;
+  const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
+                 ldv2 = (uint32_t)a.op[SLOT_V].ld * 2, ldg2 = (uint32_t)a.op[SLOT_dO].ld * 2;
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+  const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)R * ldq2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_dO], head, batch), 0, (uint32_t)R * ldg2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_K], head, batch), 0, (uint32_t)C * ldk2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_V], head, batch), 0, (uint32_t)C * ldv2, 0x00020000);
+  const char *lbase = operand_base(a.op[SLOT_L], head, batch);
+  const char *dbase = operand_base(a.op[SLOT_D], head, batch);
+
+  // ---- cached left-hand operands: K and V fragments (B operands), +Caching.swift:316-321
+  v8 kf[NKS], vf[NKS];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const int d0 = 16 * s + 8 * hi;
+    const bool ok = d0 < Dr && col < C;
+    kf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(kres, ok ? (uint32_t)col * ldk2 + d0 * 2 : OOB, 0, 0));
+    vf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(vres, ok ? (uint32_t)col * ldv2 + d0 * 2 : OOB, 0, 0));
+  }
+
+  // ---- Q / dO staging (two images each) + the L, D slices along the traversal dimension
+  uint32_t qoff[NCH], goff[NCH], rlds[NCH], tlds[NCH];
+  const uint32_t qinc = BR * ldq2, ginc = BR * ldg2;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int id = tid + i * NT;
+    const int rr = id / CPR, c = id % CPR;
+    const bool valid = c * 8 < Dr;
+    qoff[i] = valid ? rr * ldq2 + c * 16 : OOB;
+    goff[i] = valid ? rr * ldg2 + c * 16 : OOB;
+    rlds[i] = rr * ROWB + kswz<D>(rr, c) * 16;                  // row-major (swizzled), at +0 (Q) / +2*TILE (dO)
+    tlds[i] = TILE + ((c >> 2) * BR + rr) * 64 + (c & 3) * 16;  // transposable, at +TILE (Q) / +3*TILE (dO)
+  }
+  u32x4 qreg[NCH], greg[NCH];
+  float ldreg = 0.f;
+  int tile_row0 = 0;
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(qres, qoff[i], 0, 0);
+      greg[i] = __builtin_amdgcn_raw_buffer_load_b128(gres, goff[i], 0, 0);
+      qoff[i] = __builtin_elementwise_add_sat(qoff[i], qinc);
+      goff[i] = __builtin_elementwise_add_sat(goff[i], ginc);
+    }
+    if (tid < 128) {   // threads 0-63: L of the tile's rows, 64-127: D   (+Softmax.swift:356-381, :472-503)
+      const int rr = tile_row0 + (tid & 63);
+      ldreg = 0.f;
+      if (rr < R) ldreg = (tid < 64) ? load_elem(lbase, rr, a.op[SLOT_L].precision)
+                                     : load_elem(dbase, rr, a.op[SLOT_D].precision);
+    }
+    tile_row0 += BR;
+  };
+  auto write_tiles = [&](int stage) {
+    char *base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<u32x4 *>(base + rlds[i]) = qreg[i];
+      *reinterpret_cast<u32x4 *>(base + tlds[i]) = qreg[i];
+      *reinterpret_cast<u32x4 *>(base + 2 * TILE + rlds[i]) = greg[i];
+      *reinterpret_cast<u32x4 *>(base + 2 * TILE + tlds[i]) = greg[i];
+    }
+    if (tid < 128) reinterpret_cast<float *>(base + 4 * TILE)[tid] = ldreg;
+  };
+  const int n16 = lane & 15;
+  const int tr_off = ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
+  int fread[NKS];
+#pragma unroll
+  for (int t = 0; t < NKS; ++t) fread[t] = kc * ROWB + kswz<D>(kc, 2 * t + hi) * 16;
+
+  f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const int ntiles = (R + BR - 1) / BR;
+  issue_loads();
+  write_tiles(0);
+  __syncthreads();
+  for (int j = 0; j < ntiles; ++j) {
+    const char *st = smem + (j & 1) * STAGE;
+    if (j + 1 < ntiles) issue_loads();
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      // S = Q K^T and dP = dO V^T for 32 rows: lane = key column, registers = rows crow(r, hi)
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) {
+        const v8 qa = *reinterpret_cast<const v8 *>(st + rb * 32 * ROWB + fread[t]);
+        s = F::mfma(qa, kf[t], s);
+      }
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) {
+        const v8 ga = *reinterpret_cast<const v8 *>(st + 2 * TILE + rb * 32 * ROWB + fread[t]);
+        dp = F::mfma(ga, vf[t], dp);
+      }
+      // L and D of the rows this lane's registers stand for: rows 8g + 4hi + {0..3}, g = 0..3
+      const float *Ls = reinterpret_cast<const float *>(st + 4 * TILE) + rb * 32 + 4 * hi;
+      v8 pf[2], dsf[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        v8 pk, dk8;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int g = 2 * u + g2;
+          const f32x4 l4 = *reinterpret_cast<const f32x4 *>(Ls + 8 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4 *>(Ls + 64 + 8 * g);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int r = 4 * g + i;
+            const float p = fast_exp2(s[r] * a.scale2 - l4[i]);
+            pk[4 * g2 + i] = (T)p;
+            dk8[4 * g2 + i] = (T)(p * (dp[r] * a.scale - d4[i]));
+          }
+        }
+        pf[u] = pk;
+        dsf[u] = dk8;
+      }
+      // dV^T += dO^T P ; dK^T += Q^T dS  (row index permuted; rows past R have zero Q and dO rows)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+          const int off = tr_off + (db * BR + 32 * rb + 16 * u) * 64;
+          const char *gp = st + 3 * TILE + off;
+          const char *qp = st + TILE + off;
+          const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp));
+          const s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp + 8 * 64));
+          const s16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp));
+          const s16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp + 8 * 64));
+          dv[db] = F::mfma(__builtin_bit_cast(v8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7)), pf[u], dv[db]);
+          dk[db] = F::mfma(__builtin_bit_cast(v8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7)), dsf[u], dk[db]);
+        }
+    }
+    if (j + 1 < ntiles) write_tiles((j + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: dV then dK through LDS (whole-row stores)
+  constexpr int OLD = D + 4;
+  float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
+  float *orow = Os + kc * OLD;
+  constexpr int CPRO = D / 4;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const int slot = which == 0 ? SLOT_dV : SLOT_dK;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x16 &acc = which == 0 ? dv[db] : dk[db];
+        *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
+            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+      }
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
+        operand_base(a.op[slot], head, batch), 0, (uint32_t)C * (uint32_t)a.op[slot].ld * 4u, 0x00020000);
+    const uint32_t ld4 = (uint32_t)a.op[slot].ld * 4;
+#pragma unroll
+    for (int i = 0; i < 32 * CPRO / 64; ++i) {
+      const int id = lane + i * 64;
+      const int rr = id / CPRO, c = id % CPRO;
+      const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
+      const uint32_t off = (c0 + rr < C && c * 4 < Dr) ? (uint32_t)(c0 + rr) * ld4 + c * 16 : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), res, off, 0, 0);
+    }
+  }
+}
+
+} // namespace mfa

@@ -1,0 +1,69 @@
+// attn_bwd16.hip -- instantiations of the 16-bit-MFMA backward kernels for gfx950.
+#include "attn_bwd16.h"
+#include "launchers.h"
+
+namespace mfa {
+
+template <typename T, int D, int NW>
+static void launch_dq16(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  hipLaunchKernelGGL((attn_dq16<T, D, NW>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+                     (dq16_lds_bytes<D, NW>()), stream, args, g);
+}
+template <typename T, int D, int NW>
+static void launch_dkv16(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  hipLaunchKernelGGL((attn_dkv16<T, D, NW>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+                     (dkv16_lds_bytes<D, NW>()), stream, args, g);
+}
+
+template <typename T, int D, int NW>
+static void fill_dq(VariantInfo *v, const char *name) {
+  v->func = reinterpret_cast<const void *>(&attn_dq16<T, D, NW>);
+  v->name = name;
+  v->parallelization = NW * 32;
+  v->traversal = 64;
+  v->headBlock = D;
+  v->threads = NW * 64;
+  v->ldsBytes = dq16_lds_bytes<D, NW>();
+  v->cacheLeft = true;
+  v->launch = &launch_dq16<T, D, NW>;
+}
+template <typename T, int D, int NW>
+static void fill_dkv(VariantInfo *v, const char *name) {
+  v->func = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW>);
+  v->name = name;
+  v->parallelization = NW * 32;
+  v->traversal = 64;
+  v->headBlock = D;
+  v->threads = NW * 64;
+  v->ldsBytes = dkv16_lds_bytes<D, NW>();
+  v->cacheLeft = true;
+  v->launch = &launch_dkv16<T, D, NW>;
+}
+
+bool dq16_variant(int precision, int D, VariantInfo *out) {
+  if (precision == PREC_BF16) {
+    if (D == 128) { fill_dq<__bf16, 128, 8>(out, "attn_dq16_bf16_d128_w8x32"); return true; }
+    if (D == 64) { fill_dq<__bf16, 64, 8>(out, "attn_dq16_bf16_d64_w8x32"); return true; }
+  }
+  if (precision == PREC_FP16) {
+    if (D == 128) { fill_dq<_Float16, 128, 8>(out, "attn_dq16_f16_d128_w8x32"); return true; }
+    if (D == 64) { fill_dq<_Float16, 64, 8>(out, "attn_dq16_f16_d64_w8x32"); return true; }
+  }
+  return false;
+}
+
+bool dkv16_variant(int precision, int D, VariantInfo *out) {
+  if (precision == PREC_BF16) {
+    if (D == 128) { fill_dkv<__bf16, 128, 4>(out, "attn_dkv16_bf16_d128_w4x32"); return true; }
+    if (D == 64) { fill_dkv<__bf16, 64, 4>(out, "attn_dkv16_bf16_d64_w4x32"); return true; }
+  }
+  if (precision == PREC_FP16) {
+    if (D == 128) { fill_dkv<_Float16, 128, 4>(out, "attn_dkv16_f16_d128_w4x32"); return true; }
+    if (D == 64) { fill_dkv<_Float16, 64, 4>(out, "attn_dkv16_f16_d64_w4x32"); return true; }
+  }
+  return false;
+}
+
+} // namespace mfa

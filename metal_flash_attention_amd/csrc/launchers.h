@@ -28,4 +28,8 @@ bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 // one wave per SIMD, 64 query rows per wave, half-tile pipeline (see attn_fwd16_v3.h)
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
 
+// 16-bit MFMA backward kernels (Q, K, V, dO in one 16-bit type, row-major, D in {64, 128})
+bool dq16_variant(int precision, int D, VariantInfo *out);
+bool dkv16_variant(int precision, int D, VariantInfo *out);
+
 } // namespace mfa

@@ -354,3 +354,76 @@ def test_size_independent_properties_at_full_size():
     os_, _ = fwd(k, vs)
     resid = (vs.float() - v1.float() - v2.float()).abs().max().item()
     assert (os_ - o1 - o2).abs().max().item() < resid + 5e-3
+
+
+# ---- 16-bit matrix-core backward kernels (attn_dq16 / attn_dkv16) -----------------------------
+BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), (1, 100, 128), (100, 1, 64),
+                (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64)]
+
+
+@pytest.mark.parametrize("shape", BWD16_SHAPES)
+def test_backward_16bit_mfma(shape):
+    """All three kernels on the BF16 matrix cores (Q, K, V, dO BF16): within the reference's mixed
+    tolerances of the oracle fed with the rounded inputs, and within a tighter bound (2e-2 absolute on
+    the gradients, whose dS is rounded to BF16 like the reference's register precision for dS,
+    AttentionDescriptor+Precisions.swift:199-200)."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net)
+    variants = {t.name: k.variant for t, k in run.kernels.items()}
+    assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run()
+    failures, report = harness.compare(ref, got, TOL_MIXED_SHORT if C <= 20 else TOL_MIXED)
+    assert not failures, (failures, variants)
+    tight, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+    assert not tight, (tight, variants)
+    assert all(run.tails_ok.values()), run.tails_ok
+
+
+def test_backward_16bit_matches_general_kernels(monkeypatch):
+    """Same inputs through the fp32-arithmetic general kernels (MFA_BWD16_DISABLE) and the 16-bit
+    matrix-core kernels: gradients agree to the 16-bit rounding of P and dS."""
+    R, C, D = 384, 448, 128
+    net = Network(NetworkDescriptor(R, C, D), seed=31)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    fast = harness.DeviceRun(desc, net).execute()
+    monkeypatch.setenv("MFA_BWD16_DISABLE", "1")
+    run = harness.DeviceRun(desc, net)
+    assert all("generic" in k.variant for t, k in run.kernels.items() if t != AttentionKernelType.forward)
+    slow = run.execute()
+    for name in ("D", "dQ", "dK", "dV"):
+        assert np.abs(fast[name] - slow[name]).max() < 2e-2, name
+
+
+def test_backward_16bit_multi_head():
+    import torch
+    R, C, D, H, B = 130, 200, 64, 8, 2
+    nets = [Network(NetworkDescriptor(R, C, D), seed=700 + i) for i in range(H * B)]
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in AttentionKernelType}
+
+    def pack16(name):
+        a = np.stack([getattr(n, name) for n in nets]).reshape(B, H, -1, D)
+        return torch.from_numpy((np.ascontiguousarray(a).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+
+    bufs = {Op.Q: pack16("Q"), Op.K: pack16("K"), Op.V: pack16("V"), Op.dO: pack16("dO")}
+    for op, seq in ((Op.O, R), (Op.dQ, R), (Op.dK, C), (Op.dV, C)):
+        bufs[op] = torch.full((B, H, seq, D), float("nan"), device="cuda")
+    bufs[Op.L] = torch.zeros((B, H, R), device="cuda")
+    bufs[Op.D] = torch.zeros((B, H, R), device="cuda")
+    hs = {Op.Q: R * D, Op.K: C * D, Op.V: C * D, Op.O: R * D, Op.dO: R * D, Op.dQ: R * D, Op.dK: C * D,
+          Op.dV: C * D, Op.L: R, Op.D: R}
+    bs = {k: v * H for k, v in hs.items()}
+    for t in AttentionKernelType:
+        kernels[t].dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                            stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i, net in enumerate(nets):
+        round_inputs(net, desc)
+        ref = net.run()
+        for op, name in ((Op.dQ, "dQ"), (Op.dK, "dK"), (Op.dV, "dV")):
+            got = bufs[op].cpu().numpy().reshape(H * B, -1, D)[i]
+            assert np.abs(got - ref[name]).max() < 2e-2, (i, name)

@@ -16,5 +16,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$REPO/$OUT/pmc3" -o pmc3 -- python "$REPO/bench.py" $ARGS > "$REPO/$OUT/pmc3.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$REPO/$OUT/pmc4" -o pmc4 -- python "$REPO/bench.py" $ARGS > "$REPO/$OUT/pmc4.log" 2>&1
 cd "$REPO"
-python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python tools/summarize_prof.py "$OUT" "bench.py $ARGS" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

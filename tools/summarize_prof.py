@@ -1,51 +1,38 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output directories written by tools/profile_pmc.sh into a short text summary
-(per-kernel average duration from the kernel trace; per-kernel mean counter values per dispatch)."""
-import csv
+"""Condense the rocprofv3 (rocpd sqlite) outputs written by tools/profile_pmc.sh into a text summary:
+per-kernel launch statistics from the kernel trace, mean PMC counter values per dispatch."""
 import glob
 import os
+import sqlite3
 import sys
-from collections import defaultdict
-
-
-def find(outdir, pattern):
-    return sorted(glob.glob(os.path.join(outdir, "**", pattern), recursive=True))
 
 
 def main():
     out = sys.argv[1]
-    for f in find(os.path.join(out, "stats"), "*kernel_stats.csv"):
-        print("== kernel stats:", os.path.relpath(f, out))
-        for i, row in enumerate(csv.reader(open(f))):
-            if i < 12:
-                print("  ", ",".join(row)[:230])
-    for f in find(os.path.join(out, "stats"), "*kernel_trace.csv"):
-        durs = defaultdict(list)
-        rd = csv.DictReader(open(f))
-        for row in rd:
-            try:
-                durs[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-            except (KeyError, ValueError):
-                pass
-        print("== kernel trace:", os.path.relpath(f, out))
-        for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
-            print(f"   {k[:90]:90s} n={len(v):4d} avg={sum(v)/len(v)/1e3:10.1f} us min={min(v)/1e3:10.1f} us")
-            # VGPR/LDS columns if present
+    title = sys.argv[2] if len(sys.argv) > 2 else ""
+    print(f"# rocprofv3 summary: {title}")
+    print("# produced by tools/profile_pmc.sh (one --kernel-trace --stats pass + separate --pmc passes)")
+    for db in sorted(glob.glob(os.path.join(out, "stats", "*.db"))):
+        con = sqlite3.connect(db)
+        print("\n## kernel trace (ns per dispatch)")
+        q = ("select name, count(*), avg(end-start), min(end-start), max(end-start), max(vgpr_count), "
+             "max(accum_vgpr_count), max(lds_size), max(grid_x), max(workgroup_x) from kernels "
+             "where name like '%mfa%' group by name order by sum(end-start) desc")
+        for r in con.execute(q):
+            print(f"kernel={r[0]}\n  dispatches={r[1]} avg_ns={r[2]:.0f} min_ns={r[3]} max_ns={r[4]} "
+                  f"vgpr={r[5]} agpr={r[6]} lds_bytes={r[7]} grid_x={r[8]} workgroup_x={r[9]}")
     for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
-        for f in find(os.path.join(out, p), "*counter_collection.csv"):
-            acc = defaultdict(lambda: defaultdict(list))
-            meta = {}
-            for row in csv.DictReader(open(f)):
-                k = row.get("Kernel_Name", "?")
-                acc[k][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
-                meta[k] = (row.get("VGPR_Count"), row.get("Accum_VGPR_Count"), row.get("LDS_Block_Size"), row.get("Grid_Size"))
-            print("== counters:", os.path.relpath(f, out))
-            for k, cs in acc.items():
-                if "attn" not in k:
-                    continue
-                print(f"   {k[:100]}  vgpr/agpr/lds/grid={meta[k]}")
-                for c, v in cs.items():
-                    print(f"      {c:28s} mean/dispatch = {sum(v)/len(v):16.1f}   (n={len(v)})")
+        for db in sorted(glob.glob(os.path.join(out, p, "*.db"))):
+            con = sqlite3.connect(db)
+            print(f"\n## {p}: mean per dispatch")
+            q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                 "where kernel_name like '%mfa%' group by kernel_name, counter_name")
+            last = None
+            for r in con.execute(q):
+                if r[0] != last:
+                    print(f" kernel={r[0]}")
+                    last = r[0]
+                print(f"   {r[1]:28s} {r[2]:18.1f}  (n={r[3]})")
 
 
 if __name__ == "__main__":

@@ -204,11 +204,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
 }
 
 // ------------------------------------------------------------------------------------------------
-// backwardKeyValue.  Workgroup = NW waves x 32 key columns; traversal over 64-row tiles of Q / dO.
-// LDS stage = Q row-major | Q transposable | dO row-major | dO transposable | L[64] | D[64].
+// backwardKeyValue.  Workgroup = NW waves x 32 key columns (one wave per SIMD: K, V fragments and the
+// dK, dV accumulators of 32 keys x D take ~200 of the 512 registers); traversal over 32-row tiles of
+// Q / dO in a 3-stage LDS ring, one barrier per tile.
+// LDS stage = Q row-major | Q transposable | dO row-major | dO transposable | L[32] | D[32].
+// Software pipeline (as attn_fwd16_v3.h): S and dP of row block j+1 run on the matrix pipe while the
+// VALU turns block j into P and dS; then dV += dO^T P and dK += Q^T dS of block j.  The two
+// (S, dP) register sets alternate, so the loop body holds two blocks and no register copies.
+// A block past the end of R is all zeros (bounds-checked loads) and contributes exactly nothing
+// (P = 1 meets dO = 0, dS = 0), so the block count is simply rounded up to even.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NW> constexpr int dkv16_lds_bytes() {
-  constexpr int ring = 2 * (4 * 64 * D * 2 + 512);
+  constexpr int ring = 3 * (4 * 32 * D * 2 + 256);
   constexpr int epi = NW * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }
@@ -218,10 +225,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BR = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
-  constexpr int ROWB = D * 2, TILE = BR * D * 2, STAGE = 4 * TILE + 512;
+  constexpr int BR = 32, NT = NW * 64, NDB = D / 32, NKS = D / 16;
+  constexpr int ROWB = D * 2, TILE = BR * D * 2, STAGE = 4 * TILE + 256;
   constexpr int CPR = D / 8, NCH = BR * CPR / NT;
-  static_assert(BR * CPR % NT == 0, "tile must divide evenly over the workgroup");
+  static_assert(BR * CPR % NT == 0 && NCH >= 1, "tile must divide evenly over the workgroup");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -261,8 +268,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     const bool valid = c * 8 < Dr;
     qoff[i] = valid ? rr * ldq2 + c * 16 : OOB;
     goff[i] = valid ? rr * ldg2 + c * 16 : OOB;
-    rlds[i] = rr * ROWB + kswz<D>(rr, c) * 16;                  // row-major (swizzled), at +0 (Q) / +2*TILE (dO)
-    tlds[i] = TILE + ((c >> 2) * BR + rr) * 64 + (c & 3) * 16;  // transposable, at +TILE (Q) / +3*TILE (dO)
+    rlds[i] = rr * ROWB + kswz<D>(rr, c) * 16;                  // row-major (swizzled): Q at +0, dO at +2*TILE
+    tlds[i] = TILE + ((c >> 2) * BR + rr) * 64 + (c & 3) * 16;  // transposable: Q at +TILE, dO at +3*TILE
   }
   u32x4 qreg[NCH], greg[NCH];
   float ldreg = 0.f;
@@ -275,10 +282,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
       qoff[i] = __builtin_elementwise_add_sat(qoff[i], qinc);
       goff[i] = __builtin_elementwise_add_sat(goff[i], ginc);
     }
-    if (tid < 128) {   // threads 0-63: L of the tile's rows, 64-127: D   (+Softmax.swift:356-381, :472-503)
-      const int rr = tile_row0 + (tid & 63);
+    if (tid < 64) {   // threads 0-31: L of the tile's rows, 32-63: D   (+Softmax.swift:356-381, :472-503)
+      const int rr = tile_row0 + (tid & 31);
       ldreg = 0.f;
-      if (rr < R) ldreg = (tid < 64) ? load_elem(lbase, rr, a.op[SLOT_L].precision)
+      if (rr < R) ldreg = (tid < 32) ? load_elem(lbase, rr, a.op[SLOT_L].precision)
                                      : load_elem(dbase, rr, a.op[SLOT_D].precision);
     }
     tile_row0 += BR;
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
       *reinterpret_cast<u32x4 *>(base + 2 * TILE + rlds[i]) = greg[i];
       *reinterpret_cast<u32x4 *>(base + 2 * TILE + tlds[i]) = greg[i];
     }
-    if (tid < 128) reinterpret_cast<float *>(base + 4 * TILE)[tid] = ldreg;
+    if (tid < 64) reinterpret_cast<float *>(base + 4 * TILE)[tid] = ldreg;
   };
   const int n16 = lane & 15;
   const int tr_off = ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
@@ -306,72 +313,95 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
-  const int ntiles = (R + BR - 1) / BR;
+  // S = Q K^T and dP = dO V^T for the 32 rows of the tile in `stage`: lane = key column,
+  // registers = rows crow(r, hi).  Fragment reads are issued ahead of the MFMAs that use them.
+  auto scores = [&](int stage, f32x16 &s, f32x16 &dp) {
+    const char *st = smem + stage * STAGE;
+    v8 qa[NKS], ga[NKS];
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) qa[t] = *reinterpret_cast<const v8 *>(st + fread[t]);
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) ga[t] = *reinterpret_cast<const v8 *>(st + 2 * TILE + fread[t]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) s = F::mfma(qa[t], kf[t], s);
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) dp = F::mfma(ga[t], vf[t], dp);
+  };
+  // P = exp2(S*scale2 - L), dS = P (dP*scale - D), rounded to the 16-bit type and packed as B operands
+  auto softmax_grad = [&](int stage, const f32x16 &s, const f32x16 &dp, v8 (&pf)[2], v8 (&dsf)[2]) {
+    const float *Ls = reinterpret_cast<const float *>(smem + stage * STAGE + 4 * TILE) + 4 * hi;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      v8 pk, dk8;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        const int g = 2 * u + g2;     // rows 8g + 4hi + {0..3}
+        const f32x4 l4 = *reinterpret_cast<const f32x4 *>(Ls + 8 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(Ls + 32 + 8 * g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          const float p = fast_exp2(s[r] * a.scale2 - l4[i]);
+          pk[4 * g2 + i] = (T)p;
+          dk8[4 * g2 + i] = (T)(p * (dp[r] * a.scale - d4[i]));
+        }
+      }
+      pf[u] = pk;
+      dsf[u] = dk8;
+    }
+  };
+  // dV^T += dO^T P ; dK^T += Q^T dS  (row index permuted; rows past R have zero Q and dO rows)
+  auto accumulate = [&](int stage, const v8 (&pf)[2], const v8 (&dsf)[2]) {
+    const char *st = smem + stage * STAGE + tr_off;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const int off = (db * BR + 16 * u) * 64;
+        const char *gp = st + 3 * TILE + off;
+        const char *qp = st + TILE + off;
+        const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp));
+        const s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp + 8 * 64));
+        const s16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp));
+        const s16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp + 8 * 64));
+        dv[db] = F::mfma(__builtin_bit_cast(v8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7)), pf[u], dv[db]);
+        dk[db] = F::mfma(__builtin_bit_cast(v8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7)), dsf[u], dk[db]);
+      }
+  };
+
+  const int nblocks = ((R + BR - 1) / BR + 1) & ~1;   // rounded up to even (zero blocks are harmless)
   issue_loads();
   write_tiles(0);
+  issue_loads();
   __syncthreads();
-  for (int j = 0; j < ntiles; ++j) {
-    const char *st = smem + (j & 1) * STAGE;
-    if (j + 1 < ntiles) issue_loads();
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      // S = Q K^T and dP = dO V^T for 32 rows: lane = key column, registers = rows crow(r, hi)
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-      for (int t = 0; t < NKS; ++t) {
-        const v8 qa = *reinterpret_cast<const v8 *>(st + rb * 32 * ROWB + fread[t]);
-        s = F::mfma(qa, kf[t], s);
-      }
-#pragma unroll
-      for (int t = 0; t < NKS; ++t) {
-        const v8 ga = *reinterpret_cast<const v8 *>(st + 2 * TILE + rb * 32 * ROWB + fread[t]);
-        dp = F::mfma(ga, vf[t], dp);
-      }
-      // L and D of the rows this lane's registers stand for: rows 8g + 4hi + {0..3}, g = 0..3
-      const float *Ls = reinterpret_cast<const float *>(st + 4 * TILE) + rb * 32 + 4 * hi;
-      v8 pf[2], dsf[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        v8 pk, dk8;
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          const int g = 2 * u + g2;
-          const f32x4 l4 = *reinterpret_cast<const f32x4 *>(Ls + 8 * g);
-          const f32x4 d4 = *reinterpret_cast<const f32x4 *>(Ls + 64 + 8 * g);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int r = 4 * g + i;
-            const float p = fast_exp2(s[r] * a.scale2 - l4[i]);
-            pk[4 * g2 + i] = (T)p;
-            dk8[4 * g2 + i] = (T)(p * (dp[r] * a.scale - d4[i]));
-          }
-        }
-        pf[u] = pk;
-        dsf[u] = dk8;
-      }
-      // dV^T += dO^T P ; dK^T += Q^T dS  (row index permuted; rows past R have zero Q and dO rows)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-          const int off = tr_off + (db * BR + 32 * rb + 16 * u) * 64;
-          const char *gp = st + 3 * TILE + off;
-          const char *qp = st + TILE + off;
-          const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp));
-          const s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp + 8 * 64));
-          const s16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp));
-          const s16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp + 8 * 64));
-          dv[db] = F::mfma(__builtin_bit_cast(v8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7)), pf[u], dv[db]);
-          dk[db] = F::mfma(__builtin_bit_cast(v8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7)), dsf[u], dk[db]);
-        }
-    }
-    if (j + 1 < ntiles) write_tiles((j + 1) & 1);
+  f32x16 s0, dp0, s1, dp1;
+  v8 pf[2], dsf[2];
+  scores(0, s0, dp0);
+  int st_cur = 0, st_next = 1;
+  auto advance = [&]() { st_cur = st_next; st_next = (st_next == 2) ? 0 : st_next + 1; };
+  for (int j = 0; j < nblocks; j += 2) {
+    // block j: uses (s0, dp0); produces (s1, dp1) = scores of block j+1
+    write_tiles(st_next);      // tile j+1 (replaces tile j-2, whose readers passed the previous barrier)
+    issue_loads();             // tile j+2 (zeros past the end)
     __syncthreads();
+    scores(st_next, s1, dp1);
+    softmax_grad(st_cur, s0, dp0, pf, dsf);
+    accumulate(st_cur, pf, dsf);
+    advance();
+    // block j+1: uses (s1, dp1); produces (s0, dp0) = scores of block j+2
+    write_tiles(st_next);
+    issue_loads();
+    __syncthreads();
+    scores(st_next, s0, dp0);
+    softmax_grad(st_cur, s1, dp1, pf, dsf);
+    accumulate(st_cur, pf, dsf);
+    advance();
   }
 
   // ---- epilogue: dV then dK through LDS (whole-row stores)
+  __syncthreads();
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
   float *orow = Os + kc * OLD;

@@ -220,7 +220,7 @@ template <int D, int NW> constexpr int dkv16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int PRE = 1>
 __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -371,13 +371,62 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
       }
   };
 
+  v8 pf[2], dsf[2];
+  // One pipeline step with every LDS read of its first half issued up front (one wave per SIMD:
+  // nothing else hides LDS latency): row fragments of block j+1 (16 x ds_read_b128) and the
+  // transposed fragments for the first 16 rows of block j (16 x ds_read_b64_tr_b16), then the S / dP
+  // MFMAs of block j+1 interleaved (by the compiler) with the P / dS arithmetic of block j, then the
+  // accumulate MFMAs; the second 16 rows' transposed fragments are requested in between.
+  auto fused_step = [&](int st_n, int st_c, f32x16 &s_n, f32x16 &dp_n, const f32x16 &s_c, const f32x16 &dp_c) {
+    const char *sn = smem + st_n * STAGE;
+    const char *sc = smem + st_c * STAGE + tr_off;
+    v8 qa[NKS], ga[NKS], gt[NDB], qt[NDB];
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) qa[t] = *reinterpret_cast<const v8 *>(sn + fread[t]);
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) ga[t] = *reinterpret_cast<const v8 *>(sn + 2 * TILE + fread[t]);
+    auto load_t = [&](int u) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) {
+        const int off = (db * BR + 16 * u) * 64;
+        const char *gp = sc + 3 * TILE + off;
+        const char *qp = sc + TILE + off;
+        const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp));
+        const s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(gp + 8 * 64));
+        const s16x4 q0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp));
+        const s16x4 q1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(qp + 8 * 64));
+        gt[db] = __builtin_bit_cast(v8, __builtin_shufflevector(g0, g1, 0, 1, 2, 3, 4, 5, 6, 7));
+        qt[db] = __builtin_bit_cast(v8, __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    };
+    load_t(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s_n[r] = 0.f; dp_n[r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) s_n = F::mfma(qa[t], kf[t], s_n);
+#pragma unroll
+    for (int t = 0; t < NKS; ++t) dp_n = F::mfma(ga[t], vf[t], dp_n);
+    softmax_grad(st_c, s_c, dp_c, pf, dsf);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      dv[db] = F::mfma(gt[db], pf[0], dv[db]);
+      dk[db] = F::mfma(qt[db], dsf[0], dk[db]);
+    }
+    load_t(1);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+      dv[db] = F::mfma(gt[db], pf[1], dv[db]);
+      dk[db] = F::mfma(qt[db], dsf[1], dk[db]);
+    }
+  };
+
   const int nblocks = ((R + BR - 1) / BR + 1) & ~1;   // rounded up to even (zero blocks are harmless)
   issue_loads();
   write_tiles(0);
   issue_loads();
   __syncthreads();
   f32x16 s0, dp0, s1, dp1;
-  v8 pf[2], dsf[2];
   scores(0, s0, dp0);
   int st_cur = 0, st_next = 1;
   auto advance = [&]() { st_cur = st_next; st_next = (st_next == 2) ? 0 : st_next + 1; };
@@ -386,17 +435,25 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     write_tiles(st_next);      // tile j+1 (replaces tile j-2, whose readers passed the previous barrier)
     issue_loads();             // tile j+2 (zeros past the end)
     __syncthreads();
-    scores(st_next, s1, dp1);
-    softmax_grad(st_cur, s0, dp0, pf, dsf);
-    accumulate(st_cur, pf, dsf);
+    if constexpr (PRE == 1) {
+      fused_step(st_next, st_cur, s1, dp1, s0, dp0);
+    } else {
+      scores(st_next, s1, dp1);
+      softmax_grad(st_cur, s0, dp0, pf, dsf);
+      accumulate(st_cur, pf, dsf);
+    }
     advance();
     // block j+1: uses (s1, dp1); produces (s0, dp0) = scores of block j+2
     write_tiles(st_next);
     issue_loads();
     __syncthreads();
-    scores(st_next, s0, dp0);
-    softmax_grad(st_cur, s1, dp1, pf, dsf);
-    accumulate(st_cur, pf, dsf);
+    if constexpr (PRE == 1) {
+      fused_step(st_next, st_cur, s0, dp0, s1, dp1);
+    } else {
+      scores(st_next, s0, dp0);
+      softmax_grad(st_cur, s1, dp1, pf, dsf);
+      accumulate(st_cur, pf, dsf);
+    }
     advance();
   }
 

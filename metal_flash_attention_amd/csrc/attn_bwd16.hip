@@ -1,6 +1,7 @@
 // attn_bwd16.hip -- instantiations of the 16-bit-MFMA backward kernels for gfx950.
 #include "attn_bwd16.h"
 #include "launchers.h"
+#include <cstdlib>
 
 namespace mfa {
 
@@ -10,10 +11,10 @@ static void launch_dq16(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   hipLaunchKernelGGL((attn_dq16<T, D, NW>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
                      (dq16_lds_bytes<D, NW>()), stream, args, g);
 }
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int PRE = 1>
 static void launch_dkv16(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_dkv16<T, D, NW>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+  hipLaunchKernelGGL((attn_dkv16<T, D, NW, PRE>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
                      (dkv16_lds_bytes<D, NW>()), stream, args, g);
 }
 
@@ -29,9 +30,9 @@ static void fill_dq(VariantInfo *v, const char *name) {
   v->cacheLeft = true;
   v->launch = &launch_dq16<T, D, NW>;
 }
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, int PRE = 1>
 static void fill_dkv(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW>);
+  v->func = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW, PRE>);
   v->name = name;
   v->parallelization = NW * 32;
   v->traversal = 64;
@@ -39,7 +40,7 @@ static void fill_dkv(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = dkv16_lds_bytes<D, NW>();
   v->cacheLeft = true;
-  v->launch = &launch_dkv16<T, D, NW>;
+  v->launch = &launch_dkv16<T, D, NW, PRE>;
 }
 
 bool dq16_variant(int precision, int D, VariantInfo *out) {
@@ -55,6 +56,10 @@ bool dq16_variant(int precision, int D, VariantInfo *out) {
 }
 
 bool dkv16_variant(int precision, int D, VariantInfo *out) {
+  const char *knob = std::getenv("MFA_DKV16_IMPL");   // developer A/B knob: "0" = compiler-placed LDS reads
+  if (knob && knob[0] == '0' && precision == PREC_BF16 && D == 128) {
+    fill_dkv<__bf16, 128, 4, 0>(out, "attn_dkv16_bf16_d128_w4x32_nopre"); return true;
+  }
   if (precision == PREC_BF16) {
     if (D == 128) { fill_dkv<__bf16, 128, 4>(out, "attn_dkv16_bf16_d128_w4x32"); return true; }
     if (D == 64) { fill_dkv<__bf16, 64, 4>(out, "attn_dkv16_bf16_d64_w4x32"); return true; }

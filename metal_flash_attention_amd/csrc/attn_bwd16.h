@@ -138,14 +138,13 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      // the two accumulation chains are independent: alternating them keeps consecutive MFMAs off
+      // the same accumulator (a non-MFMA instruction between two dependent MFMAs costs ~43 cycles)
 #pragma unroll
       for (int t = 0; t < NKS; ++t) {
         const v8 kf = *reinterpret_cast<const v8 *>(st + kb * 32 * ROWB + fread[t]);
-        s = F::mfma(kf, qf[t], s);
-      }
-#pragma unroll
-      for (int t = 0; t < NKS; ++t) {
         const v8 vf = *reinterpret_cast<const v8 *>(st + 2 * TILE + kb * 32 * ROWB + fread[t]);
+        s = F::mfma(kf, qf[t], s);
         dp = F::mfma(vf, gf[t], dp);
       }
       // P = exp2(S*scale2 - L); dS = P (dP*scale - D).  Keys past C have zero K and V rows, so their
@@ -325,9 +324,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-    for (int t = 0; t < NKS; ++t) s = F::mfma(qa[t], kf[t], s);
-#pragma unroll
-    for (int t = 0; t < NKS; ++t) dp = F::mfma(ga[t], vf[t], dp);
+    for (int t = 0; t < NKS; ++t) {   // alternate the two independent chains
+      s = F::mfma(qa[t], kf[t], s);
+      dp = F::mfma(ga[t], vf[t], dp);
+    }
   };
   // P = exp2(S*scale2 - L), dS = P (dP*scale - D), rounded to the 16-bit type and packed as B operands
   auto softmax_grad = [&](int stage, const f32x16 &s, const f32x16 &dp, v8 (&pf)[2], v8 (&dsf)[2]) {
@@ -404,9 +404,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s_n[r] = 0.f; dp_n[r] = 0.f; }
 #pragma unroll
-    for (int t = 0; t < NKS; ++t) s_n = F::mfma(qa[t], kf[t], s_n);
-#pragma unroll
-    for (int t = 0; t < NKS; ++t) dp_n = F::mfma(ga[t], vf[t], dp_n);
+    for (int t = 0; t < NKS; ++t) {   // alternate the two independent chains
+      s_n = F::mfma(qa[t], kf[t], s_n);
+      dp_n = F::mfma(ga[t], vf[t], dp_n);
+    }
     softmax_grad(st_c, s_c, dp_c, pf, dsf);
 #pragma unroll
     for (int db = 0; db < NDB; ++db) {

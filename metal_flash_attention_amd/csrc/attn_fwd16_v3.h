@@ -101,16 +101,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
     const char *Ks = smem + stage * STAGE + kb * 32 * ROWB;
 #pragma unroll
+    f32x16 s2[RB];   // ABL == 4: second accumulator for odd k-steps (breaks the 8-deep dependent chain)
+#pragma unroll
     for (int t = 0; t < NKS; ++t) {
       const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
         if (t == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
+          for (int r = 0; r < 16; ++r) { s[b][r] = 0.f; s2[b][r] = 0.f; }
         }
-        s[b] = F::mfma(kf, qf[b][t], s[b]);
+        if (ABL == 4 && (t & 1)) s2[b] = F::mfma(kf, qf[b][t], s2[b]);
+        else s[b] = F::mfma(kf, qf[b][t], s[b]);
       }
+    }
+    if constexpr (ABL == 4) {
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[b][r] += s2[b][r];
     }
   };
 

@@ -100,7 +100,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // S^T for the 32 keys of half `kb` of the tile in `stage`: one K fragment feeds RB MFMAs
   auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
     const char *Ks = smem + stage * STAGE + kb * 32 * ROWB;
-#pragma unroll
     f32x16 s2[RB];   // ABL == 4: second accumulator for odd k-steps (breaks the 8-deep dependent chain)
 #pragma unroll
     for (int t = 0; t < NKS; ++t) {

@@ -26,6 +26,14 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md
 
+# HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+# process): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes
+# for wide coalesced reads on gfx950.  Keyed by (workload, kernel variant); null when not profiled.
+MEASURED_TRAFFIC_BYTES = {
+    ("fwd_bf16_d128", "attn_fwd16v3_bf16_d128_w8x32_thr8"):
+        {"bytes": (2 * 393328.2 + 528384.0) * 1024, "source": "profiles/r01_fwd_bf16_d128_v3_summary.txt"},
+}
+
 WORKLOADS = {
     # name: (kernel types, N, D, dtype, batch, heads)
     "fwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",)),   # headline
@@ -168,8 +176,12 @@ def main():
                    "kernel_variants": [kernels[t].variant for t in types]},
         "mfma_tflops": round(achieved_tflops * world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(achieved_tflops / peak, 4), "traffic": None,
-                     "kernel": kernels[types[0]].variant, "launch_ms": round(launch_ms, 4)},
+                     "frac": round(achieved_tflops / peak, 4),
+                     "traffic": (MEASURED_TRAFFIC_BYTES.get((args.workload, kernels[types[0]].variant)) or {}).get("bytes"),
+                     "traffic_unit": "bytes/launch (HBM, PMC)",
+                     "traffic_source": (MEASURED_TRAFFIC_BYTES.get((args.workload, kernels[types[0]].variant)) or {}).get("source"),
+                     "algorithmic_bytes": (3 * N * D * (2 if low else 4) + N * D * 4 + N * 4) * B * H if not backward else None,
+                     "kernel": "+".join(kernels[t].variant for t in types), "launch_ms": round(launch_ms, 4)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -106,11 +106,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        if (t == 0) {
+        if (t == 0 && ABL != 5) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[b][r] = 0.f; s2[b][r] = 0.f; }
         }
-        if (ABL == 4 && (t & 1)) s2[b] = F::mfma(kf, qf[b][t], s2[b]);
+        if constexpr (ABL == 5) F::mfma_vq(s[b], kf, qf[b][t], t == 0, t == NKS - 1);
+        else if (ABL == 4 && (t & 1)) s2[b] = F::mfma(kf, qf[b][t], s2[b]);
         else s[b] = F::mfma(kf, qf[b][t], s[b]);
       }
     }
@@ -241,11 +242,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int t = 0; t < NKS; ++t)
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-          if (t == 0) {
+          if constexpr (ABL == 5) {
+            F::mfma_vq(s_next[b], kf[t], qf[b][t], t == 0, t == NKS - 1);
+          } else {
+            if (t == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_next[b][r] = 0.f;
+              for (int r = 0; r < 16; ++r) s_next[b][r] = 0.f;
+            }
+            s_next[b] = F::mfma(kf[t], qf[b][t], s_next[b]);
           }
-          s_next[b] = F::mfma(kf[t], qf[b][t], s_next[b]);
         }
     }
     if constexpr (PRE != 2) load_v(0, vf0);

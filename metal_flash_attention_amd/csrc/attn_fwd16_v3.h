@@ -28,6 +28,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
 
+  // schedule options packed in ABL (0 = plain): 5 = QK MFMAs as inline asm (VGPR result, Q fragments in
+  // AGPRs); 6 = 5 + row sum on the matrix pipe (all-ones A operand)
+  constexpr bool ASMQK = (ABL == 5 || ABL == 6);
+  constexpr bool MSUM = (ABL == 6);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
@@ -106,11 +110,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        if (t == 0 && ABL != 5) {
+        if (t == 0 && !ASMQK) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { s[b][r] = 0.f; s2[b][r] = 0.f; }
         }
-        if constexpr (ABL == 5) F::mfma_vq(s[b], kf, qf[b][t], t == 0, t == NKS - 1);
+        if constexpr (ASMQK) F::mfma_vq(s[b], kf, qf[b][t], t == 0, t == NKS - 1);
         else if (ABL == 4 && (t & 1)) s2[b] = F::mfma(kf, qf[b][t], s2[b]);
         else s[b] = F::mfma(kf, qf[b][t], s[b]);
       }
@@ -133,6 +137,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
+  }
+
+  f32x16 lsum[MSUM ? RB : 1];
+  v8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
+  if constexpr (MSUM) {
+#pragma unroll
+    for (int b = 0; b < RB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) lsum[b][r] = 0.f;
   }
 
   auto mask_edge = [&](f32x16 (&s)[RB], int c0) {   // maskAttentionMatrixEdge (+Softmax.swift:228-260)
@@ -165,6 +180,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
         const float corr = fast_exp2(m[b] - m_up);
         m[b] = m_up;
         l[b] *= corr;
+        if constexpr (MSUM) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lsum[b][r] *= corr;
+        }
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -181,9 +200,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int r = 0; r < 16; ++r) {
         const float p = (ABL == 2) ? s[b][r] * a.scale2 - mb : fast_exp2(s[b][r] * a.scale2 - mb);
         s[b][r] = p;
-        ps[r & 3] += p;
+        if constexpr (!MSUM) ps[r & 3] += p;
       }
-      l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      if constexpr (!MSUM) l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {   // MFMA step u (16 keys) uses registers 8u .. 8u+7
         v8 pk;
@@ -207,6 +226,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
         for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf, pf[b][u], o[b][db]);
       }
+    if constexpr (MSUM) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int b = 0; b < RB; ++b) lsum[b] = F::mfma(ones, pf[b][u], lsum[b]);
+    }
   };
 
   v8 pf[RB][2];
@@ -242,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int t = 0; t < NKS; ++t)
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-          if constexpr (ABL == 5) {
+          if constexpr (ASMQK) {
             F::mfma_vq(s_next[b], kf[t], qf[b][t], t == 0, t == NKS - 1);
           } else {
             if (t == 0) {
@@ -263,6 +288,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf1[db], pf[b][1], o[b][db]);
+    if constexpr (MSUM) {   // onlineReduceSum on the matrix pipe (sum of the ROUNDED P, +Softmax.swift:308-321)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int b = 0; b < RB; ++b) lsum[b] = F::mfma(ones, pf[b][u], lsum[b]);
+    }
   };
 
   if constexpr (ABL == 1) {   // static priority for the second-dispatched half (T5 static form)
@@ -344,7 +375,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   char *lbase = operand_base(a.op[SLOT_L], head, batch);
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
-    const float l_tot = half_swap_add(l[b]) + 1.401298464e-45f;
+    const float l_tot = (MSUM ? lsum[b][0] : half_swap_add(l[b])) + 1.401298464e-45f;
     const float inv = 1.0f / l_tot;
     float *orow = Os + (b * 32 + q) * OLD;
 #pragma unroll

@@ -39,6 +39,9 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 4) { fill<__bf16, 128, 4, 2, 8, 1, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq"); return true; }
     if (D == 128 && impl == 5) { fill<__bf16, 128, 4, 2, 8, 0, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_vq"); return true; }
     if (D == 128 && impl == 6) { fill<__bf16, 128, 8, 1, 8, 0, 5>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_vq"); return true; }
+    if (D == 128 && impl == 7) { fill<__bf16, 128, 4, 2, 8, 1, 6>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq_msum"); return true; }
+    if (D == 128 && impl == 8) { fill<__bf16, 128, 4, 2, 8, 2, 6>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prekv_vq_msum"); return true; }
+    if (D == 128 && impl == 9) { fill<__bf16, 128, 4, 2, 8, 2, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prekv_vq"); return true; }
     if (D == 128 && impl == 13) { fill<__bf16, 128, 8, 1, 8, 0, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_splitacc"); return true; }
     if (D == 128 && impl == 12) { fill<__bf16, 128, 8, 1, 8, 0, 3>(out, "ablate_one_k_fragment_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 0) { fill<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }

@@ -27,6 +27,64 @@ namespace mfa {
 // ----------------------------------------------------------------------------------------------
 // Staging: global (any dtype / layout) -> LDS fp32 tile [ROWS][DP+1], zero padded.
 // ----------------------------------------------------------------------------------------------
+// float4 chunk e of a [ROWS][DP] tile -> (row, first column).  Eight consecutive lanes take one
+// 128-byte run of a row (coalesced), the next eight lanes the same run of the NEXT row: with the odd
+// row stride DP+1 the 32 lanes of a half-wave then hit 32 distinct LDS banks when they scatter their
+// four components with ds_write_b32 (lanes four floats apart in ONE row would be a 4-way conflict).
+template <int ROWS, int DP>
+__device__ __forceinline__ void tile_chunk(int e, int *n, int *d) {
+  if constexpr (ROWS % 4 == 0) {
+    const int g = e >> 3, c8 = e & 7;          // g: 128-byte run index, c8: float4 within the run
+    const int quad = g & 3, rest = g >> 2;     // four runs of four consecutive rows share a d-block
+    constexpr int RUNS = DP / 32;              // runs per row
+    const int dblk = rest % RUNS, rowq = rest / RUNS;
+    *n = rowq * 4 + quad;
+    *d = dblk * 32 + c8 * 4;
+  } else {
+    *n = e / (DP / 4);
+    *d = (e % (DP / 4)) * 4;
+  }
+}
+
+// Register-staged variant of the fp32 fast path (prefetch: issue the loads of tile j+1 before the
+// arithmetic of tile j, write them to LDS after it).
+template <int ROWS, int DP, int NT> struct TileRegsF32 {
+  static constexpr int N = (ROWS * DP / 4 + NT - 1) / NT;
+  float4 v[N];
+};
+__device__ __forceinline__ bool f32_fast_path(const OperandView &v, const char *base, int D) {
+  return !v.transposed && v.precision == PREC_FP32 && ((reinterpret_cast<uintptr_t>(base) & 15) == 0) &&
+         (D & 3) == 0 && (v.ld & 3) == 0;
+}
+template <int ROWS, int DP, int NT>
+__device__ __forceinline__ void tile_load_f32(TileRegsF32<ROWS, DP, NT> &r, const OperandView &v, const char *base,
+                                              int64_t n0, int64_t N, int D, int tid) {
+  constexpr int V4 = DP / 4;
+#pragma unroll
+  for (int i = 0; i < TileRegsF32<ROWS, DP, NT>::N; ++i) {
+    const int e = tid + i * NT;
+    int n, d;
+    tile_chunk<ROWS, DP>(e, &n, &d);
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < ROWS * V4 && n0 + n < N && d < D) val = *reinterpret_cast<const float4 *>(base + ((n0 + n) * v.ld + d) * 4);
+    r.v[i] = val;
+  }
+}
+template <int ROWS, int DP, int NT>
+__device__ __forceinline__ void tile_store_f32(float *__restrict__ lds, const TileRegsF32<ROWS, DP, NT> &r, int tid) {
+  constexpr int LD = DP + 1, V4 = DP / 4;
+#pragma unroll
+  for (int i = 0; i < TileRegsF32<ROWS, DP, NT>::N; ++i) {
+    const int e = tid + i * NT;
+    int n, d;
+    tile_chunk<ROWS, DP>(e, &n, &d);
+    if (e < ROWS * V4) {
+      float *dst = lds + n * LD + d;
+      dst[0] = r.v[i].x; dst[1] = r.v[i].y; dst[2] = r.v[i].z; dst[3] = r.v[i].w;
+    }
+  }
+}
+
 template <int ROWS, int DP, int NT>
 __device__ __forceinline__ void stage_tile(float *__restrict__ lds, const OperandView &v,
                                            const char *base, int64_t n0, int64_t N, int D, int tid) {
@@ -38,7 +96,8 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ lds, const Operan
     if (prec == PREC_FP32 && al16 && (D & 3) == 0 && (ld & 3) == 0) {
       constexpr int V4 = DP / 4;
       for (int e = tid; e < ROWS * V4; e += NT) {
-        const int n = e / V4, d = (e % V4) * 4;
+        int n, d;
+        tile_chunk<ROWS, DP>(e, &n, &d);
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n0 + n < N && d < D) val = *reinterpret_cast<const float4 *>(base + ((n0 + n) * ld + d) * 4);
         float *dst = lds + n * LD + d;
@@ -172,10 +231,28 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
   const char *kbase = operand_base(a.op[SLOT_K], head, batch);
   const char *vbase = operand_base(a.op[SLOT_V], head, batch);
 
+  // fp32 row-major operands (the FP32 production case): the next tile's global loads are issued
+  // before the arithmetic of this tile and land in registers; other layouts stage synchronously.
+  constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
+  const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
+  TileRegsF32<BC, DP, NT> kregs, vregs;
+  if (prefetch) {
+    tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
+    tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
+  }
   for (int c0 = 0; c0 < C; c0 += BC) {
-    stage_tile<BC, DP, NT>(Ks, a.op[SLOT_K], kbase, c0, C, D, tid);
-    stage_tile<BC, DP, NT>(Vs, a.op[SLOT_V], vbase, c0, C, D, tid);
+    if (prefetch) {
+      tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
+      tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
+    } else {
+      stage_tile<BC, DP, NT>(Ks, a.op[SLOT_K], kbase, c0, C, D, tid);
+      stage_tile<BC, DP, NT>(Vs, a.op[SLOT_V], vbase, c0, C, D, tid);
+    }
     __syncthreads();
+    if (prefetch && c0 + BC < C) {
+      tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, c0 + BC, C, D, tid);
+      tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, c0 + BC, C, D, tid);
+    }
 
     // S^T = K Q^T : lane holds query (wave*32+q), keys c0 + crow(r, hi)
     f32x16 s;
@@ -297,10 +374,28 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
 
   const char *kbase = operand_base(a.op[SLOT_K], head, batch);
   const char *vbase = operand_base(a.op[SLOT_V], head, batch);
+  // fp32 row-major operands (the FP32 production case): the next tile's global loads are issued
+  // before the arithmetic of this tile and land in registers; other layouts stage synchronously.
+  constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
+  const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
+  TileRegsF32<BC, DP, NT> kregs, vregs;
+  if (prefetch) {
+    tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
+    tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
+  }
   for (int c0 = 0; c0 < C; c0 += BC) {
-    stage_tile<BC, DP, NT>(Ks, a.op[SLOT_K], kbase, c0, C, D, tid);
-    stage_tile<BC, DP, NT>(Vs, a.op[SLOT_V], vbase, c0, C, D, tid);
+    if (prefetch) {
+      tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
+      tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
+    } else {
+      stage_tile<BC, DP, NT>(Ks, a.op[SLOT_K], kbase, c0, C, D, tid);
+      stage_tile<BC, DP, NT>(Vs, a.op[SLOT_V], vbase, c0, C, D, tid);
+    }
     __syncthreads();
+    if (prefetch && c0 + BC < C) {
+      tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, c0 + BC, C, D, tid);
+      tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, c0 + BC, C, D, tid);
+    }
     f32x16 s, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -390,9 +485,21 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   const char *gbase = operand_base(a.op[SLOT_dO], head, batch);
   const char *lbase = operand_base(a.op[SLOT_L], head, batch);
   const char *dbase = operand_base(a.op[SLOT_D], head, batch);
+  constexpr bool CAN_PREFETCH = (DP <= 128);
+  const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
+  TileRegsF32<BRW, DP, NT> qregs, gregs;
+  if (prefetch) {
+    tile_load_f32<BRW, DP, NT>(qregs, a.op[SLOT_Q], qbase, 0, R, D, tid);
+    tile_load_f32<BRW, DP, NT>(gregs, a.op[SLOT_dO], gbase, 0, R, D, tid);
+  }
   for (int r0 = 0; r0 < R; r0 += BRW) {
-    stage_tile<BRW, DP, NT>(Qs, a.op[SLOT_Q], qbase, r0, R, D, tid);
-    stage_tile<BRW, DP, NT>(dOs, a.op[SLOT_dO], gbase, r0, R, D, tid);
+    if (prefetch) {
+      tile_store_f32<BRW, DP, NT>(Qs, qregs, tid);
+      tile_store_f32<BRW, DP, NT>(dOs, gregs, tid);
+    } else {
+      stage_tile<BRW, DP, NT>(Qs, a.op[SLOT_Q], qbase, r0, R, D, tid);
+      stage_tile<BRW, DP, NT>(dOs, a.op[SLOT_dO], gbase, r0, R, D, tid);
+    }
     if (tid < 64) { // L and D slices along the traversal dimension (+Softmax.swift:356-381, :472-503)
       const int rr = tid & 31;
       float val = 0.f;
@@ -402,6 +509,10 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
       LDs[tid] = val;
     }
     __syncthreads();
+    if (prefetch && r0 + BRW < R) {
+      tile_load_f32<BRW, DP, NT>(qregs, a.op[SLOT_Q], qbase, r0 + BRW, R, D, tid);
+      tile_load_f32<BRW, DP, NT>(gregs, a.op[SLOT_dO], gbase, r0 + BRW, R, D, tid);
+    }
     // S = Q K^T (not swapped): lane holds key (wave*32+kc), rows r0 + crow(r, hi)
     f32x16 s, dp;
 #pragma unroll

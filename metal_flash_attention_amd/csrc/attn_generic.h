@@ -275,17 +275,22 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = mx * a.scale2;
-    float corr = 1.f;
-    if (m_new > m) { corr = fast_exp2(m - m_new); m = m_new; }
+    // corr = (m_new > m) ? exp2(m - m_new) : 1.  When no lane of the wave saw its maximum grow the
+    // correction is exactly 1 everywhere: skip the O-wide multiply (wave-uniform branch, same results).
+    if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
+      float corr = 1.f;
+      if (m_new > m) { corr = fast_exp2(m - m_new); m = m_new; }
+      l *= corr;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= corr;
+    }
     // softmax + onlineReduceSum, +Softmax.swift:304-324, :406-417
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] * a.scale2 - m); psum += s[r]; }
-    l = l * corr + psum;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= corr;
+    l += psum;
     // O^T += V^T P^T with the key index permuted: step t uses key crow(t, hi)
 #pragma unroll
     for (int t = 0; t < 16; ++t) {

@@ -22,6 +22,23 @@
 
 namespace mfa {
 
+// dO may be stored in a different 16-bit type than Q, K, V: the reference's low-precision mode keeps
+// Q, K, V in FP16 and dO in BF16 (AttentionDescriptor+Precisions.swift:13-17).  One MFMA needs both
+// operands in one type, so such a chunk is converted (through fp32, exact for BF16 -> fp32) when loaded.
+template <typename T, typename TG>
+__device__ __forceinline__ typename Frag16<T>::v8 convert_chunk(u32x4 raw) {
+  typedef typename Frag16<T>::v8 v8;
+  if constexpr (sizeof(T) == sizeof(TG) && __is_same(T, TG)) {
+    return __builtin_bit_cast(v8, raw);
+  } else {
+    const typename Frag16<TG>::v8 src = __builtin_bit_cast(typename Frag16<TG>::v8, raw);
+    v8 out;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out[i] = (T)(float)src[i];
+    return out;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // backwardQuery.  Workgroup = NW waves x 32 query rows; traversal over 64-key tiles.
 // LDS stage = K row-major | K transposable | V row-major.
@@ -32,7 +49,7 @@ template <int D, int NW> constexpr int dq16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, typename TG = T>
 __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -68,7 +85,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     const int d0 = 16 * s + 8 * hi;
     const bool ok = d0 < Dr && row < R;
     qf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(qres, ok ? (uint32_t)row * ldq2 + d0 * 2 : OOB, 0, 0));
-    gf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(gres, ok ? (uint32_t)row * ldg2 + d0 * 2 : OOB, 0, 0));
+    gf[s] = convert_chunk<T, TG>(__builtin_amdgcn_raw_buffer_load_b128(gres, ok ? (uint32_t)row * ldg2 + d0 * 2 : OOB, 0, 0));
     // computeD (+Softmax.swift:32-221): D = sum_d dO*O, the two half-waves split the head dimension
     const uint32_t ooff = ok ? (uint32_t)row * ldo4 + d0 * 4 : OOB;
     const f32x4 o0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ooff, 0, 0));
@@ -219,7 +236,7 @@ template <int D, int NW> constexpr int dkv16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW, int PRE = 1>
+template <typename T, int D, int NW, int PRE = 1, typename TG = T>
 __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -295,8 +312,9 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     for (int i = 0; i < NCH; ++i) {
       *reinterpret_cast<u32x4 *>(base + rlds[i]) = qreg[i];
       *reinterpret_cast<u32x4 *>(base + tlds[i]) = qreg[i];
-      *reinterpret_cast<u32x4 *>(base + 2 * TILE + rlds[i]) = greg[i];
-      *reinterpret_cast<u32x4 *>(base + 2 * TILE + tlds[i]) = greg[i];
+      const u32x4 g16 = __builtin_bit_cast(u32x4, convert_chunk<T, TG>(greg[i]));
+      *reinterpret_cast<u32x4 *>(base + 2 * TILE + rlds[i]) = g16;
+      *reinterpret_cast<u32x4 *>(base + 2 * TILE + tlds[i]) = g16;
     }
     if (tid < 64) reinterpret_cast<float *>(base + 4 * TILE)[tid] = ldreg;
   };

@@ -5,22 +5,22 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, typename TG = T>
 static void launch_dq16(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_dq16<T, D, NW>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+  hipLaunchKernelGGL((attn_dq16<T, D, NW, TG>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
                      (dq16_lds_bytes<D, NW>()), stream, args, g);
 }
-template <typename T, int D, int NW, int PRE = 1>
+template <typename T, int D, int NW, int PRE = 1, typename TG = T>
 static void launch_dkv16(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_dkv16<T, D, NW, PRE>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+  hipLaunchKernelGGL((attn_dkv16<T, D, NW, PRE, TG>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
                      (dkv16_lds_bytes<D, NW>()), stream, args, g);
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, typename TG = T>
 static void fill_dq(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_dq16<T, D, NW>);
+  v->func = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG>);
   v->name = name;
   v->parallelization = NW * 32;
   v->traversal = 64;
@@ -28,11 +28,11 @@ static void fill_dq(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = dq16_lds_bytes<D, NW>();
   v->cacheLeft = true;
-  v->launch = &launch_dq16<T, D, NW>;
+  v->launch = &launch_dq16<T, D, NW, TG>;
 }
-template <typename T, int D, int NW, int PRE = 1>
+template <typename T, int D, int NW, int PRE = 1, typename TG = T>
 static void fill_dkv(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW, PRE>);
+  v->func = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW, PRE, TG>);
   v->name = name;
   v->parallelization = NW * 32;
   v->traversal = 64;
@@ -40,10 +40,17 @@ static void fill_dkv(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = dkv16_lds_bytes<D, NW>();
   v->cacheLeft = true;
-  v->launch = &launch_dkv16<T, D, NW, PRE>;
+  v->launch = &launch_dkv16<T, D, NW, PRE, TG>;
 }
 
-bool dq16_variant(int precision, int D, VariantInfo *out) {
+// precision: storage type of Q, K, V; gprecision: storage type of dO (equal, or BF16 next to FP16)
+bool dq16_variant(int precision, int gprecision, int D, VariantInfo *out) {
+  if (precision == PREC_FP16 && gprecision == PREC_BF16) {
+    if (D == 128) { fill_dq<_Float16, 128, 8, __bf16>(out, "attn_dq16_f16_dObf16_d128_w8x32"); return true; }
+    if (D == 64) { fill_dq<_Float16, 64, 8, __bf16>(out, "attn_dq16_f16_dObf16_d64_w8x32"); return true; }
+    return false;
+  }
+  if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
     if (D == 128) { fill_dq<__bf16, 128, 8>(out, "attn_dq16_bf16_d128_w8x32"); return true; }
     if (D == 64) { fill_dq<__bf16, 64, 8>(out, "attn_dq16_bf16_d64_w8x32"); return true; }
@@ -55,7 +62,13 @@ bool dq16_variant(int precision, int D, VariantInfo *out) {
   return false;
 }
 
-bool dkv16_variant(int precision, int D, VariantInfo *out) {
+bool dkv16_variant(int precision, int gprecision, int D, VariantInfo *out) {
+  if (precision == PREC_FP16 && gprecision == PREC_BF16) {
+    if (D == 128) { fill_dkv<_Float16, 128, 4, 1, __bf16>(out, "attn_dkv16_f16_dObf16_d128_w4x32"); return true; }
+    if (D == 64) { fill_dkv<_Float16, 64, 4, 1, __bf16>(out, "attn_dkv16_f16_dObf16_d64_w4x32"); return true; }
+    return false;
+  }
+  if (precision != gprecision) return false;
   const char *knob = std::getenv("MFA_DKV16_IMPL");   // developer A/B knob: "0" = compiler-placed LDS reads
   if (knob && knob[0] == '0' && precision == PREC_BF16 && D == 128) {
     fill_dkv<__bf16, 128, 4, 0>(out, "attn_dkv16_bf16_d128_w4x32_nopre"); return true;

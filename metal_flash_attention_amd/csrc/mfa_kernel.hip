@@ -109,17 +109,18 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   // 16-bit matrix-core backward kernels: additionally dO in the same 16-bit type and FP32 outputs
   if (found && type != MFA_FORWARD && std::getenv("MFA_BWD16_DISABLE") == nullptr) {
     const int pq = kdesc->memoryPrecisions[MFA_Q];
+    const int pg = kdesc->memoryPrecisions[MFA_dO];
     const bool same = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] &&
-                      pq == kdesc->memoryPrecisions[MFA_V] && pq == kdesc->memoryPrecisions[MFA_dO];
+                      pq == kdesc->memoryPrecisions[MFA_V] && pg != MFA_FP32;
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
     if (same && rowMajor && (D % 8) == 0) {
       if (type == MFA_BACKWARD_QUERY && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 &&
           kdesc->memoryPrecisions[MFA_dQ] == MFA_FP32 && !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
-        fast = dq16_variant(pq, bucket, &variant);
+        fast = dq16_variant(pq, pg, bucket, &variant);
       if (type == MFA_BACKWARD_KEY_VALUE && kdesc->memoryPrecisions[MFA_dK] == MFA_FP32 &&
           kdesc->memoryPrecisions[MFA_dV] == MFA_FP32 && !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV])
-        fast = dkv16_variant(pq, bucket, &variant);
+        fast = dkv16_variant(pq, pg, bucket, &variant);
     }
   }
   if (found && !fast) variant = general;

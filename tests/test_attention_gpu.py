@@ -427,3 +427,23 @@ def test_backward_16bit_multi_head():
         for op, name in ((Op.dQ, "dQ"), (Op.dK, "dK"), (Op.dV, "dV")):
             got = bufs[op].cpu().numpy().reshape(H * B, -1, D)[i]
             assert np.abs(got - ref[name]).max() < 2e-2, (i, name)
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (255, 257, 64), (96, 640, 80), (1024, 1024, 128)])
+@pytest.mark.parametrize("low_mid", [False, True])
+def test_backward_reference_low_precision_mix_on_matrix_cores(shape, low_mid):
+    """The reference's own low-precision mode -- FP16 Q/K/V with BF16 dO, and with
+    lowPrecisionIntermediates FP16 L / BF16 D (AttentionDescriptor+Precisions.swift:13-17, :81-87) --
+    through the 16-bit matrix-core kernels (dO converted to FP16 on load), checked with the
+    reference's mixed tolerances against the UNROUNDED oracle, exactly as its tests do."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=R + 3 * C + D)
+    desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.FP16)
+    run = harness.DeviceRun(desc, net)
+    variants = {t.name: k.variant for t, k in run.kernels.items()}
+    assert "dObf16" in variants["backwardQuery"] and "dObf16" in variants["backwardKeyValue"], variants
+    got = run.execute()
+    ref = net.run()
+    failures, report = harness.compare(ref, got, TOL_MIXED)
+    assert not failures, (failures, variants)
+    assert all(run.tails_ok.values())

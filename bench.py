@@ -119,11 +119,14 @@ def main():
     hs = {op: (N if op in (Op.L, Op.D) else N * D) for op in bufs}
     bs = {op: v * H for op, v in hs.items()}
     stream = torch.cuda.current_stream().cuda_stream
+    # caller-owned scratch: lets a launch with too few row blocks (single head) run column-parallel
+    ws_bytes = kernels[types[0]].workspaceSize(row=N, column=N, heads=H, batches=B) if types[0].name == "forward" else 0
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if ws_bytes else None
 
     def step():
         for t in types:
             kernels[t].dispatch(bufs, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs,
-                                stream=stream)
+                                stream=stream, workspace=workspace if t.name == "forward" else None)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -173,7 +176,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"attention {'+'.join(w['types'])} N={N} D={D} {w['dtype']} Q/K/V, fp32 O/L; "
                                f"B={B} H={H} heads per GPU, batch x head sharded across GPUs, no collectives",
-                   "kernel_variants": [kernels[t].variant for t in types]},
+                   "kernel_variants": [kernels[t].variant for t in types],
+                   "split_kv_workspace_bytes": ws_bytes},
         "mfma_tflops": round(achieved_tflops * world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4),

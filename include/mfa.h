@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 1
+#define MFA_ABI_VERSION 2
 
 /* ---- status codes (replace fatalError, e.g. AttentionKernel.swift:33,
  *      AttentionDescriptor.swift:45/72/90/97, AttentionParameterRow.swift:50/57/100) -------- */
@@ -161,6 +161,13 @@ typedef struct mfa_launch_params {
   int64_t leadingDimension[MFA_BUFFER_SLOTS];
   int64_t headStride[MFA_BUFFER_SLOTS];
   int64_t batchStride[MFA_BUFFER_SLOTS];
+  /* Optional caller-owned device scratch (extension).  A forward launch with too few row blocks to
+   * fill the GPU (e.g. the reference's single-head benchmark, SquareAttentionTest.swift:159-165) is
+   * then run column-parallel: the key range is cut into pieces whose partial (O, m, l) go to this
+   * scratch and a second small kernel merges them -- no atomics.  NULL (default) = never split.
+   * Size it with mfa_attention_kernel_workspace_size.  Contents need no initialisation. */
+  void *workspace;
+  uint64_t workspaceBytes;
 } mfa_launch_params;
 void mfa_launch_params_init(mfa_launch_params *params);
 
@@ -170,6 +177,10 @@ void mfa_launch_params_init(mfa_launch_params *params);
 mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel,
                                        void *const buffers[MFA_BUFFER_SLOTS],
                                        const mfa_launch_params *params, void *stream);
+
+/* Bytes of mfa_launch_params.workspace this launch would use (0 if it would not be split). */
+mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kernel,
+                                               const mfa_launch_params *params, uint64_t *bytes);
 
 /* Timing helper: `warmup` untimed launches, then `iterations` back-to-back launches bracketed by
  * HIP events recorded on `stream` (the harness of SquareAttentionTest.swift:733-761 uses

@@ -81,6 +81,8 @@ class mfa_launch_params(ctypes.Structure):
         ("leadingDimension", ctypes.c_int64 * MFA_BUFFER_SLOTS),
         ("headStride", ctypes.c_int64 * MFA_BUFFER_SLOTS),
         ("batchStride", ctypes.c_int64 * MFA_BUFFER_SLOTS),
+        ("workspace", ctypes.c_void_p),
+        ("workspaceBytes", ctypes.c_uint64),
     ]
 
 
@@ -115,6 +117,7 @@ SYMBOLS = [
     ("mfa_attention_kernel_effective_descriptor", ctypes.c_int, [_KERNEL, _P(mfa_attention_kernel_descriptor)]),
     ("mfa_launch_params_init", None, [_P(mfa_launch_params)]),
     ("mfa_attention_kernel_launch", ctypes.c_int, [_KERNEL, _P(_BUFS), _P(mfa_launch_params), ctypes.c_void_p]),
+    ("mfa_attention_kernel_workspace_size", ctypes.c_int, [_KERNEL, _P(mfa_launch_params), _P(ctypes.c_uint64)]),
     ("mfa_attention_kernel_time", ctypes.c_int,
      [_KERNEL, _P(_BUFS), _P(mfa_launch_params), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _P(ctypes.c_float)]),
     ("mfa_device_count", ctypes.c_int, [_P(ctypes.c_int)]),

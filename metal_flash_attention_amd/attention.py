@@ -278,7 +278,8 @@ class AttentionKernel:
 
     # -- launch ------------------------------------------------------------------------------
     @staticmethod
-    def _marshal(buffers, row, column, heads, batches, leadingDimensions, headStrides, batchStrides):
+    def _marshal(buffers, row, column, heads, batches, leadingDimensions, headStrides, batchStrides,
+                 workspace=None):
         """`buffers`: dict {AttentionOperand: tensor | int} or a 10-sequence indexed by bufferBinding."""
         slots = [None] * _abi.MFA_BUFFER_SLOTS
         if isinstance(buffers, Mapping):
@@ -300,23 +301,38 @@ class AttentionKernel:
                 dst = getattr(params, name)
                 for op, v in src.items():
                     dst[AttentionOperand(op).bufferBinding] = int(v)
+        if workspace is not None:   # caller-owned scratch for column-parallel forward launches
+            params.workspace = _pointer(workspace)
+            params.workspaceBytes = int(workspace.numel() * workspace.element_size()) \
+                if hasattr(workspace, "numel") else int(getattr(workspace, "nbytes"))
         return arr, params, slots
+
+    def workspaceSize(self, *, row: int, column: int, heads: int = 1, batches: int = 1) -> int:
+        """Bytes of scratch a forward launch of this shape would use if given a workspace (0 = the
+        launch fills the GPU without splitting the key range)."""
+        params = _abi.mfa_launch_params()
+        lib().mfa_launch_params_init(ctypes.byref(params))
+        params.row, params.column, params.heads, params.batches = int(row), int(column), int(heads), int(batches)
+        out = ctypes.c_uint64()
+        check(lib().mfa_attention_kernel_workspace_size(self._handle, ctypes.byref(params), ctypes.byref(out)))
+        return int(out.value)
 
     def dispatch(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
                  leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
-                 batchStrides: Optional[Mapping] = None, stream: Optional[int] = None) -> None:
+                 batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,
+                 workspace=None) -> None:
         arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions,
-                                           headStrides, batchStrides)
+                                           headStrides, batchStrides, workspace)
         check(lib().mfa_attention_kernel_launch(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                                 ctypes.c_void_p(stream or 0)))
 
     def time(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
              leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
              batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,
-             warmup: int = 1, iterations: int = 5) -> float:
+             warmup: int = 1, iterations: int = 5, workspace=None) -> float:
         """Milliseconds for `iterations` back-to-back launches (HIP events on `stream`)."""
         arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions,
-                                           headStrides, batchStrides)
+                                           headStrides, batchStrides, workspace)
         ms = ctypes.c_float()
         check(lib().mfa_attention_kernel_time(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                               ctypes.c_void_p(stream or 0), int(warmup), int(iterations),

@@ -72,6 +72,12 @@ template <int D> constexpr int fwd16_lds_bytes() { return 2 /*buffers*/ * 2 /*K,
 // grid: 1-D, (row blocks) x heads x batches flattened; see fwd16_decode_block for the XCD-aware order
 struct Fwd16Grid {
   uint32_t rowBlocks, heads, batches;
+  // column-parallel ("split-KV") launches only: the key range is cut into `splits` pieces, each
+  // workgroup writes un-normalised partial results into the caller's workspace
+  //   wsO  [splits][heads*batches][R][D] fp32,  wsML [splits][heads*batches][R][2] = (m, l)
+  uint32_t splits;
+  float *wsO;
+  float *wsML;
 };
 
 __device__ __forceinline__ void fwd16_decode_block(const Fwd16Grid &g, uint32_t bid, uint32_t *rb,

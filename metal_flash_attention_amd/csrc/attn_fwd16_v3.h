@@ -18,7 +18,7 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
-  fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  uint32_t bid = blockIdx.x, split = 0;
+  if constexpr (SPLIT) { split = bid % grid.splits; bid /= grid.splits; }
+  fwd16_decode_block(grid, bid, &rblk, &head, &batch);
   const int R = a.R, C = a.C, Dr = a.D;
   const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
@@ -63,6 +65,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     }
   }
 
+  // ---- key range of this workgroup: everything, or piece `split` of `splits` (SPLIT launches)
+  const int tiles_total = (C + BC - 1) / BC;
+  const int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;
+  const int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_total;
+
   // ---- K/V staging (identical to v2)
   uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
@@ -71,8 +78,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const int id = tid + i * NT;
     const int row = id / CPR, c = id % CPR;
     const bool valid = c * 8 < Dr;
-    koff[i] = valid ? row * ldk2 + c * 16 : OOB;
-    voff[i] = valid ? row * ldv2 + c * 16 : OOB;
+    koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
+    voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
     klds[i] = row * ROWB + kswz<D>(row, c) * 16;
     vlds[i] = TILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
   }
@@ -300,8 +307,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   }
   // ---- prologue
-  const int ntiles = (C + BC - 1) / BC;
-  const bool ragged = (C & (BC - 1)) != 0;
+  const int ntiles = tile1 - tile0;
+  const bool ragged = (C & (BC - 1)) != 0 && tile1 == tiles_total;   // only the globally last tile is partial
   issue_loads();
   write_tiles(0);
   issue_loads();
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   f32x16 s0[RB], s1[RB];   // half score tiles (keys 0-31 / 32-63 of a tile); roles alternate
   float m_new[RB];
   qk(0, 0, s0);
-  if (ntiles == 1 && ragged) mask_edge(s0, 0);
+  if (ntiles == 1 && ragged) mask_edge(s0, tile0 * BC);
   block_max(s0, m_new);
 
   int st_cur = 0, st_next = 1;
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     if constexpr (RING == 3) {
       write_tiles(st_next);          // tile j+1 (replaces tile j-2)
       issue_loads();                 // tile j+2 (reads as zero past the end)
-      __syncthreads();
+      if constexpr (ABL != 8) __syncthreads();   // ABL 8: timing-only ablation (racy, wrong results)
     } else {
       __syncthreads();
       write_tiles(st_next);
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     } else {
       step(s1, s0, st_next, 0, st_cur, 1, true);
     }
-    if (next_is_last && ragged) mask_edge(s0, (j + 1) * BC);
+    if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
     block_max(s0, m_new);
     st_cur = st_next;
     st_next = (st_next == RING - 1) ? 0 : st_next + 1;
@@ -362,21 +369,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   qk(st_cur, 1, s1);
   exponentiate(s0, pf);
   pv(st_cur, 0, pf);
-  if (ragged) mask_edge(s1, j * BC + 32);
+  if (ragged) mask_edge(s1, (tile0 + j) * BC + 32);
   block_max(s1, m_new);
   rescale_if_needed(m_new);
   exponentiate(s1, pf);
   pv(st_cur, 1, pf);
 
-  // ---- epilogue: O /= l (+Source.swift:165-171), L = m + log2(l) (+Caching.swift:373-377)
+  // ---- epilogue: O /= l (+Source.swift:165-171), L = m + log2(l) (+Caching.swift:373-377).
+  // SPLIT launches instead publish the un-normalised (O, m, l) of their key range; attn_fwd_combine
+  // merges the pieces (no atomics: every piece has its own slab, like the reference's dQ / dK-dV split).
   __syncthreads();   // every wave is done with the ring
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (RB * 32 * OLD);
   char *lbase = operand_base(a.op[SLOT_L], head, batch);
+  const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)R;
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     const float l_tot = (MSUM ? lsum[b][0] : half_swap_add(l[b])) + 1.401298464e-45f;
-    const float inv = 1.0f / l_tot;
+    const float inv = SPLIT ? 1.0f : 1.0f / l_tot;
     float *orow = Os + (b * 32 + q) * OLD;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -385,11 +395,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
         *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
             make_float4(o[b][db][4 * g] * inv, o[b][db][4 * g + 1] * inv, o[b][db][4 * g + 2] * inv, o[b][db][4 * g + 3] * inv);
     const int64_t row = r0 + b * 32 + q;
-    if (hi == 0 && row < R) store_elem(lbase, row, a.op[SLOT_L].precision, m[b] + log2f(l_tot));
+    if (hi == 0 && row < R) {
+      if constexpr (SPLIT) {
+        grid.wsML[(slab + row) * 2] = m[b];
+        grid.wsML[(slab + row) * 2 + 1] = l_tot;
+      } else {
+        store_elem(lbase, row, a.op[SLOT_L].precision, m[b] + log2f(l_tot));
+      }
+    }
   }
+  const uint32_t ldo4 = SPLIT ? (uint32_t)Dr * 4 : (uint32_t)a.op[SLOT_O].ld * 4;
   const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
-      operand_base(a.op[SLOT_O], head, batch), 0, (uint32_t)R * (uint32_t)a.op[SLOT_O].ld * 4u, 0x00020000);
-  const uint32_t ldo4 = (uint32_t)a.op[SLOT_O].ld * 4;
+      SPLIT ? reinterpret_cast<char *>(grid.wsO + slab * Dr) : operand_base(a.op[SLOT_O], head, batch), 0,
+      (uint32_t)R * ldo4, 0x00020000);
   constexpr int CPRO = D / 4;
 #pragma unroll
   for (int i = 0; i < RB * 32 * CPRO / 64; ++i) {
@@ -400,6 +418,40 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const uint32_t off = (row < R && c * 4 < Dr) ? (uint32_t)row * ldo4 + c * 16 : OOB;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ores, off, 0, 0);
   }
+}
+
+// Merge the pieces of a column-parallel forward launch.  One wave per query row; lane c owns the four
+// head-dimension elements 4c..4c+3.  m* = max_s m_s;  w_s = exp2(m_s - m*);  l* = sum_s w_s l_s;
+// O = sum_s w_s O_s / l*;  L = m* + log2 l*  -- the online-softmax merge (+Softmax.swift:290-324) applied
+// across pieces instead of across tiles.  HBM-bound: reads splits x (D + 2) floats per row.
+__global__ __launch_bounds__(256) void attn_fwd_combine(const KernelArgs a, const Fwd16Grid grid) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t R = a.R, Dr = a.D, HB = grid.heads * grid.batches;
+  const uint64_t rowid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // over HB * R
+  if (rowid >= (uint64_t)HB * R) return;
+  const uint32_t hb = (uint32_t)(rowid / R), row = (uint32_t)(rowid % R);
+  const uint32_t head = hb % grid.heads, batch = hb / grid.heads;
+  float mstar = -3.402823466e+38f;
+  for (uint32_t s = 0; s < grid.splits; ++s) mstar = fmaxf(mstar, grid.wsML[(((uint64_t)s * HB + hb) * R + row) * 2]);
+  float lstar = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool active = (uint32_t)lane * 4 < Dr;
+  for (uint32_t s = 0; s < grid.splits; ++s) {
+    const uint64_t slab = ((uint64_t)s * HB + hb) * R + row;
+    const float w = fast_exp2(grid.wsML[slab * 2] - mstar);
+    lstar += w * grid.wsML[slab * 2 + 1];
+    if (active) {
+      const float4 v = *reinterpret_cast<const float4 *>(grid.wsO + slab * Dr + lane * 4);
+      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+    }
+  }
+  const float inv = 1.0f / lstar;
+  if (active) {
+    float *orow = reinterpret_cast<float *>(operand_base(a.op[SLOT_O], head, batch)) + (uint64_t)row * a.op[SLOT_O].ld;
+    *reinterpret_cast<float4 *>(orow + lane * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+  }
+  if (lane == 0)
+    store_elem(operand_base(a.op[SLOT_L], head, batch), row, a.op[SLOT_L].precision, mstar + log2f(lstar));
 }
 
 } // namespace mfa

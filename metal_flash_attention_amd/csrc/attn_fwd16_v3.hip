@@ -12,6 +12,15 @@ static void launch_v3(dim3 grid, hipStream_t stream, const KernelArgs &args) {
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3>
+static void launch_v3_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, true>), dim3(grid.x * grid.y * grid.z * splits),
+                     dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
+  hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
+}
+
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3>
 static void fill(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING>);
   v->name = name;
@@ -24,13 +33,19 @@ static void fill(VariantInfo *v, const char *name) {
   v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING>;
 }
 
+template <typename T, int D, int NW, int RB, int THR, int PRE>
+static void fill_with_split(VariantInfo *v, const char *name) {
+  fill<T, D, NW, RB, THR, PRE>(v, name);
+  v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE>;
+}
+
 // impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring (two waves per SIMD hide the
 // LDS latency: hoisting fragment reads measured +-0); D = 256: 4 waves x 32 rows (one per SIMD, 512
 // registers), 2-stage ring, K fragments hoisted (+11 % measured: nothing else hides the latency).  1: K fragments hoisted; 2: K + first V fragments
 // hoisted; 3: 4 waves x 64 rows (K hoisted); >= 10: developer ablations.
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
-    if (D == 128 && impl == 0) { fill<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
+    if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
     if (D == 128 && impl == 1) { fill<__bf16, 128, 8, 1, 8, 1>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek"); return true; }
     if (D == 128 && impl == 2) { fill<__bf16, 128, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prekv"); return true; }
     if (D == 128 && impl == 3) { fill<__bf16, 128, 4, 2, 8, 1>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek"); return true; }
@@ -42,17 +57,18 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 7) { fill<__bf16, 128, 4, 2, 8, 1, 6>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq_msum"); return true; }
     if (D == 128 && impl == 8) { fill<__bf16, 128, 4, 2, 8, 2, 6>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prekv_vq_msum"); return true; }
     if (D == 128 && impl == 9) { fill<__bf16, 128, 4, 2, 8, 2, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prekv_vq"); return true; }
+    if (D == 128 && impl == 14) { fill<__bf16, 128, 8, 1, 8, 0, 8>(out, "ablate_no_tile_barrier_WRONG_RESULTS"); return true; }
     if (D == 128 && impl == 13) { fill<__bf16, 128, 8, 1, 8, 0, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_splitacc"); return true; }
     if (D == 128 && impl == 12) { fill<__bf16, 128, 8, 1, 8, 0, 3>(out, "ablate_one_k_fragment_WRONG_RESULTS"); return true; }
-    if (D == 64 && impl == 0) { fill<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }
+    if (D == 64 && impl == 0) { fill_with_split<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }
     if (D == 64 && impl == 2) { fill<__bf16, 64, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_prekv"); return true; }
     if (D == 32 && impl == 0) { fill<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
     if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
   }
   if (precision == PREC_FP16) {
-    if (D == 128 && impl == 0) { fill<_Float16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8"); return true; }
-    if (D == 64 && impl == 0) { fill<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
+    if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8"); return true; }
+    if (D == 64 && impl == 0) { fill_with_split<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
     if (D == 32 && impl == 0) { fill<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill<_Float16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_prek"); return true; }
   }

@@ -14,6 +14,10 @@ struct VariantInfo {
   uint32_t ldsBytes = 0;        // dynamic LDS
   bool cacheLeft = false;       // left-hand operands cached in VGPRs (Q / Q,dO / K,V)
   void (*launch)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
+  // forward only: column-parallel launch (key range cut into `splits` pieces, partial results in the
+  // caller's workspace, then the combine kernel); nullptr if the variant has none
+  void (*launchSplit)(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream,
+                      const KernelArgs &args) = nullptr;
 };
 
 // generic (fp32-MFMA) family: returns false if (DP) is not compiled

@@ -201,7 +201,22 @@ struct LaunchPlan {
   dim3 grid;
   const VariantInfo *variant;
   bool useFallback;
+  uint32_t splits = 1;          // > 1: column-parallel forward through the caller's workspace
+  float *wsO = nullptr, *wsML = nullptr;
+  uint64_t workspaceNeeded = 0;
 };
+
+// Column-parallel heuristic: split only when the row-parallel grid cannot fill the 256 CUs and the
+// traversal is long enough to amortise the combine pass; aim at ~2 workgroups per CU, keep >= 4 key
+// tiles (256 keys) per piece.
+static uint32_t choose_splits(uint64_t blocks, uint32_t column) {
+  const uint32_t tiles = (column + 63) / 64;
+  if (blocks >= 192 || tiles < 8) return 1;
+  uint64_t s = (512 + blocks - 1) / blocks;
+  if (s > tiles / 4) s = tiles / 4;
+  if (s > 64) s = 64;
+  return s < 2 ? 1 : (uint32_t)s;
+}
 
 static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
                                  const mfa_launch_params *p, LaunchPlan *plan) {
@@ -249,6 +264,21 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   const uint32_t blocks = (par + plan->variant->parallelization - 1) / plan->variant->parallelization;
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
+  plan->splits = 1;
+  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit) {
+    const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, p->column);
+    if (s > 1) {
+      const uint64_t rows = (uint64_t)s * heads * batches * p->row;
+      plan->workspaceNeeded = rows * (D + 2) * sizeof(float);
+      if (p->workspace && p->workspaceBytes >= plan->workspaceNeeded &&
+          (reinterpret_cast<uintptr_t>(p->workspace) & 15) == 0 && (D % 4) == 0 &&
+          (uint64_t)blocks * heads * batches * s <= 0x7FFFFFFFull) {
+        plan->splits = s;
+        plan->wsO = static_cast<float *>(p->workspace);
+        plan->wsML = plan->wsO + rows * D;
+      }
+    }
+  }
   return MFA_OK;
 }
 
@@ -273,9 +303,23 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   if (st != MFA_OK) return st;
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
-  plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
+  if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, (hipStream_t)stream, plan.args);
+  else plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return hip_fail(err, plan.variant->name);
+  return MFA_OK;
+}
+
+mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kernel, const mfa_launch_params *params,
+                                               uint64_t *bytes) {
+  if (!kernel || !params || !bytes) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  *bytes = 0;
+  if (kernel->desc.type != MFA_FORWARD || !kernel->variant.launchSplit) return MFA_OK;
+  if (params->row == 0 || params->column == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "row and column must be non-zero");
+  const uint32_t heads = params->heads ? params->heads : 1, batches = params->batches ? params->batches : 1;
+  const uint32_t blocks = (params->row + kernel->variant.parallelization - 1) / kernel->variant.parallelization;
+  const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, params->column);
+  if (s > 1) *bytes = (uint64_t)s * heads * batches * params->row * (kernel->desc.headDimension + 2) * sizeof(float);
   return MFA_OK;
 }
 
@@ -294,9 +338,13 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   if (err != hipSuccess) return hip_fail(err, "hipEventCreate");
   err = hipEventCreate(&stop);
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
-  for (int i = 0; i < warmup; ++i) plan.variant->launch(plan.grid, s, plan.args);
+  auto go = [&]() {
+    if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);
+    else plan.variant->launch(plan.grid, s, plan.args);
+  };
+  for (int i = 0; i < warmup; ++i) go();
   (void)hipEventRecord(start, s);
-  for (int i = 0; i < iterations; ++i) plan.variant->launch(plan.grid, s, plan.args);
+  for (int i = 0; i < iterations; ++i) go();
   (void)hipEventRecord(stop, s);
   err = hipEventSynchronize(stop);
   if (err == hipSuccess) err = hipGetLastError();

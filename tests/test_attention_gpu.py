@@ -447,3 +447,55 @@ def test_backward_reference_low_precision_mix_on_matrix_cores(shape, low_mid):
     failures, report = harness.compare(ref, got, TOL_MIXED)
     assert not failures, (failures, variants)
     assert all(run.tails_ok.values())
+
+
+# ---- column-parallel ("split-KV") forward through a caller-provided workspace ------------------
+@pytest.mark.parametrize("shape,heads", [((4096, 4096, 64), 1), ((4096, 4096, 128), 1), ((300, 3000, 128), 2),
+                                         ((129, 8200, 64), 1), ((64, 16384, 128), 1)])
+def test_forward_split_kv_matches_unsplit_and_oracle(shape, heads):
+    """Same answer with and without the workspace (to the rounding of a different summation order),
+    and both within the tight forward bounds of the oracle."""
+    import torch
+    R, C, D = shape
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    need = kernel.workspaceSize(row=R, column=C, heads=heads)
+    assert need > 0
+    nets = [Network(NetworkDescriptor(R, C, D), seed=40 + i) for i in range(heads)]
+
+    def pack16(name):
+        a = np.stack([getattr(n, name) for n in nets])
+        return torch.from_numpy((np.ascontiguousarray(a).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+
+    q, k, v = pack16("Q"), pack16("K"), pack16("V")
+    hs = {Op.Q: R * D, Op.K: C * D, Op.V: C * D, Op.O: R * D, Op.L: R}
+    outs = []
+    for ws in (None, torch.empty(need + 64, dtype=torch.uint8, device="cuda")):
+        o = torch.full((heads, R, D), float("nan"), device="cuda")
+        l = torch.zeros((heads, R), device="cuda")
+        kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=heads,
+                        headStrides=hs, stream=torch.cuda.current_stream().cuda_stream, workspace=ws)
+        torch.cuda.synchronize()
+        outs.append((o.cpu().numpy(), l.cpu().numpy() / np.float32(harness.LOG2E)))
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 2e-3 and np.abs(outs[0][1] - outs[1][1]).max() < 1e-4
+    for i, net in enumerate(nets):
+        round_inputs(net, desc)
+        ref = net.run(backward=False)
+        assert np.abs(outs[1][0][i] - ref["O"]).max() < 1.5e-2
+        assert np.abs(outs[1][1][i] - ref["L"]).max() < 1e-3
+
+
+def test_forward_split_kv_too_small_workspace_is_ignored():
+    import torch
+    R, C, D = 256, 4096, 64
+    net = Network(NetworkDescriptor(R, C, D), seed=3)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net, run_backward=False)
+    kernel = run.kernels[AttentionKernelType.forward]
+    assert kernel.workspaceSize(row=R, column=C) > 0
+    tiny = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    kernel.dispatch(run.buffers, row=R, column=C, stream=torch.cuda.current_stream().cuda_stream, workspace=tiny)
+    torch.cuda.synchronize()
+    got = run.results()
+    round_inputs(net, desc)
+    assert np.abs(got["O"] - net.run(backward=False)["O"]).max() < 1.5e-2

@@ -31,14 +31,14 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in include/mfa.h but not exported"
     assert declared == {s[0] for s in _abi.SYMBOLS}, "ctypes table out of sync with the header"
-    assert _abi.lib().mfa_abi_version() == 1
+    assert _abi.lib().mfa_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
     # sizes are part of the ABI: a cgo/JNI/Swift binding relies on them
     assert ctypes.sizeof(_abi.mfa_attention_descriptor) == 24
     assert ctypes.sizeof(_abi.mfa_attention_kernel_descriptor) == 70
-    assert ctypes.sizeof(_abi.mfa_launch_params) == 16 + 3 * 80
+    assert ctypes.sizeof(_abi.mfa_launch_params) == 16 + 3 * 80 + 16
     assert ctypes.sizeof(_abi.mfa_parameter_row) == 22
 
 
@@ -161,3 +161,19 @@ def test_launch_argument_validation_happens_before_any_gpu_call():
     with pytest.raises(MFAError):
         k.dispatch({Op.Q: 4096, Op.K: 4096, Op.V: 4096, Op.O: 4096, Op.L: 4096}, row=64, column=64,
                    leadingDimensions={Op.Q: 8})
+
+
+def test_workspace_size_query_follows_the_split_heuristic():
+    """Column-parallel forward (extension): only 16-bit row-major forward kernels split, only when the
+    row-parallel grid cannot fill 256 CUs and the key range is long; the size is
+    splits x heads x batches x R x (D + 2) floats."""
+    low = _desc(dims=(4096, 4096, 64), low_in=True, in_type=P.BF16)
+    k = AttentionKernel(low.kernelDescriptor(T.forward))
+    one = k.workspaceSize(row=4096, column=4096)
+    assert one > 0 and one % (4096 * 66 * 4) == 0
+    splits = one // (4096 * 66 * 4)
+    assert 2 <= splits <= 16
+    assert k.workspaceSize(row=4096, column=4096, heads=32, batches=8) == 0     # already 4096 workgroups
+    assert k.workspaceSize(row=4096, column=256) == 0                           # traversal too short
+    assert AttentionKernel(_desc(dims=(4096, 4096, 64)).kernelDescriptor(T.forward)).workspaceSize(row=4096, column=4096) == 0
+    assert AttentionKernel(low.kernelDescriptor(T.backwardQuery)).workspaceSize(row=4096, column=4096) == 0

@@ -248,8 +248,8 @@ class AttentionKernel:
 
     def __del__(self):
         h = getattr(self, "_handle", None)
-        if h is not None and h.value:
-            lib().mfa_attention_kernel_destroy(h)
+        if h is not None and h.value and _abi._lib is not None:   # module globals may be gone at exit
+            _abi._lib.mfa_attention_kernel_destroy(h)
             self._handle = ctypes.c_void_p()
 
     @property

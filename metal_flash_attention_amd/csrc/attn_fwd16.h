@@ -67,6 +67,9 @@ template <int D> __device__ __forceinline__ int kswz(int row, int chunk) {
   else return chunk ^ ((row >> 2) & 3);  // D == 32
 }
 
+// the row-dependent XOR mask of kswz (kswz(row, c) == c ^ kswz_mask(row)); the swizzle is an involution
+template <int D> __device__ __forceinline__ int kswz_mask(int row) { return kswz<D>(row, 0); }
+
 template <int D> constexpr int fwd16_lds_bytes() { return 2 /*buffers*/ * 2 /*K,V*/ * 64 * D * 2; }
 
 // grid: 1-D, (row blocks) x heads x batches flattened; see fwd16_decode_block for the XCD-aware order

@@ -18,7 +18,7 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false, bool DMA = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -70,35 +70,68 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   const int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;
   const int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_total;
 
-  // ---- K/V staging (identical to v2)
+  // ---- K/V staging.  DMA == false: global -> VGPR -> LDS (as v2).  DMA == true: LDS-DMA
+  // (buffer_load_dwordx4 ... lds): instruction i of wave w fills the 1 KiB of the tile image at
+  // 16-byte positions (w*NCH + i)*64 + lane, so each lane fetches the global chunk that BELONGS at its
+  // position -- the K swizzle and the V sub-tiling are applied on the source address; no staging
+  // registers, no ds_write, and the data is tracked by vmcnt (drained before the tile's barrier).
+  static_assert(!DMA || RING == 3, "LDS-DMA staging uses the 3-stage ring");
   uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int id = tid + i * NT;
-    const int row = id / CPR, c = id % CPR;
-    const bool valid = c * 8 < Dr;
-    koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
-    voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
-    klds[i] = row * ROWB + kswz<D>(row, c) * 16;
-    vlds[i] = TILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+    if constexpr (DMA) {
+      const int p = (wave * NCH + i) * 64 + lane;
+      const int krow = p / CPR, kc = (p % CPR) ^ kswz_mask<D>(krow);
+      const int vdb = p / (BC * 4), vkey = (p / 4) % BC, vc = vdb * 4 + (p & 3);
+      koff[i] = (kc * 8 < Dr) ? (tile0 * BC + krow) * ldk2 + kc * 16 : OOB;
+      voff[i] = (vc * 8 < Dr) ? (tile0 * BC + vkey) * ldv2 + vc * 16 : OOB;
+      klds[i] = vlds[i] = 0;
+    } else {
+      const int id = tid + i * NT;
+      const int row = id / CPR, c = id % CPR;
+      const bool valid = c * 8 < Dr;
+      koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
+      voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
+      klds[i] = row * ROWB + kswz<D>(row, c) * 16;
+      vlds[i] = TILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+    }
   }
-  u32x4 kreg[NCH], vreg[NCH];
+  u32x4 kreg[DMA ? 1 : NCH], vreg[DMA ? 1 : NCH];
   auto issue_loads = [&]() {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
-      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
-      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
-      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+      for (int i = 0; i < NCH; ++i) {
+        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+        koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+        voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+      }
     }
   };
   auto write_tiles = [&](int stage) {
-    char *base = smem + stage * STAGE;
+    if constexpr (!DMA) {
+      char *base = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
-      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+      for (int i = 0; i < NCH; ++i) {
+        *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+        *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+      }
+    }
+  };
+  auto issue_dma = [&](int stage) {   // next tile in sequence -> `stage`
+    if constexpr (DMA) {
+      typedef __attribute__((address_space(3))) void *lds_ptr;
+      char *base = smem + stage * STAGE + wave * (NCH * 1024);
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(kres, (lds_ptr)(base + i * 1024), 16, koff[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + TILE + i * 1024), 16, voff[i], 0, 0, 0);
+#endif
+        koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+        voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+      }
     }
   };
 
@@ -309,9 +342,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- prologue
   const int ntiles = tile1 - tile0;
   const bool ragged = (C & (BC - 1)) != 0 && tile1 == tiles_total;   // only the globally last tile is partial
-  issue_loads();
-  write_tiles(0);
-  issue_loads();
+  if constexpr (DMA) {
+    issue_dma(0);      // tile 0 -> stage 0
+    issue_dma(1);      // tile 1 -> stage 1 (zeros past the end)
+  } else {
+    issue_loads();
+    write_tiles(0);
+    issue_loads();
+  }
   __syncthreads();
   f32x16 s0[RB], s1[RB];   // half score tiles (keys 0-31 / 32-63 of a tile); roles alternate
   float m_new[RB];
@@ -328,7 +366,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // with a second barrier before step B reads it.
   auto iteration = [&](int j, bool next_is_last) {
     rescale_if_needed(m_new);
-    if constexpr (RING == 3) {
+    if constexpr (DMA) {
+      // tile j+1 landed during the previous iteration (its DMA is drained by the vmcnt(0) hipcc puts in
+      // front of this barrier); once every wave has passed the barrier nobody reads tile j-1 any more,
+      // so its stage can take tile j+2.
+      __syncthreads();
+      issue_dma(st_next == 2 ? 0 : st_next + 1);
+    } else if constexpr (RING == 3) {
       write_tiles(st_next);          // tile j+1 (replaces tile j-2)
       issue_loads();                 // tile j+2 (reads as zero past the end)
       if constexpr (ABL != 8) __syncthreads();   // ABL 8: timing-only ablation (racy, wrong results)

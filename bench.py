@@ -73,10 +73,27 @@ def main():
                          f"(WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dist = None
+    ctl_device = "cuda"
     if world > 1:
+        # control plane only (barrier + max of one scalar; attention heads need no data-path collective).
+        # RCCL first; if it cannot initialise on this node fall back to gloo rather than lose the run.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        backend = os.environ.get("MFA_BENCH_BACKEND", "nccl")
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                ctl_device = "cpu"
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] {backend} control plane failed ({exc!r}); using gloo", file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            ctl_device = "cpu"
 
     from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
                                            AttentionOperand as Op, GEMMOperandPrecision as P)
@@ -147,7 +164,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     device_ms = ev0.elapsed_time(ev1)
-    elapsed = max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = max_over_ranks(elapsed, dist, device=ctl_device)
     if dist is not None:
         dist.barrier()
 

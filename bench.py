@@ -71,7 +71,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # ranks share a GPU only in tests
     dist = None
     ctl_device = "cuda"
     if world > 1:

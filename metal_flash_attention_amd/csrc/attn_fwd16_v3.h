@@ -334,6 +334,27 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
         for (int b = 0; b < RB; ++b) lsum[b] = F::mfma(ones, pf[b][u], lsum[b]);
     }
+    if constexpr (ABL == 9) {
+      // dictate the interleave instead of taking hipcc's (which front-loads the exp work and then issues
+      // the QK MFMAs back to back): every QK MFMA is followed by its share of the exponentiation, every
+      // PV MFMA by two transposing reads and two VALU instructions.  Masks: 0x8 MFMA, 0x2 VALU,
+      // 0x400 transcendental, 0x100 DS read.
+      constexpr int NQK = NKS * RB, NPV = 2 * NDB * RB;
+      constexpr int VALU_PER = (RB * 16 * 3 + NQK - 1) / NQK;     // fma + cvt/add share per QK MFMA
+      constexpr int EXP_PER = (RB * 16 + NQK - 1) / NQK;
+#pragma unroll
+      for (int i = 0; i < NQK; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, VALU_PER, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, EXP_PER, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NPV; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+      }
+    }
   };
 
   if constexpr (ABL == 1) {   // static priority for the second-dispatched half (T5 static form)

@@ -61,6 +61,8 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 20) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, true>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_dma"); return true; }
     if (D == 128 && impl == 21) { fill<__bf16, 128, 4, 2, 8, 1, 5, 3, true>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq_dma"); return true; }
     if (D == 128 && impl == 22) { fill<__bf16, 128, 4, 2, 8, 0, 5, 3, true>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_vq_dma"); return true; }
+    if (D == 128 && impl == 30) { fill<__bf16, 128, 8, 1, 8, 1, 9>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_sgb"); return true; }
+    if (D == 128 && impl == 31) { fill<__bf16, 128, 4, 2, 8, 1, 9>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_sgb"); return true; }
     if (D == 128 && impl == 13) { fill<__bf16, 128, 8, 1, 8, 0, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_splitacc"); return true; }
     if (D == 128 && impl == 12) { fill<__bf16, 128, 8, 1, 8, 0, 3>(out, "ablate_one_k_fragment_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }

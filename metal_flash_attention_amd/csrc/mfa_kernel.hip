@@ -192,6 +192,12 @@ static bool meets_fast_requirements(const mfa_attention_kernel *kernel, const Ke
     const int64_t per16 = 16 / (v.precision == PREC_FP32 ? 4 : 2);  // elements per 16 bytes
     if ((reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
     if (v.ld % per16 || v.headStride % per16 || v.batchStride % per16) return false;
+    // these kernels address one (head, batch) slice through a buffer descriptor with 32-bit byte
+    // offsets (prefetch may run two tiles past the end): larger slices use the general kernels
+    const bool rowOperand = (slot == SLOT_Q || slot == SLOT_O || slot == SLOT_dO || slot == SLOT_dQ);
+    const uint64_t seq = rowOperand ? args.R : args.C;
+    const uint64_t bytes = (seq + 192) * (uint64_t)v.ld * (v.precision == PREC_FP32 ? 4u : 2u);
+    if (bytes >= 0xFF000000ull) return false;
   }
   return true;
 }

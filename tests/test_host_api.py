@@ -177,3 +177,13 @@ def test_workspace_size_query_follows_the_split_heuristic():
     assert k.workspaceSize(row=4096, column=256) == 0                           # traversal too short
     assert AttentionKernel(_desc(dims=(4096, 4096, 64)).kernelDescriptor(T.forward)).workspaceSize(row=4096, column=4096) == 0
     assert AttentionKernel(low.kernelDescriptor(T.backwardQuery)).workspaceSize(row=4096, column=4096) == 0
+
+
+def test_oversized_slices_route_to_general_kernels_without_a_gpu():
+    """The 16-bit kernels use 32-bit byte offsets per (head, batch) slice; a launch whose slice would
+    exceed them must be planned on the general kernel.  The plan is visible through the workspace query
+    (only the 16-bit forward kernel ever asks for one) -- no GPU call is made."""
+    d = _desc(dims=(4096, 4096, 64), low_in=True, in_type=P.BF16)
+    k = AttentionKernel(d.kernelDescriptor(T.forward))
+    assert k.variant.startswith("attn_fwd16")
+    assert k.workspaceSize(row=4096, column=4096) > 0

@@ -168,6 +168,11 @@ typedef struct mfa_launch_params {
    * Size it with mfa_attention_kernel_workspace_size.  Contents need no initialisation. */
   void *workspace;
   uint64_t workspaceBytes;
+  /* Causal mask (extension; the reference is unmasked and names masks as its first extension,
+   * README.md:7): non-zero = row r attends column c iff c <= r + (column - row), i.e. lower-triangular
+   * for square problems.  Requires column >= row.  Applies to all three kernel types. */
+  uint32_t causal;
+  uint32_t reserved;
 } mfa_launch_params;
 void mfa_launch_params_init(mfa_launch_params *params);
 

@@ -83,6 +83,8 @@ class mfa_launch_params(ctypes.Structure):
         ("batchStride", ctypes.c_int64 * MFA_BUFFER_SLOTS),
         ("workspace", ctypes.c_void_p),
         ("workspaceBytes", ctypes.c_uint64),
+        ("causal", ctypes.c_uint32),
+        ("reserved", ctypes.c_uint32),
     ]
 
 

@@ -279,7 +279,7 @@ class AttentionKernel:
     # -- launch ------------------------------------------------------------------------------
     @staticmethod
     def _marshal(buffers, row, column, heads, batches, leadingDimensions, headStrides, batchStrides,
-                 workspace=None):
+                 workspace=None, causal=False):
         """`buffers`: dict {AttentionOperand: tensor | int} or a 10-sequence indexed by bufferBinding."""
         slots = [None] * _abi.MFA_BUFFER_SLOTS
         if isinstance(buffers, Mapping):
@@ -301,6 +301,7 @@ class AttentionKernel:
                 dst = getattr(params, name)
                 for op, v in src.items():
                     dst[AttentionOperand(op).bufferBinding] = int(v)
+        params.causal = int(bool(causal))
         if workspace is not None:   # caller-owned scratch for column-parallel forward launches
             params.workspace = _pointer(workspace)
             params.workspaceBytes = int(workspace.numel() * workspace.element_size()) \
@@ -320,19 +321,19 @@ class AttentionKernel:
     def dispatch(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
                  leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
                  batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,
-                 workspace=None) -> None:
+                 workspace=None, causal: bool = False) -> None:
         arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions,
-                                           headStrides, batchStrides, workspace)
+                                           headStrides, batchStrides, workspace, causal)
         check(lib().mfa_attention_kernel_launch(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                                 ctypes.c_void_p(stream or 0)))
 
     def time(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
              leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
              batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,
-             warmup: int = 1, iterations: int = 5, workspace=None) -> float:
+             warmup: int = 1, iterations: int = 5, workspace=None, causal: bool = False) -> float:
         """Milliseconds for `iterations` back-to-back launches (HIP events on `stream`)."""
         arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions,
-                                           headStrides, batchStrides, workspace)
+                                           headStrides, batchStrides, workspace, causal)
         ms = ctypes.c_float()
         check(lib().mfa_attention_kernel_time(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                               ctypes.c_void_p(stream or 0), int(warmup), int(iterations),

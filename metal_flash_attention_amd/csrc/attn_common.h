@@ -43,6 +43,8 @@ struct KernelArgs {
   uint32_t R, C, D;
   float scale;   // 1/sqrt(D)                 (+Softmax.swift:17-26, derivative: true)
   float scale2;  // log2(e)/sqrt(D)           (+Softmax.swift:17-26, derivative: false)
+  // extension (not in the reference): causal mask, row r sees column c iff c <= r + (C - R)
+  int32_t causal;
 };
 
 // row index inside a 32x32 MFMA C/D tile held by (register r, half hi)

@@ -233,6 +233,10 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
 
   // fp32 row-major operands (the FP32 production case): the next tile's global loads are issued
   // before the arithmetic of this tile and land in registers; other layouts stage synchronously.
+  // causal extension: row r sees column c iff c <= r + coff; columns past the last row's limit are
+  // never visited by this workgroup, the tiles on the diagonal are masked element-wise below
+  const int coff = C - R;
+  const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
   const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
   TileRegsF32<BC, DP, NT> kregs, vregs;
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
     tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
     tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
   }
-  for (int c0 = 0; c0 < C; c0 += BC) {
+  for (int c0 = 0; c0 < Cend; c0 += BC) {
     if (prefetch) {
       tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
       tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
       stage_tile<BC, DP, NT>(Vs, a.op[SLOT_V], vbase, c0, C, D, tid);
     }
     __syncthreads();
-    if (prefetch && c0 + BC < C) {
+    if (prefetch && c0 + BC < Cend) {
       tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, c0 + BC, C, D, tid);
       tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, c0 + BC, C, D, tid);
     }
@@ -268,6 +272,12 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (c0 + crow(r, hi) >= C) s[r] = mask_value();
+    }
+    if (a.causal) {    // same mechanism, applied to the columns the row may not see
+      const int64_t limit = r0 + wave * 32 + q + coff;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (c0 + crow(r, hi) > limit) s[r] = mask_value();
     }
     // onlineReduceMaximum / onlineCorrectO, +Softmax.swift:267-301
     float mx = s[0];
@@ -381,6 +391,10 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   const char *vbase = operand_base(a.op[SLOT_V], head, batch);
   // fp32 row-major operands (the FP32 production case): the next tile's global loads are issued
   // before the arithmetic of this tile and land in registers; other layouts stage synchronously.
+  // causal extension: row r sees column c iff c <= r + coff; columns past the last row's limit are
+  // never visited by this workgroup, the tiles on the diagonal are masked element-wise below
+  const int coff = C - R;
+  const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
   const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
   TileRegsF32<BC, DP, NT> kregs, vregs;
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
     tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
     tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
   }
-  for (int c0 = 0; c0 < C; c0 += BC) {
+  for (int c0 = 0; c0 < Cend; c0 += BC) {
     if (prefetch) {
       tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
       tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
       stage_tile<BC, DP, NT>(Vs, a.op[SLOT_V], vbase, c0, C, D, tid);
     }
     __syncthreads();
-    if (prefetch && c0 + BC < C) {
+    if (prefetch && c0 + BC < Cend) {
       tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, c0 + BC, C, D, tid);
       tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, c0 + BC, C, D, tid);
     }
@@ -415,7 +429,8 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
     // the zero padding comes from the async copy, +Accumulate.swift:330-346).
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = fast_exp2(s[r] * a.scale2 - Lrow);
+      float p = fast_exp2(s[r] * a.scale2 - Lrow);
+      if (a.causal && c0 + crow(r, hi) > row + coff) p = 0.f;   // masked column: P = 0, hence dS = 0
       s[r] = p * (dp[r] * a.scale - dterm);
     }
     // dQ^T += K^T dS^T, key index permuted as in forward
@@ -490,14 +505,17 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   const char *gbase = operand_base(a.op[SLOT_dO], head, batch);
   const char *lbase = operand_base(a.op[SLOT_L], head, batch);
   const char *dbase = operand_base(a.op[SLOT_D], head, batch);
+  // causal extension: rows above the workgroup's first column minus the offset see none of its columns
+  const int coff = C - R;
+  const int rstart = a.causal ? (int)(max((int64_t)0, c0 - coff) / BRW) * BRW : 0;
   constexpr bool CAN_PREFETCH = (DP <= 128);
   const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
   TileRegsF32<BRW, DP, NT> qregs, gregs;
   if (prefetch) {
-    tile_load_f32<BRW, DP, NT>(qregs, a.op[SLOT_Q], qbase, 0, R, D, tid);
-    tile_load_f32<BRW, DP, NT>(gregs, a.op[SLOT_dO], gbase, 0, R, D, tid);
+    tile_load_f32<BRW, DP, NT>(qregs, a.op[SLOT_Q], qbase, rstart, R, D, tid);
+    tile_load_f32<BRW, DP, NT>(gregs, a.op[SLOT_dO], gbase, rstart, R, D, tid);
   }
-  for (int r0 = 0; r0 < R; r0 += BRW) {
+  for (int r0 = rstart; r0 < R; r0 += BRW) {
     if (prefetch) {
       tile_store_f32<BRW, DP, NT>(Qs, qregs, tid);
       tile_store_f32<BRW, DP, NT>(dOs, gregs, tid);
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
       const float Lr = LDs[crow(r, hi)];
       const float Dr = LDs[32 + crow(r, hi)];
       p[r] = fast_exp2(s[r] * a.scale2 - Lr);
+      if (a.causal && c0 + wave * 32 + kc > r0 + crow(r, hi) + coff) p[r] = 0.f;   // masked: P = 0
       s[r] = p[r] * (dp[r] * a.scale - Dr);
     }
     // dV^T += dO^T P ; dK^T += Q^T dS   (row index permuted; padded rows of Q/dO are zero)

@@ -20,6 +20,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = generic_fwd_lds_floats<DP, NW, CACHE>() * sizeof(float);
   v->cacheLeft = CACHE;
+  v->causal = true;
   v->launch = &launch_fwd<DP, NW, CACHE>;
 }
 

@@ -260,9 +260,13 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   args->D = D;
   args->scale = 1.0f / std::sqrt((float)D);
   args->scale2 = 1.44269504089f / std::sqrt((float)D);
+  args->causal = p->causal ? 1 : 0;
+  if (p->causal && p->column < p->row)
+    return fail(MFA_ERR_INVALID_ARGUMENT, "causal masking requires column >= row");
   const uint32_t heads = p->heads ? p->heads : 1, batches = p->batches ? p->batches : 1;
   if (heads > 65535 || batches > 65535) return fail(MFA_ERR_INVALID_ARGUMENT, "heads and batches must be <= 65535");
-  plan->useFallback = kernel->hasFallback && !meets_fast_requirements(kernel, *args);
+  plan->useFallback = kernel->hasFallback && (!meets_fast_requirements(kernel, *args) ||
+                                              (args->causal && !kernel->variant.causal));
   plan->variant = plan->useFallback ? &kernel->fallback : &kernel->variant;
   // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
   // (SquareAttentionTest.swift:355-367)

@@ -151,10 +151,26 @@ void oracle_round_trip(float *x, size_t n, int precision) {
 /* ------------------------------------------------------------------------ */
 #define ROW_CHUNK 128
 
+/* `causal` is this project's extension (the reference is unmasked, README.md:7 names masks as the first
+   extension): row r may attend column c iff c <= r + (C - R).  Masked columns are simply left out of
+   every sum (maximum, exp-sum, P V, dS), which is what P = 0 there means.  causal = 0 reproduces
+   Network.swift exactly. */
+int oracle_network_run_masked(int R, int C, int D,
+                       const float *Q, const float *K, const float *V, const float *dO,
+                       float *O, float *L, float *Dt, float *dV, float *dK, float *dQ,
+                       int num_threads, int causal);
+
 int oracle_network_run(int R, int C, int D,
                        const float *Q, const float *K, const float *V, const float *dO,
                        float *O, float *L, float *Dt, float *dV, float *dK, float *dQ,
                        int num_threads) {
+  return oracle_network_run_masked(R, C, D, Q, K, V, dO, O, L, Dt, dV, dK, dQ, num_threads, 0);
+}
+
+int oracle_network_run_masked(int R, int C, int D,
+                       const float *Q, const float *K, const float *V, const float *dO,
+                       float *O, float *L, float *Dt, float *dV, float *dK, float *dQ,
+                       int num_threads, int causal) {
   const int need_bwd = (Dt || dV || dK || dQ) ? 1 : 0;
   if (need_bwd && !dO) return -1;
 #ifdef _OPENMP
@@ -189,6 +205,9 @@ int oracle_network_run(int R, int C, int D,
       for (int rr = 0; rr < rows; ++rr) {
         const int rowID = r0 + rr;
         float *p = Pc + (size_t)rr * C;
+        /* number of visible columns of this row: all of them, or c <= rowID + (C - R) */
+        int CV = C;
+        if (causal) { CV = rowID + (C - R) + 1; if (CV < 0) CV = 0; if (CV > C) CV = C; }
         /* createMatrixSRow, Network.swift:134-149 : dot over d, sequential */
         for (int c = 0; c < C; ++c) p[c] = 0.0f;
         for (int d = 0; d < D; ++d) {
@@ -198,25 +217,26 @@ int oracle_network_run(int R, int C, int D,
         }
         /* createMatrixPRow, Network.swift:151-179 */
         float maximum = -FLT_MAX;
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CV; ++c) {
           float value = scaleFactor * p[c];
           maximum = fmaxf(maximum, value);
         }
         float sum = 0.0f;
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CV; ++c) {
           float value = scaleFactor * p[c];
           sum += expf(value - maximum);
         }
         const float lse = maximum + logf(sum);
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CV; ++c) {
           float value = scaleFactor * p[c];
           p[c] = expf(value - lse);
         }
+        for (int c = CV; c < C; ++c) p[c] = 0.0f;   /* masked: P = 0 */
         if (L) L[rowID] = lse; /* createLTerm, Network.swift:181-203 (same arithmetic) */
 
         /* P * V, Network.swift:292-303 : sum over columns, sequential per d */
         for (int d = 0; d < D; ++d) orow[d] = 0.0f;
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CV; ++c) {
           const float valueP = p[c];
           const float *v = V + (size_t)c * D;
           for (int d = 0; d < D; ++d) orow[d] += valueP * v[d];
@@ -247,7 +267,7 @@ int oracle_network_run(int R, int C, int D,
         /* derivativeQ, Network.swift:383-392 : sum over columns, sequential per d */
         if (dQ) {
           for (int d = 0; d < D; ++d) orow[d] = 0.0f;
-          for (int c = 0; c < C; ++c) {
+          for (int c = 0; c < CV; ++c) {
             const float s = ds[c];
             const float *k = K + (size_t)c * D;
             for (int d = 0; d < D; ++d) orow[d] += s * k[d];

@@ -43,6 +43,8 @@ def _load():
     lib.oracle_network_init.restype = None
     lib.oracle_network_run.argtypes = [ctypes.c_int] * 3 + [fp] * 10 + [ctypes.c_int]
     lib.oracle_network_run.restype = ctypes.c_int
+    lib.oracle_network_run_masked.argtypes = [ctypes.c_int] * 3 + [fp] * 10 + [ctypes.c_int, ctypes.c_int]
+    lib.oracle_network_run_masked.restype = ctypes.c_int
     lib.oracle_network_run_f64.argtypes = [ctypes.c_int] * 3 + [dp] * 10
     lib.oracle_network_run_f64.restype = ctypes.c_int
     lib.oracle_network_loss.argtypes = [ctypes.c_int] * 3 + [fp] * 4
@@ -107,7 +109,7 @@ class Network:
         self._cache = None
 
     # -- everything in one pass (shares the row intermediates; same arithmetic) --
-    def run(self, backward: bool = True):
+    def run(self, backward: bool = True, causal: bool = False):
         R, C, D = self.rowDimension, self.columnDimension, self.headDimension
         out = {"O": np.empty((R, D), np.float32), "L": np.empty(R, np.float32)}
         if backward:
@@ -115,10 +117,10 @@ class Network:
                        dK=np.empty((C, D), np.float32), dQ=np.empty((R, D), np.float32))
         for a in (self.Q, self.K, self.V, self.dO):
             assert a.dtype == np.float32 and a.flags.c_contiguous
-        rc = _load().oracle_network_run(
+        rc = _load().oracle_network_run_masked(
             R, C, D, _fp(self.Q), _fp(self.K), _fp(self.V), _fp(self.dO),
             _fp(out["O"]), _fp(out["L"]), _fp(out.get("D")), _fp(out.get("dV")),
-            _fp(out.get("dK")), _fp(out.get("dQ")), self.threads)
+            _fp(out.get("dK")), _fp(out.get("dQ")), self.threads, int(bool(causal)))
         if rc != 0:
             raise RuntimeError(f"oracle_network_run failed: {rc}")
         return out

@@ -5,11 +5,14 @@ the C restatement."""
 import numpy as np
 
 
-def attention_f64(Q, K, V, dO=None):
+def attention_f64(Q, K, V, dO=None, causal=False):
     Q, K, V = (np.asarray(a, np.float64) for a in (Q, K, V))
     D = Q.shape[-1]
     scale = 1.0 / np.sqrt(np.float64(D))
     S = (Q @ K.T) * scale                                   # Network.swift:134-149, :153
+    if causal:  # extension: row r sees column c iff c <= r + (C - R)
+        R_, C_ = S.shape
+        S = np.where(np.arange(C_)[None, :] <= np.arange(R_)[:, None] + (C_ - R_), S, -np.inf)
     m = S.max(axis=1, keepdims=True)                        # :156-160
     lse = m + np.log(np.exp(S - m).sum(axis=1, keepdims=True))   # :163-171
     P = np.exp(S - lse)                                     # :172-176

@@ -93,10 +93,11 @@ class DeviceRun:
     """One forward+backward pass of the three kernels for a single (R, C, D) problem."""
 
     def __init__(self, desc: AttentionDescriptor, network, seed: int = 1234, heads: int = 1,
-                 run_backward: bool = True):
+                 run_backward: bool = True, causal: bool = False):
         import torch
 
         self.torch = torch
+        self.causal = causal
         self.desc = desc
         self.network = network
         R, C, D = desc.matrixDimensions
@@ -143,7 +144,7 @@ class DeviceRun:
         torch = self.torch
         stream = torch.cuda.current_stream().cuda_stream
         for t, kernel in self.kernels.items():  # forward -> backwardQuery -> backwardKeyValue
-            kernel.dispatch(self.buffers, row=self.R, column=self.C, stream=stream)
+            kernel.dispatch(self.buffers, row=self.R, column=self.C, stream=stream, causal=self.causal)
         torch.cuda.synchronize()
         return self.results()
 

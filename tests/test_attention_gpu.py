@@ -499,3 +499,44 @@ def test_forward_split_kv_too_small_workspace_is_ignored():
     got = run.results()
     round_inputs(net, desc)
     assert np.abs(got["O"] - net.run(backward=False)["O"]).max() < 1.5e-2
+
+
+# ---- causal mask (extension) --------------------------------------------------------------------
+CAUSAL_SHAPES = [(64, 64, 32), (100, 100, 40), (33, 97, 16), (1, 50, 8), (300, 300, 128), (257, 600, 64), (129, 129, 200)]
+
+
+@pytest.mark.parametrize("shape", CAUSAL_SHAPES)
+def test_causal_fp32_all_kernels(shape):
+    """Row r attends column c iff c <= r + (C - R).  FP32, all six outputs against the causal oracle
+    with the reference's FP32 tolerance."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=R + C)
+    desc = make_desc(R, C, D)
+    run = harness.DeviceRun(desc, net, causal=True)
+    got = run.execute()
+    ref = net.run(causal=True)
+    failures, report = harness.compare(ref, got, TOL_FP32)
+    assert not failures, failures
+    assert all(run.tails_ok.values())
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 555, 64), (1024, 1024, 128), (129, 640, 80)])
+def test_causal_bf16_all_kernels(shape):
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=2 * R + C)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net, causal=True)
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(causal=True)
+    failures, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+    assert not failures, (failures, [k.variant for k in run.kernels.values()])
+
+
+def test_causal_requires_column_ge_row():
+    from metal_flash_attention_amd import MFAError
+    desc = make_desc(64, 32, 16)
+    k = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    with pytest.raises(MFAError) as e:
+        k.dispatch({Op.Q: 4096, Op.K: 4096, Op.V: 4096, Op.O: 4096, Op.L: 4096}, row=64, column=32, causal=True)
+    assert e.value.status == 2

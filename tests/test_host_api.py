@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
     # sizes are part of the ABI: a cgo/JNI/Swift binding relies on them
     assert ctypes.sizeof(_abi.mfa_attention_descriptor) == 24
     assert ctypes.sizeof(_abi.mfa_attention_kernel_descriptor) == 70
-    assert ctypes.sizeof(_abi.mfa_launch_params) == 16 + 3 * 80 + 16
+    assert ctypes.sizeof(_abi.mfa_launch_params) == 16 + 3 * 80 + 16 + 8
     assert ctypes.sizeof(_abi.mfa_parameter_row) == 22
 
 

@@ -99,3 +99,21 @@ def test_round_trips_match_reference_packing():
     wantbf = ((x.view(np.uint32) >> 16) << 16).view(np.float32)
     assert np.array_equal(round_trip(x, 2), wantbf)
     assert np.array_equal(round_trip(x, 0), x)
+
+
+@pytest.mark.parametrize("shape", [(17, 17, 8), (9, 33, 5), (64, 64, 16), (40, 100, 24)])
+def test_causal_extension_matches_fp64_restatement(shape):
+    """Causal masking (this project's extension of the unmasked reference): the C oracle with columns
+    c > r + (C - R) left out of every sum equals the matrix-form fp64 restatement with S = -inf there;
+    causal=False still reproduces the committed goldens (test above)."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=17)
+    got = net.run(causal=True)
+    ref = attention_f64(net.Q, net.K, net.V, net.dO, causal=True)
+    for name in NAMES:
+        assert np.abs(got[name] - ref[name]).max() < 2e-5, name
+    # the strictly-upper-triangular part of the problem must not influence anything
+    net2 = Network(NetworkDescriptor(R, C, D), seed=17)
+    net2.V[C - 1] += 100.0   # only the last row may see the last column
+    got2 = net2.run(causal=True)
+    assert np.array_equal(got2["O"][:-1], got["O"][:-1])

@@ -49,7 +49,7 @@ template <int D, int NW> constexpr int dq16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW, typename TG = T>
+template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -142,7 +142,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
 
-  const int ntiles = (C + BC - 1) / BC;
+  // CAUSAL (extension): keys past the last row's limit are never visited; blocks crossing the diagonal
+  // get P = 0 element-wise (hence dS = 0)
+  const int coff = C - R;
+  int ntiles = (C + BC - 1) / BC;
+  if constexpr (CAUSAL) {
+    const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * 32)) - 1;
+    ntiles = (int)min((int64_t)ntiles, (last_row + coff) / BC + 1);
+  }
   issue_loads();
   write_tiles(0);
   __syncthreads();
@@ -167,13 +174,16 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       // P = exp2(S*scale2 - L); dS = P (dP*scale - D).  Keys past C have zero K and V rows, so their
       // dS multiplies zero K rows below: no mask needed (as in the reference, +Accumulate.swift:330-346).
       v8 dsf[2];
+      const int c0 = j * BC + 32 * kb;
+      const bool diag = CAUSAL && (c0 + 31 > r0 + coff);   // wave-uniform: this block crosses the diagonal
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         v8 pk;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int r = 8 * u + i;
-          const float p = fast_exp2(s[r] * a.scale2 - Lrow);
+          float p = fast_exp2(s[r] * a.scale2 - Lrow);
+          if (diag && c0 + crow(r, hi) > row + coff) p = 0.f;
           pk[i] = (T)(p * (dp[r] * a.scale - dterm));
         }
         dsf[u] = pk;
@@ -236,7 +246,7 @@ template <int D, int NW> constexpr int dkv16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW, int PRE = 1, typename TG = T>
+template <typename T, int D, int NW, int PRE = 1, typename TG = T, bool CAUSAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -274,6 +284,11 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     vf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(vres, ok ? (uint32_t)col * ldv2 + d0 * 2 : OOB, 0, 0));
   }
 
+  // CAUSAL (extension): rows r with r + (C - R) < (first key of the workgroup) see none of its keys: the
+  // traversal starts at the first row block that can; blocks crossing the diagonal get P = 0 element-wise
+  const int coff = C - R;
+  const int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * (NW * 32) - coff) / 32) : 0;
+
   // ---- Q / dO staging (two images each) + the L, D slices along the traversal dimension
   uint32_t qoff[NCH], goff[NCH], rlds[NCH], tlds[NCH];
   const uint32_t qinc = BR * ldq2, ginc = BR * ldg2;
@@ -282,14 +297,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     const int id = tid + i * NT;
     const int rr = id / CPR, c = id % CPR;
     const bool valid = c * 8 < Dr;
-    qoff[i] = valid ? rr * ldq2 + c * 16 : OOB;
-    goff[i] = valid ? rr * ldg2 + c * 16 : OOB;
+    qoff[i] = valid ? (block0 * BR + rr) * ldq2 + c * 16 : OOB;
+    goff[i] = valid ? (block0 * BR + rr) * ldg2 + c * 16 : OOB;
     rlds[i] = rr * ROWB + kswz<D>(rr, c) * 16;                  // row-major (swizzled): Q at +0, dO at +2*TILE
     tlds[i] = TILE + ((c >> 2) * BR + rr) * 64 + (c & 3) * 16;  // transposable: Q at +TILE, dO at +3*TILE
   }
   u32x4 qreg[NCH], greg[NCH];
   float ldreg = 0.f;
-  int tile_row0 = 0;
+  int tile_row0 = block0 * BR;
   auto issue_loads = [&]() {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -348,8 +363,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     }
   };
   // P = exp2(S*scale2 - L), dS = P (dP*scale - D), rounded to the 16-bit type and packed as B operands
+  int cur_row0 = block0 * BR;   // first row of the block softmax_grad is working on (advanced by the loop)
   auto softmax_grad = [&](int stage, const f32x16 &s, const f32x16 &dp, v8 (&pf)[2], v8 (&dsf)[2]) {
     const float *Ls = reinterpret_cast<const float *>(smem + stage * STAGE + 4 * TILE) + 4 * hi;
+    const bool diag = CAUSAL && (c0 + 31 > cur_row0 + coff);   // wave-uniform
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       v8 pk, dk8;
@@ -361,7 +378,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int r = 4 * g + i;
-          const float p = fast_exp2(s[r] * a.scale2 - l4[i]);
+          float p = fast_exp2(s[r] * a.scale2 - l4[i]);
+          if (diag && col > cur_row0 + crow(r, hi) + coff) p = 0.f;
           pk[4 * g2 + i] = (T)p;
           dk8[4 * g2 + i] = (T)(p * (dp[r] * a.scale - d4[i]));
         }
@@ -369,6 +387,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
       pf[u] = pk;
       dsf[u] = dk8;
     }
+    cur_row0 += BR;
   };
   // dV^T += dO^T P ; dK^T += Q^T dS  (row index permuted; rows past R have zero Q and dO rows)
   auto accumulate = [&](int stage, const v8 (&pf)[2], const v8 (&dsf)[2]) {
@@ -440,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
     }
   };
 
-  const int nblocks = ((R + BR - 1) / BR + 1) & ~1;   // rounded up to even (zero blocks are harmless)
+  const int nblocks = (((R + BR - 1) / BR - block0) + 1) & ~1;   // rounded up to even (zero blocks are harmless)
   issue_loads();
   write_tiles(0);
   issue_loads();

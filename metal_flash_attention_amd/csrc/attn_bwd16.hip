@@ -19,6 +19,19 @@ static void launch_dkv16(dim3 grid, hipStream_t stream, const KernelArgs &args) 
 }
 
 template <typename T, int D, int NW, typename TG = T>
+static void launch_dq16_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  hipLaunchKernelGGL((attn_dq16<T, D, NW, TG, true>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+                     (dq16_lds_bytes<D, NW>()), stream, args, g);
+}
+template <typename T, int D, int NW, int PRE = 1, typename TG = T>
+static void launch_dkv16_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  hipLaunchKernelGGL((attn_dkv16<T, D, NW, PRE, TG, true>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+                     (dkv16_lds_bytes<D, NW>()), stream, args, g);
+}
+
+template <typename T, int D, int NW, typename TG = T>
 static void fill_dq(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG>);
   v->name = name;
@@ -29,6 +42,9 @@ static void fill_dq(VariantInfo *v, const char *name) {
   v->ldsBytes = dq16_lds_bytes<D, NW>();
   v->cacheLeft = true;
   v->launch = &launch_dq16<T, D, NW, TG>;
+  v->launchCausal = &launch_dq16_causal<T, D, NW, TG>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG, true>);
+  v->causal = true;
 }
 template <typename T, int D, int NW, int PRE = 1, typename TG = T>
 static void fill_dkv(VariantInfo *v, const char *name) {
@@ -41,6 +57,9 @@ static void fill_dkv(VariantInfo *v, const char *name) {
   v->ldsBytes = dkv16_lds_bytes<D, NW>();
   v->cacheLeft = true;
   v->launch = &launch_dkv16<T, D, NW, PRE, TG>;
+  v->launchCausal = &launch_dkv16_causal<T, D, NW, PRE, TG>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW, PRE, TG, true>);
+  v->causal = true;
 }
 
 // precision: storage type of Q, K, V; gprecision: storage type of dO (equal, or BF16 next to FP16)

@@ -18,7 +18,8 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false, bool DMA = false>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false, bool DMA = false,
+          bool CAUSAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -68,7 +69,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- key range of this workgroup: everything, or piece `split` of `splits` (SPLIT launches)
   const int tiles_total = (C + BC - 1) / BC;
   const int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;
-  const int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_total;
+  // CAUSAL (extension): row r sees key c iff c <= r + (C - R); the workgroup stops at the tile that holds
+  // the last key its last row may see, tiles that cross the diagonal are masked element-wise.
+  const int coff = C - R;
+  int tiles_visible = tiles_total;
+  if constexpr (CAUSAL) {
+    const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * RB * 32)) - 1;
+    tiles_visible = (int)min((int64_t)tiles_total, (last_row + coff) / BC + 1);
+  }
+  const int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_visible;
 
   // ---- K/V staging.  DMA == false: global -> VGPR -> LDS (as v2).  DMA == true: LDS-DMA
   // (buffer_load_dwordx4 ... lds): instruction i of wave w fills the 1 KiB of the tile image at
@@ -196,6 +205,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (c0 + crow(r, hi) >= C) s[b][r] = mask_value();
+  };
+  // causal mask of the 32 keys starting at c0, skipped (wave-uniform test) when the whole block lies
+  // at or below the diagonal for every row of this wave
+  auto mask_causal = [&](f32x16 (&s)[RB], int c0) {
+    if constexpr (CAUSAL) {
+      if (c0 + 31 > r0 + coff) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const int64_t limit = r0 + b * 32 + q + coff;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (c0 + crow(r, hi) > limit) s[b][r] = mask_value();
+        }
+      }
+    }
   };
   auto block_max = [&](const f32x16 (&s)[RB], float (&m_new)[RB]) {   // onlineReduceMaximum
 #pragma unroll
@@ -376,6 +400,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   float m_new[RB];
   qk(0, 0, s0);
   if (ntiles == 1 && ragged) mask_edge(s0, tile0 * BC);
+  mask_causal(s0, tile0 * BC);
   block_max(s0, m_new);
 
   int st_cur = 0, st_next = 1;
@@ -410,6 +435,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     } else {
       step(s0, s1, st_cur, 1, st_cur, 0, true);
     }
+    mask_causal(s1, (tile0 + j) * BC + 32);
     block_max(s1, m_new);
     rescale_if_needed(m_new);
     if constexpr (RING == 2) __syncthreads();
@@ -422,6 +448,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       step(s1, s0, st_next, 0, st_cur, 1, true);
     }
     if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
+    mask_causal(s0, (tile0 + j + 1) * BC);
     block_max(s0, m_new);
     st_cur = st_next;
     st_next = (st_next == RING - 1) ? 0 : st_next + 1;
@@ -435,6 +462,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   exponentiate(s0, pf);
   pv(st_cur, 0, pf);
   if (ragged) mask_edge(s1, (tile0 + j) * BC + 32);
+  mask_causal(s1, (tile0 + j) * BC + 32);
   block_max(s1, m_new);
   rescale_if_needed(m_new);
   exponentiate(s1, pf);

@@ -19,6 +19,10 @@ struct VariantInfo {
   // caller's workspace, then the combine kernel); nullptr if the variant has none
   void (*launchSplit)(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream,
                       const KernelArgs &args) = nullptr;
+  // separate code object implementing the causal mask (the unmasked loop bodies stay branch-free);
+  // nullptr when `launch` handles the flag itself (general kernels) or the variant has no mask
+  void (*launchCausal)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
+  const void *funcCausal = nullptr;
 };
 
 // generic (fp32-MFMA) family: returns false if (DP) is not compiled

@@ -275,7 +275,7 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
   plan->splits = 1;
-  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit) {
+  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit && !args->causal) {
     const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, p->column);
     if (s > 1) {
       const uint64_t rows = (uint64_t)s * heads * batches * p->row;
@@ -301,6 +301,8 @@ static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const Launc
   uint64_t &mask = plan.useFallback ? kernel->attrDeviceMaskFallback : kernel->attrDeviceMask;
   if (device < 64 && (mask >> device) & 1ull) return MFA_OK;
   err = hipFuncSetAttribute(plan.variant->func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+  if (err == hipSuccess && plan.variant->funcCausal)
+    err = hipFuncSetAttribute(plan.variant->funcCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
   if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   if (device < 64) mask |= 1ull << device;
   return MFA_OK;
@@ -314,6 +316,7 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
   if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, (hipStream_t)stream, plan.args);
+  else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, (hipStream_t)stream, plan.args);
   else plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return hip_fail(err, plan.variant->name);
@@ -350,6 +353,7 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
   auto go = [&]() {
     if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);
+    else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, s, plan.args);
     else plan.variant->launch(plan.grid, s, plan.args);
   };
   for (int i = 0; i < warmup; ++i) go();

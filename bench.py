@@ -44,6 +44,9 @@ WORKLOADS = {
                             types=("forward", "backwardQuery", "backwardKeyValue")),             # config 3, batched
     "fwdbwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16,
                              types=("forward", "backwardQuery", "backwardKeyValue")),
+    "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),
+    "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
+                                    types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_n16k": dict(N=16384, D=128, dtype="bf16", batch=1, heads=32, types=("forward",)),  # config 5 shard
 }
 OPS_PER_N2 = {"forward": lambda D: 2 * D + 5, "backwardQuery": lambda D: 3 * D + 5,
@@ -143,7 +146,8 @@ def main():
     def step():
         for t in types:
             kernels[t].dispatch(bufs, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs,
-                                stream=stream, workspace=workspace if t.name == "forward" else None)
+                                stream=stream, workspace=workspace if t.name == "forward" else None,
+                                causal=bool(w.get("causal", False)))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -169,10 +173,12 @@ def main():
         dist.barrier()
 
     heads_total = B * H * world
-    ops_step = sum(OPS_PER_N2[t.name](D) for t in types) * N * N * heads_total
+    # causal workloads do (N+1)/2N of the work; GINSTR and flops count what is actually computed
+    work = (N + 1) / (2.0 * N) if w.get("causal") else 1.0
+    ops_step = sum(OPS_PER_N2[t.name](D) for t in types) * N * N * heads_total * work
     ginstrs = ops_step * args.steps / elapsed / 1e9
     # roofline of the dominant kernel, per launch on this rank, from the HIP-event time
-    flops_launch_rank = sum(FLOPS_PER_N2[t.name](D) for t in types) * N * N * B * H
+    flops_launch_rank = sum(FLOPS_PER_N2[t.name](D) for t in types) * N * N * B * H * work
     launch_ms = device_ms / args.steps
     achieved_tflops = flops_launch_rank / (launch_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[w["dtype"]]
@@ -221,7 +227,7 @@ def cpu_baseline(np, torch, w, bufs, Op, target_seconds, backward):
 
     N, D = w["N"], w["D"]
     ops_head = (OPS_PER_N2["forward"](D) + (OPS_PER_N2["backwardQuery"](D) + OPS_PER_N2["backwardKeyValue"](D)
-                                            if backward else 0)) * N * N
+                                            if backward else 0)) * N * N * ((N + 1) / (2.0 * N) if w.get("causal") else 1.0)
     threads = max_threads()
     heads_done, cpu_time, max_err = 0, 0.0, 0.0
     flat = {op: t.reshape(-1, *t.shape[2:]) for op, t in bufs.items()}
@@ -234,7 +240,7 @@ def cpu_baseline(np, torch, w, bufs, Op, target_seconds, backward):
         if backward:
             net.dO = flat[Op.dO][heads_done].float().cpu().numpy()
         t0 = time.perf_counter()
-        ref = net.run(backward=backward)
+        ref = net.run(backward=backward, causal=bool(w.get("causal", False)))
         cpu_time += time.perf_counter() - t0
         got = flat[Op.O][heads_done].cpu().numpy()
         max_err = max(max_err, float(np.abs(got - ref["O"]).max()))

@@ -529,8 +529,12 @@ def test_causal_bf16_all_kernels(shape):
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run(causal=True)
-    failures, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
-    assert not failures, (failures, [k.variant for k in run.kernels.values()])
+    variants = [k.variant for k in run.kernels.values()]
+    assert all(not v.startswith("attn_generic") for v in variants) or D % 8, variants   # matrix-core kernels own the mask
+    # D = sum dO*O is O(sqrt(D_head)) for the first causal rows (they average over very few keys), so
+    # its absolute error is larger than in the unmasked tests; the reference's own bound for D is 1e-1
+    failures, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3, D=5e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+    assert not failures, (failures, variants)
 
 
 def test_causal_requires_column_ge_row():

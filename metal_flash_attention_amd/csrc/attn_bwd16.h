@@ -64,6 +64,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  if constexpr (CAUSAL) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
   const int R = a.R, C = a.C, Dr = a.D;
   const int64_t r0 = (int64_t)rblk * (NW * 32) + wave * 32;
   const int64_t row = r0 + q;

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   uint32_t bid = blockIdx.x, split = 0;
   if constexpr (SPLIT) { split = bid % grid.splits; bid /= grid.splits; }
   fwd16_decode_block(grid, bid, &rblk, &head, &batch);
+  if constexpr (CAUSAL) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
   const int R = a.R, C = a.C, Dr = a.D;
   const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,

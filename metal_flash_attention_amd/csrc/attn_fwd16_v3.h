@@ -518,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 // head-dimension elements 4c..4c+3.  m* = max_s m_s;  w_s = exp2(m_s - m*);  l* = sum_s w_s l_s;
 // O = sum_s w_s O_s / l*;  L = m* + log2 l*  -- the online-softmax merge (+Softmax.swift:290-324) applied
 // across pieces instead of across tiles.  HBM-bound: reads splits x (D + 2) floats per row.
-__global__ __launch_bounds__(256) void attn_fwd_combine(const KernelArgs a, const Fwd16Grid grid) {
+static __global__ __launch_bounds__(256) void attn_fwd_combine(const KernelArgs a, const Fwd16Grid grid) {
   const int lane = threadIdx.x & 63;
   const uint32_t R = a.R, Dr = a.D, HB = grid.heads * grid.batches;
   const uint64_t rowid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // over HB * R

@@ -36,6 +36,8 @@ bool fwd16_variant(int precision, int D, VariantInfo *out);
 bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 // one wave per SIMD, 64 query rows per wave, half-tile pipeline (see attn_fwd16_v3.h)
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
+// 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)
+bool fwd16_v4_variant(int precision, int D, int impl, VariantInfo *out);
 
 // 16-bit MFMA backward kernels (Q, K, V, dO in one 16-bit type, row-major, D in {64, 128})
 // (gprecision = storage type of dO: the same 16-bit type, or BF16 next to FP16 Q/K/V)

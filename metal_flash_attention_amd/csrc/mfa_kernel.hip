@@ -102,6 +102,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       bool wantV1 = knob && std::strcmp(knob, "v1") == 0;
       if (knob && std::strncmp(knob, "v2:", 3) == 0) fast = fwd16_v2_variant(pq, bucket, std::atoi(knob + 3), &variant);
       else if (knob && std::strncmp(knob, "v3:", 3) == 0) fast = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &variant);
+      else if (knob && std::strncmp(knob, "v4:", 3) == 0) fast = fwd16_v4_variant(pq, bucket, std::atoi(knob + 3), &variant);
       else if (!wantV1) fast = fwd16_v3_variant(pq, bucket, 0, &variant);
       if (!fast) fast = fwd16_variant(pq, bucket, &variant);
     }

@@ -25,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # /opt/skills/guides/MI355X_MICROARCH.md
+# What the matrix pipe SUSTAINS on this chip with N(0,1) bf16 operands and nothing else running
+# (tools/probe_mfma_peak.hip, profiles/r01_probe_mfma_peak.txt): the power management settles at
+# ~1.50 GHz instead of 2.4 GHz (zero operands: 2451 TF at 2.35 GHz).  Reported next to the spec peak.
+SUSTAINED_TFLOPS_RANDOM = {"bf16": 1560.0, "f16": 1560.0}
 
 # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
 # process): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes
@@ -204,6 +208,9 @@ def main():
         "mfma_tflops": round(achieved_tflops * world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4),
+                     "sustained_peak_random_operands": SUSTAINED_TFLOPS_RANDOM.get(w["dtype"]),
+                     "frac_of_sustained": (round(achieved_tflops / SUSTAINED_TFLOPS_RANDOM[w["dtype"]], 4)
+                                           if w["dtype"] in SUSTAINED_TFLOPS_RANDOM else None),
                      "traffic": (MEASURED_TRAFFIC_BYTES.get((args.workload, kernels[types[0]].variant)) or {}).get("bytes"),
                      "traffic_unit": "bytes/launch (HBM, PMC)",
                      "traffic_source": (MEASURED_TRAFFIC_BYTES.get((args.workload, kernels[types[0]].variant)) or {}).get("source"),

@@ -26,8 +26,8 @@
 
 namespace mfa {
 
-template <int D, int NW, int RB, int RING = 3> constexpr int fwd16v2_lds_bytes() {
-  constexpr int ring = RING * 2 * 64 * D * 2;
+template <int D, int NW, int RB, int RING = 3, int KPADB = 0> constexpr int fwd16v2_lds_bytes() {
+  constexpr int ring = RING * (2 * 64 * D * 2 + 64 * KPADB);
   constexpr int epi = NW * RB * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }

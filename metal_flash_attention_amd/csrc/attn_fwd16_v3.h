@@ -18,19 +18,32 @@
 
 namespace mfa {
 
+// VD (bit mask; tools/probe_valu.hip shows that ONE wave issues at most one VALU instruction per ~7.3
+// cycles whatever its kind, so the NUMBER of instructions per wave is what could matter):
+//   1 = (removed) softmax arithmetic on register pairs through inline-asm v_pk_fma_f32 / v_pk_add_f32:
+//       -23 % VALU instructions, no measurable gain, and the asm consumers of v_exp_f32 results escape
+//       hipcc's trans-use hazard handling;
+//   2 = K rows padded by 16 bytes in LDS instead of XOR-swizzled: equally conflict-free for ds_read_b128
+//       (row stride = 16 mod 256 bytes), and the eight fragment addresses of a lane become ONE register
+//       plus immediates instead of eight registers each needing a v_add_u32 with the stage base.
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false, bool DMA = false,
-          bool CAUSAL = false>
+          bool CAUSAL = false, int VD = 0>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BC = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
-  constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 2 * TILE;
+  constexpr bool KPAD = (VD & 2) != 0;
+  constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
+  static_assert(!(KPAD && DMA), "LDS-DMA staging writes the swizzled image");
 
   // schedule options packed in ABL (0 = plain): 5 = QK MFMAs as inline asm (VGPR result, Q fragments in
   // AGPRs); 6 = 5 + row sum on the matrix pipe (all-ones A operand)
+  // timing-only ablations (WRONG RESULTS): 20 = no fragment reads from LDS in the loop, 21 = no softmax
+  // arithmetic (P = S converted), 22 = both
+  constexpr bool NOLDS = (ABL == 20 || ABL == 22), NOSOFTMAX = (ABL == 21 || ABL == 22);
   constexpr bool ASMQK = (ABL == 5 || ABL == 6);
   constexpr bool MSUM = (ABL == 6);
   const int tid = threadIdx.x;
@@ -103,8 +116,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       const bool valid = c * 8 < Dr;
       koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
       voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
-      klds[i] = row * ROWB + kswz<D>(row, c) * 16;
-      vlds[i] = TILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+      klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
+      vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
     }
   }
   u32x4 kreg[DMA ? 1 : NCH], vreg[DMA ? 1 : NCH];
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int i = 0; i < NCH; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
         __builtin_amdgcn_raw_ptr_buffer_load_lds(kres, (lds_ptr)(base + i * 1024), 16, koff[i], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + TILE + i * 1024), 16, voff[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + KTILE + i * 1024), 16, voff[i], 0, 0, 0);
 #endif
         koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
         voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
@@ -146,10 +159,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   };
 
   const int n16 = lane & 15;
-  const int vtr_off = TILE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
+  const int vtr_off = KTILE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
   int kread[NKS];
 #pragma unroll
-  for (int t = 0; t < NKS; ++t) kread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
+  for (int t = 0; t < NKS; ++t) kread[t] = q * ROWB + (KPAD ? 2 * t + hi : kswz<D>(q, 2 * t + hi)) * 16;
 
   // S^T for the 32 keys of half `kb` of the tile in `stage`: one K fragment feeds RB MFMAs
   auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     f32x16 s2[RB];   // ABL == 4: second accumulator for odd k-steps (breaks the 8-deep dependent chain)
 #pragma unroll
     for (int t = 0; t < NKS; ++t) {
-      const v8 kf = *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
+      const v8 kf = NOLDS ? qf[0][(t + 1) % NKS] : *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
         if (t == 0 && !ASMQK) {
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     }
   };
   auto block_max = [&](const f32x16 (&s)[RB], float (&m_new)[RB]) {   // onlineReduceMaximum
+    if constexpr (NOSOFTMAX) { m_new[0] = 0.f; return; }
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       float mx0 = fmaxf(s[b][0], s[b][1]), mx1 = fmaxf(s[b][2], s[b][3]);
@@ -260,14 +274,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       const float mb = m[b];
-      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (!NOSOFTMAX) {
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = (ABL == 2) ? s[b][r] * a.scale2 - mb : fast_exp2(s[b][r] * a.scale2 - mb);
-        s[b][r] = p;
-        if constexpr (!MSUM) ps[r & 3] += p;
+        for (int r = 0; r < 16; ++r) {
+          const float p = (ABL == 2) ? s[b][r] * a.scale2 - mb : fast_exp2(s[b][r] * a.scale2 - mb);
+          s[b][r] = p;
+          if constexpr (!MSUM) ps[r & 3] += p;
+        }
+        if constexpr (!MSUM) l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
       }
-      if constexpr (!MSUM) l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {   // MFMA step u (16 keys) uses registers 8u .. 8u+7
         v8 pk;
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
         const char *vp = Vs + (db * BC + 16 * u) * 64;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
         const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
-        const v8 vf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        const v8 vf = NOLDS ? qf[0][(2 * db + u) % NKS] : __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
         for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf, pf[b][u], o[b][db]);
       }
@@ -404,14 +420,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   mask_causal(s0, tile0 * BC);
   block_max(s0, m_new);
 
-  int st_cur = 0, st_next = 1;
+  int st_cur_rt = 0, st_next_rt = 1;
   // iteration j: s0 = S(tile j, keys 0-31) and its block maximum are ready on entry
   // RING == 3: tile j+1 replaces tile j-2, whose last reader finished before the barrier of the
   // previous iteration, so one barrier per tile suffices.  RING == 2 (head dimensions whose three
   // stages would not fit the 160 KiB LDS): tile j+1 replaces tile j-1, still being read by slower
   // waves until they reach this iteration's first barrier -- write after it, and publish the tile
   // with a second barrier before step B reads it.
-  auto iteration = [&](int j, bool next_is_last) {
+  auto iteration = [&](int j, bool next_is_last, int st_cur, int st_next) {
     rescale_if_needed(m_new);
     if constexpr (DMA) {
       // tile j+1 landed during the previous iteration (its DMA is drained by the vmcnt(0) hipcc puts in
@@ -451,12 +467,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
     mask_causal(s0, (tile0 + j + 1) * BC);
     block_max(s0, m_new);
-    st_cur = st_next;
-    st_next = (st_next == RING - 1) ? 0 : st_next + 1;
+  };
+  auto advance = [&]() {
+    st_cur_rt = st_next_rt;
+    st_next_rt = (st_next_rt == RING - 1) ? 0 : st_next_rt + 1;
   };
   int j = 0;
-  for (; j + 2 < ntiles; ++j) iteration(j, false);
-  if (j + 1 < ntiles) { iteration(j, true); ++j; }
+  for (; j + 2 < ntiles; ++j) { iteration(j, false, st_cur_rt, st_next_rt); advance(); }
+  if (j + 1 < ntiles) { iteration(j, true, st_cur_rt, st_next_rt); advance(); ++j; }
+  const int st_cur = st_cur_rt;
   // last tile (j = ntiles-1): both halves, no successor
   rescale_if_needed(m_new);
   qk(st_cur, 1, s1);

@@ -4,11 +4,11 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool DMA = false>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool DMA = false, int VD = 0>
 static void launch_v3(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, DMA>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
-                     (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, DMA, false, VD>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+                     (fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>()), stream, args, g);
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3>
@@ -20,17 +20,17 @@ static void launch_v3_split(dim3 grid, uint32_t splits, float *wsO, float *wsML,
   hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool DMA = false>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool DMA = false, int VD = 0>
 static void fill(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, DMA>);
+  v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, DMA, false, VD>);
   v->name = name;
   v->parallelization = NW * RB * 32;
   v->traversal = 64;
   v->headBlock = D;
   v->threads = NW * 64;
-  v->ldsBytes = fwd16v2_lds_bytes<D, NW, RB, RING>();
+  v->ldsBytes = fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>();
   v->cacheLeft = true;
-  v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, DMA>;
+  v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, DMA, VD>;
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE>
@@ -73,6 +73,11 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 22) { fill<__bf16, 128, 4, 2, 8, 0, 5, 3, true>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_vq_dma"); return true; }
     if (D == 128 && impl == 30) { fill<__bf16, 128, 8, 1, 8, 1, 9>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_sgb"); return true; }
     if (D == 128 && impl == 31) { fill<__bf16, 128, 4, 2, 8, 1, 9>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_sgb"); return true; }
+    if (D == 128 && impl == 50) { fill<__bf16, 128, 8, 1, 8, 0, 20>(out, "ablate_no_lds_reads_WRONG_RESULTS"); return true; }
+    if (D == 128 && impl == 51) { fill<__bf16, 128, 8, 1, 8, 0, 21>(out, "ablate_no_softmax_WRONG_RESULTS"); return true; }
+    if (D == 128 && impl == 52) { fill<__bf16, 128, 8, 1, 8, 0, 22>(out, "ablate_no_lds_reads_no_softmax_WRONG_RESULTS"); return true; }
+    if (D == 128 && impl == 41) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, false, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_kpad"); return true; }
+    if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, false, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
     if (D == 128 && impl == 13) { fill<__bf16, 128, 8, 1, 8, 0, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_splitacc"); return true; }
     if (D == 128 && impl == 12) { fill<__bf16, 128, 8, 1, 8, 0, 3>(out, "ablate_one_k_fragment_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }

@@ -1,0 +1,59 @@
+// attn_dkv16_rs.hip -- instantiations of the role-split backwardKeyValue kernel (attn_dkv16_rs.h).
+#include "attn_dkv16_rs.h"
+#include "launchers.h"
+
+namespace mfa {
+
+template <typename T, int D, typename TG, bool CAUSAL, int ABL = 0>
+static void launch_rs(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, CAUSAL, ABL>), dim3(grid.x * grid.y * grid.z), dim3(512), (dkv16rs_lds_bytes<D>()), stream,
+                     args, g);
+}
+
+template <typename T, int D, typename TG = T>
+static void fill(VariantInfo *v, const char *name) {
+  v->func = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false>);
+  v->name = name;
+  v->parallelization = 128;   // key columns per workgroup: 4 wave pairs x 32
+  v->traversal = 32;
+  v->headBlock = D;
+  v->threads = 512;
+  v->ldsBytes = dkv16rs_lds_bytes<D>();
+  v->cacheLeft = true;
+  v->launch = &launch_rs<T, D, TG, false>;
+  v->launchCausal = &launch_rs<T, D, TG, true>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, true>);
+  v->causal = true;
+}
+
+bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
+  if (impl >= 1 && impl <= 4 && precision == PREC_BF16 && gprecision == PREC_BF16 && D == 128) {   // timing-only ablations
+    fill<__bf16, 128>(out, "ablate_dkv16rs_WRONG_RESULTS");
+    out->launchCausal = nullptr; out->funcCausal = nullptr; out->causal = false;
+    switch (impl) {
+      case 1: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 1>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 1>; break;
+      case 2: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 2>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 2>; break;
+      case 3: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 3>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 3>; break;
+      default: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 4>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 4>; break;
+    }
+    return true;
+  }
+  if (precision == PREC_FP16 && gprecision == PREC_BF16) {
+    if (D == 128) { fill<_Float16, 128, __bf16>(out, "attn_dkv16rs_f16_dObf16_d128_p4x32"); return true; }
+    if (D == 64) { fill<_Float16, 64, __bf16>(out, "attn_dkv16rs_f16_dObf16_d64_p4x32"); return true; }
+    return false;
+  }
+  if (precision != gprecision) return false;
+  if (precision == PREC_BF16) {
+    if (D == 128) { fill<__bf16, 128>(out, "attn_dkv16rs_bf16_d128_p4x32"); return true; }
+    if (D == 64) { fill<__bf16, 64>(out, "attn_dkv16rs_bf16_d64_p4x32"); return true; }
+  }
+  if (precision == PREC_FP16) {
+    if (D == 128) { fill<_Float16, 128>(out, "attn_dkv16rs_f16_d128_p4x32"); return true; }
+    if (D == 64) { fill<_Float16, 64>(out, "attn_dkv16rs_f16_d64_p4x32"); return true; }
+  }
+  return false;
+}
+
+} // namespace mfa

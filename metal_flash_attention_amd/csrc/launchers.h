@@ -43,5 +43,7 @@ bool fwd16_v4_variant(int precision, int D, int impl, VariantInfo *out);
 // (gprecision = storage type of dO: the same 16-bit type, or BF16 next to FP16 Q/K/V)
 bool dq16_variant(int precision, int gprecision, int D, VariantInfo *out);
 bool dkv16_variant(int precision, int gprecision, int D, VariantInfo *out);
+// role-split wave pairs: one wave of a SIMD accumulates dV, its partner dK (see attn_dkv16_rs.h)
+bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInfo *out);
 
 } // namespace mfa

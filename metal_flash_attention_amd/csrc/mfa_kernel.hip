@@ -121,7 +121,14 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         fast = dq16_variant(pq, pg, bucket, &variant);
       if (type == MFA_BACKWARD_KEY_VALUE && kdesc->memoryPrecisions[MFA_dK] == MFA_FP32 &&
           kdesc->memoryPrecisions[MFA_dV] == MFA_FP32 && !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV])
-        fast = dkv16_variant(pq, pg, bucket, &variant);
+      {
+        // MFA_DKV16_IMPL (developer knob for A/B runs): "w4" = one wave per key block (attn_dkv16), "rs:<n>" =
+        // role-split wave pairs, ablation n.  Default: role-split wave pairs (attn_dkv16_rs).
+        const char *knob = std::getenv("MFA_DKV16_IMPL");
+        const bool wantW4 = knob && (std::strcmp(knob, "w4") == 0 || knob[0] == '0');
+        if (!wantW4) fast = dkv16_rs_variant(pq, pg, bucket, (knob && std::strncmp(knob, "rs:", 3) == 0) ? std::atoi(knob + 3) : 0, &variant);
+        if (!fast) fast = dkv16_variant(pq, pg, bucket, &variant);
+      }
     }
   }
   if (found && !fast) variant = general;

@@ -361,18 +361,22 @@ BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), 
                 (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64)]
 
 
+@pytest.mark.parametrize("dkv_impl", ["w4", "rs"])
 @pytest.mark.parametrize("shape", BWD16_SHAPES)
-def test_backward_16bit_mfma(shape):
-    """All three kernels on the BF16 matrix cores (Q, K, V, dO BF16): within the reference's mixed
+def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
+    """dkv_impl: one wave per key block / role-split wave pairs (attn_dkv16_rs.h).
+    All three kernels on the BF16 matrix cores (Q, K, V, dO BF16): within the reference's mixed
     tolerances of the oracle fed with the rounded inputs, and within a tighter bound (2e-2 absolute on
     the gradients, whose dS is rounded to BF16 like the reference's register precision for dS,
     AttentionDescriptor+Precisions.swift:199-200)."""
+    monkeypatch.setenv("MFA_DKV16_IMPL", dkv_impl)
     R, C, D = shape
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
     run = harness.DeviceRun(desc, net)
     variants = {t.name: k.variant for t, k in run.kernels.items()}
     assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
+    assert ("attn_dkv16rs" in variants["backwardKeyValue"]) == (dkv_impl == "rs"), variants
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run()

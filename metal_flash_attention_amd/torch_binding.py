@@ -1,0 +1,100 @@
+"""PyTorch-ROCm binding of the three attention kernels (the "caller" layer the
+reference does not have -- only its tests call the kernels, Tests/FlashAttentionTests/Attention/*.swift).
+
+    from metal_flash_attention_amd.torch_binding import flash_attention
+    o = flash_attention(q, k, v, causal=False)      # q [B, H, R, D], k / v [B, H, C, D]; bf16, fp16 or fp32
+    o.sum().backward()                              # dQ, dK, dV through backwardQuery / backwardKeyValue
+
+forward  = AttentionKernelType.forward           -> O (fp32), L (fp32, saved for backward)
+backward = AttentionKernelType.backwardQuery     -> D, dQ      (needs O, dO, L)
+           AttentionKernelType.backwardKeyValue  -> dK, dV     (needs L, D)
+exactly the dispatch order of the reference's test (SquareAttentionTest.swift:355-368).  torch owns the
+device memory and the stream; all arithmetic happens in libmfa_hip.so (no eager fallback: a missing
+library or a CPU tensor raises).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+from .attention import (AttentionDescriptor, AttentionKernel, AttentionKernelType, AttentionOperand as Op,
+                        GEMMOperandPrecision as P)
+
+_KERNELS: Dict[Tuple, AttentionKernel] = {}
+
+
+def _kernel(dtype: torch.dtype, R: int, C: int, D: int, kind: AttentionKernelType) -> AttentionKernel:
+    key = (dtype, R, C, D, kind)
+    k = _KERNELS.get(key)
+    if k is None:
+        desc = AttentionDescriptor()
+        desc.lowPrecisionInputs = dtype != torch.float32
+        if dtype != torch.float32:
+            desc.lowPrecisionInputType = P.BF16 if dtype == torch.bfloat16 else P.FP16
+        desc.lowPrecisionIntermediates = False
+        desc.matrixDimensions = (R, C, D)
+        desc.transposeState = (False, False, False, False)
+        k = _KERNELS[key] = AttentionKernel(desc.kernelDescriptor(kind))
+    return k
+
+
+def _check(q, k, v):
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise RuntimeError("flash_attention: tensors must live on the GPU (there is no CPU path)")
+    if q.dtype not in (torch.bfloat16, torch.float16, torch.float32) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise TypeError("flash_attention: q, k, v must share one of bfloat16 / float16 / float32")
+    if q.dim() != 4 or k.dim() != 4 or v.shape != k.shape or q.shape[:2] != k.shape[:2] or q.shape[3] != k.shape[3]:
+        raise ValueError("flash_attention: expected q [B, H, R, D] and k, v [B, H, C, D]")
+
+
+def _strides(B, H, R, C, D):
+    hs = {Op.Q: R * D, Op.K: C * D, Op.V: C * D, Op.O: R * D, Op.L: R, Op.D: R,
+          Op.dO: R * D, Op.dV: C * D, Op.dK: C * D, Op.dQ: R * D}
+    return hs, {op: s * H for op, s in hs.items()}
+
+
+class _FlashAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool):
+        _check(q, k, v)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, H, R, D = q.shape
+        C = k.shape[2]
+        o = torch.empty((B, H, R, D), dtype=torch.float32, device=q.device)
+        l = torch.empty((B, H, R), dtype=torch.float32, device=q.device)
+        kernel = _kernel(q.dtype, R, C, D, AttentionKernelType.forward)
+        hs, bs = _strides(B, H, R, C, D)
+        need = kernel.workspaceSize(row=R, column=C, heads=H, batches=B)
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal else None
+        kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
+                        headStrides=hs, batchStrides=bs, stream=torch.cuda.current_stream().cuda_stream,
+                        workspace=ws, causal=causal)
+        ctx.save_for_backward(q, k, v, o, l)
+        ctx.causal = causal
+        return o.to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        q, k, v, o, l = ctx.saved_tensors
+        B, H, R, D = q.shape
+        C = k.shape[2]
+        # dO in the kernels' gradient storage type (AttentionDescriptor+Precisions.swift:13-17): BF16 whenever
+        # the inputs are 16-bit (also next to FP16 Q/K/V, the reference's mix), FP32 with FP32 inputs
+        do = grad_out.to(torch.float32 if q.dtype == torch.float32 else torch.bfloat16).contiguous()
+        dq = torch.empty((B, H, R, D), dtype=torch.float32, device=q.device)
+        dk = torch.empty((B, H, C, D), dtype=torch.float32, device=q.device)
+        dv = torch.empty((B, H, C, D), dtype=torch.float32, device=q.device)
+        dterm = torch.empty((B, H, R), dtype=torch.float32, device=q.device)
+        bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
+        hs, bs = _strides(B, H, R, C, D)
+        stream = torch.cuda.current_stream().cuda_stream
+        for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
+            _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
+                                                     batchStrides=bs, stream=stream, causal=ctx.causal)
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None
+
+
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False) -> torch.Tensor:
+    """softmax(q k^T / sqrt(D)) v per (batch, head); causal: row r sees column c iff c <= r + (C - R)."""
+    return _FlashAttention.apply(q, k, v, causal)

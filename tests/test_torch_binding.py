@@ -1,0 +1,60 @@
+"""PyTorch autograd binding (metal_flash_attention_amd/torch_binding.py): forward and gradients against a
+plain fp32 torch implementation of the same function on the same (rounded) inputs."""
+import math
+
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def reference(q, k, v, causal):
+    q, k, v = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    s = q @ k.transpose(-1, -2) / math.sqrt(q.shape[-1])
+    if causal:
+        R, C = s.shape[-2:]
+        mask = torch.arange(C, device=s.device)[None, :] <= torch.arange(R, device=s.device)[:, None] + (C - R)
+        s = s.masked_fill(~mask, float("-inf"))
+    o = torch.softmax(s, dim=-1) @ v
+    return q, k, v, o
+
+
+def test_cpu_tensors_are_refused():
+    from metal_flash_attention_amd.torch_binding import flash_attention
+    q = torch.zeros(1, 1, 8, 16)
+    with pytest.raises(RuntimeError, match="GPU"):
+        flash_attention(q, q, q)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("shape", [(2, 3, 200, 200, 64), (1, 2, 129, 300, 128), (1, 1, 64, 64, 40)])
+def test_forward_and_gradients_match_torch(shape, causal, dtype, tol):
+    from metal_flash_attention_amd.torch_binding import flash_attention
+    B, H, R, C, D = shape
+    g = torch.Generator(device="cuda").manual_seed(R + C)
+    q = torch.randn(B, H, R, D, generator=g, device="cuda").to(dtype).requires_grad_(True)
+    k = torch.randn(B, H, C, D, generator=g, device="cuda").to(dtype).requires_grad_(True)
+    v = torch.randn(B, H, C, D, generator=g, device="cuda").to(dtype).requires_grad_(True)
+    w = torch.randn(B, H, R, D, generator=g, device="cuda").to(dtype)          # upstream gradient
+    o = flash_attention(q, k, v, causal=causal)
+    assert o.dtype == dtype and o.shape == (B, H, R, D)
+    o.backward(w)
+    qr, kr, vr, orf = reference(q, k, v, causal)
+    orf.backward(w.float())
+    assert (o.float() - orf).abs().max().item() < tol
+    for got, ref, name in ((q.grad, qr.grad, "dQ"), (k.grad, kr.grad, "dK"), (v.grad, vr.grad, "dV")):
+        assert got.dtype == dtype
+        assert (got.float() - ref).abs().max().item() < max(tol, 5e-2 if dtype != torch.float32 else 0), name
+
+
+@pytest.mark.gpu
+def test_long_single_head_uses_split_kv_workspace():
+    from metal_flash_attention_amd.torch_binding import flash_attention
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q = torch.randn(1, 1, 256, 64, generator=g, device="cuda").bfloat16()
+    k = torch.randn(1, 1, 8192, 64, generator=g, device="cuda").bfloat16()
+    v = torch.randn(1, 1, 8192, 64, generator=g, device="cuda").bfloat16()
+    o = flash_attention(q, k, v)
+    _, _, _, ref = reference(q, k, v, False)
+    assert (o.float() - ref).abs().max().item() < 2e-2

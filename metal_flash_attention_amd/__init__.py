@@ -18,3 +18,4 @@ from .attention import (  # noqa: F401
     selectParameterRow,
     setParameterFile,
 )
+from .gemm import GEMMDescriptor, GEMMKernel, GEMMKernelDescriptor  # noqa: F401,E402

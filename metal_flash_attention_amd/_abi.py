@@ -92,6 +92,62 @@ class mfa_launch_params(ctypes.Structure):
 _P = ctypes.POINTER
 _KERNEL = ctypes.c_void_p
 _BUFS = ctypes.c_void_p * MFA_BUFFER_SLOTS
+class mfa_gemm_descriptor(ctypes.Structure):   # include/mfa_gemm.h
+    _fields_ = [
+        ("batchDimension", ctypes.c_uint32),
+        ("hasLeadingDimensions", ctypes.c_uint8), ("loadPreviousC", ctypes.c_uint8),
+        ("hasMatrixDimensions", ctypes.c_uint8), ("hasMemoryPrecisions", ctypes.c_uint8),
+        ("hasTransposeState", ctypes.c_uint8), ("transposeA", ctypes.c_uint8), ("transposeB", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8),
+        ("leadingDimensionA", ctypes.c_uint32), ("leadingDimensionB", ctypes.c_uint32), ("leadingDimensionC", ctypes.c_uint32),
+        ("M", ctypes.c_uint32), ("N", ctypes.c_uint32), ("K", ctypes.c_uint32),
+        ("precisionA", ctypes.c_int32), ("precisionB", ctypes.c_int32), ("precisionC", ctypes.c_int32),
+    ]
+
+
+class mfa_gemm_kernel_descriptor(ctypes.Structure):
+    _fields_ = [
+        ("blockM", ctypes.c_uint16), ("blockN", ctypes.c_uint16), ("blockK", ctypes.c_uint16),
+        ("leadingBlockA", ctypes.c_uint16), ("leadingBlockB", ctypes.c_uint16), ("leadingBlockC", ctypes.c_uint16),
+        ("memoryPrecisionA", ctypes.c_int32), ("memoryPrecisionB", ctypes.c_int32), ("memoryPrecisionC", ctypes.c_int32),
+        ("registerPrecisionA", ctypes.c_int32), ("registerPrecisionB", ctypes.c_int32), ("registerPrecisionC", ctypes.c_int32),
+        ("splitsM", ctypes.c_uint16), ("splitsN", ctypes.c_uint16),
+        ("preferAsyncLoad", ctypes.c_uint8), ("preferAsyncStore", ctypes.c_uint8),
+        ("transposeA", ctypes.c_uint8), ("transposeB", ctypes.c_uint8),
+        ("complete", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 3),
+    ]
+
+
+class mfa_gemm_launch_params(ctypes.Structure):
+    _fields_ = [
+        ("M", ctypes.c_uint32), ("N", ctypes.c_uint32), ("K", ctypes.c_uint32),
+        ("leadingDimensionA", ctypes.c_uint32), ("leadingDimensionB", ctypes.c_uint32), ("leadingDimensionC", ctypes.c_uint32),
+        ("loadPreviousC", ctypes.c_uint32), ("batchDimension", ctypes.c_uint32),
+        ("batchStrideA", ctypes.c_uint64), ("batchStrideB", ctypes.c_uint64), ("batchStrideC", ctypes.c_uint64),
+    ]
+
+
+_GEMM = ctypes.c_void_p
+
+GEMM_SYMBOLS = [
+    ("mfa_gemm_descriptor_init", None, [ctypes.POINTER(mfa_gemm_descriptor)]),
+    ("mfa_gemm_launch_params_init", None, [ctypes.POINTER(mfa_gemm_launch_params)]),
+    ("mfa_gemm_descriptor_kernel_descriptor", ctypes.c_int,
+     [ctypes.POINTER(mfa_gemm_descriptor), ctypes.POINTER(mfa_gemm_kernel_descriptor)]),
+    ("mfa_gemm_kernel_create", ctypes.c_int, [ctypes.POINTER(mfa_gemm_kernel_descriptor), ctypes.POINTER(_GEMM)]),
+    ("mfa_gemm_kernel_destroy", None, [_GEMM]),
+    ("mfa_gemm_kernel_block_dimensions", ctypes.c_int,
+     [_GEMM, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16)]),
+    ("mfa_gemm_kernel_threadgroup_size", ctypes.c_uint32, [_GEMM]),
+    ("mfa_gemm_kernel_threadgroup_memory_allocation", ctypes.c_uint32, [_GEMM]),
+    ("mfa_gemm_kernel_variant", ctypes.c_char_p, [_GEMM]),
+    ("mfa_gemm_kernel_launch", ctypes.c_int,
+     [_GEMM, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(mfa_gemm_launch_params), ctypes.c_void_p]),
+    ("mfa_gemm_kernel_time", ctypes.c_int,
+     [_GEMM, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(mfa_gemm_launch_params), ctypes.c_void_p,
+      ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+]
+
 SYMBOLS = [
     ("mfa_precision_name", ctypes.c_char_p, [ctypes.c_int]),
     ("mfa_precision_size", ctypes.c_int, [ctypes.c_int]),
@@ -155,7 +211,7 @@ def lib() -> ctypes.CDLL:
     except ImportError:
         pass
     handle = ctypes.CDLL(LIB_PATH)
-    for name, restype, argtypes in SYMBOLS:
+    for name, restype, argtypes in SYMBOLS + GEMM_SYMBOLS:
         fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
         fn.restype = restype
         fn.argtypes = argtypes

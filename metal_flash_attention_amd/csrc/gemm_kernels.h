@@ -1,0 +1,278 @@
+// gemm_kernels.h -- GEMM operator kernels for gfx950.
+//
+//   C[m][n] = sum_k A(m, k) B(k, n) (+ previous C)      reference: Sources/FlashAttention/GEMM/GEMMKernel/
+//   (GEMMKernel+Source.swift:9-84 kernel body, GEMMKernel+Multiply.swift:113-212 the K loop,
+//    GEMMKernel+Caching.swift accumulator load/store with the optional previous C).
+//
+// Two code objects, both 256 work-items = 2 x 2 waves, each wave owning a 64 x 64 block of C as 2 x 2 MFMA
+// tiles (the reference's "splits" (2, 2), GEMMDescriptor.swift:207-211, re-derived for 64-wide waves and
+// 32 x 32 matrix-core tiles instead of 8 x 8 simdgroup matrices):
+//
+// * gemm_f32mfma: every storage-precision mix, transpose state, leading dimension, alignment and ragged
+//   edge.  Operands are converted to fp32 while staged (element-wise, bounds-checked; BF16 by bit
+//   placement, GEMMHeaders.swift:402-409) and multiplied with v_mfma_f32_32x32x2_f32, which is exact fp32
+//   FMA arithmetic -- what the reference's FP32 register precision asks for.  Roofline: 157 TFLOP/s.
+// * gemm_16: A and B in the same 16-bit type with 16-byte-aligned rows.  16-byte chunks are copied to LDS
+//   unchanged (bounds-checked buffer loads, zeros outside the matrix) into one of the two images the
+//   attention kernels use -- k-contiguous rows for ds_read_b128 when the operand's memory is k-major,
+//   [x/32][k][32] for ds_read_b64_tr_b16 when it is not -- and multiplied with v_mfma_f32_32x32x16.
+//   Roofline: 2.5 PFLOP/s spec, 1.56 PFLOP/s sustained on random operands.
+//
+// Both accumulate in fp32 whatever the C storage type (the reference accumulates in FP16 when A, B and C
+// are all FP16, GEMMDescriptor.swift:188-193; fp32 is at least as accurate), then add the previous C if
+// asked and store with the reference's rounding: FP16 round-to-nearest, BF16 truncation.
+#pragma once
+#include "attn_fwd16.h"
+
+namespace mfa {
+
+struct GemmArgs {
+  const void *A, *B;
+  void *C;
+  uint32_t M, N, K, ldA, ldB, ldC;
+  int32_t precA, precB, precC;
+  int32_t transA, transB, loadC;
+  uint64_t bsA, bsB, bsC;   // batch strides, elements
+};
+
+// epilogue shared by both kernels: acc[mb][nb] holds C rows (bm + 32 mb + crow(r, hi)), column bn + 32 nb + (lane & 31)
+__device__ __forceinline__ void gemm_store(const GemmArgs &g, char *C, const f32x16 (&acc)[2][2], int row0, int col0, int lane) {
+  const int i = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const uint32_t col = col0 + 32 * nb + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t row = row0 + 32 * mb + crow(r, hi);
+        if (row < g.M && col < g.N) {
+          const int64_t idx = (int64_t)row * g.ldC + col;
+          float v = acc[mb][nb][r];
+          if (g.loadC) v += load_elem(C, idx, g.precC);
+          store_elem(C, idx, g.precC, v);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// general kernel: fp32 arithmetic, element-wise staging
+// ------------------------------------------------------------------------------------------------
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_F32_BK = 16, GEMM_F32_BKP = GEMM_F32_BK + 4;
+
+__global__ __launch_bounds__(256) void gemm_f32mfma(const GemmArgs g) {
+  constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_F32_BK, BKP = GEMM_F32_BKP, PER = BM * BK / 256;
+  __shared__ __attribute__((aligned(16))) float As[2][BM * BKP];   // [m][k], k contiguous, pitch 20 floats (80 B:
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * BKP];   //  16 rows of a ds_read_b128 group hit 16 distinct 16-byte slots)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+  const uint32_t bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const char *A = (const char *)g.A + (uint64_t)blockIdx.z * g.bsA * elem_size(g.precA);
+  const char *B = (const char *)g.B + (uint64_t)blockIdx.z * g.bsB * elem_size(g.precB);
+  char *C = (char *)g.C + (uint64_t)blockIdx.z * g.bsC * elem_size(g.precC);
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+  // per-thread staging slots: the index that is contiguous in MEMORY runs fastest over the threads
+  int64_t aoff[PER], boff[PER];
+  int alds[PER], blds[PER], ak[PER], bk[PER];
+  bool aok[PER], bok[PER];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int idx = tid + 256 * e;
+    const int m = g.transA ? idx % BM : idx / BK, ka = g.transA ? idx / BM : idx % BK;
+    const int n = g.transB ? idx / BK : idx % BN, kb = g.transB ? idx % BK : idx / BN;
+    aok[e] = bm + m < g.M;
+    bok[e] = bn + n < g.N;
+    ak[e] = ka;
+    bk[e] = kb;
+    aoff[e] = g.transA ? (int64_t)ka * g.ldA + (bm + m) : (int64_t)(bm + m) * g.ldA + ka;
+    boff[e] = g.transB ? (int64_t)(bn + n) * g.ldB + kb : (int64_t)kb * g.ldB + (bn + n);
+    alds[e] = m * BKP + ka;
+    blds[e] = n * BKP + kb;
+  }
+  const int64_t astep = g.transA ? (int64_t)BK * g.ldA : BK, bstep = g.transB ? BK : (int64_t)BK * g.ldB;
+  float ra[PER], rb[PER];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      ra[e] = (aok[e] && k0 + ak[e] < g.K) ? load_elem(A, aoff[e], g.precA) : 0.f;
+      rb[e] = (bok[e] && k0 + bk[e] < g.K) ? load_elem(B, boff[e], g.precB) : 0.f;
+      aoff[e] += astep;
+      boff[e] += bstep;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+      As[buf][alds[e]] = ra[e];
+      Bs[buf][blds[e]] = rb[e];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const uint32_t nk = (g.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (uint32_t kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);   // next tile in flight while this one is multiplied
+#pragma unroll
+    for (int j = 0; j < BK / 8; ++j) {
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = *reinterpret_cast<const f32x4 *>(&As[buf][(wm + 32 * t + i) * BKP + 8 * j + 4 * hi]);
+        b[t] = *reinterpret_cast<const f32x4 *>(&Bs[buf][(wn + 32 * t + i) * BKP + 8 * j + 4 * hi]);
+      }
+      // the MFMA contracts the k of lane-half 0 with the k of lane-half 1: element e of both halves
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb][e], b[nb][e], acc[mb][nb], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  gemm_store(g, C, acc, bm + wm, bn + wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit kernel: A and B in one 16-bit type, rows 16-byte aligned
+// ------------------------------------------------------------------------------------------------
+// LDS image of one operand tile (X = 128 rows of M or N, BK = 64 deep):
+//   KMAJOR (memory is k-contiguous: A not transposed, B transposed): [x][64 k], 128-byte rows, 16-byte chunk
+//     index XOR-swizzled by (x >> 1) & 7 (16 rows of a read group -> 16 distinct 16-byte slots); fragment = ds_read_b128.
+//   XMAJOR (memory is x-contiguous: A transposed, B not transposed): [x / 32][64 k][32 x] (64-byte rows);
+//     fragment = two ds_read_b64_tr_b16, exactly the V^T gather of the attention forward kernel.
+constexpr int GEMM16_BK = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_16(const GemmArgs g) {
+  typedef Frag16<T> F;
+  typedef typename F::v8 v8;
+  constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM16_BK, TILE = BM * BK * 2;   // 16 KiB per operand tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];                // 2 stages x (A | B) = 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
+  const uint32_t bm = blockIdx.y * BM, bn = blockIdx.x * BN;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+  const uint32_t ldA2 = g.ldA * 2, ldB2 = g.ldB * 2;
+  // buffer resources bound the matrices (rows x pitch): chunks outside read as zeros
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>((const char *)g.A + (uint64_t)blockIdx.z * g.bsA * 2), 0, (g.transA ? g.K : g.M) * ldA2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char *>((const char *)g.B + (uint64_t)blockIdx.z * g.bsB * 2), 0, (g.transB ? g.N : g.K) * ldB2, 0x00020000);
+  char *C = (char *)g.C + (uint64_t)blockIdx.z * g.bsC * elem_size(g.precC);
+
+  // staging: 1024 chunks of 16 bytes per operand tile, 4 per thread.
+  //   KMAJOR: chunk = (x, c) with c = 8-element group along k (8 per row);   global (x0 + x) * ld + k0 + 8c
+  //   XMAJOR: chunk = (k, c) with c = 8-element group along x (16 per row);  global (k0 + k) * ld + x0 + 8c
+  const bool akm = !g.transA, bkm = g.transB;
+  uint32_t aoff[4], boff[4], alds[4], blds[4];
+  auto plan = [&](bool kmajor, uint32_t x0, uint32_t X, uint32_t ld2, uint32_t (&off)[4], uint32_t (&lds)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      if (kmajor) {
+        const int x = idx >> 3, c = idx & 7;
+        // row inside the matrix and the chunk's first element inside the row (row tails beyond X*... are
+        // cut by k < K at run time through the offset, see advance)
+        off[e] = (x0 + x < X) ? (x0 + x) * ld2 + c * 16 : OOB;
+        lds[e] = x * 128 + ((c ^ ((x >> 1) & 7)) * 16);
+      } else {
+        const int k = idx >> 4, c = idx & 15;
+        off[e] = (x0 + 8 * c < X) ? k * ld2 + (x0 + 8 * c) * 2 : OOB;
+        lds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
+      }
+    }
+  };
+  plan(akm, bm, g.M, ldA2, aoff, alds);
+  plan(bkm, bn, g.N, ldB2, boff, blds);
+  // k-bound: KMAJOR chunks at k >= K must read zero: their row still lies inside the resource, so the test is
+  // explicit (K % 8 == 0 is a launch requirement for this kernel, so chunks never straddle K)
+  u32x4 ra[4], rb[4];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + 256 * e;
+      const uint32_t ka = akm ? k0 + 8 * (idx & 7) : k0 + (idx >> 4);
+      const uint32_t kb = bkm ? k0 + 8 * (idx & 7) : k0 + (idx >> 4);
+      ra[e] = __builtin_amdgcn_raw_buffer_load_b128(ares, ka < g.K ? aoff[e] : OOB, 0, 0);
+      rb[e] = __builtin_amdgcn_raw_buffer_load_b128(bres, kb < g.K ? boff[e] : OOB, 0, 0);
+      aoff[e] = __builtin_elementwise_add_sat(aoff[e], akm ? (uint32_t)BK * 2 : (uint32_t)BK * ldA2);
+      boff[e] = __builtin_elementwise_add_sat(boff[e], bkm ? (uint32_t)BK * 2 : (uint32_t)BK * ldB2);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char *base = smem + buf * 2 * TILE;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      *reinterpret_cast<u32x4 *>(base + alds[e]) = ra[e];
+      *reinterpret_cast<u32x4 *>(base + TILE + blds[e]) = rb[e];
+    }
+  };
+  // fragment of k-step s (16 k) for the 32 rows x0..x0+31 of a tile image
+  const int n16 = lane & 15;
+  // transposing gather in NATURAL k order (element j of lane-half hi = k 16 s + 8 hi + j, the order of the
+  // k-major ds_read_b128 fragment it may be paired with): the 16-lane groups address rows (n16 >> 2) + 8 hi
+  // and, for the second read, 4 rows further.  (The attention kernels use rows + 4 hi / + 8, a permuted
+  // order that matches their score registers; here the two operands of one MFMA can come from both images.)
+  const int tr_lane = ((n16 >> 2) + 8 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
+  auto fragment = [&](const char *img, bool kmajor, int x0, int s) -> v8 {
+    if (kmajor) {
+      const int x = x0 + i, c = 2 * s + hi;
+      return *reinterpret_cast<const v8 *>(img + x * 128 + ((c ^ ((x >> 1) & 7)) * 16));
+    }
+    const char *p = img + ((x0 >> 5) * BK + 16 * s) * 64 + tr_lane;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * 64));
+    return __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const uint32_t nk = (g.K + BK - 1) / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (uint32_t kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const char *Ai = smem + buf * 2 * TILE, *Bi = Ai + TILE;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      v8 a[2], b[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        a[t] = fragment(Ai, akm, wm + 32 * t, s);
+        b[t] = fragment(Bi, bkm, wn + 32 * t, s);
+      }
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = F::mfma(a[mb], b[nb], acc[mb][nb]);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+  gemm_store(g, C, acc, bm + wm, bn + wn, lane);
+}
+
+} // namespace mfa

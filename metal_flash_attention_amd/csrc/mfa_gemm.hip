@@ -1,0 +1,171 @@
+// mfa_gemm.hip -- host side of the GEMM operator (include/mfa_gemm.h): descriptor -> kernel descriptor,
+// code-object selection, launch.  Reference: Sources/FlashAttention/GEMM/GEMMDescriptor/GEMMDescriptor.swift,
+// GEMMKernelDescriptor.swift, GEMMKernel/GEMMKernel.swift.
+#include "../../include/mfa_gemm.h"
+#include "gemm_kernels.h"
+#include "mfa_internal.h"
+
+#include <cstring>
+#include <string>
+
+using namespace mfa;
+
+struct mfa_gemm_kernel {
+  mfa_gemm_kernel_descriptor desc;
+  bool fast16 = false;          // A and B in one 16-bit type: gemm_16 when the launch is 16-byte aligned
+  std::string name;
+};
+
+static bool valid_precision(int p) { return p == MFA_FP32 || p == MFA_FP16 || p == MFA_BF16; }
+
+extern "C" void mfa_gemm_descriptor_init(mfa_gemm_descriptor *d) {
+  if (!d) return;
+  std::memset(d, 0, sizeof(*d));
+  d->batchDimension = 1;
+}
+
+extern "C" void mfa_gemm_launch_params_init(mfa_gemm_launch_params *p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->batchDimension = 1;
+}
+
+// GEMMKernelDescriptor.init(descriptor:) (GEMMDescriptor.swift:98-322), with the device-dependent parts
+// re-derived for gfx950: one block shape per arithmetic (the reference picks 32x32 / 48x48 blocks by Apple
+// core count), 2 x 2 waves, operands multiplied in their own 16-bit type only when A and B share it
+// (one MFMA needs both operands in one type), otherwise promoted to FP32 as the reference does for BF16 on
+// pre-Apple9 GPUs (:195-202).
+extern "C" mfa_status mfa_gemm_descriptor_kernel_descriptor(const mfa_gemm_descriptor *d, mfa_gemm_kernel_descriptor *out) {
+  if (!d || !out) return fail(MFA_ERR_INVALID_ARGUMENT, "null pointer");
+  if (!d->hasMatrixDimensions || !d->hasMemoryPrecisions || !d->hasTransposeState)
+    return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, "Descriptor was incomplete.");   // GEMMDescriptor.swift:110
+  if (!valid_precision(d->precisionA) || !valid_precision(d->precisionB) || !valid_precision(d->precisionC))
+    return fail(MFA_ERR_INVALID_ARGUMENT, "unknown GEMMOperandPrecision");
+  std::memset(out, 0, sizeof(*out));
+  out->memoryPrecisionA = d->precisionA;
+  out->memoryPrecisionB = d->precisionB;
+  out->memoryPrecisionC = d->precisionC;
+  const bool fast16 = d->precisionA != MFA_FP32 && d->precisionA == d->precisionB;
+  out->registerPrecisionA = fast16 ? d->precisionA : MFA_FP32;
+  out->registerPrecisionB = fast16 ? d->precisionB : MFA_FP32;
+  out->registerPrecisionC = MFA_FP32;
+  out->blockM = GEMM_BM;
+  out->blockN = GEMM_BN;
+  out->blockK = fast16 ? GEMM16_BK : GEMM_F32_BK;
+  out->leadingBlockA = fast16 ? GEMM16_BK : GEMM_F32_BKP;
+  out->leadingBlockB = fast16 ? GEMM16_BK : GEMM_F32_BKP;
+  out->leadingBlockC = 0;              // C never passes through LDS
+  out->splitsM = 2;
+  out->splitsN = 2;
+  out->preferAsyncLoad = 0;            // no async-copy engine is used: plain global -> register -> LDS staging
+  out->preferAsyncStore = 0;
+  out->transposeA = d->transposeA ? 1 : 0;
+  out->transposeB = d->transposeB ? 1 : 0;
+  out->complete = 1;
+  return MFA_OK;
+}
+
+extern "C" mfa_status mfa_gemm_kernel_create(const mfa_gemm_kernel_descriptor *kd, mfa_gemm_kernel **out) {
+  if (!kd || !out) return fail(MFA_ERR_INVALID_ARGUMENT, "null pointer");
+  if (!kd->complete) return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, "Descriptor was incomplete.");
+  if (!valid_precision(kd->memoryPrecisionA) || !valid_precision(kd->memoryPrecisionB) || !valid_precision(kd->memoryPrecisionC))
+    return fail(MFA_ERR_INVALID_ARGUMENT, "unknown GEMMOperandPrecision");
+  auto *k = new mfa_gemm_kernel();
+  k->desc = *kd;
+  k->fast16 = kd->memoryPrecisionA != MFA_FP32 && kd->memoryPrecisionA == kd->memoryPrecisionB &&
+              kd->registerPrecisionA == kd->memoryPrecisionA;
+  // the object reports what it really uses
+  k->desc.blockM = GEMM_BM;
+  k->desc.blockN = GEMM_BN;
+  k->desc.blockK = k->fast16 ? GEMM16_BK : GEMM_F32_BK;
+  k->desc.splitsM = k->desc.splitsN = 2;
+  k->name = k->fast16 ? (kd->memoryPrecisionA == MFA_BF16 ? "gemm_16_bf16_128x128x64_w2x2" : "gemm_16_f16_128x128x64_w2x2")
+                      : "gemm_f32mfma_128x128x16_w2x2";
+  *out = k;
+  return MFA_OK;
+}
+
+extern "C" void mfa_gemm_kernel_destroy(mfa_gemm_kernel *k) { delete k; }
+
+extern "C" mfa_status mfa_gemm_kernel_block_dimensions(const mfa_gemm_kernel *k, uint16_t *M, uint16_t *N, uint16_t *K) {
+  if (!k) return fail(MFA_ERR_INVALID_ARGUMENT, "null kernel");
+  if (M) *M = k->desc.blockM;
+  if (N) *N = k->desc.blockN;
+  if (K) *K = k->desc.blockK;
+  return MFA_OK;
+}
+extern "C" uint32_t mfa_gemm_kernel_threadgroup_size(const mfa_gemm_kernel *k) { return k ? 256 : 0; }
+extern "C" uint32_t mfa_gemm_kernel_threadgroup_memory_allocation(const mfa_gemm_kernel *k) {
+  if (!k) return 0;
+  return k->fast16 ? 2 * 2 * GEMM_BM * GEMM16_BK * 2 : 2 * 2 * GEMM_BM * GEMM_F32_BKP * 4;
+}
+extern "C" const char *mfa_gemm_kernel_variant(const mfa_gemm_kernel *k) { return k ? k->name.c_str() : ""; }
+
+static mfa_status prepare(const mfa_gemm_kernel *k, const void *A, const void *B, void *C, const mfa_gemm_launch_params *p,
+                          GemmArgs *g, dim3 *grid, bool *use16) {
+  if (!k || !p) return fail(MFA_ERR_INVALID_ARGUMENT, "null pointer");
+  if (p->M == 0 || p->N == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "matrix dimensions must be positive");
+  if (!A || !B || !C) return fail(MFA_ERR_INVALID_ARGUMENT, "null operand buffer");
+  const bool tA = k->desc.transposeA, tB = k->desc.transposeB;
+  // chooseLeadingDimension (GEMMDescriptor.swift:340-363)
+  const uint32_t expA = tA ? p->M : p->K, expB = tB ? p->K : p->N, expC = p->N;
+  const uint32_t ldA = p->leadingDimensionA ? p->leadingDimensionA : expA;
+  const uint32_t ldB = p->leadingDimensionB ? p->leadingDimensionB : expB;
+  const uint32_t ldC = p->leadingDimensionC ? p->leadingDimensionC : expC;
+  if (ldA < expA || ldB < expB || ldC < expC) return fail(MFA_ERR_INVALID_ARGUMENT, "Leading block dimension was too small.");
+  const uint32_t batch = p->batchDimension ? p->batchDimension : 1;
+  *g = GemmArgs{A, B, C, p->M, p->N, p->K, ldA, ldB, ldC, k->desc.memoryPrecisionA, k->desc.memoryPrecisionB,
+                k->desc.memoryPrecisionC, tA, tB, p->loadPreviousC ? 1 : 0, p->batchStrideA, p->batchStrideB, p->batchStrideC};
+  *grid = dim3((p->N + GEMM_BN - 1) / GEMM_BN, (p->M + GEMM_BM - 1) / GEMM_BM, batch);
+  // 16-byte chunks must not straddle a row end or K, and 32-bit byte offsets must cover the operands
+  auto aligned = [](const void *ptr, uint32_t ld, uint64_t bs) { return ((uintptr_t)ptr & 15) == 0 && ld % 8 == 0 && bs % 8 == 0; };
+  const uint64_t bytesA = (uint64_t)(tA ? p->K : p->M) * ldA * 2, bytesB = (uint64_t)(tB ? p->N : p->K) * ldB * 2;
+  *use16 = k->fast16 && p->K % 8 == 0 && aligned(A, ldA, p->batchStrideA) && aligned(B, ldB, p->batchStrideB) &&
+           bytesA < 0xFFFFFF00ull && bytesB < 0xFFFFFF00ull;
+  return MFA_OK;
+}
+
+static void launch_one(const GemmArgs &g, dim3 grid, bool use16, hipStream_t s) {
+  if (use16 && g.precA == PREC_BF16) hipLaunchKernelGGL(gemm_16<__bf16>, grid, dim3(256), 0, s, g);
+  else if (use16) hipLaunchKernelGGL(gemm_16<_Float16>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(gemm_f32mfma, grid, dim3(256), 0, s, g);
+}
+
+extern "C" mfa_status mfa_gemm_kernel_launch(const mfa_gemm_kernel *k, const void *A, const void *B, void *C,
+                                             const mfa_gemm_launch_params *p, void *stream) {
+  GemmArgs g;
+  dim3 grid;
+  bool use16;
+  const mfa_status st = prepare(k, A, B, C, p, &g, &grid, &use16);
+  if (st != MFA_OK) return st;
+  if (p->K == 0 && !p->loadPreviousC) {   // empty sum: C = 0 (the kernels handle nk == 0 except for their prologue loads)
+    g.K = 0;
+  }
+  launch_one(g, grid, use16 && p->K > 0, (hipStream_t)stream);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(MFA_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
+  return MFA_OK;
+}
+
+extern "C" mfa_status mfa_gemm_kernel_time(const mfa_gemm_kernel *k, const void *A, const void *B, void *C,
+                                           const mfa_gemm_launch_params *p, void *stream, int warmup, int iterations, float *ms) {
+  if (!ms || iterations <= 0) return fail(MFA_ERR_INVALID_ARGUMENT, "bad timing arguments");
+  GemmArgs g;
+  dim3 grid;
+  bool use16;
+  const mfa_status st = prepare(k, A, B, C, p, &g, &grid, &use16);
+  if (st != MFA_OK) return st;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MFA_ERR_HIP, "hipEventCreate failed");
+  for (int i = 0; i < warmup; ++i) launch_one(g, grid, use16 && p->K > 0, s);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iterations; ++i) launch_one(g, grid, use16 && p->K > 0, s);
+  (void)hipEventRecord(e1, s);
+  hipError_t e = hipEventSynchronize(e1);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(MFA_ERR_HIP, std::string("gemm timing: ") + hipGetErrorString(e));
+  return MFA_OK;
+}

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 2
+#define MFA_ABI_VERSION 3
 
 /* ---- status codes (replace fatalError, e.g. AttentionKernel.swift:33,
  *      AttentionDescriptor.swift:45/72/90/97, AttentionParameterRow.swift:50/57/100) -------- */
@@ -173,6 +173,13 @@ typedef struct mfa_launch_params {
    * for square problems.  Requires column >= row.  Applies to all three kernel types. */
   uint32_t causal;
   uint32_t reserved;
+  /* Variable sequence lengths (extension): device arrays of `batches` uint32
+   * entries, or NULL.  Batch entry b uses the first rowLengths[b] rows and columnLengths[b] columns of its
+   * row x column problem (entries are clamped to row / column); the rest of its buffers is padding that is
+   * neither read into the result nor written.  With `causal`, columnLengths[b] >= rowLengths[b] is the
+   * caller's responsibility.  All three kernel types; launches with lengths are never column-split. */
+  const uint32_t *rowLengths;
+  const uint32_t *columnLengths;
 } mfa_launch_params;
 void mfa_launch_params_init(mfa_launch_params *params);
 

@@ -85,6 +85,8 @@ class mfa_launch_params(ctypes.Structure):
         ("workspaceBytes", ctypes.c_uint64),
         ("causal", ctypes.c_uint32),
         ("reserved", ctypes.c_uint32),
+        ("rowLengths", ctypes.c_void_p),
+        ("columnLengths", ctypes.c_void_p),
     ]
 
 

@@ -279,7 +279,7 @@ class AttentionKernel:
     # -- launch ------------------------------------------------------------------------------
     @staticmethod
     def _marshal(buffers, row, column, heads, batches, leadingDimensions, headStrides, batchStrides,
-                 workspace=None, causal=False):
+                 workspace=None, causal=False, rowLengths=None, columnLengths=None):
         """`buffers`: dict {AttentionOperand: tensor | int} or a 10-sequence indexed by bufferBinding."""
         slots = [None] * _abi.MFA_BUFFER_SLOTS
         if isinstance(buffers, Mapping):
@@ -302,6 +302,9 @@ class AttentionKernel:
                 for op, v in src.items():
                     dst[AttentionOperand(op).bufferBinding] = int(v)
         params.causal = int(bool(causal))
+        # variable sequence lengths (extension): device arrays of `batches` uint32 / int32 entries
+        params.rowLengths = _pointer(rowLengths)
+        params.columnLengths = _pointer(columnLengths)
         if workspace is not None:   # caller-owned scratch for column-parallel forward launches
             params.workspace = _pointer(workspace)
             params.workspaceBytes = int(workspace.numel() * workspace.element_size()) \
@@ -321,9 +324,9 @@ class AttentionKernel:
     def dispatch(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
                  leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
                  batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,
-                 workspace=None, causal: bool = False) -> None:
+                 workspace=None, causal: bool = False, rowLengths=None, columnLengths=None) -> None:
         arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions,
-                                           headStrides, batchStrides, workspace, causal)
+                                           headStrides, batchStrides, workspace, causal, rowLengths, columnLengths)
         check(lib().mfa_attention_kernel_launch(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                                 ctypes.c_void_p(stream or 0)))
 

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   uint32_t rblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
   if constexpr (CAUSAL) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
-  const int R = a.R, C = a.C, Dr = a.D;
+  int R = a.R, C = a.C;
+  const int Dr = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t r0 = (int64_t)rblk * (NW * 32) + wave * 32;
   const int64_t row = r0 + q;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
@@ -262,7 +264,9 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
   const int lane = tid & 63, kc = lane & 31, hi = lane >> 5;
   uint32_t cblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &cblk, &head, &batch);
-  const int R = a.R, C = a.C, Dr = a.D;
+  int R = a.R, C = a.C;
+  const int Dr = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t c0 = (int64_t)cblk * (NW * 32) + wave * 32;
   const int64_t col = c0 + kc;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,

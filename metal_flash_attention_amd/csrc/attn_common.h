@@ -45,6 +45,9 @@ struct KernelArgs {
   float scale2;  // log2(e)/sqrt(D)           (+Softmax.swift:17-26, derivative: false)
   // extension (not in the reference): causal mask, row r sees column c iff c <= r + (C - R)
   int32_t causal;
+  // extension: per-batch-entry sequence lengths (device arrays of `batches` entries, or null): entry b
+  // uses the first rowLen[b] rows and colLen[b] columns of its R x C problem; the rest is padding
+  const uint32_t *rowLen, *colLen;
 };
 
 // row index inside a 32x32 MFMA C/D tile held by (register r, half hi)
@@ -76,6 +79,13 @@ __device__ __forceinline__ int elem_size(int prec) { return prec == PREC_FP32 ? 
 __device__ __forceinline__ char *operand_base(const OperandView &v, uint32_t head, uint32_t batch) {
   const int64_t off = (int64_t)head * v.headStride + (int64_t)batch * v.batchStride;
   return (char *)v.ptr + off * elem_size(v.precision);
+}
+
+// the problem size of one batch entry (variable-length extension); rows / columns beyond it are never
+// loaded (bounds-checked resources shrink with it) nor stored
+__device__ __forceinline__ void batch_lengths(const KernelArgs &a, uint32_t batch, int &R, int &C) {
+  if (a.rowLen) R = min(R, (int)a.rowLen[batch]);
+  if (a.colLen) C = min(C, (int)a.colLen[batch]);
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
   const int lane = tid & 63, kc = lane & 31, hi = lane >> 5;
   uint32_t cblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &cblk, &head, &batch);
-  const int R = a.R, C = a.C, Dr = a.D;
+  int R = a.R, C = a.C;
+  const int Dr = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t c0 = (int64_t)cblk * 128 + pair * 32;
   const int64_t col = c0 + kc;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldg2 = (uint32_t)a.op[SLOT_dO].ld * 2;

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16(const KernelArgs a, const 
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
-  const int R = a.R, C = a.C;
+  int R = a.R, C = a.C;
+  batch_lengths(a, batch, R, C);
   const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
 
   const char *qbase = operand_base(a.op[SLOT_Q], head, batch);

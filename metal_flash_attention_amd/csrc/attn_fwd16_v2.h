@@ -69,7 +69,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, con
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
-  const int R = a.R, C = a.C, Dr = a.D;
+  int R = a.R, C = a.C;
+  const int Dr = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
                  ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;

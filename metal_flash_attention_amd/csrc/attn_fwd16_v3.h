@@ -54,7 +54,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   if constexpr (SPLIT) { split = bid % grid.splits; bid /= grid.splits; }
   fwd16_decode_block(grid, bid, &rblk, &head, &batch);
   if constexpr (CAUSAL) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
-  const int R = a.R, C = a.C, Dr = a.D;
+  int R = a.R, C = a.C;
+  const int Dr = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
                  ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (RB * 32 * OLD);
   char *lbase = operand_base(a.op[SLOT_L], head, batch);
-  const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)R;
+  const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)a.R;
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     const float l_tot = (MSUM ? lsum[b][0] : half_swap_add(l[b])) + 1.401298464e-45f;

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v4(const KernelArgs a, con
   if constexpr (SPLIT) { split = bid % grid.splits; bid /= grid.splits; }
   fwd16_decode_block(grid, bid, &rblk, &head, &batch);
   if constexpr (CAUSAL) rblk = grid.rowBlocks - 1 - rblk;
-  const int R = a.R, C = a.C, Dr = a.D;
+  int R = a.R, C = a.C;
+  const int Dr = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t r0 = (int64_t)rblk * (NW * 32) + wave * 32;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
                  ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v4(const KernelArgs a, con
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
   char *lbase = operand_base(a.op[SLOT_L], head, batch);
-  const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)R;
+  const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)a.R;
   {
     const float l_tot = half_swap_add(l) + 1.401298464e-45f;
     const float inv = SPLIT ? 1.0f : 1.0f / l_tot;

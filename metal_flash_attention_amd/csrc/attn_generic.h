@@ -204,7 +204,9 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   const uint32_t head = blockIdx.y, batch = blockIdx.z;
   const int64_t r0 = (int64_t)blockIdx.x * BR;
-  const int R = a.R, C = a.C, D = a.D;
+  int R = a.R, C = a.C;
+  const int D = a.D;
+  batch_lengths(a, batch, R, C);
 
   float *Qs = smem;
   float *Ks = CACHE ? smem : smem + BR * LD;
@@ -338,7 +340,9 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   const uint32_t head = blockIdx.y, batch = blockIdx.z;
   const int64_t r0 = (int64_t)blockIdx.x * BR;
-  const int R = a.R, C = a.C, D = a.D;
+  int R = a.R, C = a.C;
+  const int D = a.D;
+  batch_lengths(a, batch, R, C);
   const int64_t row = r0 + wave * 32 + q;
 
   float *Qs = smem;
@@ -469,7 +473,9 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   const int lane = tid & 63, kc = lane & 31, hi = lane >> 5;
   const uint32_t head = blockIdx.y, batch = blockIdx.z;
   const int64_t c0 = (int64_t)blockIdx.x * BCOL;
-  const int R = a.R, C = a.C, D = a.D;
+  int R = a.R, C = a.C;
+  const int D = a.D;
+  batch_lengths(a, batch, R, C);
 
   float *Kst = smem;                                  // [BCOL][LD]
   float *Vst = CACHE ? smem : smem + BCOL * LD;       // [BCOL][LD]

@@ -269,6 +269,8 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   args->scale = 1.0f / std::sqrt((float)D);
   args->scale2 = 1.44269504089f / std::sqrt((float)D);
   args->causal = p->causal ? 1 : 0;
+  args->rowLen = p->rowLengths;
+  args->colLen = p->columnLengths;
   if (p->causal && p->column < p->row)
     return fail(MFA_ERR_INVALID_ARGUMENT, "causal masking requires column >= row");
   const uint32_t heads = p->heads ? p->heads : 1, batches = p->batches ? p->batches : 1;
@@ -283,7 +285,7 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
   plan->splits = 1;
-  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit && !args->causal) {
+  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit && !args->causal && !args->rowLen && !args->colLen) {
     const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, p->column);
     if (s > 1) {
       const uint64_t rows = (uint64_t)s * heads * batches * p->row;

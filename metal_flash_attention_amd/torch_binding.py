@@ -56,7 +56,7 @@ def _strides(B, H, R, C, D):
 
 class _FlashAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, causal: bool):
+    def forward(ctx, q, k, v, causal: bool, q_lengths=None, k_lengths=None):
         _check(q, k, v)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, H, R, D = q.shape
@@ -66,12 +66,19 @@ class _FlashAttention(torch.autograd.Function):
         kernel = _kernel(q.dtype, R, C, D, AttentionKernelType.forward)
         hs, bs = _strides(B, H, R, C, D)
         need = kernel.workspaceSize(row=R, column=C, heads=H, batches=B)
-        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal else None
+        lengths = q_lengths is not None or k_lengths is not None
+        if lengths:   # padding rows of the outputs are not written by the kernels: define them as zero
+            o.zero_()
+            l.zero_()
+            q_lengths = None if q_lengths is None else q_lengths.to(device=q.device, dtype=torch.int32).contiguous()
+            k_lengths = None if k_lengths is None else k_lengths.to(device=q.device, dtype=torch.int32).contiguous()
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal and not lengths else None
         kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
                         headStrides=hs, batchStrides=bs, stream=torch.cuda.current_stream().cuda_stream,
-                        workspace=ws, causal=causal)
+                        workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths)
         ctx.save_for_backward(q, k, v, o, l)
         ctx.causal = causal
+        ctx.lengths = (q_lengths, k_lengths)
         return o.to(q.dtype)
 
     @staticmethod
@@ -82,19 +89,24 @@ class _FlashAttention(torch.autograd.Function):
         # dO in the kernels' gradient storage type (AttentionDescriptor+Precisions.swift:13-17): BF16 whenever
         # the inputs are 16-bit (also next to FP16 Q/K/V, the reference's mix), FP32 with FP32 inputs
         do = grad_out.to(torch.float32 if q.dtype == torch.float32 else torch.bfloat16).contiguous()
-        dq = torch.empty((B, H, R, D), dtype=torch.float32, device=q.device)
-        dk = torch.empty((B, H, C, D), dtype=torch.float32, device=q.device)
-        dv = torch.empty((B, H, C, D), dtype=torch.float32, device=q.device)
-        dterm = torch.empty((B, H, R), dtype=torch.float32, device=q.device)
+        alloc = torch.zeros if ctx.lengths != (None, None) else torch.empty   # padding gets zero gradients
+        dq = alloc((B, H, R, D), dtype=torch.float32, device=q.device)
+        dk = alloc((B, H, C, D), dtype=torch.float32, device=q.device)
+        dv = alloc((B, H, C, D), dtype=torch.float32, device=q.device)
+        dterm = alloc((B, H, R), dtype=torch.float32, device=q.device)
         bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
         hs, bs = _strides(B, H, R, C, D)
         stream = torch.cuda.current_stream().cuda_stream
         for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
             _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
-                                                     batchStrides=bs, stream=stream, causal=ctx.causal)
-        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None
+                                                     batchStrides=bs, stream=stream, causal=ctx.causal,
+                                                     rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1])
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None, None
 
 
-def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False) -> torch.Tensor:
-    """softmax(q k^T / sqrt(D)) v per (batch, head); causal: row r sees column c iff c <= r + (C - R)."""
-    return _FlashAttention.apply(q, k, v, causal)
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False,
+                    q_lengths: torch.Tensor = None, k_lengths: torch.Tensor = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(D)) v per (batch, head); causal: row r sees column c iff c <= r + (C - R).
+    q_lengths / k_lengths ([B] integers, optional): batch entry b uses only its first q_lengths[b] rows and
+    k_lengths[b] keys (padded batches); padding rows of the output and of the gradients are zero."""
+    return _FlashAttention.apply(q, k, v, causal, q_lengths, k_lengths)

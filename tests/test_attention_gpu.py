@@ -10,7 +10,7 @@ from harness import TOL_FP32, TOL_MIXED, TOL_MIXED_SHORT
 from metal_flash_attention_amd import (
     AttentionDescriptor, AttentionKernel, AttentionKernelType, AttentionOperand, GEMMOperandPrecision,
 )
-from oracle import Network, NetworkDescriptor
+from oracle import Network, NetworkDescriptor, round_trip
 
 pytestmark = pytest.mark.gpu
 P = GEMMOperandPrecision
@@ -577,3 +577,63 @@ def test_forward_role_alternating_kernel(shape, causal, impl, monkeypatch):
     failures, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3))
     assert not failures, failures
     assert run.tails_ok["O"] and run.tails_ok["L"] and not np.isnan(got["O"]).any()
+
+
+# ---- variable sequence lengths per batch entry (extension) -------------
+@pytest.mark.parametrize("low,causal", [(False, False), (False, True), (True, False), (True, True)])
+def test_variable_sequence_lengths(low, causal):
+    """A padded batch [B, H, Rmax, D] / [B, H, Cmax, D] with per-entry lengths: every entry must equal the
+    oracle run on its own (rows, columns) slice, and nothing beyond an entry's length may be written."""
+    import torch
+    B, H, Rmax, Cmax, D = 4, 2, 200, 333, 64
+    rlen = [200, 77, 1, 130]
+    clen = [333, 100, 64, 130]
+    in_type = P.BF16
+    desc = make_desc(Rmax, Cmax, D, low_in=low, in_type=in_type)
+    kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in AttentionKernelType}
+    rng = np.random.default_rng(11)
+    host = {n: rng.standard_normal((B, H, Rmax if n in ("Q", "dO") else Cmax, D)).astype(np.float32) for n in ("Q", "K", "V", "dO")}
+    if low:
+        for n in host:
+            host[n] = round_trip(host[n], int(P.BF16))
+
+    def dev_in(x):
+        if not low:
+            return torch.from_numpy(x).cuda()
+        return torch.from_numpy((np.ascontiguousarray(x).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+
+    bufs = {Op.Q: dev_in(host["Q"]), Op.K: dev_in(host["K"]), Op.V: dev_in(host["V"]), Op.dO: dev_in(host["dO"])}
+    poison = float("nan")
+    bufs[Op.O] = torch.full((B, H, Rmax, D), poison, device="cuda")
+    bufs[Op.L] = torch.full((B, H, Rmax), poison, device="cuda")
+    bufs[Op.D] = torch.full((B, H, Rmax), poison, device="cuda")
+    bufs[Op.dQ] = torch.full((B, H, Rmax, D), poison, device="cuda")
+    bufs[Op.dK] = torch.full((B, H, Cmax, D), poison, device="cuda")
+    bufs[Op.dV] = torch.full((B, H, Cmax, D), poison, device="cuda")
+    hs = {Op.Q: Rmax * D, Op.K: Cmax * D, Op.V: Cmax * D, Op.O: Rmax * D, Op.L: Rmax, Op.D: Rmax,
+          Op.dO: Rmax * D, Op.dV: Cmax * D, Op.dK: Cmax * D, Op.dQ: Rmax * D}
+    bs = {op: s * H for op, s in hs.items()}
+    rl = torch.tensor(rlen, dtype=torch.int32, device="cuda")
+    cl = torch.tensor(clen, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for t in (AttentionKernelType.forward, AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):
+        kernels[t].dispatch(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                            stream=stream, causal=causal, rowLengths=rl, columnLengths=cl)
+    torch.cuda.synchronize()
+    out = {op: bufs[op].cpu().numpy() for op in (Op.O, Op.L, Op.D, Op.dQ, Op.dK, Op.dV)}
+    tol = dict(O=1.5e-2, L=1e-3, D=5e-2, dV=2e-2, dK=2e-2, dQ=2e-2) if low else TOL_FP32
+    for b in range(B):
+        R, C = rlen[b], clen[b]
+        for h in range(H):
+            net = Network(NetworkDescriptor(R, C, D), seed=0)
+            net.Q, net.K, net.V, net.dO = (np.ascontiguousarray(host[n][b, h, :(R if n in ("Q", "dO") else C)]) for n in ("Q", "K", "V", "dO"))
+            net.invalidate()
+            ref = net.run(causal=causal)
+            got = dict(O=out[Op.O][b, h, :R], L=out[Op.L][b, h, :R] / np.float32(harness.LOG2E),
+                       D=out[Op.D][b, h, :R] * np.sqrt(np.float32(D)), dQ=out[Op.dQ][b, h, :R],
+                       dK=out[Op.dK][b, h, :C], dV=out[Op.dV][b, h, :C])
+            failures, report = harness.compare(ref, got, tol)
+            assert not failures, (b, h, failures, [k.variant for k in kernels.values()])
+            # padding untouched
+            for op, n in ((Op.O, R), (Op.L, R), (Op.D, R), (Op.dQ, R), (Op.dK, C), (Op.dV, C)):
+                assert np.isnan(out[op][b, h, n:]).all(), (op, b, h)

@@ -58,3 +58,23 @@ def test_long_single_head_uses_split_kv_workspace():
     o = flash_attention(q, k, v)
     _, _, _, ref = reference(q, k, v, False)
     assert (o.float() - ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("causal", [False, True])
+def test_padded_batch_with_lengths(causal):
+    from metal_flash_attention_amd.torch_binding import flash_attention
+    B, H, N, D = 3, 2, 160, 64
+    lens = torch.tensor([160, 40, 97])
+    g = torch.Generator(device="cuda").manual_seed(9)
+    q, k, v = (torch.randn(B, H, N, D, generator=g, device="cuda").bfloat16().requires_grad_(True) for _ in range(3))
+    w = torch.randn(B, H, N, D, generator=g, device="cuda").bfloat16()
+    o = flash_attention(q, k, v, causal=causal, q_lengths=lens, k_lengths=lens)
+    o.backward(w)
+    for b, n in enumerate(lens.tolist()):
+        qr, kr, vr, orf = reference(q[b:b + 1, :, :n], k[b:b + 1, :, :n], v[b:b + 1, :, :n], causal)
+        orf.backward(w[b:b + 1, :, :n].float())
+        assert (o[b, :, :n].float() - orf[0]).abs().max().item() < 3e-2
+        assert (o[b, :, n:] == 0).all() and (q.grad[b, :, n:] == 0).all() and (k.grad[b, :, n:] == 0).all()
+        for got, ref in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+            assert (got[b, :, :n].float() - ref[0]).abs().max().item() < 5e-2

@@ -36,12 +36,13 @@ struct GemmArgs {
 };
 
 // epilogue shared by both kernels: acc[mb][nb] holds C rows (bm + 32 mb + crow(r, hi)), column bn + 32 nb + (lane & 31)
-__device__ __forceinline__ void gemm_store(const GemmArgs &g, char *C, const f32x16 (&acc)[2][2], int row0, int col0, int lane) {
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_store(const GemmArgs &g, char *C, const f32x16 (&acc)[MT][NT], int row0, int col0, int lane) {
   const int i = lane & 31, hi = lane >> 5;
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NT; ++nb) {
       const uint32_t col = col0 + 32 * nb + i;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -144,28 +145,39 @@ __global__ __launch_bounds__(256) void gemm_f32mfma(const GemmArgs g) {
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
-  gemm_store(g, C, acc, bm + wm, bn + wn, lane);
+  gemm_store<2, 2>(g, C, acc, bm + wm, bn + wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
-// 16-bit kernel: A and B in one 16-bit type, rows 16-byte aligned
+// 16-bit kernels: A and B in one 16-bit type, rows 16-byte aligned
 // ------------------------------------------------------------------------------------------------
-// LDS image of one operand tile (X = 128 rows of M or N, BK = 64 deep):
+// Block = (WR x WC) waves, each owning (MT x NT) MFMA tiles of 32 x 32:  BM = 32 WR MT, BN = 32 WC NT, BK = 64.
+//   <2, 2, 2, 2>: 128 x 128, 256 work-items, 64 KiB LDS  -- small problems (more workgroups)
+//   <2, 4, 4, 2>: 256 x 256, 512 work-items, 128 KiB LDS -- large problems: half the LDS staging bytes per
+//                 MFMA (ds_write_b128 moves only ~79 B/clk/CU, MI355X_MICROARCH.md LDS table: at 128 x 128
+//                 the staging writes alone take ~80 % of the matrix time), 0.75 instead of 1 fragment read
+//                 per MFMA and 32 instead of 16 MFMAs per wave between barriers.
+// LDS image of one operand tile (X rows of M or N, BK = 64 deep):
 //   KMAJOR (memory is k-contiguous: A not transposed, B transposed): [x][64 k], 128-byte rows, 16-byte chunk
 //     index XOR-swizzled by (x >> 1) & 7 (16 rows of a read group -> 16 distinct 16-byte slots); fragment = ds_read_b128.
 //   XMAJOR (memory is x-contiguous: A transposed, B not transposed): [x / 32][64 k][32 x] (64-byte rows);
-//     fragment = two ds_read_b64_tr_b16, exactly the V^T gather of the attention forward kernel.
+//     fragment = two ds_read_b64_tr_b16, the V^T gather of the attention forward kernel.
 constexpr int GEMM16_BK = 64;
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_16(const GemmArgs g) {
+template <int WR, int WC, int MT, int NT> constexpr int gemm16_lds_bytes() { return 2 * (32 * WR * MT + 32 * WC * NT) * GEMM16_BK * 2; }
+
+template <typename T, int WR, int WC, int MT, int NT>
+__global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
-  constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM16_BK, TILE = BM * BK * 2;   // 16 KiB per operand tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE];                // 2 stages x (A | B) = 64 KiB
+  constexpr int BM = 32 * WR * MT, BN = 32 * WC * NT, BK = GEMM16_BK, NTHR = WR * WC * 64;
+  constexpr int ATILE = BM * BK * 2, BTILE = BN * BK * 2, STAGE = ATILE + BTILE;
+  constexpr int ACH = BM * 8 / NTHR, BCH = BN * 8 / NTHR;   // 16-byte chunks per thread and tile
+  static_assert(BM * 8 % NTHR == 0 && BN * 8 % NTHR == 0, "tiles must divide evenly over the workgroup");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A | B)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, hi = lane >> 5;
   const uint32_t bm = blockIdx.y * BM, bn = blockIdx.x * BN;
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = (wave / WC) * (MT * 32), wn = (wave % WC) * (NT * 32);
   constexpr uint32_t OOB = 0xFFFFFF00u;
   const uint32_t ldA2 = g.ldA * 2, ldB2 = g.ldB * 2;
   // buffer resources bound the matrices (rows x pitch): chunks outside read as zeros
@@ -175,52 +187,62 @@ __global__ __launch_bounds__(256) void gemm_16(const GemmArgs g) {
       const_cast<char *>((const char *)g.B + (uint64_t)blockIdx.z * g.bsB * 2), 0, (g.transB ? g.N : g.K) * ldB2, 0x00020000);
   char *C = (char *)g.C + (uint64_t)blockIdx.z * g.bsC * elem_size(g.precC);
 
-  // staging: 1024 chunks of 16 bytes per operand tile, 4 per thread.
-  //   KMAJOR: chunk = (x, c) with c = 8-element group along k (8 per row);   global (x0 + x) * ld + k0 + 8c
-  //   XMAJOR: chunk = (k, c) with c = 8-element group along x (16 per row);  global (k0 + k) * ld + x0 + 8c
+  // staging, chunk id = tid + NTHR e:
+  //   KMAJOR: chunk = (x, c) with c = 8-element group along k (8 per row);     global (x0 + x) * ld + k0 + 8c
+  //   XMAJOR: chunk = (k, c) with c = 8-element group along x (X / 8 per row); global (k0 + k) * ld + x0 + 8c
   const bool akm = !g.transA, bkm = g.transB;
-  uint32_t aoff[4], boff[4], alds[4], blds[4];
-  auto plan = [&](bool kmajor, uint32_t x0, uint32_t X, uint32_t ld2, uint32_t (&off)[4], uint32_t (&lds)[4]) {
+  uint32_t aoff[ACH], boff[BCH], alds[ACH], blds[BCH];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * e;
-      if (kmajor) {
-        const int x = idx >> 3, c = idx & 7;
-        // row inside the matrix and the chunk's first element inside the row (row tails beyond X*... are
-        // cut by k < K at run time through the offset, see advance)
-        off[e] = (x0 + x < X) ? (x0 + x) * ld2 + c * 16 : OOB;
-        lds[e] = x * 128 + ((c ^ ((x >> 1) & 7)) * 16);
-      } else {
-        const int k = idx >> 4, c = idx & 15;
-        off[e] = (x0 + 8 * c < X) ? k * ld2 + (x0 + 8 * c) * 2 : OOB;
-        lds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
-      }
+  for (int e = 0; e < ACH; ++e) {
+    const int idx = tid + NTHR * e;
+    if (akm) {
+      const int x = idx >> 3, c = idx & 7;
+      aoff[e] = (bm + x < g.M) ? (bm + x) * ldA2 + c * 16 : OOB;
+      alds[e] = x * 128 + ((c ^ ((x >> 1) & 7)) * 16);
+    } else {
+      const int k = idx / (BM / 8), c = idx % (BM / 8);
+      aoff[e] = (bm + 8 * c < g.M) ? k * ldA2 + (bm + 8 * c) * 2 : OOB;
+      alds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
     }
-  };
-  plan(akm, bm, g.M, ldA2, aoff, alds);
-  plan(bkm, bn, g.N, ldB2, boff, blds);
-  // k-bound: KMAJOR chunks at k >= K must read zero: their row still lies inside the resource, so the test is
-  // explicit (K % 8 == 0 is a launch requirement for this kernel, so chunks never straddle K)
-  u32x4 ra[4], rb[4];
+  }
+#pragma unroll
+  for (int e = 0; e < BCH; ++e) {
+    const int idx = tid + NTHR * e;
+    if (bkm) {
+      const int x = idx >> 3, c = idx & 7;
+      boff[e] = (bn + x < g.N) ? (bn + x) * ldB2 + c * 16 : OOB;
+      blds[e] = x * 128 + ((c ^ ((x >> 1) & 7)) * 16);
+    } else {
+      const int k = idx / (BN / 8), c = idx % (BN / 8);
+      boff[e] = (bn + 8 * c < g.N) ? k * ldB2 + (bn + 8 * c) * 2 : OOB;
+      blds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
+    }
+  }
+  // k-bound: a KMAJOR chunk at k >= K still lies inside the resource (next row), so the test is explicit
+  // (K % 8 == 0 is a launch requirement of this kernel: chunks never straddle K)
+  u32x4 ra[ACH], rb[BCH];
   auto gload = [&](uint32_t k0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int idx = tid + 256 * e;
-      const uint32_t ka = akm ? k0 + 8 * (idx & 7) : k0 + (idx >> 4);
-      const uint32_t kb = bkm ? k0 + 8 * (idx & 7) : k0 + (idx >> 4);
+    for (int e = 0; e < ACH; ++e) {
+      const int idx = tid + NTHR * e;
+      const uint32_t ka = akm ? k0 + 8 * (idx & 7) : k0 + idx / (BM / 8);
       ra[e] = __builtin_amdgcn_raw_buffer_load_b128(ares, ka < g.K ? aoff[e] : OOB, 0, 0);
-      rb[e] = __builtin_amdgcn_raw_buffer_load_b128(bres, kb < g.K ? boff[e] : OOB, 0, 0);
       aoff[e] = __builtin_elementwise_add_sat(aoff[e], akm ? (uint32_t)BK * 2 : (uint32_t)BK * ldA2);
+    }
+#pragma unroll
+    for (int e = 0; e < BCH; ++e) {
+      const int idx = tid + NTHR * e;
+      const uint32_t kb = bkm ? k0 + 8 * (idx & 7) : k0 + idx / (BN / 8);
+      rb[e] = __builtin_amdgcn_raw_buffer_load_b128(bres, kb < g.K ? boff[e] : OOB, 0, 0);
       boff[e] = __builtin_elementwise_add_sat(boff[e], bkm ? (uint32_t)BK * 2 : (uint32_t)BK * ldB2);
     }
   };
   auto lstore = [&](int buf) {
-    char *base = smem + buf * 2 * TILE;
+    char *base = smem + buf * STAGE;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      *reinterpret_cast<u32x4 *>(base + alds[e]) = ra[e];
-      *reinterpret_cast<u32x4 *>(base + TILE + blds[e]) = rb[e];
-    }
+    for (int e = 0; e < ACH; ++e) *reinterpret_cast<u32x4 *>(base + alds[e]) = ra[e];
+#pragma unroll
+    for (int e = 0; e < BCH; ++e) *reinterpret_cast<u32x4 *>(base + ATILE + blds[e]) = rb[e];
   };
   // fragment of k-step s (16 k) for the 32 rows x0..x0+31 of a tile image
   const int n16 = lane & 15;
@@ -240,11 +262,11 @@ __global__ __launch_bounds__(256) void gemm_16(const GemmArgs g) {
     return __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < NT; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
@@ -255,24 +277,23 @@ __global__ __launch_bounds__(256) void gemm_16(const GemmArgs g) {
   for (uint32_t kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
-    const char *Ai = smem + buf * 2 * TILE, *Bi = Ai + TILE;
+    const char *Ai = smem + buf * STAGE, *Bi = Ai + ATILE;
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      v8 a[2], b[2];
+      v8 a[MT], b[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        a[t] = fragment(Ai, akm, wm + 32 * t, s);
-        b[t] = fragment(Bi, bkm, wn + 32 * t, s);
-      }
+      for (int t = 0; t < MT; ++t) a[t] = fragment(Ai, akm, wm + 32 * t, s);
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int t = 0; t < NT; ++t) b[t] = fragment(Bi, bkm, wn + 32 * t, s);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = F::mfma(a[mb], b[nb], acc[mb][nb]);
+      for (int mb = 0; mb < MT; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = F::mfma(a[mb], b[nb], acc[mb][nb]);
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
-  gemm_store(g, C, acc, bm + wm, bn + wn, lane);
+  gemm_store<MT, NT>(g, C, acc, bm + wm, bn + wn, lane);
 }
 
 } // namespace mfa

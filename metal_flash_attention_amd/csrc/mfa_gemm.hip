@@ -13,8 +13,20 @@ using namespace mfa;
 struct mfa_gemm_kernel {
   mfa_gemm_kernel_descriptor desc;
   bool fast16 = false;          // A and B in one 16-bit type: gemm_16 when the launch is 16-byte aligned
+  bool big = false;             // 256 x 256 block (8 waves) instead of 128 x 128 (4 waves)
   std::string name;
 };
+
+// number of compute units the block-size heuristic fills (MI355X: 256; queried once)
+static int compute_units() {
+  static int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus;
+}
 
 static bool valid_precision(int p) { return p == MFA_FP32 || p == MFA_FP16 || p == MFA_BF16; }
 
@@ -49,14 +61,19 @@ extern "C" mfa_status mfa_gemm_descriptor_kernel_descriptor(const mfa_gemm_descr
   out->registerPrecisionA = fast16 ? d->precisionA : MFA_FP32;
   out->registerPrecisionB = fast16 ? d->precisionB : MFA_FP32;
   out->registerPrecisionC = MFA_FP32;
-  out->blockM = GEMM_BM;
-  out->blockN = GEMM_BN;
+  // block size by how many workgroups the problem yields (the reference: 32 x 32 vs 48 x 48 blocks by
+  // "actualGroups <= idealGroups", GEMMDescriptor.swift:262-318): the 256 x 256 block of the 16-bit kernel
+  // halves LDS staging per MFMA but needs >= 3/4 of the compute units' worth of workgroups to pay
+  const uint64_t bigGroups = (uint64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) * (d->batchDimension ? d->batchDimension : 1);
+  const bool big = fast16 && bigGroups * 4 >= (uint64_t)compute_units() * 3;
+  out->blockM = big ? 256 : GEMM_BM;
+  out->blockN = big ? 256 : GEMM_BN;
   out->blockK = fast16 ? GEMM16_BK : GEMM_F32_BK;
   out->leadingBlockA = fast16 ? GEMM16_BK : GEMM_F32_BKP;
   out->leadingBlockB = fast16 ? GEMM16_BK : GEMM_F32_BKP;
   out->leadingBlockC = 0;              // C never passes through LDS
   out->splitsM = 2;
-  out->splitsN = 2;
+  out->splitsN = big ? 4 : 2;
   out->preferAsyncLoad = 0;            // no async-copy engine is used: plain global -> register -> LDS staging
   out->preferAsyncStore = 0;
   out->transposeA = d->transposeA ? 1 : 0;
@@ -74,13 +91,16 @@ extern "C" mfa_status mfa_gemm_kernel_create(const mfa_gemm_kernel_descriptor *k
   k->desc = *kd;
   k->fast16 = kd->memoryPrecisionA != MFA_FP32 && kd->memoryPrecisionA == kd->memoryPrecisionB &&
               kd->registerPrecisionA == kd->memoryPrecisionA;
+  k->big = k->fast16 && kd->blockM >= 256 && kd->blockN >= 256;
   // the object reports what it really uses
-  k->desc.blockM = GEMM_BM;
-  k->desc.blockN = GEMM_BN;
+  k->desc.blockM = k->big ? 256 : GEMM_BM;
+  k->desc.blockN = k->big ? 256 : GEMM_BN;
   k->desc.blockK = k->fast16 ? GEMM16_BK : GEMM_F32_BK;
-  k->desc.splitsM = k->desc.splitsN = 2;
-  k->name = k->fast16 ? (kd->memoryPrecisionA == MFA_BF16 ? "gemm_16_bf16_128x128x64_w2x2" : "gemm_16_f16_128x128x64_w2x2")
-                      : "gemm_f32mfma_128x128x16_w2x2";
+  k->desc.splitsM = 2;
+  k->desc.splitsN = k->big ? 4 : 2;
+  const char *type = kd->memoryPrecisionA == MFA_BF16 ? "bf16" : "f16";
+  k->name = !k->fast16 ? "gemm_f32mfma_128x128x16_w2x2"
+                       : std::string("gemm_16_") + type + (k->big ? "_256x256x64_w2x4" : "_128x128x64_w2x2");
   *out = k;
   return MFA_OK;
 }
@@ -94,10 +114,11 @@ extern "C" mfa_status mfa_gemm_kernel_block_dimensions(const mfa_gemm_kernel *k,
   if (K) *K = k->desc.blockK;
   return MFA_OK;
 }
-extern "C" uint32_t mfa_gemm_kernel_threadgroup_size(const mfa_gemm_kernel *k) { return k ? 256 : 0; }
+extern "C" uint32_t mfa_gemm_kernel_threadgroup_size(const mfa_gemm_kernel *k) { return !k ? 0 : (k->big ? 512 : 256); }
 extern "C" uint32_t mfa_gemm_kernel_threadgroup_memory_allocation(const mfa_gemm_kernel *k) {
   if (!k) return 0;
-  return k->fast16 ? 2 * 2 * GEMM_BM * GEMM16_BK * 2 : 2 * 2 * GEMM_BM * GEMM_F32_BKP * 4;
+  if (!k->fast16) return 2 * 2 * GEMM_BM * GEMM_F32_BKP * 4;
+  return k->big ? gemm16_lds_bytes<2, 4, 4, 2>() : gemm16_lds_bytes<2, 2, 2, 2>();
 }
 extern "C" const char *mfa_gemm_kernel_variant(const mfa_gemm_kernel *k) { return k ? k->name.c_str() : ""; }
 
@@ -116,7 +137,7 @@ static mfa_status prepare(const mfa_gemm_kernel *k, const void *A, const void *B
   const uint32_t batch = p->batchDimension ? p->batchDimension : 1;
   *g = GemmArgs{A, B, C, p->M, p->N, p->K, ldA, ldB, ldC, k->desc.memoryPrecisionA, k->desc.memoryPrecisionB,
                 k->desc.memoryPrecisionC, tA, tB, p->loadPreviousC ? 1 : 0, p->batchStrideA, p->batchStrideB, p->batchStrideC};
-  *grid = dim3((p->N + GEMM_BN - 1) / GEMM_BN, (p->M + GEMM_BM - 1) / GEMM_BM, batch);
+  *grid = dim3((p->N + GEMM_BN - 1) / GEMM_BN, (p->M + GEMM_BM - 1) / GEMM_BM, batch);   // general / small block
   // 16-byte chunks must not straddle a row end or K, and 32-bit byte offsets must cover the operands
   auto aligned = [](const void *ptr, uint32_t ld, uint64_t bs) { return ((uintptr_t)ptr & 15) == 0 && ld % 8 == 0 && bs % 8 == 0; };
   const uint64_t bytesA = (uint64_t)(tA ? p->K : p->M) * ldA * 2, bytesB = (uint64_t)(tB ? p->N : p->K) * ldB * 2;
@@ -125,10 +146,40 @@ static mfa_status prepare(const mfa_gemm_kernel *k, const void *A, const void *B
   return MFA_OK;
 }
 
-static void launch_one(const GemmArgs &g, dim3 grid, bool use16, hipStream_t s) {
-  if (use16 && g.precA == PREC_BF16) hipLaunchKernelGGL(gemm_16<__bf16>, grid, dim3(256), 0, s, g);
-  else if (use16) hipLaunchKernelGGL(gemm_16<_Float16>, grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL(gemm_f32mfma, grid, dim3(256), 0, s, g);
+// dynamic LDS above 64 KiB has to be enabled per function (once per process and device is enough: the
+// attribute is sticky)
+template <typename K> static hipError_t enable_lds(K kernel, int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+static hipError_t launch_one(const mfa_gemm_kernel *k, const GemmArgs &g, dim3 grid, bool use16, hipStream_t s) {
+  if (!use16) {
+    hipLaunchKernelGGL(gemm_f32mfma, grid, dim3(256), 0, s, g);
+    return hipSuccess;
+  }
+  hipError_t e = hipSuccess;
+  const bool bf = g.precA == PREC_BF16;
+  if (k->big) {
+    constexpr int LDS = gemm16_lds_bytes<2, 4, 4, 2>();
+    const dim3 gb((g.N + 255) / 256, (g.M + 255) / 256, grid.z);
+    if (bf) {
+      e = enable_lds(gemm_16<__bf16, 2, 4, 4, 2>, LDS);
+      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<__bf16, 2, 4, 4, 2>), gb, dim3(512), LDS, s, g);
+    } else {
+      e = enable_lds(gemm_16<_Float16, 2, 4, 4, 2>, LDS);
+      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<_Float16, 2, 4, 4, 2>), gb, dim3(512), LDS, s, g);
+    }
+  } else {
+    constexpr int LDS = gemm16_lds_bytes<2, 2, 2, 2>();
+    if (bf) {
+      e = enable_lds(gemm_16<__bf16, 2, 2, 2, 2>, LDS);
+      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<__bf16, 2, 2, 2, 2>), grid, dim3(256), LDS, s, g);
+    } else {
+      e = enable_lds(gemm_16<_Float16, 2, 2, 2, 2>, LDS);
+      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<_Float16, 2, 2, 2, 2>), grid, dim3(256), LDS, s, g);
+    }
+  }
+  return e;
 }
 
 extern "C" mfa_status mfa_gemm_kernel_launch(const mfa_gemm_kernel *k, const void *A, const void *B, void *C,
@@ -138,11 +189,8 @@ extern "C" mfa_status mfa_gemm_kernel_launch(const mfa_gemm_kernel *k, const voi
   bool use16;
   const mfa_status st = prepare(k, A, B, C, p, &g, &grid, &use16);
   if (st != MFA_OK) return st;
-  if (p->K == 0 && !p->loadPreviousC) {   // empty sum: C = 0 (the kernels handle nk == 0 except for their prologue loads)
-    g.K = 0;
-  }
-  launch_one(g, grid, use16 && p->K > 0, (hipStream_t)stream);
-  const hipError_t e = hipGetLastError();
+  hipError_t e = launch_one(k, g, grid, use16, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipGetLastError();
   if (e != hipSuccess) return fail(MFA_ERR_HIP, std::string("gemm launch: ") + hipGetErrorString(e));
   return MFA_OK;
 }
@@ -158,9 +206,9 @@ extern "C" mfa_status mfa_gemm_kernel_time(const mfa_gemm_kernel *k, const void 
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(MFA_ERR_HIP, "hipEventCreate failed");
-  for (int i = 0; i < warmup; ++i) launch_one(g, grid, use16 && p->K > 0, s);
+  for (int i = 0; i < warmup; ++i) (void)launch_one(k, g, grid, use16, s);
   (void)hipEventRecord(e0, s);
-  for (int i = 0; i < iterations; ++i) launch_one(g, grid, use16 && p->K > 0, s);
+  for (int i = 0; i < iterations; ++i) (void)launch_one(k, g, grid, use16, s);
   (void)hipEventRecord(e1, s);
   hipError_t e = hipEventSynchronize(e1);
   if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);

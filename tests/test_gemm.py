@@ -206,7 +206,7 @@ def test_adversarial_shapes(case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("transpose", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("precision", [P.BF16, P.FP16])
-@pytest.mark.parametrize("shape", [(512, 512, 512), (511, 513, 512), (129, 1000, 264), (64, 64, 8)])
+@pytest.mark.parametrize("shape", [(512, 512, 512), (511, 513, 512), (129, 1000, 264), (64, 64, 8), (3500, 3700, 200)])
 def test_16bit_matrix_core_path(shape, precision, transpose):
     """A and B in one 16-bit type with aligned rows take gemm_16 (all four transpose states, ragged M and N,
     K a multiple of 8); C in FP32.  Against the fp64 loop on the rounded inputs."""
@@ -221,6 +221,7 @@ def test_16bit_matrix_core_path(shape, precision, transpose):
     d = make(M, N, K, (precision, precision, P.FP32), transpose, ld)
     got, k = run_gemm(d, A, B, prev)
     assert k.variant.startswith("gemm_16"), k.variant
+    assert ("256x256" in k.variant) == (M >= 3000), k.variant      # enough workgroups -> the 8-wave 256 x 256 block
     want = og.naive(M, N, K, A, B, prev, ld, tA, tB, False, f64=True)
     assert np.abs(got - want).max() < 1e-3 * np.sqrt(K), k.variant
 

@@ -1,5 +1,6 @@
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_torch_binding.py tests/test_c_abi.py -q -m gpu -x > gpurun_out/pytest_torch.txt 2>&1; echo "rc=$?" >> gpurun_out/pytest_torch.txt
-tail -n 12 gpurun_out/pytest_torch.txt
+timeout 900 python -m pytest tests/test_gemm.py -q -m gpu -x > gpurun_out/pytest_gemm.txt 2>&1; echo "rc=$?" >> gpurun_out/pytest_gemm.txt
+tail -n 12 gpurun_out/pytest_gemm.txt
+timeout 300 python tools/bench_gemm.py --sizes 2048,4096,8192 --dtypes bf16 > gpurun_out/bench_gemm2.txt 2>&1; cat gpurun_out/bench_gemm2.txt

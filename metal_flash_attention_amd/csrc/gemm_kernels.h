@@ -12,7 +12,7 @@
 //   edge.  Operands are converted to fp32 while staged (element-wise, bounds-checked; BF16 by bit
 //   placement, GEMMHeaders.swift:402-409) and multiplied with v_mfma_f32_32x32x2_f32, which is exact fp32
 //   FMA arithmetic -- what the reference's FP32 register precision asks for.  Roofline: 157 TFLOP/s.
-// * gemm_16: A and B in the same 16-bit type with 16-byte-aligned rows.  16-byte chunks are copied to LDS
+// * gemm_16: A and B in the same 16-bit type (any leading dimension, any K).  16-byte chunks are copied to LDS
 //   unchanged (bounds-checked buffer loads, zeros outside the matrix) into one of the two images the
 //   attention kernels use -- k-contiguous rows for ds_read_b128 when the operand's memory is k-major,
 //   [x/32][k][32] for ds_read_b64_tr_b16 when it is not -- and multiplied with v_mfma_f32_32x32x16.
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_f32mfma(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// 16-bit kernels: A and B in one 16-bit type, rows 16-byte aligned
+// 16-bit kernels: A and B in one 16-bit type
 // ------------------------------------------------------------------------------------------------
 // Block = (WR x WC) waves, each owning (MT x NT) MFMA tiles of 32 x 32:  BM = 32 WR MT, BN = 32 WC NT, BK = 64.
 //   <2, 2, 2, 2>: 128 x 128, 256 work-items, 64 KiB LDS  -- small problems (more workgroups)
@@ -181,10 +181,12 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   constexpr uint32_t OOB = 0xFFFFFF00u;
   const uint32_t ldA2 = g.ldA * 2, ldB2 = g.ldB * 2;
   // buffer resources bound the matrices (rows x pitch): chunks outside read as zeros
+  // (sizes rounded up to whole dwords: the range check is per dword, and with an odd element count the
+  // dword that holds the last element ends 2 bytes past the matrix -- still inside the same 4-byte word)
   const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char *>((const char *)g.A + (uint64_t)blockIdx.z * g.bsA * 2), 0, (g.transA ? g.K : g.M) * ldA2, 0x00020000);
+      const_cast<char *>((const char *)g.A + (uint64_t)blockIdx.z * g.bsA * 2), 0, ((g.transA ? g.K : g.M) * ldA2 + 3u) & ~3u, 0x00020000);
   const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char *>((const char *)g.B + (uint64_t)blockIdx.z * g.bsB * 2), 0, (g.transB ? g.N : g.K) * ldB2, 0x00020000);
+      const_cast<char *>((const char *)g.B + (uint64_t)blockIdx.z * g.bsB * 2), 0, ((g.transB ? g.N : g.K) * ldB2 + 3u) & ~3u, 0x00020000);
   char *C = (char *)g.C + (uint64_t)blockIdx.z * g.bsC * elem_size(g.precC);
 
   // staging, chunk id = tid + NTHR e:
@@ -218,15 +220,24 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
       blds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
     }
   }
-  // k-bound: a KMAJOR chunk at k >= K still lies inside the resource (next row), so the test is explicit
-  // (K % 8 == 0 is a launch requirement of this kernel: chunks never straddle K)
+  // k-bound: a KMAJOR chunk at k >= K still lies inside the resource (it reads the next row), so the test is
+  // explicit; a chunk that straddles K (K % 8 != 0, last k tile only) keeps its first K - k elements.
+  // Rows need no 16-byte alignment: gfx950 under ROCm serves unaligned buffer loads (odd leading dimensions
+  // just cost extra memory transactions).
+  auto keep_first = [](u32x4 r, int n) {   // n in 1..7 sixteen-bit elements
+#pragma unroll
+    for (int d = 0; d < 4; ++d) r[d] = (2 * d + 1 < n) ? r[d] : (2 * d < n ? (r[d] & 0xFFFFu) : 0u);
+    return r;
+  };
   u32x4 ra[ACH], rb[BCH];
   auto gload = [&](uint32_t k0) {
+    const bool tail = k0 + BK > g.K && (g.K & 7) != 0;   // wave-uniform: only the last k tile of a ragged K
 #pragma unroll
     for (int e = 0; e < ACH; ++e) {
       const int idx = tid + NTHR * e;
       const uint32_t ka = akm ? k0 + 8 * (idx & 7) : k0 + idx / (BM / 8);
       ra[e] = __builtin_amdgcn_raw_buffer_load_b128(ares, ka < g.K ? aoff[e] : OOB, 0, 0);
+      if (tail && akm && ka < g.K && ka + 8 > g.K) ra[e] = keep_first(ra[e], (int)(g.K - ka));
       aoff[e] = __builtin_elementwise_add_sat(aoff[e], akm ? (uint32_t)BK * 2 : (uint32_t)BK * ldA2);
     }
 #pragma unroll
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
       const int idx = tid + NTHR * e;
       const uint32_t kb = bkm ? k0 + 8 * (idx & 7) : k0 + idx / (BN / 8);
       rb[e] = __builtin_amdgcn_raw_buffer_load_b128(bres, kb < g.K ? boff[e] : OOB, 0, 0);
+      if (tail && bkm && kb < g.K && kb + 8 > g.K) rb[e] = keep_first(rb[e], (int)(g.K - kb));
       boff[e] = __builtin_elementwise_add_sat(boff[e], bkm ? (uint32_t)BK * 2 : (uint32_t)BK * ldB2);
     }
   };

@@ -138,11 +138,9 @@ static mfa_status prepare(const mfa_gemm_kernel *k, const void *A, const void *B
   *g = GemmArgs{A, B, C, p->M, p->N, p->K, ldA, ldB, ldC, k->desc.memoryPrecisionA, k->desc.memoryPrecisionB,
                 k->desc.memoryPrecisionC, tA, tB, p->loadPreviousC ? 1 : 0, p->batchStrideA, p->batchStrideB, p->batchStrideC};
   *grid = dim3((p->N + GEMM_BN - 1) / GEMM_BN, (p->M + GEMM_BM - 1) / GEMM_BM, batch);   // general / small block
-  // 16-byte chunks must not straddle a row end or K, and 32-bit byte offsets must cover the operands
-  auto aligned = [](const void *ptr, uint32_t ld, uint64_t bs) { return ((uintptr_t)ptr & 15) == 0 && ld % 8 == 0 && bs % 8 == 0; };
+  // 32-bit byte offsets must cover the operands (buffer addressing); alignment is not required
   const uint64_t bytesA = (uint64_t)(tA ? p->K : p->M) * ldA * 2, bytesB = (uint64_t)(tB ? p->N : p->K) * ldB * 2;
-  *use16 = k->fast16 && p->K % 8 == 0 && aligned(A, ldA, p->batchStrideA) && aligned(B, ldB, p->batchStrideB) &&
-           bytesA < 0xFFFFFF00ull && bytesB < 0xFFFFFF00ull;
+  *use16 = k->fast16 && bytesA < 0xFFFFFF00ull && bytesB < 0xFFFFFF00ull;
   return MFA_OK;
 }
 

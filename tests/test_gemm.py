@@ -227,6 +227,33 @@ def test_16bit_matrix_core_path(shape, precision, transpose):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transpose", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("shape", [(255, 257, 251), (127, 129, 77), (1, 1, 1), (33, 70, 9)])
+def test_16bit_path_with_unaligned_rows_and_ragged_k(shape, transpose):
+    """Odd leading dimensions (rows start at 2-byte alignment) and K % 8 != 0 still run on the 16-bit matrix
+    cores: unaligned 16-byte loads, the chunk that straddles K keeps only its first K - k elements.  The
+    operands are surrounded by large canary values, so a single stray element would show."""
+    from oracle.network import round_trip
+    M, N, K = shape
+    tA, tB = transpose
+    ld = ((M if tA else K) + 1, (K if tB else N) + 3, N + 5)     # odd / unaligned pitches
+    rng = np.random.default_rng(M * N + K)
+    A = np.full((K if tA else M) * ld[0], 1e4, np.float32)
+    B = np.full((N if tB else K) * ld[1], -1e4, np.float32)
+    a = A.reshape(-1, ld[0]); b = B.reshape(-1, ld[1])
+    a[:, :(M if tA else K)] = round_trip(rng.standard_normal((a.shape[0], (M if tA else K))).astype(np.float32), int(P.BF16))
+    b[:, :(K if tB else N)] = round_trip(rng.standard_normal((b.shape[0], (K if tB else N))).astype(np.float32), int(P.BF16))
+    prev = np.zeros(M * ld[2], np.float32)
+    d = make(M, N, K, (P.BF16, P.BF16, P.FP32), transpose, ld)
+    got, k = run_gemm(d, A, B, prev)
+    assert k.variant.startswith("gemm_16"), k.variant
+    want = og.naive(M, N, K, A, B, prev, ld, tA, tB, False, f64=True)
+    g = got.reshape(M, ld[2])[:, :N]
+    w = want.reshape(M, ld[2])[:, :N]
+    assert np.abs(g - w).max() < 1e-3 * np.sqrt(K), (k.variant, float(np.abs(g - w).max()))
+
+
+@pytest.mark.gpu
 def test_batched_gemm_extension():
     import torch
     M, N, K, batch = 96, 160, 64, 5

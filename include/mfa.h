@@ -72,7 +72,11 @@ typedef struct mfa_attention_descriptor {
    * MFA_FP16 reproduces +Precisions.swift:13-17 exactly (Q,K,V FP16; dO BF16).
    * MFA_BF16 stores Q,K,V,dO all as BF16 (what BASELINE.json's bf16 configs use). */
   uint8_t lowPrecisionInputType;
-  uint8_t reserved[3];
+  /* Extension (the reference keeps O, dV, dK, dQ in FP32 and leaves the cast to
+   * clients, +Precisions.swift:119-143): non-zero = the kernels store O, dQ, dK, dV directly in
+   * lowPrecisionInputType (BF16 by truncation, FP16 round-to-nearest) and backwardQuery reads that O. */
+  uint8_t lowPrecisionOutputs;
+  uint8_t reserved[2];
 } mfa_attention_descriptor;
 void mfa_attention_descriptor_init(mfa_attention_descriptor *desc); /* AttentionDescriptor() */
 

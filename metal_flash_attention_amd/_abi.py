@@ -39,7 +39,8 @@ class mfa_attention_descriptor(ctypes.Structure):
         ("transposeV", ctypes.c_uint8),
         ("transposeO", ctypes.c_uint8),
         ("lowPrecisionInputType", ctypes.c_uint8),
-        ("reserved", ctypes.c_uint8 * 3),
+        ("lowPrecisionOutputs", ctypes.c_uint8),
+        ("reserved", ctypes.c_uint8 * 2),
     ]
 
 

@@ -154,6 +154,7 @@ class AttentionDescriptor:
         self.transposeState: Optional[Tuple[bool, bool, bool, bool]] = None  # (Q, K, V, O)
         # extension: storage type of low-precision inputs (FP16 = reference behaviour)
         self.lowPrecisionInputType: GEMMOperandPrecision = GEMMOperandPrecision.FP16
+        self.lowPrecisionOutputs: bool = False   # extension: O, dQ, dK, dV stored in lowPrecisionInputType
 
     def _to_c(self) -> _abi.mfa_attention_descriptor:
         c = _abi.mfa_attention_descriptor()
@@ -161,6 +162,7 @@ class AttentionDescriptor:
         c.lowPrecisionInputs = int(bool(self.lowPrecisionInputs))
         c.lowPrecisionIntermediates = int(bool(self.lowPrecisionIntermediates))
         c.lowPrecisionInputType = int(self.lowPrecisionInputType)
+        c.lowPrecisionOutputs = 1 if self.lowPrecisionOutputs else 0
         if self.matrixDimensions is not None:
             c.hasMatrixDimensions = 1
             c.row, c.column, c.head = (int(x) for x in self.matrixDimensions)

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   constexpr uint32_t OOB = 0xFFFFFF00u;
   const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)R * ldq2, 0x00020000);
   const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_dO], head, batch), 0, (uint32_t)R * ldg2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_O], head, batch), 0, (uint32_t)R * ldo4, 0x00020000);
+  const bool o32 = a.op[SLOT_O].precision == PREC_FP32;
+  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_O], head, batch), 0, (uint32_t)R * (o32 ? ldo4 : ldo4 / 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_K], head, batch), 0, (uint32_t)C * ldk2, 0x00020000);
   const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_V], head, batch), 0, (uint32_t)C * ldv2, 0x00020000);
 
@@ -90,11 +91,17 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     qf[s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(qres, ok ? (uint32_t)row * ldq2 + d0 * 2 : OOB, 0, 0));
     gf[s] = convert_chunk<T, TG>(__builtin_amdgcn_raw_buffer_load_b128(gres, ok ? (uint32_t)row * ldg2 + d0 * 2 : OOB, 0, 0));
     // computeD (+Softmax.swift:32-221): D = sum_d dO*O, the two half-waves split the head dimension
-    const uint32_t ooff = ok ? (uint32_t)row * ldo4 + d0 * 4 : OOB;
-    const f32x4 o0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ooff, 0, 0));
-    const f32x4 o1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ok ? ooff + 16 : OOB, 0, 0));
+    if (o32) {
+      const uint32_t ooff = ok ? (uint32_t)row * ldo4 + d0 * 4 : OOB;
+      const f32x4 o0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ooff, 0, 0));
+      const f32x4 o1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ores, ok ? ooff + 16 : OOB, 0, 0));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dterm += (float)gf[s][i] * o0[i] + (float)gf[s][4 + i] * o1[i];
+      for (int i = 0; i < 4; ++i) dterm += (float)gf[s][i] * o0[i] + (float)gf[s][4 + i] * o1[i];
+    } else {   // O stored in the inputs' 16-bit type (fused output cast of the forward kernel)
+      const v8 o8 = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(ores, ok ? (uint32_t)row * (ldo4 / 2) + d0 * 2 : OOB, 0, 0));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dterm += (float)gf[s][i] * (float)o8[i];
+    }
   }
   dterm = half_swap_add(dterm) * a.scale;
   float Lrow = 0.f;
@@ -218,18 +225,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
           make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
   if (hi == 0 && row < R) store_elem(operand_base(a.op[SLOT_D], head, batch), row, a.op[SLOT_D].precision, dterm);
-  const __amdgpu_buffer_rsrc_t dqres = __builtin_amdgcn_make_buffer_rsrc(
-      operand_base(a.op[SLOT_dQ], head, batch), 0, (uint32_t)R * (uint32_t)a.op[SLOT_dQ].ld * 4u, 0x00020000);
-  const uint32_t lddq4 = (uint32_t)a.op[SLOT_dQ].ld * 4;
-  constexpr int CPRO = D / 4;
-#pragma unroll
-  for (int i = 0; i < 32 * CPRO / 64; ++i) {
-    const int id = lane + i * 64;
-    const int rr = id / CPRO, c = id % CPRO;
-    const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
-    const uint32_t off = (r0 + rr < R && c * 4 < Dr) ? (uint32_t)(r0 + rr) * lddq4 + c * 16 : OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), dqres, off, 0, 0);
-  }
+  store_block_rows<T, D>(Os, operand_base(a.op[SLOT_dQ], head, batch), a.op[SLOT_dQ].precision, (uint32_t)a.op[SLOT_dQ].ld,
+                         r0, R, Dr, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,7 +502,6 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
   float *orow = Os + kc * OLD;
-  constexpr int CPRO = D / 4;
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     const int slot = which == 0 ? SLOT_dV : SLOT_dK;
@@ -517,17 +513,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
         *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
             make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
       }
-    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
-        operand_base(a.op[slot], head, batch), 0, (uint32_t)C * (uint32_t)a.op[slot].ld * 4u, 0x00020000);
-    const uint32_t ld4 = (uint32_t)a.op[slot].ld * 4;
-#pragma unroll
-    for (int i = 0; i < 32 * CPRO / 64; ++i) {
-      const int id = lane + i * 64;
-      const int rr = id / CPRO, c = id % CPRO;
-      const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
-      const uint32_t off = (c0 + rr < C && c * 4 < Dr) ? (uint32_t)(c0 + rr) * ld4 + c * 16 : OOB;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), res, off, 0, 0);
-    }
+    store_block_rows<T, D>(Os, operand_base(a.op[slot], head, batch), a.op[slot].precision, (uint32_t)a.op[slot].ld, c0, C, Dr, lane);
   }
 }
 

@@ -297,7 +297,6 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
   float *orow = Os + kc * OLD;
-  constexpr int CPRO = D / 4;
 #pragma unroll
   for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -305,17 +304,7 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
       *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
           make_float4(acc[db][4 * g], acc[db][4 * g + 1], acc[db][4 * g + 2], acc[db][4 * g + 3]);
   const int slot = role ? SLOT_dK : SLOT_dV;
-  const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
-      operand_base(a.op[slot], head, batch), 0, (uint32_t)C * (uint32_t)a.op[slot].ld * 4u, 0x00020000);
-  const uint32_t ld4 = (uint32_t)a.op[slot].ld * 4;
-#pragma unroll
-  for (int i = 0; i < 32 * CPRO / 64; ++i) {
-    const int id = lane + i * 64;
-    const int rr = id / CPRO, c = id % CPRO;
-    const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
-    const uint32_t off = (c0 + rr < C && c * 4 < Dr) ? (uint32_t)(c0 + rr) * ld4 + c * 16 : OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), res, off, 0, 0);
-  }
+  store_block_rows<T, D>(Os, operand_base(a.op[slot], head, batch), a.op[slot].precision, (uint32_t)a.op[slot].ld, c0, C, Dr, lane);
 }
 
 } // namespace mfa

@@ -59,6 +59,43 @@ template <> struct Frag16<_Float16> {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
+// two fp32 values -> one dword of the 16-bit storage type, with the reference's store rounding: BF16 by
+// truncation (GEMMHeaders.swift:461-471, +Caching.swift:395-401), FP16 round-to-nearest
+template <typename T> __device__ __forceinline__ uint32_t pack16(float a, float b) {
+  if constexpr (__is_same(T, __bf16)) {
+    return (__builtin_bit_cast(uint32_t, a) >> 16) | (__builtin_bit_cast(uint32_t, b) & 0xFFFF0000u);
+  } else {
+    const f16x2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, h);
+  }
+}
+
+// Whole-row store of a 32-row x D block that a wave has laid out in LDS ([32][D + 4] floats) to a row-major
+// operand kept in FP32 or -- fused output cast, SURVEY.md section 8f rank 2 -- in the 16-bit type T.
+// `bound` = number of valid rows of the operand (per batch entry), `Dr` = real head dimension.
+template <typename T, int D>
+__device__ __forceinline__ void store_block_rows(const float *Os, char *base, int prec, uint32_t ld, int64_t r0, int64_t bound,
+                                                 int Dr, int lane, float scale = 1.0f) {
+  constexpr int OLD = D + 4, CPRO = D / 4;
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+  const uint32_t esz = prec == PREC_FP32 ? 4u : 2u;
+  const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(base, 0, (uint32_t)bound * ld * esz, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 32 * CPRO / 64; ++i) {
+    const int id = lane + i * 64;
+    const int rr = id / CPRO, c = id % CPRO;
+    float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
+    val.x *= scale; val.y *= scale; val.z *= scale; val.w *= scale;
+    const bool ok = r0 + rr < bound && c * 4 < Dr;
+    if (prec == PREC_FP32) {
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), res, ok ? (uint32_t)(r0 + rr) * ld * 4 + c * 16 : OOB, 0, 0);
+    } else {
+      const u32x2 h = {pack16<T>(val.x, val.y), pack16<T>(val.z, val.w)};
+      __builtin_amdgcn_raw_buffer_store_b64(h, res, ok ? (uint32_t)(r0 + rr) * ld * 2 + c * 8 : OOB, 0, 0);
+    }
+  }
+}
+
 // 16-byte chunk index swizzle of the row-major K image (ds_read_b128 is conflict-free when the 16
 // rows of a lane group land on 16 distinct 16-B slots of the 256-B bank row)
 template <int D> __device__ __forceinline__ int kswz(int row, int chunk) {

@@ -519,19 +519,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       }
     }
   }
-  const uint32_t ldo4 = SPLIT ? (uint32_t)Dr * 4 : (uint32_t)a.op[SLOT_O].ld * 4;
-  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
-      SPLIT ? reinterpret_cast<char *>(grid.wsO + slab * Dr) : operand_base(a.op[SLOT_O], head, batch), 0,
-      (uint32_t)R * ldo4, 0x00020000);
-  constexpr int CPRO = D / 4;
+  // whole-row stores: SPLIT -> fp32 slab of the workspace; otherwise O in FP32 or, fused cast, the 16-bit type
 #pragma unroll
-  for (int i = 0; i < RB * 32 * CPRO / 64; ++i) {
-    const int id = lane + i * 64;
-    const int rr = id / CPRO, c = id % CPRO;
-    const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
-    const int64_t row = r0 + rr;
-    const uint32_t off = (row < R && c * 4 < Dr) ? (uint32_t)row * ldo4 + c * 16 : OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ores, off, 0, 0);
+  for (int b = 0; b < RB; ++b) {
+    if constexpr (SPLIT)
+      store_block_rows<T, D>(Os + b * 32 * OLD, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr,
+                             r0 + 32 * b, R, Dr, lane);
+    else
+      store_block_rows<T, D>(Os + b * 32 * OLD, operand_base(a.op[SLOT_O], head, batch), a.op[SLOT_O].precision,
+                             (uint32_t)a.op[SLOT_O].ld, r0 + 32 * b, R, Dr, lane);
   }
 }
 
@@ -562,8 +558,17 @@ static __global__ __launch_bounds__(256) void attn_fwd_combine(const KernelArgs 
   }
   const float inv = 1.0f / lstar;
   if (active) {
-    float *orow = reinterpret_cast<float *>(operand_base(a.op[SLOT_O], head, batch)) + (uint64_t)row * a.op[SLOT_O].ld;
-    *reinterpret_cast<float4 *>(orow + lane * 4) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    char *obase = operand_base(a.op[SLOT_O], head, batch);
+    const int64_t idx = (int64_t)row * a.op[SLOT_O].ld + lane * 4;
+    const int oprec = a.op[SLOT_O].precision;
+    if (oprec == PREC_FP32) {
+      *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obase) + idx) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    } else {
+      store_elem(obase, idx, oprec, acc.x * inv);
+      store_elem(obase, idx + 1, oprec, acc.y * inv);
+      store_elem(obase, idx + 2, oprec, acc.z * inv);
+      store_elem(obase, idx + 3, oprec, acc.w * inv);
+    }
   }
   if (lane == 0)
     store_elem(operand_base(a.op[SLOT_L], head, batch), row, a.op[SLOT_L].precision, mstar + log2f(lstar));

@@ -300,20 +300,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v4(const KernelArgs a, con
       }
     }
   }
-  const uint32_t ldo4 = SPLIT ? (uint32_t)Dr * 4 : (uint32_t)a.op[SLOT_O].ld * 4;
-  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(
-      SPLIT ? reinterpret_cast<char *>(grid.wsO + slab * Dr) : operand_base(a.op[SLOT_O], head, batch), 0,
-      (uint32_t)R * ldo4, 0x00020000);
-  constexpr int CPRO = D / 4;
-#pragma unroll
-  for (int i = 0; i < 32 * CPRO / 64; ++i) {
-    const int id = lane + i * 64;
-    const int rr = id / CPRO, c = id % CPRO;
-    const float4 val = *reinterpret_cast<const float4 *>(Os + rr * OLD + c * 4);
-    const int64_t row = r0 + rr;
-    const uint32_t off = (row < R && c * 4 < Dr) ? (uint32_t)row * ldo4 + c * 16 : OOB;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), ores, off, 0, 0);
-  }
+  if constexpr (SPLIT)
+    store_block_rows<T, D>(Os, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr, r0, R, Dr, lane);
+  else
+    store_block_rows<T, D>(Os, operand_base(a.op[SLOT_O], head, batch), a.op[SLOT_O].precision, (uint32_t)a.op[SLOT_O].ld,
+                           r0, R, Dr, lane);
 }
 
 } // namespace mfa

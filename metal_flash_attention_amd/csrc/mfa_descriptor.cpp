@@ -202,6 +202,8 @@ static void memory_precisions(const mfa_attention_descriptor &d, int8_t *out) {
     out[MFA_L] = out[MFA_D] = MFA_FP32;  // (:85-86)
   }
   out[MFA_O] = out[MFA_dV] = out[MFA_dK] = out[MFA_dQ] = MFA_FP32;  // (:140-143)
+  if (d.lowPrecisionOutputs)   // extension: fused output cast
+    out[MFA_O] = out[MFA_dV] = out[MFA_dK] = out[MFA_dQ] = bf16Inputs ? MFA_BF16 : MFA_FP16;
 }
 
 // AttentionDescriptor.registerPrecisions (+Precisions.swift:149-215).  gfx950 converts BF16 in

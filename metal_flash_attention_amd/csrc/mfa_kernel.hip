@@ -95,7 +95,8 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const bool same = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
-    if (same && rowMajor && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 && (D % 8) == 0) {
+    const int po = kdesc->memoryPrecisions[MFA_O];   // FP32, or the inputs' 16-bit type (fused output cast)
+    if (same && rowMajor && (po == MFA_FP32 || po == pq) && (D % 8) == 0) {
       // MFA_FWD16_IMPL (developer knob for A/B runs): "v1" = unpipelined kernel, "v2:<n>" = full-tile
       // pipeline schedule n, "v3:<n>" = half-tile pipeline schedule n.  Default: v3 schedule 0.
       const char *knob = std::getenv("MFA_FWD16_IMPL");
@@ -116,11 +117,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
     if (same && rowMajor && (D % 8) == 0) {
-      if (type == MFA_BACKWARD_QUERY && kdesc->memoryPrecisions[MFA_O] == MFA_FP32 &&
-          kdesc->memoryPrecisions[MFA_dQ] == MFA_FP32 && !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
+      auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
+      if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ) &&
+          !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
         fast = dq16_variant(pq, pg, bucket, &variant);
-      if (type == MFA_BACKWARD_KEY_VALUE && kdesc->memoryPrecisions[MFA_dK] == MFA_FP32 &&
-          kdesc->memoryPrecisions[MFA_dV] == MFA_FP32 && !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV])
+      if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
+          kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV] &&
+          !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV])
       {
         // MFA_DKV16_IMPL (developer knob for A/B runs): "w4" = one wave per key block (attn_dkv16), "rs:<n>" =
         // role-split wave pairs, ablation n.  Default: role-split wave pairs (attn_dkv16_rs).

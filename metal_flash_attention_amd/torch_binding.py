@@ -5,7 +5,7 @@ reference does not have -- only its tests call the kernels, Tests/FlashAttention
     o = flash_attention(q, k, v, causal=False)      # q [B, H, R, D], k / v [B, H, C, D]; bf16, fp16 or fp32
     o.sum().backward()                              # dQ, dK, dV through backwardQuery / backwardKeyValue
 
-forward  = AttentionKernelType.forward           -> O (fp32), L (fp32, saved for backward)
+forward  = AttentionKernelType.forward           -> O (the inputs' dtype, fused cast), L (fp32), both saved
 backward = AttentionKernelType.backwardQuery     -> D, dQ      (needs O, dO, L)
            AttentionKernelType.backwardKeyValue  -> dK, dV     (needs L, D)
 exactly the dispatch order of the reference's test (SquareAttentionTest.swift:355-368).  torch owns the
@@ -32,6 +32,7 @@ def _kernel(dtype: torch.dtype, R: int, C: int, D: int, kind: AttentionKernelTyp
         desc.lowPrecisionInputs = dtype != torch.float32
         if dtype != torch.float32:
             desc.lowPrecisionInputType = P.BF16 if dtype == torch.bfloat16 else P.FP16
+            desc.lowPrecisionOutputs = True     # O, dQ, dK, dV leave the kernels already in the inputs' type
         desc.lowPrecisionIntermediates = False
         desc.matrixDimensions = (R, C, D)
         desc.transposeState = (False, False, False, False)
@@ -61,7 +62,7 @@ class _FlashAttention(torch.autograd.Function):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, H, R, D = q.shape
         C = k.shape[2]
-        o = torch.empty((B, H, R, D), dtype=torch.float32, device=q.device)
+        o = torch.empty((B, H, R, D), dtype=q.dtype, device=q.device)      # fused output cast: no fp32 copy of O
         l = torch.empty((B, H, R), dtype=torch.float32, device=q.device)
         kernel = _kernel(q.dtype, R, C, D, AttentionKernelType.forward)
         hs, bs = _strides(B, H, R, C, D)
@@ -79,7 +80,7 @@ class _FlashAttention(torch.autograd.Function):
         ctx.save_for_backward(q, k, v, o, l)
         ctx.causal = causal
         ctx.lengths = (q_lengths, k_lengths)
-        return o.to(q.dtype)
+        return o
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -90,9 +91,9 @@ class _FlashAttention(torch.autograd.Function):
         # the inputs are 16-bit (also next to FP16 Q/K/V, the reference's mix), FP32 with FP32 inputs
         do = grad_out.to(torch.float32 if q.dtype == torch.float32 else torch.bfloat16).contiguous()
         alloc = torch.zeros if ctx.lengths != (None, None) else torch.empty   # padding gets zero gradients
-        dq = alloc((B, H, R, D), dtype=torch.float32, device=q.device)
-        dk = alloc((B, H, C, D), dtype=torch.float32, device=q.device)
-        dv = alloc((B, H, C, D), dtype=torch.float32, device=q.device)
+        dq = alloc((B, H, R, D), dtype=q.dtype, device=q.device)
+        dk = alloc((B, H, C, D), dtype=q.dtype, device=q.device)
+        dv = alloc((B, H, C, D), dtype=q.dtype, device=q.device)
         dterm = alloc((B, H, R), dtype=torch.float32, device=q.device)
         bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
         hs, bs = _strides(B, H, R, C, D)
@@ -101,7 +102,7 @@ class _FlashAttention(torch.autograd.Function):
             _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
                                                      batchStrides=bs, stream=stream, causal=ctx.causal,
                                                      rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1])
-        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None, None
+        return dq, dk, dv, None, None, None
 
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False,

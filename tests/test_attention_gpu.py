@@ -637,3 +637,46 @@ def test_variable_sequence_lengths(low, causal):
             # padding untouched
             for op, n in ((Op.O, R), (Op.L, R), (Op.D, R), (Op.dQ, R), (Op.dK, C), (Op.dV, C)):
                 assert np.isnan(out[op][b, h, n:]).all(), (op, b, h)
+
+
+# ---- fused 16-bit output cast (extension) ------------------------------
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+@pytest.mark.parametrize("shape,causal", [((256, 256, 128), False), ((300, 555, 64), False), ((129, 77, 40), False),
+                                          ((1024, 1024, 128), True), ((100, 1000, 128), False)])
+def test_low_precision_outputs(shape, causal, in_type):
+    """O, dQ, dK, dV stored directly in the inputs' 16-bit type by the matrix-core kernels (no separate cast
+    pass); backwardQuery reads the 16-bit O for its D term.  Reference mixed tolerances."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=R + 2 * C + D)
+    desc = make_desc(R, C, D, low_in=True, in_type=in_type)
+    desc.lowPrecisionOutputs = True
+    prec = desc.memoryPrecisions
+    assert all(prec[op] == in_type for op in (Op.O, Op.dQ, Op.dK, Op.dV))
+    run = harness.DeviceRun(desc, net, causal=causal)
+    variants = [k.variant for k in run.kernels.values()]
+    if D % 8 == 0:
+        assert all(not v.startswith("attn_generic") for v in variants), variants
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(causal=causal)
+    failures, report = harness.compare(ref, got, TOL_MIXED)
+    assert not failures, (failures, variants)
+    assert all(run.tails_ok.values()), run.tails_ok
+
+
+def test_low_precision_outputs_split_kv():
+    import torch
+    R, C, D = 256, 8192, 64
+    net = Network(NetworkDescriptor(R, C, D), seed=5)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    desc.lowPrecisionOutputs = True
+    run = harness.DeviceRun(desc, net, run_backward=False)
+    kernel = run.kernels[AttentionKernelType.forward]
+    need = kernel.workspaceSize(row=R, column=C)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    kernel.dispatch(run.buffers, row=R, column=C, stream=torch.cuda.current_stream().cuda_stream, workspace=ws)
+    torch.cuda.synchronize()
+    got = run.results()
+    round_inputs(net, desc)
+    assert np.abs(got["O"] - net.run(backward=False)["O"]).max() < 2e-2

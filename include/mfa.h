@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 3
+#define MFA_ABI_VERSION 4
 
 /* ---- status codes (replace fatalError, e.g. AttentionKernel.swift:33,
  *      AttentionDescriptor.swift:45/72/90/97, AttentionParameterRow.swift:50/57/100) -------- */
@@ -184,7 +184,20 @@ typedef struct mfa_launch_params {
    * caller's responsibility.  All three kernel types; launches with lengths are never column-split. */
   const uint32_t *rowLengths;
   const uint32_t *columnLengths;
+  /* Block-sparse mask (extension; the reference names block sparsity next to masks, README.md:7, :210):
+   * device bitmap with one bit per block of MFA_MASK_BLOCK_ROWS (256) rows x MFA_MASK_BLOCK_COLUMNS (128)
+   * columns, row blocks major, `blockMaskWords` 32-bit words per row block (bit b of word w = column block
+   * 32 w + b); set = the block is attended (subject to `causal` and the lengths), clear = the block is never
+   * loaded.  NULL = dense.  Strides in words select a mask per head / batch entry (0 = shared).  Rows none of
+   * whose blocks are set get O = 0, dQ = 0 and a hugely negative L.  All three kernel types. */
+  const uint32_t *blockMask;
+  uint32_t blockMaskWords;
+  uint32_t reserved2;
+  int64_t blockMaskHeadStride;
+  int64_t blockMaskBatchStride;
 } mfa_launch_params;
+#define MFA_MASK_BLOCK_ROWS 256
+#define MFA_MASK_BLOCK_COLUMNS 128
 void mfa_launch_params_init(mfa_launch_params *params);
 
 /* buffers[slot] = device pointer bound at AttentionOperand.bufferBinding `slot`; slots the

@@ -88,7 +88,14 @@ class mfa_launch_params(ctypes.Structure):
         ("reserved", ctypes.c_uint32),
         ("rowLengths", ctypes.c_void_p),
         ("columnLengths", ctypes.c_void_p),
+        ("blockMask", ctypes.c_void_p),
+        ("blockMaskWords", ctypes.c_uint32),
+        ("reserved2", ctypes.c_uint32),
+        ("blockMaskHeadStride", ctypes.c_int64),
+        ("blockMaskBatchStride", ctypes.c_int64),
     ]
+
+MFA_MASK_BLOCK_ROWS, MFA_MASK_BLOCK_COLUMNS = 256, 128
 
 
 # every symbol include/mfa.h declares: (name, restype, argtypes)

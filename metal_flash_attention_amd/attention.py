@@ -281,7 +281,8 @@ class AttentionKernel:
     # -- launch ------------------------------------------------------------------------------
     @staticmethod
     def _marshal(buffers, row, column, heads, batches, leadingDimensions, headStrides, batchStrides,
-                 workspace=None, causal=False, rowLengths=None, columnLengths=None):
+                 workspace=None, causal=False, rowLengths=None, columnLengths=None, blockMask=None,
+                 blockMaskWords=0, blockMaskStrides=(0, 0)):
         """`buffers`: dict {AttentionOperand: tensor | int} or a 10-sequence indexed by bufferBinding."""
         slots = [None] * _abi.MFA_BUFFER_SLOTS
         if isinstance(buffers, Mapping):
@@ -307,6 +308,10 @@ class AttentionKernel:
         # variable sequence lengths (extension): device arrays of `batches` uint32 / int32 entries
         params.rowLengths = _pointer(rowLengths)
         params.columnLengths = _pointer(columnLengths)
+        # block-sparse mask (extension): device bitmap, one bit per 256 x 128 block, blockMaskWords words per row block
+        params.blockMask = _pointer(blockMask)
+        params.blockMaskWords = int(blockMaskWords)
+        params.blockMaskHeadStride, params.blockMaskBatchStride = (int(x) for x in blockMaskStrides)
         if workspace is not None:   # caller-owned scratch for column-parallel forward launches
             params.workspace = _pointer(workspace)
             params.workspaceBytes = int(workspace.numel() * workspace.element_size()) \
@@ -326,9 +331,11 @@ class AttentionKernel:
     def dispatch(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
                  leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
                  batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,
-                 workspace=None, causal: bool = False, rowLengths=None, columnLengths=None) -> None:
+                 workspace=None, causal: bool = False, rowLengths=None, columnLengths=None, blockMask=None,
+                 blockMaskWords: int = 0, blockMaskStrides=(0, 0)) -> None:
         arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions,
-                                           headStrides, batchStrides, workspace, causal, rowLengths, columnLengths)
+                                           headStrides, batchStrides, workspace, causal, rowLengths, columnLengths,
+                                           blockMask, blockMaskWords, blockMaskStrides)
         check(lib().mfa_attention_kernel_launch(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                                 ctypes.c_void_p(stream or 0)))
 

@@ -48,7 +48,13 @@ struct KernelArgs {
   // extension: per-batch-entry sequence lengths (device arrays of `batches` entries, or null): entry b
   // uses the first rowLen[b] rows and colLen[b] columns of its R x C problem; the rest is padding
   const uint32_t *rowLen, *colLen;
+  // extension: block mask, one bit per (256 rows x 128 columns) block, row-major bitmap with `maskWords`
+  // 32-bit words per row block; strides in words (0 = one mask shared by all heads / batch entries)
+  const uint32_t *mask;
+  uint32_t maskWords;
+  int64_t maskHeadStride, maskBatchStride;
 };
+constexpr int MASK_BLOCK_ROWS = 256, MASK_BLOCK_COLUMNS = 128;
 
 // row index inside a 32x32 MFMA C/D tile held by (register r, half hi)
 __device__ __forceinline__ constexpr int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -27,7 +27,7 @@ namespace mfa {
 //       (row stride = 16 mod 256 bytes), and the eight fragment addresses of a lane become ONE register
 //       plus immediates instead of eight registers each needing a v_add_u32 with the stage base.
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false, bool DMA = false,
-          bool CAUSAL = false, int VD = 0>
+          bool CAUSAL = false, int VD = 0, bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 
   // ---- key range of this workgroup: everything, or piece `split` of `splits` (SPLIT launches)
   const int tiles_total = (C + BC - 1) / BC;
-  const int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;
+  int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;   // (SPARSE: first tile of the current run)
   // CAUSAL (extension): row r sees key c iff c <= r + (C - R); the workgroup stops at the tile that holds
   // the last key its last row may see, tiles that cross the diagonal are masked element-wise.
   const int coff = C - R;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * RB * 32)) - 1;
     tiles_visible = (int)min((int64_t)tiles_total, (last_row + coff) / BC + 1);
   }
-  const int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_visible;
+  int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_visible;
 
   // ---- K/V staging.  DMA == false: global -> VGPR -> LDS (as v2).  DMA == true: LDS-DMA
   // (buffer_load_dwordx4 ... lds): instruction i of wave w fills the 1 KiB of the tile image at
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // registers, no ds_write, and the data is tracked by vmcnt (drained before the tile's barrier).
   static_assert(!DMA || RING == 3, "LDS-DMA staging uses the 3-stage ring");
   uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
+  uint32_t kbase0[SPARSE ? NCH : 1], vbase0[SPARSE ? NCH : 1];   // SPARSE: offsets of tile 0, koff/voff restart per run
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -120,6 +121,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
       klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
       vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+      if constexpr (SPARSE) {
+        kbase0[i] = valid ? row * ldk2 + c * 16 : OOB;
+        vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
+      }
     }
   }
   u32x4 kreg[DMA ? 1 : NCH], vreg[DMA ? 1 : NCH];
@@ -403,6 +408,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   if constexpr (ABL == 1) {   // static priority for the second-dispatched half (T5 static form)
     if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
   }
+  static_assert(!(SPARSE && (SPLIT || DMA)), "block-sparse launches are row-parallel with register staging");
+  // One contiguous run of key tiles [tile0, tile1): prologue, pipelined loop, tail.  Dense launches make one
+  // call; block-sparse launches one per run of active tiles, the online-softmax state (m, l, O) carried
+  // across in registers.
+  auto traverse = [&]() {
+  if constexpr (SPARSE) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      koff[i] = __builtin_elementwise_add_sat(kbase0[i], (uint32_t)tile0 * kinc);
+      voff[i] = __builtin_elementwise_add_sat(vbase0[i], (uint32_t)tile0 * vinc);
+    }
+  }
   // ---- prologue
   const int ntiles = tile1 - tile0;
   const bool ragged = (C & (BC - 1)) != 0 && tile1 == tiles_total;   // only the globally last tile is partial
@@ -489,6 +506,32 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   rescale_if_needed(m_new);
   exponentiate(s1, pf);
   pv(st_cur, 1, pf);
+  };   // traverse
+
+  if constexpr (!SPARSE) {
+    traverse();
+  } else {
+    // Block mask (extension): bit (row block of 256 rows, column block of 128 keys) of the caller's bitmap;
+    // the workgroup's rows lie inside one row block, a 64-key tile inside one column block.  Runs of
+    // consecutive active tiles are traversed one after the other; inactive tiles are never loaded.
+    const uint32_t *mrow = a.mask + (int64_t)head * a.maskHeadStride + (int64_t)batch * a.maskBatchStride +
+                           (uint64_t)(((uint64_t)rblk * (NW * RB * 32)) >> 8) * a.maskWords;
+    auto active = [&](int tile) { const int cb = tile >> 1; return ((mrow[cb >> 5] >> (cb & 31)) & 1u) != 0; };
+    const int tend = tile1;
+    bool first = true;
+    int t = 0;
+    while (t < tend) {
+      if (!active(t)) { ++t; continue; }
+      int e = t + 1;
+      while (e < tend && active(e)) ++e;
+      if (!first) __syncthreads();   // every wave is done with the previous run's ring stages
+      first = false;
+      tile0 = t;
+      tile1 = e;
+      traverse();
+      t = e;
+    }
+  }
 
   // ---- epilogue: O /= l (+Source.swift:165-171), L = m + log2(l) (+Caching.swift:373-377).
   // SPLIT launches instead publish the un-normalised (O, m, l) of their key range; attn_fwd_combine
@@ -501,7 +544,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     const float l_tot = (MSUM ? lsum[b][0] : half_swap_add(l[b])) + 1.401298464e-45f;
-    const float inv = SPLIT ? 1.0f : 1.0f / l_tot;
+    const float inv = SPLIT ? 1.0f : ((SPARSE && !(l_tot > 1e-30f)) ? 0.f : 1.0f / l_tot);   // SPARSE: a row may see no key at all
     float *orow = Os + (b * 32 + q) * OLD;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)

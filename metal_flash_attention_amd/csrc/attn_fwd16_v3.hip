@@ -41,8 +41,22 @@ static void launch_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &ar
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE>
+static void launch_v3_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  if (args.causal)
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true, 0, true>), dim3(grid.x * grid.y * grid.z),
+                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
+  else
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, false, 0, true>), dim3(grid.x * grid.y * grid.z),
+                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
+}
+
+template <typename T, int D, int NW, int RB, int THR, int PRE>
 static void fill_with_split(VariantInfo *v, const char *name) {
   fill<T, D, NW, RB, THR, PRE>(v, name);
+  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE>;
+  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, false, 0, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true, 0, true>);
   v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE>;
   v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true>);

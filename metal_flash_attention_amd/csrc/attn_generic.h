@@ -46,6 +46,16 @@ __device__ __forceinline__ void tile_chunk(int e, int *n, int *d) {
   }
 }
 
+// block mask (extension): bit (row block of 256 rows, column block of 128 columns), see attn_common.h.  The
+// general kernels skip inactive blocks tile by tile (and then stage synchronously: no register prefetch)
+__device__ __forceinline__ const uint32_t *mask_base(const KernelArgs &a, uint32_t head, uint32_t batch) {
+  return a.mask ? a.mask + (int64_t)head * a.maskHeadStride + (int64_t)batch * a.maskBatchStride : nullptr;
+}
+__device__ __forceinline__ bool mask_bit(const uint32_t *m, uint32_t words, int64_t row, int64_t col) {
+  const uint32_t cb = (uint32_t)(col / MASK_BLOCK_COLUMNS);
+  return ((m[(uint64_t)(row / MASK_BLOCK_ROWS) * words + (cb >> 5)] >> (cb & 31)) & 1u) != 0;
+}
+
 // Register-staged variant of the fp32 fast path (prefetch: issue the loads of tile j+1 before the
 // arithmetic of tile j, write them to LDS after it).
 template <int ROWS, int DP, int NT> struct TileRegsF32 {
@@ -240,13 +250,15 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
   const int coff = C - R;
   const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
-  const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
+  const uint32_t *mrow = mask_base(a, head, batch);
+  const bool prefetch = !mrow && CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
   TileRegsF32<BC, DP, NT> kregs, vregs;
   if (prefetch) {
     tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
     tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
   }
   for (int c0 = 0; c0 < Cend; c0 += BC) {
+    if (mrow && !mask_bit(mrow, a.maskWords, r0, c0)) continue;   // workgroup-uniform: the block is never loaded
     if (prefetch) {
       tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
       tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
   }
 
   const float l_tot = l + __shfl_xor(l, 32);
-  const float inv = 1.0f / l_tot;           // +Source.swift:165-171
+  const float inv = (m > -1e37f) ? 1.0f / l_tot : 0.f;   // +Source.swift:165-171 (0: a row whose every block is masked out)
   float *Os = smem;                         // [BR][LD]
   float *orow = Os + (wave * 32 + q) * LD;
 #pragma unroll
@@ -400,13 +412,15 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   const int coff = C - R;
   const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
-  const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
+  const uint32_t *mrow = mask_base(a, head, batch);
+  const bool prefetch = !mrow && CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
   TileRegsF32<BC, DP, NT> kregs, vregs;
   if (prefetch) {
     tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
     tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
   }
   for (int c0 = 0; c0 < Cend; c0 += BC) {
+    if (mrow && !mask_bit(mrow, a.maskWords, r0, c0)) continue;   // workgroup-uniform: the block is never loaded
     if (prefetch) {
       tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
       tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
@@ -515,13 +529,15 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   const int coff = C - R;
   const int rstart = a.causal ? (int)(max((int64_t)0, c0 - coff) / BRW) * BRW : 0;
   constexpr bool CAN_PREFETCH = (DP <= 128);
-  const bool prefetch = CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
+  const uint32_t *mbase = mask_base(a, head, batch);
+  const bool prefetch = !mbase && CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
   TileRegsF32<BRW, DP, NT> qregs, gregs;
   if (prefetch) {
     tile_load_f32<BRW, DP, NT>(qregs, a.op[SLOT_Q], qbase, rstart, R, D, tid);
     tile_load_f32<BRW, DP, NT>(gregs, a.op[SLOT_dO], gbase, rstart, R, D, tid);
   }
   for (int r0 = rstart; r0 < R; r0 += BRW) {
+    if (mbase && !mask_bit(mbase, a.maskWords, r0, c0)) continue;   // workgroup-uniform
     if (prefetch) {
       tile_store_f32<BRW, DP, NT>(Qs, qregs, tid);
       tile_store_f32<BRW, DP, NT>(dOs, gregs, tid);

@@ -21,6 +21,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->ldsBytes = generic_dq_lds_floats<DP, NW, CACHE>() * sizeof(float);
   v->cacheLeft = CACHE;
   v->causal = true;
+  v->sparse = true;
   v->launch = &launch_dq<DP, NW, CACHE>;
 }
 

@@ -21,6 +21,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->ldsBytes = generic_fwd_lds_floats<DP, NW, CACHE>() * sizeof(float);
   v->cacheLeft = CACHE;
   v->causal = true;
+  v->sparse = true;
   v->launch = &launch_fwd<DP, NW, CACHE>;
 }
 

@@ -23,6 +23,11 @@ struct VariantInfo {
   // nullptr when `launch` handles the flag itself (general kernels) or the variant has no mask
   void (*launchCausal)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
   const void *funcCausal = nullptr;
+  // code objects that honour KernelArgs.mask (block-sparse extension; the launcher picks the causal or the
+  // unmasked one from args.causal); nullptr = the variant has none and the general kernels serve the launch
+  void (*launchSparse)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
+  const void *funcSparse = nullptr, *funcSparseCausal = nullptr;
+  bool sparse = false;   // `launch` itself honours the mask (general kernels)
 };
 
 // generic (fp32-MFMA) family: returns false if (DP) is not compiled

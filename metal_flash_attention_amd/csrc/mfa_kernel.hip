@@ -274,12 +274,19 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   args->causal = p->causal ? 1 : 0;
   args->rowLen = p->rowLengths;
   args->colLen = p->columnLengths;
+  args->mask = p->blockMask;
+  args->maskWords = p->blockMaskWords;
+  args->maskHeadStride = p->blockMaskHeadStride;
+  args->maskBatchStride = p->blockMaskBatchStride;
+  if (p->blockMask && p->blockMaskWords * 32ull * MASK_BLOCK_COLUMNS < p->column)
+    return fail(MFA_ERR_INVALID_ARGUMENT, "blockMaskWords does not cover `column`");
   if (p->causal && p->column < p->row)
     return fail(MFA_ERR_INVALID_ARGUMENT, "causal masking requires column >= row");
   const uint32_t heads = p->heads ? p->heads : 1, batches = p->batches ? p->batches : 1;
   if (heads > 65535 || batches > 65535) return fail(MFA_ERR_INVALID_ARGUMENT, "heads and batches must be <= 65535");
   plan->useFallback = kernel->hasFallback && (!meets_fast_requirements(kernel, *args) ||
-                                              (args->causal && !kernel->variant.causal));
+                                              (args->causal && !kernel->variant.causal) ||
+                                              (args->mask && !kernel->variant.launchSparse && !kernel->variant.sparse));
   plan->variant = plan->useFallback ? &kernel->fallback : &kernel->variant;
   // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
   // (SquareAttentionTest.swift:355-367)
@@ -288,7 +295,7 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
   plan->splits = 1;
-  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit && !args->causal && !args->rowLen && !args->colLen) {
+  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit && !args->causal && !args->rowLen && !args->colLen && !args->mask) {
     const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, p->column);
     if (s > 1) {
       const uint64_t rows = (uint64_t)s * heads * batches * p->row;
@@ -316,6 +323,10 @@ static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const Launc
   err = hipFuncSetAttribute(plan.variant->func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
   if (err == hipSuccess && plan.variant->funcCausal)
     err = hipFuncSetAttribute(plan.variant->funcCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+  if (err == hipSuccess && plan.variant->funcSparse)
+    err = hipFuncSetAttribute(plan.variant->funcSparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+  if (err == hipSuccess && plan.variant->funcSparseCausal)
+    err = hipFuncSetAttribute(plan.variant->funcSparseCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
   if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   if (device < 64) mask |= 1ull << device;
   return MFA_OK;
@@ -329,6 +340,7 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
   if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, (hipStream_t)stream, plan.args);
+  else if (plan.args.mask && plan.variant->launchSparse) plan.variant->launchSparse(plan.grid, (hipStream_t)stream, plan.args);
   else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, (hipStream_t)stream, plan.args);
   else plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
   hipError_t err = hipGetLastError();
@@ -366,6 +378,7 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
   auto go = [&]() {
     if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);
+    else if (plan.args.mask && plan.variant->launchSparse) plan.variant->launchSparse(plan.grid, s, plan.args);
     else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, s, plan.args);
     else plan.variant->launch(plan.grid, s, plan.args);
   };

@@ -5,7 +5,14 @@ the C restatement."""
 import numpy as np
 
 
-def attention_f64(Q, K, V, dO=None, causal=False):
+def block_mask_to_dense(bits, R, C, block_rows=256, block_columns=128):
+    """bits: bool [ceil(R / block_rows)][ceil(C / block_columns)] -> bool [R][C] (extension: block-sparse mask)."""
+    return np.repeat(np.repeat(np.asarray(bits, bool), block_rows, axis=0), block_columns, axis=1)[:R, :C]
+
+
+def attention_f64(Q, K, V, dO=None, causal=False, mask=None):
+    """mask (extension): bool [R][C], True = attended.  Rows that see no column at all get O = 0, L = -inf and
+    contribute nothing to any gradient."""
     Q, K, V = (np.asarray(a, np.float64) for a in (Q, K, V))
     D = Q.shape[-1]
     scale = 1.0 / np.sqrt(np.float64(D))
@@ -13,9 +20,14 @@ def attention_f64(Q, K, V, dO=None, causal=False):
     if causal:  # extension: row r sees column c iff c <= r + (C - R)
         R_, C_ = S.shape
         S = np.where(np.arange(C_)[None, :] <= np.arange(R_)[:, None] + (C_ - R_), S, -np.inf)
+    if mask is not None:
+        S = np.where(mask, S, -np.inf)
+    empty = ~np.isfinite(S).any(axis=1, keepdims=True)
+    S = np.where(empty, 0.0, S)                             # placeholder rows, zeroed below
     m = S.max(axis=1, keepdims=True)                        # :156-160
     lse = m + np.log(np.exp(S - m).sum(axis=1, keepdims=True))   # :163-171
-    P = np.exp(S - lse)                                     # :172-176
+    P = np.where(empty, 0.0, np.exp(S - lse))               # :172-176
+    lse = np.where(empty, -np.inf, lse)
     out = {"O": P @ V, "L": lse[:, 0]}                      # :286-311, :181-203
     if dO is None:
         return out

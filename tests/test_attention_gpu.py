@@ -680,3 +680,56 @@ def test_low_precision_outputs_split_kv():
     got = run.results()
     round_inputs(net, desc)
     assert np.abs(got["O"] - net.run(backward=False)["O"]).max() < 2e-2
+
+
+# ---- block-sparse mask (extension) ------------------------------------
+def _random_block_mask(R, C, density, rng, keep_empty_row=False):
+    rb, cb = (R + 255) // 256, (C + 127) // 128
+    bits = rng.random((rb, cb)) < density
+    for i in range(rb):
+        if not bits[i].any() and not (keep_empty_row and i == rb - 1):
+            bits[i, rng.integers(0, cb)] = True
+    if keep_empty_row:
+        bits[rb - 1, :] = False
+    words = (cb + 31) // 32
+    packed = np.zeros((rb, words), np.uint32)
+    for i in range(rb):
+        for j in range(cb):
+            if bits[i, j]:
+                packed[i, j // 32] |= np.uint32(1) << np.uint32(j % 32)
+    return bits, packed, words
+
+
+@pytest.mark.parametrize("low", [False, True])
+@pytest.mark.parametrize("shape,causal,empty", [((600, 900, 64), False, False), ((1024, 1024, 128), True, False),
+                                                ((700, 1300, 128), False, True), ((300, 200, 40), False, False)])
+def test_block_sparse_mask(shape, causal, empty, low):
+    """All three kernels under a 256 x 128 block mask, against the fp64 matrix-form oracle with the same mask;
+    a row block with no active block at all must give O = 0 and zero gradients."""
+    import torch
+    from oracle.network_np import attention_f64, block_mask_to_dense
+    R, C, D = shape
+    rng = np.random.default_rng(R + C)
+    bits, packed, words = _random_block_mask(R, C, 0.4, rng, keep_empty_row=empty)
+    net = Network(NetworkDescriptor(R, C, D), seed=R * 3 + C)
+    desc = make_desc(R, C, D, low_in=low, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net)
+    mask_dev = torch.from_numpy(packed.view(np.int32)).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    for t, kernel in run.kernels.items():
+        kernel.dispatch(run.buffers, row=R, column=C, stream=stream, causal=causal, blockMask=mask_dev, blockMaskWords=words)
+    torch.cuda.synchronize()
+    got = run.results()
+    if low:
+        round_inputs(net, desc)
+    ref = attention_f64(net.Q, net.K, net.V, net.dO, causal=causal, mask=block_mask_to_dense(bits, R, C))
+    rows_alive = np.isfinite(ref["L"])
+    tol = dict(O=1.5e-2, D=5e-2, dV=2e-2, dK=2e-2, dQ=2e-2) if low else dict(O=2e-5, D=2e-5, dV=3e-5, dK=3e-5, dQ=3e-5)
+    for name, bound in tol.items():
+        err = np.abs(got[name] - ref[name]).max()
+        assert err < bound, (name, float(err), [k.variant for k in run.kernels.values()])
+    assert np.abs(got["L"][rows_alive] - ref["L"][rows_alive]).max() < (1e-3 if low else 2e-5)
+    if empty:
+        dead = ~rows_alive
+        assert dead.any() and (got["O"][dead] == 0).all() and (got["dQ"][dead] == 0).all() and (got["L"][dead] < -1e30).all()
+    assert all(run.tails_ok.values())

@@ -31,14 +31,14 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in include/mfa.h but not exported"
     assert declared == {s[0] for s in _abi.SYMBOLS}, "ctypes table out of sync with the header"
-    assert _abi.lib().mfa_abi_version() == 3
+    assert _abi.lib().mfa_abi_version() == 4
 
 
 def test_struct_layouts_match_header():
     # sizes are part of the ABI: a cgo/JNI/Swift binding relies on them
     assert ctypes.sizeof(_abi.mfa_attention_descriptor) == 24
     assert ctypes.sizeof(_abi.mfa_attention_kernel_descriptor) == 70
-    assert ctypes.sizeof(_abi.mfa_launch_params) == 16 + 3 * 80 + 16 + 8 + 16
+    assert ctypes.sizeof(_abi.mfa_launch_params) == 16 + 3 * 80 + 16 + 8 + 16 + 32
     assert ctypes.sizeof(_abi.mfa_parameter_row) == 22
 
 

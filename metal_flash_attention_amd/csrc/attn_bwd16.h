@@ -49,7 +49,7 @@ template <int D, int NW> constexpr int dq16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false>
+template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false, bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -131,6 +131,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
     }
   };
+  // SPARSE (block-mask extension): tiles are not consecutive, so the offsets are those of tile 0 plus tile * pitch
+  auto issue_loads_at = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, __builtin_elementwise_add_sat(koff[i], (uint32_t)tile * kinc), 0, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, __builtin_elementwise_add_sat(voff[i], (uint32_t)tile * vinc), 0, 0);
+    }
+  };
   auto write_tiles = [&](int stage) {
     char *base = smem + stage * STAGE;
 #pragma unroll
@@ -160,12 +168,27 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * 32)) - 1;
     ntiles = (int)min((int64_t)ntiles, (last_row + coff) / BC + 1);
   }
-  issue_loads();
-  write_tiles(0);
+  // block mask: bit (row block of 256 rows = this workgroup, column block of 128 keys = two tiles)
+  const uint32_t *mrow = nullptr;
+  if constexpr (SPARSE)
+    mrow = a.mask + (int64_t)head * a.maskHeadStride + (int64_t)batch * a.maskBatchStride +
+           (uint64_t)(((uint64_t)rblk * (NW * 32)) >> 8) * a.maskWords;
+  auto next_active = [&](int t) {   // first active tile >= t (ntiles if none); dense: t itself
+    if constexpr (SPARSE) {
+      while (t < ntiles && !((mrow[(t >> 1) >> 5] >> ((t >> 1) & 31)) & 1u)) ++t;
+    }
+    return t;
+  };
+  int j = next_active(0), stage = 0;
+  if (j < ntiles) {
+    if constexpr (SPARSE) issue_loads_at(j); else issue_loads();
+    write_tiles(0);
+  }
   __syncthreads();
-  for (int j = 0; j < ntiles; ++j) {
-    const char *st = smem + (j & 1) * STAGE;
-    if (j + 1 < ntiles) issue_loads();
+  while (j < ntiles) {
+    const char *st = smem + stage * STAGE;
+    const int jn = next_active(j + 1);
+    if (jn < ntiles) { if constexpr (SPARSE) issue_loads_at(jn); else issue_loads(); }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       // S^T = K Q^T and dP^T = V dO^T for 32 keys: lane = query row, registers = keys crow(r, hi)
@@ -210,8 +233,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
           dq[db] = F::mfma(ktf, dsf[u], dq[db]);
         }
     }
-    if (j + 1 < ntiles) write_tiles((j + 1) & 1);
+    if (jn < ntiles) write_tiles(stage ^ 1);
     __syncthreads();
+    stage ^= 1;
+    j = jn;
   }
 
   // ---- epilogue: dQ through LDS (whole-row stores); D written pre-scaled (+Caching.swift:381-413)

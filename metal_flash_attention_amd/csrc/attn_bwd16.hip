@@ -31,6 +31,15 @@ static void launch_dkv16_causal(dim3 grid, hipStream_t stream, const KernelArgs 
                      (dkv16_lds_bytes<D, NW>()), stream, args, g);
 }
 
+template <typename T, int D, int NW, typename TG>
+static void launch_dq16_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  if (args.causal)
+    hipLaunchKernelGGL((attn_dq16<T, D, NW, TG, true, true>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64), (dq16_lds_bytes<D, NW>()), stream, args, g);
+  else
+    hipLaunchKernelGGL((attn_dq16<T, D, NW, TG, false, true>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64), (dq16_lds_bytes<D, NW>()), stream, args, g);
+}
+
 template <typename T, int D, int NW, typename TG = T>
 static void fill_dq(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG>);
@@ -45,6 +54,9 @@ static void fill_dq(VariantInfo *v, const char *name) {
   v->launchCausal = &launch_dq16_causal<T, D, NW, TG>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG, true>);
   v->causal = true;
+  v->launchSparse = &launch_dq16_sparse<T, D, NW, TG>;
+  v->funcSparse = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG, false, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG, true, true>);
 }
 template <typename T, int D, int NW, int PRE = 1, typename TG = T>
 static void fill_dkv(VariantInfo *v, const char *name) {

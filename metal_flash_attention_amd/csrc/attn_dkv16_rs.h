@@ -33,15 +33,16 @@
 
 namespace mfa {
 
+constexpr int DKV16RS_MAX_ROW_BLOCKS = 4096;   // 256-row blocks a block-sparse launch can list (R <= 1 Mi rows)
 template <int D> constexpr int dkv16rs_lds_bytes() {
-  constexpr int ring = 4 * (2 * 32 * D * 2 + 256) + 4 * 2 * 4096;
+  constexpr int ring = 4 * (2 * 32 * D * 2 + 256) + 4 * 2 * 4096 + 2 * DKV16RS_MAX_ROW_BLOCKS + 16;
   constexpr int epi = 8 * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }
 
 // ABL: timing-only ablations (WRONG RESULTS): 1 = no global loads in the loop, 2 = no staging at all,
 // 3 = no barrier, 4 = no L/D/P LDS traffic in the arithmetic
-template <typename T, int D, typename TG = T, bool CAUSAL = false, int ABL = 0>
+template <typename T, int D, typename TG = T, bool CAUSAL = false, int ABL = 0, bool SPARSE = false>
 __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -85,14 +86,15 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
 
   // CAUSAL (extension): the traversal starts at the first row block that sees the workgroup's first key
   const int coff = C - R;
-  const int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * 128 - coff) / 32) : 0;
+  int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * 128 - coff) / 32) : 0;   // (SPARSE: first row block of the current run)
 
   // ---- Q / dO staging + L, D slices; one 16-byte chunk per thread and operand
   const bool stager = tid < NCHUNK;
   const int srow = tid / CPR, sc = tid % CPR;
   const bool svalid = stager && sc * 8 < Dr;
-  uint32_t qoff = svalid ? (block0 * BR + srow) * ldq2 + sc * 16 : OOB;
-  uint32_t goff = svalid ? (block0 * BR + srow) * ldg2 + sc * 16 : OOB;
+  const uint32_t qbase0 = svalid ? srow * ldq2 + sc * 16 : OOB, gbase0 = svalid ? srow * ldg2 + sc * 16 : OOB;   // row block 0
+  uint32_t qoff = __builtin_elementwise_add_sat(qbase0, (uint32_t)block0 * BR * ldq2);
+  uint32_t goff = __builtin_elementwise_add_sat(gbase0, (uint32_t)block0 * BR * ldg2);
   const uint32_t wlds = ((sc >> 2) * BR + srow) * 64 + (((sc & 3) ^ ((srow >> 2) & 3)) * 16);   // Q at +0, dO at +TILE
   const uint32_t qinc = BR * ldq2, ginc = BR * ldg2;
   u32x4 qreg, greg;
@@ -106,7 +108,21 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
   const __amdgpu_buffer_rsrc_t ldres = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<char *>(wave == 0 ? lbase : dbase), 0, (uint32_t)R * ldesz, 0x00020000);
   uint32_t ldoff = (uint32_t)(block0 * BR + lane) * ldesz;
+  // SPARSE (block-mask extension): the traversal visits the 32-row blocks of the ACTIVE 256-row blocks only,
+  // as one continuous sequence (no pipeline restart at the gaps): step n works on row block blk(n), looked up
+  // in a table of active 256-row blocks that thread 0 builds in LDS behind the exchange buffer.
+  uint16_t *act = reinterpret_cast<uint16_t *>(smem + XBUF + 4 * 2 * 4096 + 16);
+  int nact = 0, nload = 0;
+  auto blk = [&](int n) { return (int)act[n >> 3] * 8 + (n & 7); };
   auto issue_loads = [&]() {
+    if constexpr (SPARSE) {
+      const bool in = (nload >> 3) < nact;
+      const uint32_t b = in ? (uint32_t)blk(nload) : 0u;
+      ++nload;
+      qoff = in ? __builtin_elementwise_add_sat(qbase0, b * BR * ldq2) : OOB;
+      goff = in ? __builtin_elementwise_add_sat(gbase0, b * BR * ldg2) : OOB;
+      ldoff = in ? (b * BR + lane) * ldesz : OOB;
+    }
     qreg = __builtin_amdgcn_raw_buffer_load_b128(qres, qoff, 0, 0);
     greg = __builtin_amdgcn_raw_buffer_load_b128(gres, goff, 0, 0);
     qoff = __builtin_elementwise_add_sat(qoff, qinc);
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
 
-  const int nblocks = (R + BR - 1) / BR - block0;
+  int nblocks = (R + BR - 1) / BR - block0;   // (SPARSE: row blocks of the current run)
   auto staging = [&](int t) {   // after the barrier: row block t+2 -> LDS (replaces t-2, last read in step t-1), loads of t+3 (zeros past the end)
     if constexpr (ABL != 3) __syncthreads();
     if constexpr (ABL != 2) write_tiles((t + 2) & 3);
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
       const float *Ls = reinterpret_cast<const float *>(smem + (cur & 3) * STAGE + 2 * TILE) + (ROLE ? 32 : 0) + 4 * hi;
       char *xp = xb + (cur & 1) * 4096;
       if constexpr (ROLE == 0) {
-        const int row0 = (block0 + cur) * BR;
+        const int row0 = (SPARSE ? blk(cur) : block0 + cur) * BR;
         const bool diag = CAUSAL && (c0 + 31 > row0 + coff);   // wave-uniform
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -283,14 +299,36 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
       }
     }
   };
-  issue_loads();
-  write_tiles(0);
-  issue_loads();
-  write_tiles(1);
-  issue_loads();              // row block 2 in flight
-  __syncthreads();
-  if (role == 0) run(std::integral_constant<int, 0>{});
-  else run(std::integral_constant<int, 1>{});
+  // one contiguous run of row blocks [block0, block0 + nblocks): prologue + this wave's role
+  auto traverse_rows = [&]() {
+    issue_loads();
+    write_tiles(0);
+    issue_loads();
+    write_tiles(1);
+    issue_loads();              // row block 2 in flight
+    __syncthreads();
+    if (role == 0) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 1>{});
+  };
+  if constexpr (!SPARSE) {
+    traverse_rows();
+  } else {
+    // block mask: bit (row block of 256 rows = 8 steps, column block of 128 keys = this workgroup)
+    const uint32_t *mcol = a.mask + (int64_t)head * a.maskHeadStride + (int64_t)batch * a.maskBatchStride + (cblk >> 5);
+    const int rb_end = ((R + BR - 1) / BR + 7) / 8;
+    int *count = reinterpret_cast<int *>(smem + XBUF + 4 * 2 * 4096);
+    if (tid == 0) {
+      int n = 0;
+      for (int rb = block0 / 8; rb < rb_end && n < DKV16RS_MAX_ROW_BLOCKS; ++rb)   // (causal: rows before block0 see none of these keys)
+        if ((mcol[(uint64_t)rb * a.maskWords] >> (cblk & 31)) & 1u) act[n++] = (uint16_t)rb;
+      *count = n;
+    }
+    __syncthreads();
+    nact = *count;
+    block0 = 0;             // unused by the sparse addressing
+    nblocks = 8 * nact;     // blocks past R inside the last active group are all zeros and contribute nothing
+    if (nact > 0) traverse_rows();
+  }
 
   // ---- epilogue: this wave's accumulator through LDS (whole-row stores): dV (V-wave) or dK (K-wave)
   __syncthreads();

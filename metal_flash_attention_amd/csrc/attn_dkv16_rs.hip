@@ -11,6 +11,15 @@ static void launch_rs(dim3 grid, hipStream_t stream, const KernelArgs &args) {
                      args, g);
 }
 
+template <typename T, int D, typename TG>
+static void launch_rs_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  if (args.causal)
+    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, true, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(512), (dkv16rs_lds_bytes<D>()), stream, args, g);
+  else
+    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, false, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(512), (dkv16rs_lds_bytes<D>()), stream, args, g);
+}
+
 template <typename T, int D, typename TG = T>
 static void fill(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false>);
@@ -25,12 +34,16 @@ static void fill(VariantInfo *v, const char *name) {
   v->launchCausal = &launch_rs<T, D, TG, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, true>);
   v->causal = true;
+  v->launchSparse = &launch_rs_sparse<T, D, TG>;
+  v->funcSparse = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false, 0, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, true, 0, true>);
 }
 
 bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
   if (impl >= 1 && impl <= 4 && precision == PREC_BF16 && gprecision == PREC_BF16 && D == 128) {   // timing-only ablations
     fill<__bf16, 128>(out, "ablate_dkv16rs_WRONG_RESULTS");
     out->launchCausal = nullptr; out->funcCausal = nullptr; out->causal = false;
+    out->launchSparse = nullptr; out->funcSparse = nullptr; out->funcSparseCausal = nullptr;
     switch (impl) {
       case 1: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 1>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 1>; break;
       case 2: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 2>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 2>; break;

@@ -286,7 +286,9 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   if (heads > 65535 || batches > 65535) return fail(MFA_ERR_INVALID_ARGUMENT, "heads and batches must be <= 65535");
   plan->useFallback = kernel->hasFallback && (!meets_fast_requirements(kernel, *args) ||
                                               (args->causal && !kernel->variant.causal) ||
-                                              (args->mask && !kernel->variant.launchSparse && !kernel->variant.sparse));
+                                              (args->mask && !kernel->variant.launchSparse && !kernel->variant.sparse) ||
+                                              // attn_dkv16_rs lists at most 4096 active 256-row blocks in LDS
+                                              (args->mask && type == MFA_BACKWARD_KEY_VALUE && p->row > 4096u * 256u));
   plan->variant = plan->useFallback ? &kernel->fallback : &kernel->variant;
   // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
   // (SquareAttentionTest.swift:355-367)

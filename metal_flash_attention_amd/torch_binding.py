@@ -57,7 +57,7 @@ def _strides(B, H, R, C, D):
 
 class _FlashAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, causal: bool, q_lengths=None, k_lengths=None):
+    def forward(ctx, q, k, v, causal: bool, q_lengths=None, k_lengths=None, block_mask=None):
         _check(q, k, v)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, H, R, D = q.shape
@@ -68,18 +68,23 @@ class _FlashAttention(torch.autograd.Function):
         hs, bs = _strides(B, H, R, C, D)
         need = kernel.workspaceSize(row=R, column=C, heads=H, batches=B)
         lengths = q_lengths is not None or k_lengths is not None
+        mask_kw = {}
+        if block_mask is not None:   # int32 [ceil(R / 256)][words]: bit b of word w = column block 32 w + b (128 keys each)
+            block_mask = block_mask.to(device=q.device, dtype=torch.int32).contiguous()
+            mask_kw = dict(blockMask=block_mask, blockMaskWords=int(block_mask.shape[-1]))
         if lengths:   # padding rows of the outputs are not written by the kernels: define them as zero
             o.zero_()
             l.zero_()
             q_lengths = None if q_lengths is None else q_lengths.to(device=q.device, dtype=torch.int32).contiguous()
             k_lengths = None if k_lengths is None else k_lengths.to(device=q.device, dtype=torch.int32).contiguous()
-        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal and not lengths else None
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal and not lengths and not mask_kw else None
         kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
                         headStrides=hs, batchStrides=bs, stream=torch.cuda.current_stream().cuda_stream,
-                        workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths)
+                        workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
         ctx.save_for_backward(q, k, v, o, l)
         ctx.causal = causal
         ctx.lengths = (q_lengths, k_lengths)
+        ctx.mask_kw = mask_kw
         return o
 
     @staticmethod
@@ -101,13 +106,26 @@ class _FlashAttention(torch.autograd.Function):
         for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
             _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
                                                      batchStrides=bs, stream=stream, causal=ctx.causal,
-                                                     rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1])
-        return dq, dk, dv, None, None, None
+                                                     rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1], **ctx.mask_kw)
+        return dq, dk, dv, None, None, None, None
+
+
+def pack_block_mask(bits: torch.Tensor) -> torch.Tensor:
+    """bool [row blocks of 256][column blocks of 128] -> the int32 bitmap the kernels read."""
+    rb, cb = bits.shape
+    words = (cb + 31) // 32
+    padded = torch.zeros((rb, words * 32), dtype=torch.int64, device=bits.device)
+    padded[:, :cb] = bits.to(torch.int64)
+    weights = (1 << torch.arange(32, dtype=torch.int64, device=bits.device))
+    packed = (padded.view(rb, words, 32) * weights).sum(-1)
+    return torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
 
 
 def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False,
-                    q_lengths: torch.Tensor = None, k_lengths: torch.Tensor = None) -> torch.Tensor:
+                    q_lengths: torch.Tensor = None, k_lengths: torch.Tensor = None,
+                    block_mask: torch.Tensor = None) -> torch.Tensor:
     """softmax(q k^T / sqrt(D)) v per (batch, head); causal: row r sees column c iff c <= r + (C - R).
     q_lengths / k_lengths ([B] integers, optional): batch entry b uses only its first q_lengths[b] rows and
-    k_lengths[b] keys (padded batches); padding rows of the output and of the gradients are zero."""
-    return _FlashAttention.apply(q, k, v, causal, q_lengths, k_lengths)
+    k_lengths[b] keys (padded batches); padding rows of the output and of the gradients are zero.
+    block_mask (optional, from pack_block_mask): blocks of 256 rows x 128 keys that are attended at all."""
+    return _FlashAttention.apply(q, k, v, causal, q_lengths, k_lengths, block_mask)

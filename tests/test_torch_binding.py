@@ -78,3 +78,23 @@ def test_padded_batch_with_lengths(causal):
         assert (o[b, :, n:] == 0).all() and (q.grad[b, :, n:] == 0).all() and (k.grad[b, :, n:] == 0).all()
         for got, ref in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
             assert (got[b, :, :n].float() - ref[0]).abs().max().item() < 5e-2
+
+
+@pytest.mark.gpu
+def test_block_mask_through_the_binding():
+    from metal_flash_attention_amd.torch_binding import flash_attention, pack_block_mask
+    B, H, N, D = 1, 2, 1024, 64
+    g = torch.Generator(device="cuda").manual_seed(4)
+    q, k, v = (torch.randn(B, H, N, D, generator=g, device="cuda").bfloat16().requires_grad_(True) for _ in range(3))
+    bits = torch.rand(N // 256, N // 128, generator=g, device="cuda") < 0.5
+    bits[:, 0] = True                                  # every row block sees something
+    o = flash_attention(q, k, v, block_mask=pack_block_mask(bits))
+    o.float().sum().backward()
+    dense = bits.repeat_interleave(256, 0).repeat_interleave(128, 1)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    s = (qr @ kr.transpose(-1, -2) / math.sqrt(D)).masked_fill(~dense, float("-inf"))
+    ref = torch.softmax(s, dim=-1) @ vr
+    ref.sum().backward()
+    assert (o.float() - ref).abs().max().item() < 3e-2
+    for got, want in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
+        assert (got.float() - want).abs().max().item() < 6e-2

@@ -25,27 +25,12 @@
 namespace mfa {
 
 template <typename T> struct Frag16;
-// The *_vq members are the same instruction written as inline asm with an explicit register-file
-// assignment: destination (= C) in VGPRs, B operand in AGPRs.  hipcc otherwise puts every MFMA result
-// in the accumulator file and copies score tiles back with v_accvgpr_read before the VALU can touch
-// them (32 moves per 32-key step).  `first` starts a chain with C = 0 (early-clobber: the result
-// tuple must not alias the A/B inputs); `last` appends the 12 wait states an 8-pass MFMA result needs
-// before a VALU read -- the compiler does not model hazards of instructions inside an asm string.
-// Back-to-back MFMAs on exactly the same accumulator need none.
-#define MFA_MFMA_VQ(NAME, MNEMONIC)                                                                   \
-  static __device__ __forceinline__ void NAME(f32x16 &c, v8 a, v8 b, bool first, bool last) {          \
-    if (first) asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));                     \
-    else if (last) asm volatile(MNEMONIC " %0, %1, %2, %0\n\ts_nop 11" : "+v"(c) : "v"(a), "a"(b));     \
-    else asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));                           \
-  }
-
 template <> struct Frag16<__bf16> {
   typedef bf16x8 v8;
   typedef bf16x4 v4;
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
-  MFA_MFMA_VQ(mfma_vq, "v_mfma_f32_32x32x16_bf16")
 };
 template <> struct Frag16<_Float16> {
   typedef f16x8 v8;
@@ -53,7 +38,6 @@ template <> struct Frag16<_Float16> {
   static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
-  MFA_MFMA_VQ(mfma_vq, "v_mfma_f32_32x32x16_f16")
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;

@@ -26,7 +26,7 @@ namespace mfa {
 //   2 = K rows padded by 16 bytes in LDS instead of XOR-swizzled: equally conflict-free for ds_read_b128
 //       (row stride = 16 mod 256 bytes), and the eight fragment addresses of a lane become ONE register
 //       plus immediates instead of eight registers each needing a v_add_u32 with the stage base.
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false, bool DMA = false,
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false,
           bool CAUSAL = false, int VD = 0, bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
@@ -37,15 +37,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
-  static_assert(!(KPAD && DMA), "LDS-DMA staging writes the swizzled image");
-
-  // schedule options packed in ABL (0 = plain): 5 = QK MFMAs as inline asm (VGPR result, Q fragments in
-  // AGPRs); 6 = 5 + row sum on the matrix pipe (all-ones A operand)
-  // timing-only ablations (WRONG RESULTS): 20 = no fragment reads from LDS in the loop, 21 = no softmax
-  // arithmetic (P = S converted), 22 = both
+  // ABL: timing-only ablations (WRONG RESULTS): 2 = exp2 replaced by an FMA, 3 = one K fragment address, 8 = no
+  // per-tile barrier, 20 = no fragment reads from LDS in the loop, 21 = no softmax arithmetic, 22 = 20 + 21
   constexpr bool NOLDS = (ABL == 20 || ABL == 22), NOSOFTMAX = (ABL == 21 || ABL == 22);
-  constexpr bool ASMQK = (ABL == 5 || ABL == 6);
-  constexpr bool MSUM = (ABL == 6);
+
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
@@ -95,76 +90,42 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   }
   int tile1 = SPLIT ? (int)((uint64_t)(split + 1) * tiles_total / grid.splits) : tiles_visible;
 
-  // ---- K/V staging.  DMA == false: global -> VGPR -> LDS (as v2).  DMA == true: LDS-DMA
-  // (buffer_load_dwordx4 ... lds): instruction i of wave w fills the 1 KiB of the tile image at
-  // 16-byte positions (w*NCH + i)*64 + lane, so each lane fetches the global chunk that BELONGS at its
-  // position -- the K swizzle and the V sub-tiling are applied on the source address; no staging
-  // registers, no ds_write, and the data is tracked by vmcnt (drained before the tile's barrier).
-  static_assert(!DMA || RING == 3, "LDS-DMA staging uses the 3-stage ring");
+  // ---- K/V staging: global -> VGPR -> LDS (LDS-DMA staging measured 12 % slower)
   uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
   uint32_t kbase0[SPARSE ? NCH : 1], vbase0[SPARSE ? NCH : 1];   // SPARSE: offsets of tile 0, koff/voff restart per run
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    if constexpr (DMA) {
-      const int p = (wave * NCH + i) * 64 + lane;
-      const int krow = p / CPR, kc = (p % CPR) ^ kswz_mask<D>(krow);
-      const int vdb = p / (BC * 4), vkey = (p / 4) % BC, vc = vdb * 4 + (p & 3);
-      koff[i] = (kc * 8 < Dr) ? (tile0 * BC + krow) * ldk2 + kc * 16 : OOB;
-      voff[i] = (vc * 8 < Dr) ? (tile0 * BC + vkey) * ldv2 + vc * 16 : OOB;
-      klds[i] = vlds[i] = 0;
-    } else {
-      const int id = tid + i * NT;
-      const int row = id / CPR, c = id % CPR;
-      const bool valid = c * 8 < Dr;
-      koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
-      voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
-      klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
-      vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
-      if constexpr (SPARSE) {
-        kbase0[i] = valid ? row * ldk2 + c * 16 : OOB;
-        vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
-      }
+    const int id = tid + i * NT;
+    const int row = id / CPR, c = id % CPR;
+    const bool valid = c * 8 < Dr;
+    koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
+    voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
+    klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
+    vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+    if constexpr (SPARSE) {
+      kbase0[i] = valid ? row * ldk2 + c * 16 : OOB;
+      vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
     }
   }
-  u32x4 kreg[DMA ? 1 : NCH], vreg[DMA ? 1 : NCH];
+  u32x4 kreg[NCH], vreg[NCH];
   auto issue_loads = [&]() {
-    if constexpr (!DMA) {
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
-        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
-        koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
-        voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
-      }
+    for (int i = 0; i < NCH; ++i) {
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
     }
   };
   auto write_tiles = [&](int stage) {
-    if constexpr (!DMA) {
-      char *base = smem + stage * STAGE;
+    char *base = smem + stage * STAGE;
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-        *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
-        *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
-      }
+    for (int i = 0; i < NCH; ++i) {
+      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
     }
   };
-  auto issue_dma = [&](int stage) {   // next tile in sequence -> `stage`
-    if constexpr (DMA) {
-      typedef __attribute__((address_space(3))) void *lds_ptr;
-      char *base = smem + stage * STAGE + wave * (NCH * 1024);
-#pragma unroll
-      for (int i = 0; i < NCH; ++i) {
-#if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(kres, (lds_ptr)(base + i * 1024), 16, koff[i], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + KTILE + i * 1024), 16, voff[i], 0, 0, 0);
-#endif
-        koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
-        voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
-      }
-    }
-  };
-
   const int n16 = lane & 15;
   const int vtr_off = KTILE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
   int kread[NKS];
@@ -174,26 +135,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // S^T for the 32 keys of half `kb` of the tile in `stage`: one K fragment feeds RB MFMAs
   auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
     const char *Ks = smem + stage * STAGE + kb * 32 * ROWB;
-    f32x16 s2[RB];   // ABL == 4: second accumulator for odd k-steps (breaks the 8-deep dependent chain)
 #pragma unroll
     for (int t = 0; t < NKS; ++t) {
       const v8 kf = NOLDS ? qf[0][(t + 1) % NKS] : *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        if (t == 0 && !ASMQK) {
+        if (t == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { s[b][r] = 0.f; s2[b][r] = 0.f; }
+          for (int r = 0; r < 16; ++r) s[b][r] = 0.f;
         }
-        if constexpr (ASMQK) F::mfma_vq(s[b], kf, qf[b][t], t == 0, t == NKS - 1);
-        else if (ABL == 4 && (t & 1)) s2[b] = F::mfma(kf, qf[b][t], s2[b]);
-        else s[b] = F::mfma(kf, qf[b][t], s[b]);
+        s[b] = F::mfma(kf, qf[b][t], s[b]);
       }
-    }
-    if constexpr (ABL == 4) {
-#pragma unroll
-      for (int b = 0; b < RB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[b][r] += s2[b][r];
     }
   };
 
@@ -207,17 +159,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
-  }
-
-  f32x16 lsum[MSUM ? RB : 1];
-  v8 ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
-  if constexpr (MSUM) {
-#pragma unroll
-    for (int b = 0; b < RB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) lsum[b][r] = 0.f;
   }
 
   auto mask_edge = [&](f32x16 (&s)[RB], int c0) {   // maskAttentionMatrixEdge (+Softmax.swift:228-260)
@@ -266,10 +207,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
         const float corr = fast_exp2(m[b] - m_up);
         m[b] = m_up;
         l[b] *= corr;
-        if constexpr (MSUM) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) lsum[b][r] *= corr;
-        }
 #pragma unroll
         for (int db = 0; db < NDB; ++db)
 #pragma unroll
@@ -287,9 +224,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
         for (int r = 0; r < 16; ++r) {
           const float p = (ABL == 2) ? s[b][r] * a.scale2 - mb : fast_exp2(s[b][r] * a.scale2 - mb);
           s[b][r] = p;
-          if constexpr (!MSUM) ps[r & 3] += p;
+          ps[r & 3] += p;
         }
-        if constexpr (!MSUM) l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        l[b] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {   // MFMA step u (16 keys) uses registers 8u .. 8u+7
@@ -314,12 +251,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
         for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf, pf[b][u], o[b][db]);
       }
-    if constexpr (MSUM) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int b = 0; b < RB; ++b) lsum[b] = F::mfma(ones, pf[b][u], lsum[b]);
-    }
   };
 
   v8 pf[RB][2];
@@ -355,15 +286,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int t = 0; t < NKS; ++t)
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
-          if constexpr (ASMQK) {
-            F::mfma_vq(s_next[b], kf[t], qf[b][t], t == 0, t == NKS - 1);
-          } else {
-            if (t == 0) {
+          if (t == 0) {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) s_next[b][r] = 0.f;
-            }
-            s_next[b] = F::mfma(kf[t], qf[b][t], s_next[b]);
+            for (int r = 0; r < 16; ++r) s_next[b][r] = 0.f;
           }
+          s_next[b] = F::mfma(kf[t], qf[b][t], s_next[b]);
         }
     }
     if constexpr (PRE != 2) load_v(0, vf0);
@@ -376,39 +303,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf1[db], pf[b][1], o[b][db]);
-    if constexpr (MSUM) {   // onlineReduceSum on the matrix pipe (sum of the ROUNDED P, +Softmax.swift:308-321)
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int b = 0; b < RB; ++b) lsum[b] = F::mfma(ones, pf[b][u], lsum[b]);
-    }
-    if constexpr (ABL == 9) {
-      // dictate the interleave instead of taking hipcc's (which front-loads the exp work and then issues
-      // the QK MFMAs back to back): every QK MFMA is followed by its share of the exponentiation, every
-      // PV MFMA by two transposing reads and two VALU instructions.  Masks: 0x8 MFMA, 0x2 VALU,
-      // 0x400 transcendental, 0x100 DS read.
-      constexpr int NQK = NKS * RB, NPV = 2 * NDB * RB;
-      constexpr int VALU_PER = (RB * 16 * 3 + NQK - 1) / NQK;     // fma + cvt/add share per QK MFMA
-      constexpr int EXP_PER = (RB * 16 + NQK - 1) / NQK;
-#pragma unroll
-      for (int i = 0; i < NQK; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x2, VALU_PER, 0);
-        __builtin_amdgcn_sched_group_barrier(0x400, EXP_PER, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < NPV; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
-      }
-    }
   };
 
-  if constexpr (ABL == 1) {   // static priority for the second-dispatched half (T5 static form)
-    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-  }
-  static_assert(!(SPARSE && (SPLIT || DMA)), "block-sparse launches are row-parallel with register staging");
+  static_assert(!(SPARSE && SPLIT), "block-sparse launches are row-parallel");
   // One contiguous run of key tiles [tile0, tile1): prologue, pipelined loop, tail.  Dense launches make one
   // call; block-sparse launches one per run of active tiles, the online-softmax state (m, l, O) carried
   // across in registers.
@@ -423,14 +320,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- prologue
   const int ntiles = tile1 - tile0;
   const bool ragged = (C & (BC - 1)) != 0 && tile1 == tiles_total;   // only the globally last tile is partial
-  if constexpr (DMA) {
-    issue_dma(0);      // tile 0 -> stage 0
-    issue_dma(1);      // tile 1 -> stage 1 (zeros past the end)
-  } else {
-    issue_loads();
-    write_tiles(0);
-    issue_loads();
-  }
+  issue_loads();
+  write_tiles(0);
+  issue_loads();
   __syncthreads();
   f32x16 s0[RB], s1[RB];   // half score tiles (keys 0-31 / 32-63 of a tile); roles alternate
   float m_new[RB];
@@ -448,13 +340,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // with a second barrier before step B reads it.
   auto iteration = [&](int j, bool next_is_last, int st_cur, int st_next) {
     rescale_if_needed(m_new);
-    if constexpr (DMA) {
-      // tile j+1 landed during the previous iteration (its DMA is drained by the vmcnt(0) hipcc puts in
-      // front of this barrier); once every wave has passed the barrier nobody reads tile j-1 any more,
-      // so its stage can take tile j+2.
-      __syncthreads();
-      issue_dma(st_next == 2 ? 0 : st_next + 1);
-    } else if constexpr (RING == 3) {
+    if constexpr (RING == 3) {
       write_tiles(st_next);          // tile j+1 (replaces tile j-2)
       issue_loads();                 // tile j+2 (reads as zero past the end)
       if constexpr (ABL != 8) __syncthreads();   // ABL 8: timing-only ablation (racy, wrong results)
@@ -543,7 +429,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)a.R;
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
-    const float l_tot = (MSUM ? lsum[b][0] : half_swap_add(l[b])) + 1.401298464e-45f;
+    const float l_tot = half_swap_add(l[b]) + 1.401298464e-45f;
     const float inv = SPLIT ? 1.0f : ((SPARSE && !(l_tot > 1e-30f)) ? 0.f : 1.0f / l_tot);   // SPARSE: a row may see no key at all
     float *orow = Os + (b * 32 + q) * OLD;
 #pragma unroll

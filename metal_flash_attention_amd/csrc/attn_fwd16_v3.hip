@@ -4,10 +4,10 @@
 
 namespace mfa {
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool DMA = false, int VD = 0>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, int VD = 0>
 static void launch_v3(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, DMA, false, VD>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, false, VD>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
                      (fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>()), stream, args, g);
 }
 
@@ -20,9 +20,9 @@ static void launch_v3_split(dim3 grid, uint32_t splits, float *wsO, float *wsML,
   hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool DMA = false, int VD = 0>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, int VD = 0>
 static void fill(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, DMA, false, VD>);
+  v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, false, VD>);
   v->name = name;
   v->parallelization = NW * RB * 32;
   v->traversal = 64;
@@ -30,13 +30,13 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>();
   v->cacheLeft = true;
-  v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, DMA, VD>;
+  v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, VD>;
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE>
 static void launch_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true>), dim3(grid.x * grid.y * grid.z),
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true>), dim3(grid.x * grid.y * grid.z),
                      dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
 }
 
@@ -44,10 +44,10 @@ template <typename T, int D, int NW, int RB, int THR, int PRE>
 static void launch_v3_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
   if (args.causal)
-    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true, 0, true>), dim3(grid.x * grid.y * grid.z),
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true, 0, true>), dim3(grid.x * grid.y * grid.z),
                        dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
   else
-    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, false, 0, true>), dim3(grid.x * grid.y * grid.z),
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, 0, true>), dim3(grid.x * grid.y * grid.z),
                        dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
 }
 
@@ -55,47 +55,37 @@ template <typename T, int D, int NW, int RB, int THR, int PRE>
 static void fill_with_split(VariantInfo *v, const char *name) {
   fill<T, D, NW, RB, THR, PRE>(v, name);
   v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE>;
-  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, false, 0, true>);
-  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true, 0, true>);
+  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, 0, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true, 0, true>);
   v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE>;
   v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE>;
-  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, true>);
+  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true>);
   v->causal = true;
 }
 
-// impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring (two waves per SIMD hide the
-// LDS latency: hoisting fragment reads measured +-0); D = 256: 4 waves x 32 rows (one per SIMD, 512
-// registers), 2-stage ring, K fragments hoisted (+11 % measured: nothing else hides the latency).  1: K fragments hoisted; 2: K + first V fragments
-// hoisted; 3: 4 waves x 64 rows (K hoisted); >= 10: developer ablations.
+// impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring (two waves per SIMD hide the LDS latency:
+// hoisting fragment reads measured +-0); D = 256: 4 waves x 32 rows (one per SIMD, 512 registers), 2-stage ring,
+// K fragments hoisted (+11 % measured: nothing else hides the latency).
+// Developer schedules (MFA_FWD16_IMPL=v3:<n>): 1 / 2 = K / K + first V fragments hoisted; 41 = K rows padded instead
+// of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind the decomposition in DESIGN.md 4.2.
+// Schedules that were measured and removed (numbers in DESIGN.md 4.2, profiles/ab*.txt): 4 waves x 64 rows with
+// asm-placed QK MFMAs, row sum on the matrix pipe, split QK accumulator, LDS-DMA staging, sched_group_barrier
+// interleave, static wave priority, packed-VALU softmax.
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
     if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
     if (D == 128 && impl == 1) { fill<__bf16, 128, 8, 1, 8, 1>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek"); return true; }
     if (D == 128 && impl == 2) { fill<__bf16, 128, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prekv"); return true; }
-    if (D == 128 && impl == 3) { fill<__bf16, 128, 4, 2, 8, 1>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek"); return true; }
-    if (D == 128 && impl == 10) { fill<__bf16, 128, 8, 1, 8, 0, 1>(out, "ablate_setprio_young_half"); return true; }
+    if (D == 128 && impl == 41) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_kpad"); return true; }
     if (D == 128 && impl == 11) { fill<__bf16, 128, 8, 1, 8, 0, 2>(out, "ablate_no_exp_WRONG_RESULTS"); return true; }
-    if (D == 128 && impl == 4) { fill<__bf16, 128, 4, 2, 8, 1, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq"); return true; }
-    if (D == 128 && impl == 5) { fill<__bf16, 128, 4, 2, 8, 0, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_vq"); return true; }
-    if (D == 128 && impl == 6) { fill<__bf16, 128, 8, 1, 8, 0, 5>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_vq"); return true; }
-    if (D == 128 && impl == 7) { fill<__bf16, 128, 4, 2, 8, 1, 6>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq_msum"); return true; }
-    if (D == 128 && impl == 8) { fill<__bf16, 128, 4, 2, 8, 2, 6>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prekv_vq_msum"); return true; }
-    if (D == 128 && impl == 9) { fill<__bf16, 128, 4, 2, 8, 2, 5>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prekv_vq"); return true; }
+    if (D == 128 && impl == 12) { fill<__bf16, 128, 8, 1, 8, 0, 3>(out, "ablate_one_k_fragment_WRONG_RESULTS"); return true; }
     if (D == 128 && impl == 14) { fill<__bf16, 128, 8, 1, 8, 0, 8>(out, "ablate_no_tile_barrier_WRONG_RESULTS"); return true; }
-    if (D == 128 && impl == 20) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, true>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_dma"); return true; }
-    if (D == 128 && impl == 21) { fill<__bf16, 128, 4, 2, 8, 1, 5, 3, true>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_vq_dma"); return true; }
-    if (D == 128 && impl == 22) { fill<__bf16, 128, 4, 2, 8, 0, 5, 3, true>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_vq_dma"); return true; }
-    if (D == 128 && impl == 30) { fill<__bf16, 128, 8, 1, 8, 1, 9>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_sgb"); return true; }
-    if (D == 128 && impl == 31) { fill<__bf16, 128, 4, 2, 8, 1, 9>(out, "attn_fwd16v3_bf16_d128_w4x64_thr8_prek_sgb"); return true; }
     if (D == 128 && impl == 50) { fill<__bf16, 128, 8, 1, 8, 0, 20>(out, "ablate_no_lds_reads_WRONG_RESULTS"); return true; }
     if (D == 128 && impl == 51) { fill<__bf16, 128, 8, 1, 8, 0, 21>(out, "ablate_no_softmax_WRONG_RESULTS"); return true; }
     if (D == 128 && impl == 52) { fill<__bf16, 128, 8, 1, 8, 0, 22>(out, "ablate_no_lds_reads_no_softmax_WRONG_RESULTS"); return true; }
-    if (D == 128 && impl == 41) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, false, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_kpad"); return true; }
-    if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, false, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
-    if (D == 128 && impl == 13) { fill<__bf16, 128, 8, 1, 8, 0, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_splitacc"); return true; }
-    if (D == 128 && impl == 12) { fill<__bf16, 128, 8, 1, 8, 0, 3>(out, "ablate_one_k_fragment_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }
     if (D == 64 && impl == 2) { fill<__bf16, 64, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_prekv"); return true; }
+    if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
     if (D == 32 && impl == 0) { fill<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
     if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
+  if ((int64_t)rblk * (NW * 32) >= R) return;   // padded batch entry: the whole workgroup lies beyond its rows
   const int64_t r0 = (int64_t)rblk * (NW * 32) + wave * 32;
   const int64_t row = r0 + q;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
+  if ((int64_t)cblk * (NW * 32) >= C) return;   // padded batch entry: the whole workgroup lies beyond its keys
   const int64_t c0 = (int64_t)cblk * (NW * 32) + wave * 32;
   const int64_t col = c0 + kc;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
+  if ((int64_t)cblk * 128 >= C) return;   // padded batch entry: the whole workgroup lies beyond its keys
   const int64_t c0 = (int64_t)cblk * 128 + pair * 32;
   const int64_t col = c0 + kc;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldg2 = (uint32_t)a.op[SLOT_dO].ld * 2;

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
+  if (!SPLIT && (int64_t)rblk * (NW * RB * 32) >= R) return;   // padded batch entry: the whole workgroup lies beyond its rows
   const int64_t r0 = (int64_t)rblk * (NW * RB * 32) + wave * (RB * 32);
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
                  ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;

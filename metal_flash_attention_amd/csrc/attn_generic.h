@@ -205,7 +205,7 @@ template <int DP, int NW, bool CACHE> constexpr int generic_dkv_lds_floats() {
 // forward: O = softmax(Q K^T / sqrt(D)) V,  L = m + log2(l)       (+Source.swift:158-200)
 // grid = (ceil(R / (32*NW)), heads, batches); block = 64*NW.
 // ----------------------------------------------------------------------------------------------
-template <int DP, int NW, bool CACHE>
+template <int DP, int NW, bool CACHE, bool MASKED = false>
 __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1, BR = NW * 32, BC = 32, NT = NW * 64, NDB = DP / 32, NS = DP / 2;
@@ -250,15 +250,17 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
   const int coff = C - R;
   const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
-  const uint32_t *mrow = mask_base(a, head, batch);
-  const bool prefetch = !mrow && CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
+  const uint32_t *mrow = MASKED ? mask_base(a, head, batch) : nullptr;   // MASKED: separate code objects, the dense ones carry no mask code
+  const bool prefetch = !MASKED && CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
   TileRegsF32<BC, DP, NT> kregs, vregs;
   if (prefetch) {
     tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
     tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
   }
   for (int c0 = 0; c0 < Cend; c0 += BC) {
-    if (mrow && !mask_bit(mrow, a.maskWords, r0, c0)) continue;   // workgroup-uniform: the block is never loaded
+    if constexpr (MASKED) {
+      if (!mask_bit(mrow, a.maskWords, r0, c0)) continue;   // workgroup-uniform: the block is never loaded
+    }
     if (prefetch) {
       tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
       tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) 
 // ----------------------------------------------------------------------------------------------
 // backward dQ: D = rowsum(dO*O)/sqrt(D); dQ = sum_c dS K                (+Source.swift:202-242)
 // ----------------------------------------------------------------------------------------------
-template <int DP, int NW, bool CACHE>
+template <int DP, int NW, bool CACHE, bool MASKED = false>
 __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1, BR = NW * 32, BC = 32, NT = NW * 64, NDB = DP / 32, NS = DP / 2;
@@ -412,15 +414,17 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   const int coff = C - R;
   const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
-  const uint32_t *mrow = mask_base(a, head, batch);
-  const bool prefetch = !mrow && CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
+  const uint32_t *mrow = MASKED ? mask_base(a, head, batch) : nullptr;   // MASKED: separate code objects, the dense ones carry no mask code
+  const bool prefetch = !MASKED && CAN_PREFETCH && f32_fast_path(a.op[SLOT_K], kbase, D) && f32_fast_path(a.op[SLOT_V], vbase, D);
   TileRegsF32<BC, DP, NT> kregs, vregs;
   if (prefetch) {
     tile_load_f32<BC, DP, NT>(kregs, a.op[SLOT_K], kbase, 0, C, D, tid);
     tile_load_f32<BC, DP, NT>(vregs, a.op[SLOT_V], vbase, 0, C, D, tid);
   }
   for (int c0 = 0; c0 < Cend; c0 += BC) {
-    if (mrow && !mask_bit(mrow, a.maskWords, r0, c0)) continue;   // workgroup-uniform: the block is never loaded
+    if constexpr (MASKED) {
+      if (!mask_bit(mrow, a.maskWords, r0, c0)) continue;   // workgroup-uniform: the block is never loaded
+    }
     if (prefetch) {
       tile_store_f32<BC, DP, NT>(Ks, kregs, tid);
       tile_store_f32<BC, DP, NT>(Vs, vregs, tid);
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
 //                                                                      (+Source.swift:244-293)
 // grid = (ceil(C / (32*NW)), heads, batches)
 // ----------------------------------------------------------------------------------------------
-template <int DP, int NW, bool CACHE>
+template <int DP, int NW, bool CACHE, bool MASKED = false>
 __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1, BCOL = NW * 32, BRW = 32, NT = NW * 64, NDB = DP / 32, NS = DP / 2;
@@ -529,15 +533,17 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   const int coff = C - R;
   const int rstart = a.causal ? (int)(max((int64_t)0, c0 - coff) / BRW) * BRW : 0;
   constexpr bool CAN_PREFETCH = (DP <= 128);
-  const uint32_t *mbase = mask_base(a, head, batch);
-  const bool prefetch = !mbase && CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
+  const uint32_t *mbase = MASKED ? mask_base(a, head, batch) : nullptr;
+  const bool prefetch = !MASKED && CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
   TileRegsF32<BRW, DP, NT> qregs, gregs;
   if (prefetch) {
     tile_load_f32<BRW, DP, NT>(qregs, a.op[SLOT_Q], qbase, rstart, R, D, tid);
     tile_load_f32<BRW, DP, NT>(gregs, a.op[SLOT_dO], gbase, rstart, R, D, tid);
   }
   for (int r0 = rstart; r0 < R; r0 += BRW) {
-    if (mbase && !mask_bit(mbase, a.maskWords, r0, c0)) continue;   // workgroup-uniform
+    if constexpr (MASKED) {
+      if (!mask_bit(mbase, a.maskWords, r0, c0)) continue;   // workgroup-uniform
+    }
     if (prefetch) {
       tile_store_f32<BRW, DP, NT>(Qs, qregs, tid);
       tile_store_f32<BRW, DP, NT>(dOs, gregs, tid);

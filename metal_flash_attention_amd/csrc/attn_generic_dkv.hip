@@ -1,6 +1,7 @@
 // attn_generic_dkv.hip -- instantiations of the generic (fp32-MFMA) dkv kernel for gfx950.
 #include "attn_generic.h"
 #include "launchers.h"
+#include <cstdlib>
 
 namespace mfa {
 
@@ -8,6 +9,12 @@ template <int DP, int NW, bool CACHE>
 static void launch_dkv(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
   hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE>), grid, dim3(NW * 64), lds, stream, args);
+}
+
+template <int DP, int NW, bool CACHE>
+static void launch_dkv_masked(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
+  hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE, true>), grid, dim3(NW * 64), lds, stream, args);
 }
 
 template <int DP, int NW, bool CACHE>
@@ -21,7 +28,8 @@ static void fill(VariantInfo *v, const char *name) {
   v->ldsBytes = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
   v->cacheLeft = CACHE;
   v->causal = true;
-  v->sparse = true;
+  v->launchSparse = &launch_dkv_masked<DP, NW, CACHE>;   // block mask: own code objects
+  v->funcSparse = reinterpret_cast<const void *>(&attn_generic_dkv<DP, NW, CACHE, true>);
   v->launch = &launch_dkv<DP, NW, CACHE>;
 }
 
@@ -29,7 +37,7 @@ bool generic_dkv_variant(int DP, VariantInfo *out) {
   switch (DP) {
     case 32:  fill<32, 4, true>(out, "attn_generic_dkv_f32mfma_d32_w4_cached"); return true;
     case 64:  fill<64, 4, true>(out, "attn_generic_dkv_f32mfma_d64_w4_cached"); return true;
-    case 128: fill<128, 4, true>(out, "attn_generic_dkv_f32mfma_d128_w4_cached"); return true;
+    case 128: fill<128, 4, true>(out, "attn_generic_dkv_f32mfma_d128_w4_cached"); return true;   // (2 waves per workgroup, i.e. half the LDS and twice the workgroups per CU: 10-15 % slower, measured)
     case 256: fill<256, 1, false>(out, "attn_generic_dkv_f32mfma_d256_w1_lds"); return true;
     default: return false;
   }

@@ -1,6 +1,6 @@
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests/test_attention_gpu.py -q -m gpu -x -k "variable_sequence or block_sparse" > gpurun_out/pytest_var.txt 2>&1; echo "rc=$?" >> gpurun_out/pytest_var.txt
-tail -n 4 gpurun_out/pytest_var.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE OK')" > gpurun_out/smoke.txt 2>&1; tail -n 4 gpurun_out/smoke.txt
+timeout 200 bash tools/time_kernels.sh fwdbwd_f32_d128 > gpurun_out/time_f32.txt 2>&1
+cat gpurun_out/time_f32.txt
+timeout 300 python -m pytest tests/test_attention_gpu.py -q -m gpu -x -k "block_sparse" > gpurun_out/pytest_bs.txt 2>&1; tail -n 3 gpurun_out/pytest_bs.txt

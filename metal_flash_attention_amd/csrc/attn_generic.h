@@ -205,8 +205,11 @@ template <int DP, int NW, bool CACHE> constexpr int generic_dkv_lds_floats() {
 // forward: O = softmax(Q K^T / sqrt(D)) V,  L = m + log2(l)       (+Source.swift:158-200)
 // grid = (ceil(R / (32*NW)), heads, batches); block = 64*NW.
 // ----------------------------------------------------------------------------------------------
+// Two workgroups per compute unit for DP <= 128 (LDS: 2 x 66 KiB): capping the kernel at 256 registers costs
+// a 28-byte spill outside the loop and buys the second resident workgroup: 2.71 -> 2.29 ms at N=4096 D=128 fp32,
+// 32 heads (the same cap on the dQ kernel spills 188 bytes and loses 10 %, so it stays uncapped).
 template <int DP, int NW, bool CACHE, bool MASKED = false>
-__global__ __launch_bounds__(NW * 64) void attn_generic_fwd(const KernelArgs a) {
+__global__ __launch_bounds__(NW * 64, (DP <= 128 ? 2 : 1)) void attn_generic_fwd(const KernelArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1, BR = NW * 32, BC = 32, NT = NW * 64, NDB = DP / 32, NS = DP / 2;
   const int tid = threadIdx.x;

@@ -70,7 +70,8 @@ static void fill_with_split(VariantInfo *v, const char *name) {
 // of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind the decomposition in DESIGN.md 4.2.
 // Schedules that were measured and removed (numbers in DESIGN.md 4.2, profiles/ab*.txt): 4 waves x 64 rows with
 // asm-placed QK MFMAs, row sum on the matrix pipe, split QK accumulator, LDS-DMA staging, sched_group_barrier
-// interleave, static wave priority, packed-VALU softmax.
+// interleave, static wave priority, packed-VALU softmax; at D = 64, 64 rows per wave with two waves per SIMD (+-0:
+// that size is VALU-bound, not LDS-bound).
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
     if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }

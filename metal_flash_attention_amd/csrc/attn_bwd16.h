@@ -41,10 +41,16 @@ __device__ __forceinline__ typename Frag16<T>::v8 convert_chunk(u32x4 raw) {
 
 // ------------------------------------------------------------------------------------------------
 // backwardQuery.  Workgroup = NW waves x 32 query rows; traversal over 64-key tiles.
-// LDS stage = K row-major | K transposable | V row-major.
+// LDS stage = K | V.  K is needed both as row fragments (A of S^T = K Q^T) and transposed (A of dQ^T += K^T dS^T):
+// ONE image serves both, [D/32][64 keys][32 elements] with the four 16-byte chunks of each 64-byte row
+// XOR-swizzled by (key >> 2) & 3 -- conflict-free for ds_read_b128 (16 lanes of a read group land on 16
+// distinct slots) and for ds_read_b64_tr_b16 (every lane supplies its own address, so the swizzle folds into
+// two lane constants), the layout attn_dkv16_rs.h uses for Q and dO.  V is only read as row fragments and
+// keeps the swizzled row-major image.  (An earlier version kept two K images: 3 tiles per stage, which did not
+// fit D = 256.)  D <= 128: 8 waves (two per SIMD); D = 256: 4 waves with 512 registers each.
 // ------------------------------------------------------------------------------------------------
 template <int D, int NW> constexpr int dq16_lds_bytes() {
-  constexpr int ring = 2 * 3 * 64 * D * 2;
+  constexpr int ring = 2 * 2 * 64 * D * 2;
   constexpr int epi = NW * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   typedef typename F::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BC = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
-  constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 3 * TILE;
+  constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 2 * TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
 
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   if (row < R) Lrow = load_elem(operand_base(a.op[SLOT_L], head, batch), row, a.op[SLOT_L].precision);
 
   // ---- K/V staging
-  uint32_t koff[NCH], voff[NCH], klds[NCH], ktlds[NCH], vlds[NCH];
+  uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -118,9 +124,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     const bool valid = c * 8 < Dr;
     koff[i] = valid ? rr * ldk2 + c * 16 : OOB;
     voff[i] = valid ? rr * ldv2 + c * 16 : OOB;
-    klds[i] = rr * ROWB + kswz<D>(rr, c) * 16;                        // K row-major (swizzled)
-    ktlds[i] = TILE + ((c >> 2) * BC + rr) * 64 + (c & 3) * 16;       // K transposable [D/32][64][32]
-    vlds[i] = 2 * TILE + rr * ROWB + kswz<D>(rr, c) * 16;             // V row-major (swizzled)
+    klds[i] = ((c >> 2) * BC + rr) * 64 + (((c & 3) ^ ((rr >> 2) & 3)) * 16);   // K: [D/32][64][32], chunks swizzled
+    vlds[i] = TILE + rr * ROWB + kswz<D>(rr, c) * 16;                           // V: row-major (swizzled)
   }
   u32x4 kreg[NCH], vreg[NCH];
   auto issue_loads = [&]() {
@@ -145,15 +150,21 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
-      *reinterpret_cast<u32x4 *>(base + ktlds[i]) = kreg[i];
       *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
     }
   };
   const int n16 = lane & 15;
-  const int tr_off = ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
-  int fread[NKS];   // row-fragment offsets (row q of a 32-row block; same swizzle for rows q and q+32)
+  // transposing reads of K: rows (n16 >> 2) + 4 hi and + 8 of a 16-key group; this lane's 8-byte piece is number
+  // (n16 & 3) of 32-byte half (lane >> 4) & 1 of the row; (row >> 2) & 3 == hi resp. (hi + 2) & 3
+  const int trow = (n16 >> 2) + 4 * hi, tchunk = 2 * ((lane >> 4) & 1) + ((n16 & 3) >> 1), thalf = (n16 & 3) & 1;
+  const int tr0 = trow * 64 + ((tchunk ^ (hi & 3)) * 16) + thalf * 8;
+  const int tr1 = (trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8;
+  int fread[NKS], kfread[NKS];   // row-fragment offsets of key q of a 32-key block: V (row-major) and K (blocked image)
 #pragma unroll
-  for (int t = 0; t < NKS; ++t) fread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
+  for (int t = 0; t < NKS; ++t) {
+    fread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
+    kfread[t] = ((t >> 1) * BC + q) * 64 + (((2 * (t & 1) + hi) ^ ((q >> 2) & 3)) * 16);
+  }
 
   f32x16 dq[NDB];
 #pragma unroll
@@ -200,8 +211,8 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       // the same accumulator (a non-MFMA instruction between two dependent MFMAs costs ~43 cycles)
 #pragma unroll
       for (int t = 0; t < NKS; ++t) {
-        const v8 kf = *reinterpret_cast<const v8 *>(st + kb * 32 * ROWB + fread[t]);
-        const v8 vf = *reinterpret_cast<const v8 *>(st + 2 * TILE + kb * 32 * ROWB + fread[t]);
+        const v8 kf = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfread[t]);
+        const v8 vf = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + fread[t]);
         s = F::mfma(kf, qf[t], s);
         dp = F::mfma(vf, gf[t], dp);
       }
@@ -227,9 +238,9 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
-          const char *kp = st + TILE + tr_off + (db * BC + 32 * kb + 16 * u) * 64;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp));
-          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + 8 * 64));
+          const char *kp = st + (db * BC + 32 * kb + 16 * u) * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr0));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr1));
           const v8 ktf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
           dq[db] = F::mfma(ktf, dsf[u], dq[db]);
         }

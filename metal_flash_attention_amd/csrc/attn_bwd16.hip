@@ -79,16 +79,19 @@ bool dq16_variant(int precision, int gprecision, int D, VariantInfo *out) {
   if (precision == PREC_FP16 && gprecision == PREC_BF16) {
     if (D == 128) { fill_dq<_Float16, 128, 8, __bf16>(out, "attn_dq16_f16_dObf16_d128_w8x32"); return true; }
     if (D == 64) { fill_dq<_Float16, 64, 8, __bf16>(out, "attn_dq16_f16_dObf16_d64_w8x32"); return true; }
+    if (D == 256) { fill_dq<_Float16, 256, 4, __bf16>(out, "attn_dq16_f16_dObf16_d256_w4x32"); return true; }
     return false;
   }
   if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
     if (D == 128) { fill_dq<__bf16, 128, 8>(out, "attn_dq16_bf16_d128_w8x32"); return true; }
     if (D == 64) { fill_dq<__bf16, 64, 8>(out, "attn_dq16_bf16_d64_w8x32"); return true; }
+    if (D == 256) { fill_dq<__bf16, 256, 4>(out, "attn_dq16_bf16_d256_w4x32"); return true; }   // one wave per SIMD: dQ alone takes 128 registers
   }
   if (precision == PREC_FP16) {
     if (D == 128) { fill_dq<_Float16, 128, 8>(out, "attn_dq16_f16_d128_w8x32"); return true; }
     if (D == 64) { fill_dq<_Float16, 64, 8>(out, "attn_dq16_f16_d64_w8x32"); return true; }
+    if (D == 256) { fill_dq<_Float16, 256, 4>(out, "attn_dq16_f16_d256_w4x32"); return true; }
   }
   return false;
 }

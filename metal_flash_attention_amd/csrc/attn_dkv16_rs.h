@@ -34,35 +34,39 @@
 namespace mfa {
 
 constexpr int DKV16RS_MAX_ROW_BLOCKS = 4096;   // 256-row blocks a block-sparse launch can list (R <= 1 Mi rows)
+// wave pairs per workgroup: four (two waves per SIMD) up to D = 128; at D = 256 one accumulator alone takes 128
+// registers, so a wave gets a SIMD to itself (512 registers) and the workgroup holds two pairs
+template <int D> constexpr int dkv16rs_pairs() { return D <= 128 ? 4 : 2; }
 template <int D> constexpr int dkv16rs_lds_bytes() {
-  constexpr int ring = 4 * (2 * 32 * D * 2 + 256) + 4 * 2 * 4096 + 2 * DKV16RS_MAX_ROW_BLOCKS + 16;
-  constexpr int epi = 8 * 32 * (D + 4) * 4;
+  constexpr int ring = 4 * (2 * 32 * D * 2 + 256) + dkv16rs_pairs<D>() * 2 * 4096 + 2 * DKV16RS_MAX_ROW_BLOCKS + 16;
+  constexpr int epi = 2 * dkv16rs_pairs<D>() * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }
 
 // ABL: timing-only ablations (WRONG RESULTS): 1 = no global loads in the loop, 2 = no staging at all,
 // 3 = no barrier, 4 = no L/D/P LDS traffic in the arithmetic
 template <typename T, int D, typename TG = T, bool CAUSAL = false, int ABL = 0, bool SPARSE = false>
-__global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const Fwd16Grid grid) {
+__global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BR = 32, NT = 512, NDB = D / 32, NKS = D / 16, RING = 4;
+  constexpr int NPAIR = dkv16rs_pairs<D>(), WGCOLS = NPAIR * 32;
+  constexpr int BR = 32, NT = NPAIR * 128, NDB = D / 32, NKS = D / 16, RING = 4;
   constexpr int TILE = BR * D * 2, STAGE = 2 * TILE + 256, XBUF = RING * STAGE;
-  constexpr int CPR = D / 8, NCHUNK = BR * CPR;   // 16-byte chunks per operand tile (512 at D = 128, 256 at D = 64)
-  static_assert(NCHUNK <= NT, "one chunk per thread and operand");
+  constexpr int CPR = D / 8, NCHUNK = BR * CPR;   // 16-byte chunks per operand tile (256 / 512 / 1024 at D = 64 / 128 / 256)
+  constexpr int SCH = (NCHUNK + NT - 1) / NT;     // chunks per thread and operand (1; 4 at D = 256)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int pair = wave & 3, role = wave >> 2;   // role 0: V-wave (dV), role 1: K-wave (dK)
+  const int pair = wave % NPAIR, role = wave / NPAIR;   // role 0: V-wave (dV), role 1: K-wave (dK)
   const int lane = tid & 63, kc = lane & 31, hi = lane >> 5;
   uint32_t cblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &cblk, &head, &batch);
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
-  if ((int64_t)cblk * 128 >= C) return;   // padded batch entry: the whole workgroup lies beyond its keys
-  const int64_t c0 = (int64_t)cblk * 128 + pair * 32;
+  if ((int64_t)cblk * WGCOLS >= C) return;   // padded batch entry: the whole workgroup lies beyond its keys
+  const int64_t c0 = (int64_t)cblk * WGCOLS + pair * 32;
   const int64_t col = c0 + kc;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldg2 = (uint32_t)a.op[SLOT_dO].ld * 2;
   constexpr uint32_t OOB = 0xFFFFFF00u;
@@ -87,18 +91,25 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
 
   // CAUSAL (extension): the traversal starts at the first row block that sees the workgroup's first key
   const int coff = C - R;
-  int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * 128 - coff) / 32) : 0;   // (SPARSE: first row block of the current run)
+  int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * WGCOLS - coff) / 32) : 0;   // (SPARSE: first row block of the current run)
 
-  // ---- Q / dO staging + L, D slices; one 16-byte chunk per thread and operand
-  const bool stager = tid < NCHUNK;
-  const int srow = tid / CPR, sc = tid % CPR;
-  const bool svalid = stager && sc * 8 < Dr;
-  const uint32_t qbase0 = svalid ? srow * ldq2 + sc * 16 : OOB, gbase0 = svalid ? srow * ldg2 + sc * 16 : OOB;   // row block 0
-  uint32_t qoff = __builtin_elementwise_add_sat(qbase0, (uint32_t)block0 * BR * ldq2);
-  uint32_t goff = __builtin_elementwise_add_sat(gbase0, (uint32_t)block0 * BR * ldg2);
-  const uint32_t wlds = ((sc >> 2) * BR + srow) * 64 + (((sc & 3) ^ ((srow >> 2) & 3)) * 16);   // Q at +0, dO at +TILE
+  // ---- Q / dO staging + L, D slices; SCH 16-byte chunks per thread and operand
+  uint32_t qbase0[SCH], gbase0[SCH], qoff[SCH], goff[SCH], wlds[SCH];   // *base0: row block 0
+  bool stager[SCH];
+#pragma unroll
+  for (int i = 0; i < SCH; ++i) {
+    const int id = tid + i * NT;
+    stager[i] = id < NCHUNK;
+    const int srow = id / CPR, sc = id % CPR;
+    const bool svalid = stager[i] && sc * 8 < Dr;
+    qbase0[i] = svalid ? srow * ldq2 + sc * 16 : OOB;
+    gbase0[i] = svalid ? srow * ldg2 + sc * 16 : OOB;
+    qoff[i] = __builtin_elementwise_add_sat(qbase0[i], (uint32_t)block0 * BR * ldq2);
+    goff[i] = __builtin_elementwise_add_sat(gbase0[i], (uint32_t)block0 * BR * ldg2);
+    wlds[i] = ((sc >> 2) * BR + srow) * 64 + (((sc & 3) ^ ((srow >> 2) & 3)) * 16);   // Q at +0, dO at +TILE
+  }
   const uint32_t qinc = BR * ldq2, ginc = BR * ldg2;
-  u32x4 qreg, greg;
+  u32x4 qreg[SCH], greg[SCH];
   float ldreg = 0.f;
   // L (wave 0) and D (wave 1) slices of a row block, 32 lanes each: one uniform resource and precision per
   // wave, rows past R read as zero through the resource bounds   (+Softmax.swift:356-381, :472-503)
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
   // SPARSE (block-mask extension): the traversal visits the 32-row blocks of the ACTIVE 256-row blocks only,
   // as one continuous sequence (no pipeline restart at the gaps): step n works on row block blk(n), looked up
   // in a table of active 256-row blocks that thread 0 builds in LDS behind the exchange buffer.
-  uint16_t *act = reinterpret_cast<uint16_t *>(smem + XBUF + 4 * 2 * 4096 + 16);
+  uint16_t *act = reinterpret_cast<uint16_t *>(smem + XBUF + NPAIR * 2 * 4096 + 16);
   int nact = 0, nload = 0;
   auto blk = [&](int n) { return (int)act[n >> 3] * 8 + (n & 7); };
   auto issue_loads = [&]() {
@@ -120,14 +131,20 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
       const bool in = (nload >> 3) < nact;
       const uint32_t b = in ? (uint32_t)blk(nload) : 0u;
       ++nload;
-      qoff = in ? __builtin_elementwise_add_sat(qbase0, b * BR * ldq2) : OOB;
-      goff = in ? __builtin_elementwise_add_sat(gbase0, b * BR * ldg2) : OOB;
+#pragma unroll
+      for (int i = 0; i < SCH; ++i) {
+        qoff[i] = in ? __builtin_elementwise_add_sat(qbase0[i], b * BR * ldq2) : OOB;
+        goff[i] = in ? __builtin_elementwise_add_sat(gbase0[i], b * BR * ldg2) : OOB;
+      }
       ldoff = in ? (b * BR + lane) * ldesz : OOB;
     }
-    qreg = __builtin_amdgcn_raw_buffer_load_b128(qres, qoff, 0, 0);
-    greg = __builtin_amdgcn_raw_buffer_load_b128(gres, goff, 0, 0);
-    qoff = __builtin_elementwise_add_sat(qoff, qinc);
-    goff = __builtin_elementwise_add_sat(goff, ginc);
+#pragma unroll
+    for (int i = 0; i < SCH; ++i) {
+      qreg[i] = __builtin_amdgcn_raw_buffer_load_b128(qres, qoff[i], 0, 0);
+      greg[i] = __builtin_amdgcn_raw_buffer_load_b128(gres, goff[i], 0, 0);
+      qoff[i] = __builtin_elementwise_add_sat(qoff[i], qinc);
+      goff[i] = __builtin_elementwise_add_sat(goff[i], ginc);
+    }
     if (ldloader) {
       if (ldprec == PREC_FP32) {
         ldreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ldres, ldoff, 0, 0));
@@ -140,10 +157,12 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
   };
   auto write_tiles = [&](int stage) {
     char *base = smem + stage * STAGE;
-    if (stager) {
-      *reinterpret_cast<u32x4 *>(base + wlds) = qreg;
-      *reinterpret_cast<u32x4 *>(base + TILE + wlds) = __builtin_bit_cast(u32x4, convert_chunk<T, TG>(greg));
-    }
+#pragma unroll
+    for (int i = 0; i < SCH; ++i)
+      if (stager[i]) {
+        *reinterpret_cast<u32x4 *>(base + wlds[i]) = qreg[i];
+        *reinterpret_cast<u32x4 *>(base + TILE + wlds[i]) = __builtin_bit_cast(u32x4, convert_chunk<T, TG>(greg[i]));
+      }
     if (ldloader) reinterpret_cast<float *>(base + 2 * TILE)[wave * 32 + lane] = ldreg;
   };
 
@@ -315,13 +334,14 @@ __global__ __launch_bounds__(512) void attn_dkv16_rs(const KernelArgs a, const F
     traverse_rows();
   } else {
     // block mask: bit (row block of 256 rows = 8 steps, column block of 128 keys = this workgroup)
-    const uint32_t *mcol = a.mask + (int64_t)head * a.maskHeadStride + (int64_t)batch * a.maskBatchStride + (cblk >> 5);
+    const uint32_t mcb = (uint32_t)(((uint64_t)cblk * WGCOLS) >> 7);   // 128-column block of the mask this workgroup lies in
+    const uint32_t *mcol = a.mask + (int64_t)head * a.maskHeadStride + (int64_t)batch * a.maskBatchStride + (mcb >> 5);
     const int rb_end = ((R + BR - 1) / BR + 7) / 8;
-    int *count = reinterpret_cast<int *>(smem + XBUF + 4 * 2 * 4096);
+    int *count = reinterpret_cast<int *>(smem + XBUF + NPAIR * 2 * 4096);
     if (tid == 0) {
       int n = 0;
       for (int rb = block0 / 8; rb < rb_end && n < DKV16RS_MAX_ROW_BLOCKS; ++rb)   // (causal: rows before block0 see none of these keys)
-        if ((mcol[(uint64_t)rb * a.maskWords] >> (cblk & 31)) & 1u) act[n++] = (uint16_t)rb;
+        if ((mcol[(uint64_t)rb * a.maskWords] >> (mcb & 31)) & 1u) act[n++] = (uint16_t)rb;
       *count = n;
     }
     __syncthreads();

@@ -7,7 +7,7 @@ namespace mfa {
 template <typename T, int D, typename TG, bool CAUSAL, int ABL = 0>
 static void launch_rs(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, CAUSAL, ABL>), dim3(grid.x * grid.y * grid.z), dim3(512), (dkv16rs_lds_bytes<D>()), stream,
+  hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, CAUSAL, ABL>), dim3(grid.x * grid.y * grid.z), dim3(dkv16rs_pairs<D>() * 128), (dkv16rs_lds_bytes<D>()), stream,
                      args, g);
 }
 
@@ -15,19 +15,19 @@ template <typename T, int D, typename TG>
 static void launch_rs_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
   if (args.causal)
-    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, true, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(512), (dkv16rs_lds_bytes<D>()), stream, args, g);
+    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, true, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(dkv16rs_pairs<D>() * 128), (dkv16rs_lds_bytes<D>()), stream, args, g);
   else
-    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, false, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(512), (dkv16rs_lds_bytes<D>()), stream, args, g);
+    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, false, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(dkv16rs_pairs<D>() * 128), (dkv16rs_lds_bytes<D>()), stream, args, g);
 }
 
 template <typename T, int D, typename TG = T>
 static void fill(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false>);
   v->name = name;
-  v->parallelization = 128;   // key columns per workgroup: 4 wave pairs x 32
+  v->parallelization = dkv16rs_pairs<D>() * 32;   // key columns per workgroup: wave pairs x 32
   v->traversal = 32;
   v->headBlock = D;
-  v->threads = 512;
+  v->threads = dkv16rs_pairs<D>() * 128;
   v->ldsBytes = dkv16rs_lds_bytes<D>();
   v->cacheLeft = true;
   v->launch = &launch_rs<T, D, TG, false>;
@@ -55,16 +55,19 @@ bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInf
   if (precision == PREC_FP16 && gprecision == PREC_BF16) {
     if (D == 128) { fill<_Float16, 128, __bf16>(out, "attn_dkv16rs_f16_dObf16_d128_p4x32"); return true; }
     if (D == 64) { fill<_Float16, 64, __bf16>(out, "attn_dkv16rs_f16_dObf16_d64_p4x32"); return true; }
+    if (D == 256) { fill<_Float16, 256, __bf16>(out, "attn_dkv16rs_f16_dObf16_d256_p2x32"); return true; }
     return false;
   }
   if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
     if (D == 128) { fill<__bf16, 128>(out, "attn_dkv16rs_bf16_d128_p4x32"); return true; }
     if (D == 64) { fill<__bf16, 64>(out, "attn_dkv16rs_bf16_d64_p4x32"); return true; }
+    if (D == 256) { fill<__bf16, 256>(out, "attn_dkv16rs_bf16_d256_p2x32"); return true; }
   }
   if (precision == PREC_FP16) {
     if (D == 128) { fill<_Float16, 128>(out, "attn_dkv16rs_f16_d128_p4x32"); return true; }
     if (D == 64) { fill<_Float16, 64>(out, "attn_dkv16rs_f16_d64_p4x32"); return true; }
+    if (D == 256) { fill<_Float16, 256>(out, "attn_dkv16rs_f16_d256_p2x32"); return true; }
   }
   return false;
 }

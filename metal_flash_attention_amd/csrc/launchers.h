@@ -44,7 +44,7 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
 // 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)
 bool fwd16_v4_variant(int precision, int D, int impl, VariantInfo *out);
 
-// 16-bit MFMA backward kernels (Q, K, V, dO in one 16-bit type, row-major, D in {64, 128})
+// 16-bit MFMA backward kernels (Q, K, V, dO in one 16-bit type, row-major, D in {64, 128, 256})
 // (gprecision = storage type of dO: the same 16-bit type, or BF16 next to FP16 Q/K/V)
 bool dq16_variant(int precision, int gprecision, int D, VariantInfo *out);
 bool dkv16_variant(int precision, int gprecision, int D, VariantInfo *out);

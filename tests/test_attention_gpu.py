@@ -358,7 +358,7 @@ def test_size_independent_properties_at_full_size():
 
 # ---- 16-bit matrix-core backward kernels (attn_dq16 / attn_dkv16) -----------------------------
 BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), (1, 100, 128), (100, 1, 64),
-                (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64)]
+                (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64), (256, 256, 256), (300, 333, 200), (65, 700, 256)]
 
 
 @pytest.mark.parametrize("dkv_impl", ["w4", "rs"])
@@ -371,6 +371,8 @@ def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
     AttentionDescriptor+Precisions.swift:199-200)."""
     monkeypatch.setenv("MFA_DKV16_IMPL", dkv_impl)
     R, C, D = shape
+    if dkv_impl == "w4" and D > 128:
+        pytest.skip("the one-wave-per-key-block kernel stops at D = 128")
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
     run = harness.DeviceRun(desc, net)
@@ -524,7 +526,7 @@ def test_causal_fp32_all_kernels(shape):
     assert all(run.tails_ok.values())
 
 
-@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 555, 64), (1024, 1024, 128), (129, 640, 80)])
+@pytest.mark.parametrize("shape", [(256, 256, 128), (300, 555, 64), (1024, 1024, 128), (129, 640, 80), (320, 448, 256)])
 def test_causal_bf16_all_kernels(shape):
     R, C, D = shape
     net = Network(NetworkDescriptor(R, C, D), seed=2 * R + C)
@@ -702,7 +704,8 @@ def _random_block_mask(R, C, density, rng, keep_empty_row=False):
 
 @pytest.mark.parametrize("low", [False, True])
 @pytest.mark.parametrize("shape,causal,empty", [((600, 900, 64), False, False), ((1024, 1024, 128), True, False),
-                                                ((700, 1300, 128), False, True), ((300, 200, 40), False, False)])
+                                                ((700, 1300, 128), False, True), ((300, 200, 40), False, False),
+                                                ((520, 1100, 256), False, False)])
 def test_block_sparse_mask(shape, causal, empty, low):
     """All three kernels under a 256 x 128 block mask, against the fp64 matrix-form oracle with the same mask;
     a row block with no active block at all must give O = 0 and zero gradients."""

@@ -38,7 +38,7 @@ bool generic_dkv_variant(int DP, VariantInfo *out) {
     case 32:  fill<32, 4, true>(out, "attn_generic_dkv_f32mfma_d32_w4_cached"); return true;
     case 64:  fill<64, 4, true>(out, "attn_generic_dkv_f32mfma_d64_w4_cached"); return true;
     case 128: fill<128, 4, true>(out, "attn_generic_dkv_f32mfma_d128_w4_cached"); return true;   // (2 waves per workgroup, i.e. half the LDS and twice the workgroups per CU: 10-15 % slower, measured)
-    case 256: fill<256, 1, false>(out, "attn_generic_dkv_f32mfma_d256_w1_lds"); return true;
+    case 256: fill<256, 4, true>(out, "attn_generic_dkv_f32mfma_d256_w4_cached"); return true;
     default: return false;
   }
 }

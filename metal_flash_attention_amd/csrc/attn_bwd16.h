@@ -55,7 +55,11 @@ template <int D, int NW> constexpr int dq16_lds_bytes() {
   return ring > epi ? ring : epi;
 }
 
-template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false, bool SPARSE = false>
+// SPLIT (traversal-parallel launch for grids that cannot fill the GPU, e.g. the reference's single-head
+// benchmark shape): the key range is cut into grid.splits pieces, each workgroup leaves its partial dQ in its
+// own fp32 slab of the caller's workspace ([split][head x batch][R][D]) and attn_bwd_combine adds the slabs --
+// no atomics, like the reference's refusal of an atomic dQ (README.md:11).  D is written by piece 0.
+template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false, bool SPARSE = false, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -69,12 +73,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
-  fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  uint32_t bid = blockIdx.x, split = 0;
+  if constexpr (SPLIT) { split = bid % grid.splits; bid /= grid.splits; }
+  fwd16_decode_block(grid, bid, &rblk, &head, &batch);
   if constexpr (CAUSAL) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
-  if ((int64_t)rblk * (NW * 32) >= R) return;   // padded batch entry: the whole workgroup lies beyond its rows
+  if (!SPLIT && (int64_t)rblk * (NW * 32) >= R) return;   // padded batch entry: the whole workgroup lies beyond its rows
   const int64_t r0 = (int64_t)rblk * (NW * 32) + wave * 32;
   const int64_t row = r0 + q;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
@@ -191,7 +197,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     }
     return t;
   };
-  int j = next_active(0), stage = 0;
+  int tile_lo = 0;
+  if constexpr (SPLIT) {   // this workgroup's piece of the (visible) key tiles
+    static_assert(!(SPLIT && SPARSE), "masked launches are not split");
+    tile_lo = (int)((uint64_t)split * ntiles / grid.splits);
+    ntiles = (int)((uint64_t)(split + 1) * ntiles / grid.splits);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      koff[i] = __builtin_elementwise_add_sat(koff[i], (uint32_t)tile_lo * kinc);
+      voff[i] = __builtin_elementwise_add_sat(voff[i], (uint32_t)tile_lo * vinc);
+    }
+  }
+  int j = next_active(tile_lo), stage = 0;
   if (j < ntiles) {
     if constexpr (SPARSE) issue_loads_at(j); else issue_loads();
     write_tiles(0);
@@ -261,9 +278,45 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
           make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
-  if (hi == 0 && row < R) store_elem(operand_base(a.op[SLOT_D], head, batch), row, a.op[SLOT_D].precision, dterm);
-  store_block_rows<T, D>(Os, operand_base(a.op[SLOT_dQ], head, batch), a.op[SLOT_dQ].precision, (uint32_t)a.op[SLOT_dQ].ld,
-                         r0, R, Dr, lane);
+  if ((!SPLIT || split == 0) && hi == 0 && row < R)
+    store_elem(operand_base(a.op[SLOT_D], head, batch), row, a.op[SLOT_D].precision, dterm);
+  if constexpr (SPLIT) {
+    const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)a.R;
+    store_block_rows<T, D>(Os, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr, r0, R, Dr, lane);
+  } else {
+    store_block_rows<T, D>(Os, operand_base(a.op[SLOT_dQ], head, batch), a.op[SLOT_dQ].precision, (uint32_t)a.op[SLOT_dQ].ld,
+                           r0, R, Dr, lane);
+  }
+}
+
+// Sum of the partial results of a traversal-parallel backward launch: out[row][d] = sum over pieces of
+// ws[piece][head x batch][row][d].  One wave per row, lane c owns elements 4c..4c+3.  `slot` = destination operand
+// (dQ, dK or dV), `rows` = its sequence length, `ws` = first slab of that operand.  HBM-bound.
+static __global__ __launch_bounds__(256) void attn_bwd_combine(const KernelArgs a, const Fwd16Grid grid, int slot, uint32_t rows,
+                                                               const float *ws) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t Dr = a.D, HB = grid.heads * grid.batches;
+  const uint64_t rowid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // over HB * rows
+  if (rowid >= (uint64_t)HB * rows) return;
+  const uint32_t hb = (uint32_t)(rowid / rows), row = (uint32_t)(rowid % rows);
+  const uint32_t head = hb % grid.heads, batch = hb / grid.heads;
+  if ((uint32_t)lane * 4 >= Dr) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (uint32_t s = 0; s < grid.splits; ++s) {
+    const float4 v = *reinterpret_cast<const float4 *>(ws + (((uint64_t)s * HB + hb) * rows + row) * Dr + lane * 4);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  char *obase = operand_base(a.op[slot], head, batch);
+  const int64_t idx = (int64_t)row * a.op[slot].ld + lane * 4;
+  const int prec = a.op[slot].precision;
+  if (prec == PREC_FP32) {
+    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obase) + idx) = acc;
+  } else {
+    store_elem(obase, idx, prec, acc.x);
+    store_elem(obase, idx + 1, prec, acc.y);
+    store_elem(obase, idx + 2, prec, acc.z);
+    store_elem(obase, idx + 3, prec, acc.w);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -45,7 +45,9 @@ template <int D> constexpr int dkv16rs_lds_bytes() {
 
 // ABL: timing-only ablations (WRONG RESULTS): 1 = no global loads in the loop, 2 = no staging at all,
 // 3 = no barrier, 4 = no L/D/P LDS traffic in the arithmetic
-template <typename T, int D, typename TG = T, bool CAUSAL = false, int ABL = 0, bool SPARSE = false>
+// SPLIT: traversal-parallel launch (see attn_dq16): the row blocks are cut into grid.splits pieces, partial dV and
+// dK go to fp32 slabs of the caller's workspace (dV slabs first, then dK slabs), attn_bwd_combine adds them.
+template <typename T, int D, typename TG = T, bool CAUSAL = false, int ABL = 0, bool SPARSE = false, bool SPLIT = false>
 __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -61,11 +63,13 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
   const int pair = wave % NPAIR, role = wave / NPAIR;   // role 0: V-wave (dV), role 1: K-wave (dK)
   const int lane = tid & 63, kc = lane & 31, hi = lane >> 5;
   uint32_t cblk, head, batch;
-  fwd16_decode_block(grid, blockIdx.x, &cblk, &head, &batch);
+  uint32_t bid = blockIdx.x, split = 0;
+  if constexpr (SPLIT) { split = bid % grid.splits; bid /= grid.splits; }
+  fwd16_decode_block(grid, bid, &cblk, &head, &batch);
   int R = a.R, C = a.C;
   const int Dr = a.D;
   batch_lengths(a, batch, R, C);
-  if ((int64_t)cblk * WGCOLS >= C) return;   // padded batch entry: the whole workgroup lies beyond its keys
+  if (!SPLIT && (int64_t)cblk * WGCOLS >= C) return;   // padded batch entry: the whole workgroup lies beyond its keys
   const int64_t c0 = (int64_t)cblk * WGCOLS + pair * 32;
   const int64_t col = c0 + kc;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldg2 = (uint32_t)a.op[SLOT_dO].ld * 2;
@@ -92,6 +96,14 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
   // CAUSAL (extension): the traversal starts at the first row block that sees the workgroup's first key
   const int coff = C - R;
   int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * WGCOLS - coff) / 32) : 0;   // (SPARSE: first row block of the current run)
+  int block_end = (R + 31) / 32;
+  if constexpr (SPLIT) {   // this workgroup's piece of the row blocks [block0, block_end)
+    static_assert(!(SPLIT && SPARSE), "masked launches are not split");
+    const int nb = block_end - block0;
+    const int lo = block0 + (int)((uint64_t)split * nb / grid.splits);
+    block_end = block0 + (int)((uint64_t)(split + 1) * nb / grid.splits);
+    block0 = lo;
+  }
 
   // ---- Q / dO staging + L, D slices; SCH 16-byte chunks per thread and operand
   uint32_t qbase0[SCH], gbase0[SCH], qoff[SCH], goff[SCH], wlds[SCH];   // *base0: row block 0
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
 
-  int nblocks = (R + BR - 1) / BR - block0;   // (SPARSE: row blocks of the current run)
+  int nblocks = block_end - block0;   // (SPARSE: row blocks of the current run)
   auto staging = [&](int t) {   // after the barrier: row block t+2 -> LDS (replaces t-2, last read in step t-1), loads of t+3 (zeros past the end)
     if constexpr (ABL != 3) __syncthreads();
     if constexpr (ABL != 2) write_tiles((t + 2) & 3);
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
     else run(std::integral_constant<int, 1>{});
   };
   if constexpr (!SPARSE) {
-    traverse_rows();
+    if (nblocks > 0) traverse_rows();
   } else {
     // block mask: bit (row block of 256 rows = 8 steps, column block of 128 keys = this workgroup)
     const uint32_t mcb = (uint32_t)(((uint64_t)cblk * WGCOLS) >> 7);   // 128-column block of the mask this workgroup lies in
@@ -363,7 +375,13 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
       *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
           make_float4(acc[db][4 * g], acc[db][4 * g + 1], acc[db][4 * g + 2], acc[db][4 * g + 3]);
   const int slot = role ? SLOT_dK : SLOT_dV;
-  store_block_rows<T, D>(Os, operand_base(a.op[slot], head, batch), a.op[slot].precision, (uint32_t)a.op[slot].ld, c0, C, Dr, lane);
+  if constexpr (SPLIT) {
+    const size_t hb = (size_t)grid.heads * grid.batches;
+    const size_t slab = (((size_t)role * grid.splits + split) * hb + (size_t)batch * grid.heads + head) * (size_t)a.C;
+    store_block_rows<T, D>(Os, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr, c0, C, Dr, lane);
+  } else {
+    store_block_rows<T, D>(Os, operand_base(a.op[slot], head, batch), a.op[slot].precision, (uint32_t)a.op[slot].ld, c0, C, Dr, lane);
+  }
 }
 
 } // namespace mfa

@@ -20,6 +20,20 @@ static void launch_rs_sparse(dim3 grid, hipStream_t stream, const KernelArgs &ar
     hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, false, 0, true>), dim3(grid.x * grid.y * grid.z), dim3(dkv16rs_pairs<D>() * 128), (dkv16rs_lds_bytes<D>()), stream, args, g);
 }
 
+template <typename T, int D, typename TG>
+static void launch_rs_split(dim3 grid, uint32_t splits, float *ws, float *, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, ws, nullptr};
+  const dim3 blocks(grid.x * grid.y * grid.z * splits), threads(dkv16rs_pairs<D>() * 128);
+  if (args.causal)
+    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, true, 0, false, true>), blocks, threads, (dkv16rs_lds_bytes<D>()), stream, args, g);
+  else
+    hipLaunchKernelGGL((attn_dkv16_rs<T, D, TG, false, 0, false, true>), blocks, threads, (dkv16rs_lds_bytes<D>()), stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.C;
+  const float *dk_slabs = ws + (uint64_t)splits * rows * args.D;   // dV slabs first, then dK slabs
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dV, args.C, (const float *)ws);
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dK, args.C, dk_slabs);
+}
+
 template <typename T, int D, typename TG = T>
 static void fill(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false>);
@@ -37,6 +51,9 @@ static void fill(VariantInfo *v, const char *name) {
   v->launchSparse = &launch_rs_sparse<T, D, TG>;
   v->funcSparse = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false, 0, true>);
   v->funcSparseCausal = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, true, 0, true>);
+  v->launchSplit = &launch_rs_split<T, D, TG>;
+  v->funcSplit = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, false, 0, false, true>);
+  v->funcSplitCausal = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, true, 0, false, true>);
 }
 
 bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
@@ -44,6 +61,7 @@ bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInf
     fill<__bf16, 128>(out, "ablate_dkv16rs_WRONG_RESULTS");
     out->launchCausal = nullptr; out->funcCausal = nullptr; out->causal = false;
     out->launchSparse = nullptr; out->funcSparse = nullptr; out->funcSparseCausal = nullptr;
+    out->launchSplit = nullptr; out->funcSplit = nullptr; out->funcSplitCausal = nullptr;
     switch (impl) {
       case 1: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 1>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 1>; break;
       case 2: out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 2>); out->launch = &launch_rs<__bf16, 128, __bf16, false, 2>; break;

@@ -28,6 +28,9 @@ struct VariantInfo {
   void (*launchSparse)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
   const void *funcSparse = nullptr, *funcSparseCausal = nullptr;
   bool sparse = false;   // `launch` itself honours the mask (general kernels)
+  // code objects of launchSplit that need the large-LDS attribute (backward kernels; the forward split variant
+  // is registered by its launcher's first use of the same attribute path)
+  const void *funcSplit = nullptr, *funcSplitCausal = nullptr;
 };
 
 // generic (fp32-MFMA) family: returns false if (DP) is not compiled

@@ -235,6 +235,14 @@ static uint32_t choose_splits(uint64_t blocks, uint32_t column) {
   return s < 2 ? 1 : (uint32_t)s;
 }
 
+// bytes of workspace a launch cut into `s` pieces needs
+static uint64_t split_workspace_bytes(int type, uint32_t s, uint32_t heads, uint32_t batches, uint32_t row, uint32_t column, uint32_t D) {
+  const uint64_t hb = (uint64_t)heads * batches;
+  if (type == MFA_FORWARD) return (uint64_t)s * hb * row * (D + 2) * sizeof(float);          // O slabs + (m, l)
+  if (type == MFA_BACKWARD_QUERY) return (uint64_t)s * hb * row * D * sizeof(float);         // dQ slabs
+  return 2ull * s * hb * column * D * sizeof(float);                                         // dV slabs, then dK slabs
+}
+
 static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
                                  const mfa_launch_params *p, LaunchPlan *plan) {
   if (!kernel || !buffers || !p) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
@@ -297,17 +305,21 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
   plan->splits = 1;
-  if (type == MFA_FORWARD && !plan->useFallback && plan->variant->launchSplit && !args->causal && !args->rowLen && !args->colLen && !args->mask) {
-    const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, p->column);
+  // Traversal-parallel launches through the caller's workspace, for grids that cannot fill the GPU: forward cuts
+  // the key range (partial (O, m, l), online-softmax merge), backwardQuery the key range and backwardKeyValue
+  // the row range (partial dQ / dK, dV in fp32 slabs, summed by attn_bwd_combine).
+  const bool splittable = !plan->useFallback && plan->variant->launchSplit && !args->rowLen && !args->colLen && !args->mask &&
+                          (type != MFA_FORWARD || !args->causal);
+  if (splittable) {
+    const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column);
     if (s > 1) {
-      const uint64_t rows = (uint64_t)s * heads * batches * p->row;
-      plan->workspaceNeeded = rows * (D + 2) * sizeof(float);
+      plan->workspaceNeeded = split_workspace_bytes(type, s, heads, batches, p->row, p->column, D);
       if (p->workspace && p->workspaceBytes >= plan->workspaceNeeded &&
           (reinterpret_cast<uintptr_t>(p->workspace) & 15) == 0 && (D % 4) == 0 &&
           (uint64_t)blocks * heads * batches * s <= 0x7FFFFFFFull) {
         plan->splits = s;
         plan->wsO = static_cast<float *>(p->workspace);
-        plan->wsML = plan->wsO + rows * D;
+        plan->wsML = plan->wsO + (uint64_t)s * heads * batches * p->row * D;   // forward only
       }
     }
   }
@@ -329,6 +341,10 @@ static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const Launc
     err = hipFuncSetAttribute(plan.variant->funcSparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
   if (err == hipSuccess && plan.variant->funcSparseCausal)
     err = hipFuncSetAttribute(plan.variant->funcSparseCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+  if (err == hipSuccess && plan.variant->funcSplit)
+    err = hipFuncSetAttribute(plan.variant->funcSplit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+  if (err == hipSuccess && plan.variant->funcSplitCausal)
+    err = hipFuncSetAttribute(plan.variant->funcSplitCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
   if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   if (device < 64) mask |= 1ull << device;
   return MFA_OK;
@@ -354,12 +370,15 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
                                                uint64_t *bytes) {
   if (!kernel || !params || !bytes) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
   *bytes = 0;
-  if (kernel->desc.type != MFA_FORWARD || !kernel->variant.launchSplit) return MFA_OK;
+  if (!kernel->variant.launchSplit) return MFA_OK;
   if (params->row == 0 || params->column == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "row and column must be non-zero");
+  const int type = kernel->desc.type;
+  if (params->rowLengths || params->columnLengths || params->blockMask || (type == MFA_FORWARD && params->causal)) return MFA_OK;
   const uint32_t heads = params->heads ? params->heads : 1, batches = params->batches ? params->batches : 1;
-  const uint32_t blocks = (params->row + kernel->variant.parallelization - 1) / kernel->variant.parallelization;
-  const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, params->column);
-  if (s > 1) *bytes = (uint64_t)s * heads * batches * params->row * (kernel->desc.headDimension + 2) * sizeof(float);
+  const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? params->column : params->row;
+  const uint32_t blocks = (par + kernel->variant.parallelization - 1) / kernel->variant.parallelization;
+  const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? params->row : params->column);
+  if (s > 1) *bytes = split_workspace_bytes(type, s, heads, batches, params->row, params->column, kernel->desc.headDimension);
   return MFA_OK;
 }
 

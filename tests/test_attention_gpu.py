@@ -738,3 +738,39 @@ def test_block_sparse_mask(shape, causal, empty, low):
         dead = ~rows_alive
         assert dead.any() and (got["O"][dead] == 0).all() and (got["dQ"][dead] == 0).all() and (got["L"][dead] < -1e30).all()
     assert all(run.tails_ok.values())
+
+
+# ---- traversal-parallel backward launches through a caller-provided workspace ------------------------
+@pytest.mark.parametrize("shape,causal", [((4096, 4096, 64), False), ((2048, 4096, 128), False), ((3000, 3000, 128), True),
+                                          ((1024, 2048, 256), False)])
+def test_backward_split_matches_unsplit_and_oracle(shape, causal):
+    """Single-head backward launches cannot fill 256 CUs: with a workspace the key (dQ) / row (dK, dV) range is cut
+    into pieces whose fp32 partial results are summed by a second kernel.  Same answer as without the
+    workspace (to the rounding of a different summation order) and within the tight bounds of the oracle."""
+    import torch
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=R + C + D + 1)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net, causal=causal)
+    base = run.execute()
+    stream = torch.cuda.current_stream().cuda_stream
+    used = 0
+    for t in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):
+        k = run.kernels[t]
+        need = k.workspaceSize(row=R, column=C)
+        assert need > 0, (t, k.variant)
+        used += 1
+        ws = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+        outputs = (Op.dQ,) if t == AttentionKernelType.backwardQuery else (Op.dK, Op.dV)
+        for op in outputs:   # poison this kernel's outputs: the split path must rewrite all of them
+            run.buffers[op][: run.buffers[op].numel() // 2].fill_(0x7F)
+        k.dispatch(run.buffers, row=R, column=C, stream=stream, causal=causal, workspace=ws)
+    torch.cuda.synchronize()
+    got = run.results()
+    for name in ("dQ", "dK", "dV", "D"):
+        assert np.abs(got[name] - base[name]).max() < 2e-3, name
+    round_inputs(net, desc)
+    ref = net.run(causal=causal)
+    failures, report = harness.compare(ref, got, dict(D=5e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+    assert not failures, failures
+    assert all(run.tails_ok.values())

@@ -176,7 +176,11 @@ def test_workspace_size_query_follows_the_split_heuristic():
     assert k.workspaceSize(row=4096, column=4096, heads=32, batches=8) == 0     # already 4096 workgroups
     assert k.workspaceSize(row=4096, column=256) == 0                           # traversal too short
     assert AttentionKernel(_desc(dims=(4096, 4096, 64)).kernelDescriptor(T.forward)).workspaceSize(row=4096, column=4096) == 0
-    assert AttentionKernel(low.kernelDescriptor(T.backwardQuery)).workspaceSize(row=4096, column=4096) == 0
+    # the 16-bit backward kernels split their traversal too: dQ slabs (splits x R x D floats), dV + dK slabs
+    dq = AttentionKernel(low.kernelDescriptor(T.backwardQuery)).workspaceSize(row=4096, column=4096)
+    dkv = AttentionKernel(low.kernelDescriptor(T.backwardKeyValue)).workspaceSize(row=4096, column=4096)
+    assert dq > 0 and dq % (4096 * 64 * 4) == 0 and dkv > 0 and dkv % (2 * 4096 * 64 * 4) == 0
+    assert AttentionKernel(_desc(dims=(4096, 4096, 64)).kernelDescriptor(T.backwardQuery)).workspaceSize(row=4096, column=4096) == 0
 
 
 def test_oversized_slices_route_to_general_kernels_without_a_gpu():

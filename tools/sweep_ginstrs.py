@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """FWD / dQ / dK-dV GINSTR/s in the format of the reference's tables (README.md:108-175,
 Documentation/FlashAttention Variants.xlsx "Generalization"): per kernel, per head dimension, at N = 8192 and
-16384; single head (the reference's benchmark shape; forward uses the column-parallel workspace) and 32 heads.
+16384; single head (the reference's benchmark shape; all three kernels get a workspace and split their traversal)
+and 32 heads.
   GINSTR = (2D+5) N^2 forward, (3D+5) N^2 backward-dQ, (4D+5) N^2 backward-dK/dV  (README.md:108-124)."""
 import ctypes
 import os
@@ -41,10 +42,8 @@ for dtype in _args.dtypes.split(","):
                 out, names = [], []
                 for t in KT:
                     k = AttentionKernel(desc.kernelDescriptor(t))
-                    ws = None
-                    if t == KT.forward:
-                        need = k.workspaceSize(row=N, column=N, heads=H)
-                        ws = torch.empty(need, dtype=torch.uint8, device="cuda") if need else None
+                    need = k.workspaceSize(row=N, column=N, heads=H)   # traversal-parallel launch when the grid is small
+                    ws = torch.empty(need, dtype=torch.uint8, device="cuda") if need else None
                     k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, workspace=ws)   # L, D exist before the backward kernels
                     iters = 3 if dtype == "f32" else 5
                     arr, params, keep = k._marshal(bufs, N, N, H, 1, None, hs, None, ws, False)

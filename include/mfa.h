@@ -165,10 +165,11 @@ typedef struct mfa_launch_params {
   int64_t leadingDimension[MFA_BUFFER_SLOTS];
   int64_t headStride[MFA_BUFFER_SLOTS];
   int64_t batchStride[MFA_BUFFER_SLOTS];
-  /* Optional caller-owned device scratch (extension).  A forward launch with too few row blocks to
-   * fill the GPU (e.g. the reference's single-head benchmark, SquareAttentionTest.swift:159-165) is
-   * then run column-parallel: the key range is cut into pieces whose partial (O, m, l) go to this
-   * scratch and a second small kernel merges them -- no atomics.  NULL (default) = never split.
+  /* Optional caller-owned device scratch (extension).  A launch with too few workgroups to fill the
+   * GPU (e.g. the reference's single-head benchmark, SquareAttentionTest.swift:159-165) is then run
+   * traversal-parallel: forward and backwardQuery cut the key range, backwardKeyValue the row range;
+   * the pieces' partial results (forward: un-normalised O, m, l; backward: fp32 gradient slabs) go to
+   * this scratch and a second small kernel merges them -- no atomics.  NULL (default) = never split.
    * Size it with mfa_attention_kernel_workspace_size.  Contents need no initialisation. */
   void *workspace;
   uint64_t workspaceBytes;

@@ -33,33 +33,35 @@ static void fill(VariantInfo *v, const char *name) {
   v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, VD>;
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING>
 static void launch_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true>), dim3(grid.x * grid.y * grid.z),
-                     dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true>), dim3(grid.x * grid.y * grid.z),
+                     dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING>
 static void launch_v3_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
   if (args.causal)
-    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true, 0, true>), dim3(grid.x * grid.y * grid.z),
-                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, 0, true>), dim3(grid.x * grid.y * grid.z),
+                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
   else
-    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, 0, true>), dim3(grid.x * grid.y * grid.z),
-                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, 3>()), stream, args, g);
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, 0, true>), dim3(grid.x * grid.y * grid.z),
+                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE>
+// product variants: the dense code object plus its causal, block-sparse and column-parallel siblings
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING = 3>
 static void fill_with_split(VariantInfo *v, const char *name) {
-  fill<T, D, NW, RB, THR, PRE>(v, name);
-  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE>;
-  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, false, 0, true>);
-  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true, 0, true>);
-  v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE>;
-  v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE>;
-  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, 3, false, true>);
+  fill<T, D, NW, RB, THR, PRE, 0, RING>(v, name);
+  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE, RING>;
+  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, 0, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, 0, true>);
+  v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE, 0, RING>;
+  v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, true>);
+  v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE, RING>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true>);
   v->causal = true;
 }
 
@@ -87,15 +89,15 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 64 && impl == 0) { fill_with_split<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }
     if (D == 64 && impl == 2) { fill<__bf16, 64, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_prekv"); return true; }
     if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
-    if (D == 32 && impl == 0) { fill<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
-    if (D == 256 && impl == 0) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
+    if (D == 32 && impl == 0) { fill_with_split<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
+    if (D == 256 && impl == 0) { fill_with_split<__bf16, 256, 4, 1, 8, 1, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
     if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
   }
   if (precision == PREC_FP16) {
     if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
-    if (D == 32 && impl == 0) { fill<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
-    if (D == 256 && impl == 0) { fill<_Float16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_prek"); return true; }
+    if (D == 32 && impl == 0) { fill_with_split<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
+    if (D == 256 && impl == 0) { fill_with_split<_Float16, 256, 4, 1, 8, 1, 2>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_prek"); return true; }
   }
   return false;
 }

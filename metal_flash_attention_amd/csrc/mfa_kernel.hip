@@ -117,10 +117,11 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
     if (same && rowMajor && (D % 8) == 0) {
+      const int bucket16 = bucket < 64 ? 64 : bucket;   // the backward pair starts at D = 64 (smaller heads are zero-padded)
       auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
       if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ) &&
           !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
-        fast = dq16_variant(pq, pg, bucket, &variant);
+        fast = dq16_variant(pq, pg, bucket16, &variant);
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
           kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV] &&
           !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV])
@@ -129,8 +130,8 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         // role-split wave pairs, ablation n.  Default: role-split wave pairs (attn_dkv16_rs).
         const char *knob = std::getenv("MFA_DKV16_IMPL");
         const bool wantW4 = knob && (std::strcmp(knob, "w4") == 0 || knob[0] == '0');
-        if (!wantW4) fast = dkv16_rs_variant(pq, pg, bucket, (knob && std::strncmp(knob, "rs:", 3) == 0) ? std::atoi(knob + 3) : 0, &variant);
-        if (!fast) fast = dkv16_variant(pq, pg, bucket, &variant);
+        if (!wantW4) fast = dkv16_rs_variant(pq, pg, bucket16, (knob && std::strncmp(knob, "rs:", 3) == 0) ? std::atoi(knob + 3) : 0, &variant);
+        if (!fast) fast = dkv16_variant(pq, pg, bucket16, &variant);
       }
     }
   }

@@ -159,6 +159,13 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
     }
   };
+  constexpr int WEVERY = 2 * NDB / NCH;   // matrix instructions between two staging writes in the main loop
+  static_assert(NCH <= 2 * NDB && (2 * NDB) % NCH == 0, "staging chunks must spread evenly over the dQ accumulation");
+  auto write_chunk = [&](int stage, int i) {
+    char *base = smem + stage * STAGE;
+    *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+    *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+  };
   const int n16 = lane & 15;
   // transposing reads of K: rows (n16 >> 2) + 4 hi and + 8 of a 16-key group; this lane's 8-byte piece is number
   // (n16 & 3) of 32-byte half (lane >> 4) & 1 of the row; (row >> 2) & 3 == hi resp. (hi + 2) & 3
@@ -214,6 +221,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     write_tiles(0);
   }
   __syncthreads();
+  // Q / dO fragments, L and D have no consumer before the loop: without this wait hipcc waits for them in front of
+  // the first matrix instructions INSIDE the loop, with counts that in steady state also drain the prefetch of the
+  // next tile issued a few instructions earlier (vmcnt counts in order).  s_waitcnt vmcnt(0) (expcnt, lgkmcnt free).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   while (j < ntiles) {
     const char *st = smem + stage * STAGE;
     const int jn = next_active(j + 1);
@@ -250,11 +261,16 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
         }
         dsf[u] = pk;
       }
-      // dQ^T += K^T dS^T (K transposed by the LDS read; key index permuted as in forward)
+      // dQ^T += K^T dS^T (K transposed by the LDS read; key index permuted as in forward).  The staging writes of
+      // the next tile go between the matrix instructions of the second half: issued as one burst in front of the
+      // barrier they keep the LDS busy for ~800 cycles (D = 256) during which no wave has anything to run.  The
+      // other stage has no readers in this iteration; past the last tile the registers hold stale data that
+      // nobody reads.
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
+          if (kb == 1 && (u * NDB + db) % WEVERY == 0) write_chunk(stage ^ 1, (u * NDB + db) / WEVERY);
           const char *kp = st + (db * BC + 32 * kb + 16 * u) * 64;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr0));
           const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr1));
@@ -262,7 +278,6 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
           dq[db] = F::mfma(ktf, dsf[u], dq[db]);
         }
     }
-    if (jn < ntiles) write_tiles(stage ^ 1);
     __syncthreads();
     stage ^= 1;
     j = jn;

@@ -15,6 +15,7 @@
 //   * per step and wave: 32 MFMAs against 8 + 16 LDS reads and ~110 VALU instructions.
 #pragma once
 #include "attn_fwd16_v2.h"
+#include <type_traits>
 
 namespace mfa {
 
@@ -34,6 +35,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BC = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
   constexpr bool KPAD = (VD & 2) != 0;
+  constexpr bool VPIPE = (VD & 4) != 0;   // V^T fragments double-buffered in groups of four MFMAs (see step)
+  constexpr bool WSPREAD = (VD & 8) != 0; // staging writes of the next tile issued between the matrix instructions of step A
   constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
@@ -113,6 +116,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto issue_loads = [&]() {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
+      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+    }
+  };
+  auto stage_part = [&](int stage, int i0, int i1) {   // write chunks [i0, i1) of tile j+1, then request them for tile j+2
+    char *base = smem + stage * STAGE;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+    }
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
       kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
       vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
       koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
@@ -261,7 +279,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // instead of being exposed in front of every MFMA (hipcc otherwise issues each ds_read one MFMA
   // ahead of its consumer).  sched_barrier(0) pins the reads above the arithmetic.
   auto step = [&](f32x16 (&s_cur)[RB], f32x16 (&s_next)[RB], int k_stage, int k_kb, int v_stage, int v_kb,
-                  bool do_qk) {
+                  bool do_qk, auto spread, int wstage) {
     const char *Ks = smem + k_stage * STAGE + k_kb * 32 * ROWB;
     const char *Vs = smem + v_stage * STAGE + vtr_off + v_kb * 32 * 64;
     v8 kf[NKS];
@@ -278,6 +296,50 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
         vf[db] = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
       }
     };
+    if constexpr (VPIPE) {
+      // One wave per SIMD has nobody to hide its LDS latency: request the V^T fragments of four MFMAs while the
+      // previous four run (hipcc otherwise issues each pair of transposed reads one MFMA ahead of its consumer).
+      // sched_barrier(0x406) pins matrix and LDS instructions, VALU / SALU / transcendental work may still move.
+      constexpr int G = 4, NG = 2 * NDB / G;
+      static_assert(RB == 1 && (2 * NDB) % G == 0, "VPIPE: one row block per wave");
+      auto load_group = [&](int g, v8 (&vf)[G]) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int idx = g * G + i, u = idx / NDB, db = idx % NDB;
+          const char *vp = Vs + (db * BC + 16 * u) * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
+          vf[i] = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      };
+      v8 vg[2][G];
+      load_group(0, vg[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      exponentiate(s_cur, pf);
+      if (do_qk) {
+#pragma unroll
+        for (int t = 0; t < NKS; ++t) {
+          if (t == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_next[0][r] = 0.f;
+          }
+          s_next[0] = F::mfma(kf[t], qf[0][t], s_next[0]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) load_group(g + 1, vg[(g + 1) & 1]);
+        if constexpr (decltype(spread)::value) stage_part(wstage, NCH * g / NG, NCH * (g + 1) / NG);
+        __builtin_amdgcn_sched_barrier(0x406);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int idx = g * G + i, u = idx / NDB, db = idx % NDB;
+          o[0][db] = F::mfma(vg[g & 1][i], pf[0][u], o[0][db]);
+        }
+        __builtin_amdgcn_sched_barrier(0x406);
+      }
+      return;
+    }
     v8 vf0[NDB], vf1[NDB];
     if constexpr (PRE == 2) load_v(0, vf0);
     __builtin_amdgcn_sched_barrier(0);
@@ -341,6 +403,52 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // with a second barrier before step B reads it.
   auto iteration = [&](int j, bool next_is_last, int st_cur, int st_next) {
     rescale_if_needed(m_new);
+    if constexpr (WSPREAD && RING == 3) {
+      // tile j+1 is only read from step B on: stage it in the middle of step A, behind this wave's own K fragment
+      // reads, and publish it with the barrier between the two steps (every wave past the previous iteration's
+      // barrier has finished tile j-2, which the writes replace).  sched_barrier(0x40E): memory instructions keep
+      // their place, matrix / vector / scalar work may move across.
+      static_assert(PRE == 0 || VPIPE, "WSPREAD: unhoisted schedule or grouped V reads");
+      if constexpr (VPIPE) {
+        step(s0, s1, st_cur, 1, st_cur, 0, true, std::true_type{}, st_next);
+      } else {
+        qk(st_cur, 1, s1);
+        __builtin_amdgcn_sched_barrier(0x40E);
+        stage_part(st_next, 0, NCH);
+        __builtin_amdgcn_sched_barrier(0x40E);
+        exponentiate(s0, pf);
+        pv(st_cur, 0, pf);
+      }
+      mask_causal(s1, (tile0 + j) * BC + 32);
+      block_max(s1, m_new);
+      rescale_if_needed(m_new);
+      __syncthreads();
+      if constexpr (PRE == 0) {
+        qk(st_next, 0, s0);
+        exponentiate(s1, pf);
+        pv(st_cur, 1, pf);
+      } else {
+        step(s1, s0, st_next, 0, st_cur, 1, true, std::false_type{}, 0);
+      }
+      if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
+      mask_causal(s0, (tile0 + j + 1) * BC);
+      block_max(s0, m_new);
+      return;
+    }
+    if constexpr (WSPREAD && RING == 2) {
+      static_assert(VPIPE, "WSPREAD with a 2-stage ring: grouped V reads");
+      __syncthreads();
+      step(s0, s1, st_cur, 1, st_cur, 0, true, std::true_type{}, st_next);
+      mask_causal(s1, (tile0 + j) * BC + 32);
+      block_max(s1, m_new);
+      rescale_if_needed(m_new);
+      __syncthreads();
+      step(s1, s0, st_next, 0, st_cur, 1, true, std::false_type{}, 0);
+      if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
+      mask_causal(s0, (tile0 + j + 1) * BC);
+      block_max(s0, m_new);
+      return;
+    }
     if constexpr (RING == 3) {
       write_tiles(st_next);          // tile j+1 (replaces tile j-2)
       issue_loads();                 // tile j+2 (reads as zero past the end)
@@ -356,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       exponentiate(s0, pf);
       pv(st_cur, 0, pf);
     } else {
-      step(s0, s1, st_cur, 1, st_cur, 0, true);
+      step(s0, s1, st_cur, 1, st_cur, 0, true, std::false_type{}, 0);
     }
     mask_causal(s1, (tile0 + j) * BC + 32);
     block_max(s1, m_new);
@@ -368,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       exponentiate(s1, pf);
       pv(st_cur, 1, pf);
     } else {
-      step(s1, s0, st_next, 0, st_cur, 1, true);
+      step(s1, s0, st_next, 0, st_cur, 1, true, std::false_type{}, 0);
     }
     if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
     mask_causal(s0, (tile0 + j + 1) * BC);

@@ -11,10 +11,10 @@ static void launch_v3(dim3 grid, hipStream_t stream, const KernelArgs &args) {
                      (fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>()), stream, args, g);
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, int VD = 0>
 static void launch_v3_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
-  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, true>), dim3(grid.x * grid.y * grid.z * splits),
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, true, false, VD>), dim3(grid.x * grid.y * grid.z * splits),
                      dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
   const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
   hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
@@ -33,43 +33,47 @@ static void fill(VariantInfo *v, const char *name) {
   v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, VD>;
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int RING>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING, int VD>
 static void launch_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true>), dim3(grid.x * grid.y * grid.z),
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD>), dim3(grid.x * grid.y * grid.z),
                      dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
 }
 
-template <typename T, int D, int NW, int RB, int THR, int PRE, int RING>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING, int VD>
 static void launch_v3_sparse(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
   if (args.causal)
-    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, 0, true>), dim3(grid.x * grid.y * grid.z),
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD, true>), dim3(grid.x * grid.y * grid.z),
                        dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
   else
-    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, 0, true>), dim3(grid.x * grid.y * grid.z),
+    hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, VD, true>), dim3(grid.x * grid.y * grid.z),
                        dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
 }
 
 // product variants: the dense code object plus its causal, block-sparse and column-parallel siblings
-template <typename T, int D, int NW, int RB, int THR, int PRE, int RING = 3>
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING = 3, int VD = 0>
 static void fill_with_split(VariantInfo *v, const char *name) {
-  fill<T, D, NW, RB, THR, PRE, 0, RING>(v, name);
-  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE, RING>;
-  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, 0, true>);
-  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, 0, true>);
-  v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE, 0, RING>;
-  v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, true>);
-  v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE, RING>;
-  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true>);
+  fill<T, D, NW, RB, THR, PRE, 0, RING, VD>(v, name);
+  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE, RING, VD>;
+  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, VD, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD, true>);
+  v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE, 0, RING, VD>;
+  v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, true, false, VD>);
+  v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE, RING, VD>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD>);
   v->causal = true;
 }
 
 // impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring (two waves per SIMD hide the LDS latency:
 // hoisting fragment reads measured +-0); D = 256: 4 waves x 32 rows (one per SIMD, 512 registers), 2-stage ring,
-// K fragments hoisted (+11 % measured: nothing else hides the latency).
-// Developer schedules (MFA_FWD16_IMPL=v3:<n>): 1 / 2 = K / K + first V fragments hoisted; 41 = K rows padded instead
-// of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind the decomposition in DESIGN.md 4.2.
+// K fragments hoisted (+11 % measured: nothing else hides the latency), V^T fragments double-buffered in groups
+// of four MFMAs and the staging writes of the next tile spread between those groups instead of one burst behind the
+// barrier (+11 % measured: 64 KiB of ds_write_b128 per tile kept the LDS busy while no wave had work).
+// Developer schedules (MFA_FWD16_IMPL=v3:<n>): 1 / 2 = K / K + first V fragments hoisted (D = 256: 2 = the previous
+// product without grouped reads / spread writes, 3 = grouped reads only); 3 / 4 / 5 at D = 128 = grouped reads /
+// + spread writes / writes in the middle of step A (all within +-1 % with two waves per SIMD); 41 = K rows padded
+// instead of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind the decomposition in DESIGN.md 4.2.
 // Schedules that were measured and removed (numbers in DESIGN.md 4.2, profiles/ab*.txt): 4 waves x 64 rows with
 // asm-placed QK MFMAs, row sum on the matrix pipe, split QK accumulator, LDS-DMA staging, sched_group_barrier
 // interleave, static wave priority, packed-VALU softmax; at D = 64, 64 rows per wave with two waves per SIMD (+-0:
@@ -90,14 +94,20 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 64 && impl == 2) { fill<__bf16, 64, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_prekv"); return true; }
     if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
     if (D == 32 && impl == 0) { fill_with_split<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
-    if (D == 256 && impl == 0) { fill_with_split<__bf16, 256, 4, 1, 8, 1, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
+    if (D == 256 && impl == 0) { fill_with_split<__bf16, 256, 4, 1, 8, 1, 2, 12>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_spread"); return true; }
+    if (D == 256 && impl == 2) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
     if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
+    if (D == 256 && impl == 3) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2, 4>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek_vpipe"); return true; }
+    if (D == 128 && impl == 4) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 12>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe_wspread"); return true; }
+    if (D == 128 && impl == 5) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, 8>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_wmid"); return true; }
+    if (D == 64 && impl == 5) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 8>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_wmid"); return true; }
+    if (D == 128 && impl == 3) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe"); return true; }
   }
   if (precision == PREC_FP16) {
     if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
     if (D == 32 && impl == 0) { fill_with_split<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
-    if (D == 256 && impl == 0) { fill_with_split<_Float16, 256, 4, 1, 8, 1, 2>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_prek"); return true; }
+    if (D == 256 && impl == 0) { fill_with_split<_Float16, 256, 4, 1, 8, 1, 2, 12>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_spread"); return true; }
   }
   return false;
 }

@@ -166,7 +166,10 @@ constexpr int GEMM16_BK = 64;
 
 template <int WR, int WC, int MT, int NT> constexpr int gemm16_lds_bytes() { return 2 * (32 * WR * MT + 32 * WC * NT) * GEMM16_BK * 2; }
 
-template <typename T, int WR, int WC, int MT, int NT>
+// AKM / BKM: the operand's image kind (k-major rows or [x/32][k][32]) is a compile-time property, so the k loop is
+// one straight-line block (as run-time flags every fragment read was a branch and hipcc could not schedule LDS
+// reads against MFMAs across them).
+template <typename T, int WR, int WC, int MT, int NT, bool AKM, bool BKM>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   // staging, chunk id = tid + NTHR e:
   //   KMAJOR: chunk = (x, c) with c = 8-element group along k (8 per row);     global (x0 + x) * ld + k0 + 8c
   //   XMAJOR: chunk = (k, c) with c = 8-element group along x (X / 8 per row); global (k0 + k) * ld + x0 + 8c
-  const bool akm = !g.transA, bkm = g.transB;
+  constexpr bool akm = AKM, bkm = BKM;   // host: AKM = !transA, BKM = transB
   uint32_t aoff[ACH], boff[BCH], alds[ACH], blds[BCH];
 #pragma unroll
   for (int e = 0; e < ACH; ++e) {
@@ -256,6 +259,11 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
 #pragma unroll
     for (int e = 0; e < BCH; ++e) *reinterpret_cast<u32x4 *>(base + ATILE + blds[e]) = rb[e];
   };
+  auto lstore_chunk = [&](int buf, int e) {   // chunk e of the A chunks followed by the B chunks
+    char *base = smem + buf * STAGE;
+    if (e < ACH) *reinterpret_cast<u32x4 *>(base + alds[e < ACH ? e : 0]) = ra[e < ACH ? e : 0];
+    else *reinterpret_cast<u32x4 *>(base + ATILE + blds[e >= ACH ? e - ACH : 0]) = rb[e >= ACH ? e - ACH : 0];
+  };
   // fragment of k-step s (16 k) for the 32 rows x0..x0+31 of a tile image
   const int n16 = lane & 15;
   // transposing gather in NATURAL k order (element j of lane-half hi = k 16 s + 8 hi + j, the order of the
@@ -297,12 +305,23 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
       for (int t = 0; t < MT; ++t) a[t] = fragment(Ai, akm, wm + 32 * t, s);
 #pragma unroll
       for (int t = 0; t < NT; ++t) b[t] = fragment(Bi, bkm, wn + 32 * t, s);
+      // The staging writes of the next k tile go between the matrix instructions of the last k-step instead of
+      // one burst in front of the barrier (a wide LDS store occupies the store path for ~13 cycles and loads do
+      // not overlap it).  The other stage has no readers in this iteration; past the last tile the registers hold
+      // stale data that nobody reads.
 #pragma unroll
       for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < NT; ++nb) acc[mb][nb] = F::mfma(a[mb], b[nb], acc[mb][nb]);
+        for (int nb = 0; nb < NT; ++nb) {
+          if (s == BK / 16 - 1) {
+            constexpr int PER = (ACH + BCH) / (MT * NT);
+            static_assert((ACH + BCH) % (MT * NT) == 0, "staging chunks must spread evenly over the last k-step");
+#pragma unroll
+            for (int e = 0; e < PER; ++e) lstore_chunk(buf ^ 1, (mb * NT + nb) * PER + e);
+          }
+          acc[mb][nb] = F::mfma(a[mb], b[nb], acc[mb][nb]);
+        }
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
   }
   gemm_store<MT, NT>(g, C, acc, bm + wm, bn + wn, lane);

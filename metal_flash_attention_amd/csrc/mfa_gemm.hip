@@ -150,34 +150,36 @@ template <typename K> static hipError_t enable_lds(K kernel, int bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+template <typename T, bool AKM, bool BKM>
+static hipError_t launch16(bool big, const GemmArgs &g, dim3 grid, hipStream_t s) {
+  hipError_t e;
+  if (big) {
+    constexpr int LDS = gemm16_lds_bytes<2, 4, 4, 2>();
+    e = enable_lds(gemm_16<T, 2, 4, 4, 2, AKM, BKM>, LDS);
+    if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<T, 2, 4, 4, 2, AKM, BKM>), grid, dim3(512), LDS, s, g);
+  } else {
+    constexpr int LDS = gemm16_lds_bytes<2, 2, 2, 2>();
+    e = enable_lds(gemm_16<T, 2, 2, 2, 2, AKM, BKM>, LDS);
+    if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<T, 2, 2, 2, 2, AKM, BKM>), grid, dim3(256), LDS, s, g);
+  }
+  return e;
+}
+
+// image kinds of the two operands: k-major rows when the memory order has k contiguous (A not transposed, B transposed)
+template <typename T>
+static hipError_t launch16_images(bool big, bool akm, bool bkm, const GemmArgs &g, dim3 grid, hipStream_t s) {
+  if (akm) return bkm ? launch16<T, true, true>(big, g, grid, s) : launch16<T, true, false>(big, g, grid, s);
+  return bkm ? launch16<T, false, true>(big, g, grid, s) : launch16<T, false, false>(big, g, grid, s);
+}
+
 static hipError_t launch_one(const mfa_gemm_kernel *k, const GemmArgs &g, dim3 grid, bool use16, hipStream_t s) {
   if (!use16) {
     hipLaunchKernelGGL(gemm_f32mfma, grid, dim3(256), 0, s, g);
     return hipSuccess;
   }
-  hipError_t e = hipSuccess;
-  const bool bf = g.precA == PREC_BF16;
-  if (k->big) {
-    constexpr int LDS = gemm16_lds_bytes<2, 4, 4, 2>();
-    const dim3 gb((g.N + 255) / 256, (g.M + 255) / 256, grid.z);
-    if (bf) {
-      e = enable_lds(gemm_16<__bf16, 2, 4, 4, 2>, LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<__bf16, 2, 4, 4, 2>), gb, dim3(512), LDS, s, g);
-    } else {
-      e = enable_lds(gemm_16<_Float16, 2, 4, 4, 2>, LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<_Float16, 2, 4, 4, 2>), gb, dim3(512), LDS, s, g);
-    }
-  } else {
-    constexpr int LDS = gemm16_lds_bytes<2, 2, 2, 2>();
-    if (bf) {
-      e = enable_lds(gemm_16<__bf16, 2, 2, 2, 2>, LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<__bf16, 2, 2, 2, 2>), grid, dim3(256), LDS, s, g);
-    } else {
-      e = enable_lds(gemm_16<_Float16, 2, 2, 2, 2>, LDS);
-      if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<_Float16, 2, 2, 2, 2>), grid, dim3(256), LDS, s, g);
-    }
-  }
-  return e;
+  const dim3 gb((g.N + 255) / 256, (g.M + 255) / 256, grid.z);
+  return (g.precA == PREC_BF16) ? launch16_images<__bf16>(k->big, !g.transA, g.transB, g, k->big ? gb : grid, s)
+                                : launch16_images<_Float16>(k->big, !g.transA, g.transB, g, k->big ? gb : grid, s);
 }
 
 extern "C" mfa_status mfa_gemm_kernel_launch(const mfa_gemm_kernel *k, const void *A, const void *B, void *C,

@@ -298,13 +298,22 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
     const int buf = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
     const char *Ai = smem + buf * STAGE, *Bi = Ai + ATILE;
+    v8 fa[2][MT], fb[2][NT];   // fragments of k-step s + 1 are requested before the matrix instructions of step s
+#pragma unroll
+    for (int t = 0; t < MT; ++t) fa[0][t] = fragment(Ai, akm, wm + 32 * t, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fb[0][t] = fragment(Bi, bkm, wn + 32 * t, 0);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      v8 a[MT], b[NT];
+      v8 (&a)[MT] = fa[s & 1];
+      v8 (&b)[NT] = fb[s & 1];
+      if (s + 1 < BK / 16) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a[t] = fragment(Ai, akm, wm + 32 * t, s);
+        for (int t = 0; t < MT; ++t) fa[(s + 1) & 1][t] = fragment(Ai, akm, wm + 32 * t, s + 1);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = fragment(Bi, bkm, wn + 32 * t, s);
+        for (int t = 0; t < NT; ++t) fb[(s + 1) & 1][t] = fragment(Bi, bkm, wn + 32 * t, s + 1);
+        __builtin_amdgcn_sched_barrier(0x406);   // LDS and matrix instructions keep this order; vector / scalar work may move
+      }
       // The staging writes of the next k tile go between the matrix instructions of the last k-step instead of
       // one burst in front of the barrier (a wide LDS store occupies the store path for ~13 cycles and loads do
       // not overlap it).  The other stage has no readers in this iteration; past the last tile the registers hold

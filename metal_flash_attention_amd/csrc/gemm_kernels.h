@@ -169,7 +169,12 @@ template <int WR, int WC, int MT, int NT> constexpr int gemm16_lds_bytes() { ret
 // AKM / BKM: the operand's image kind (k-major rows or [x/32][k][32]) is a compile-time property, so the k loop is
 // one straight-line block (as run-time flags every fragment read was a branch and hipcc could not schedule LDS
 // reads against MFMAs across them).
-template <typename T, int WR, int WC, int MT, int NT, bool AKM, bool BKM>
+// DMA: tiles go global -> LDS directly (buffer_load_dwordx4 ... lds): instruction e of wave w fills the 1 KiB of an
+// image at 16-byte positions (w * CH + e) * 64 + lane, so each lane fetches the chunk that BELONGS at its position
+// (the swizzle is applied on the source address).  No staging registers, no ds_write_b128 (whose VGPR -> LDS
+// transfer costs ~13 cycles per wave-instruction and overlaps nothing).  Needs whole, 16-byte aligned chunks: the
+// host selects it only for K % 8 == 0 and aligned operands.
+template <typename T, int WR, int WC, int MT, int NT, bool AKM, bool BKM, bool DMA = false>
 __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -197,30 +202,35 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   //   XMAJOR: chunk = (k, c) with c = 8-element group along x (X / 8 per row); global (k0 + k) * ld + x0 + 8c
   constexpr bool akm = AKM, bkm = BKM;   // host: AKM = !transA, BKM = transB
   uint32_t aoff[ACH], boff[BCH], alds[ACH], blds[BCH];
+  uint32_t akk[ACH], bkk[BCH];   // k of the chunk inside a tile (for the k-bound test)
 #pragma unroll
   for (int e = 0; e < ACH; ++e) {
-    const int idx = tid + NTHR * e;
+    const int idx = DMA ? (wave * ACH + e) * 64 + lane : tid + NTHR * e;   // DMA: 16-byte position in the image
     if (akm) {
-      const int x = idx >> 3, c = idx & 7;
+      const int x = idx >> 3, c = DMA ? (idx & 7) ^ ((x >> 1) & 7) : idx & 7;
       aoff[e] = (bm + x < g.M) ? (bm + x) * ldA2 + c * 16 : OOB;
       alds[e] = x * 128 + ((c ^ ((x >> 1) & 7)) * 16);
+      akk[e] = 8 * c;
     } else {
-      const int k = idx / (BM / 8), c = idx % (BM / 8);
+      const int k = DMA ? (idx >> 2) % BK : idx / (BM / 8), c = DMA ? ((idx >> 2) / BK) * 4 + (idx & 3) : idx % (BM / 8);
       aoff[e] = (bm + 8 * c < g.M) ? k * ldA2 + (bm + 8 * c) * 2 : OOB;
       alds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
+      akk[e] = k;
     }
   }
 #pragma unroll
   for (int e = 0; e < BCH; ++e) {
-    const int idx = tid + NTHR * e;
+    const int idx = DMA ? (wave * BCH + e) * 64 + lane : tid + NTHR * e;
     if (bkm) {
-      const int x = idx >> 3, c = idx & 7;
+      const int x = idx >> 3, c = DMA ? (idx & 7) ^ ((x >> 1) & 7) : idx & 7;
       boff[e] = (bn + x < g.N) ? (bn + x) * ldB2 + c * 16 : OOB;
       blds[e] = x * 128 + ((c ^ ((x >> 1) & 7)) * 16);
+      bkk[e] = 8 * c;
     } else {
-      const int k = idx / (BN / 8), c = idx % (BN / 8);
+      const int k = DMA ? (idx >> 2) % BK : idx / (BN / 8), c = DMA ? ((idx >> 2) / BK) * 4 + (idx & 3) : idx % (BN / 8);
       boff[e] = (bn + 8 * c < g.N) ? k * ldB2 + (bn + 8 * c) * 2 : OOB;
       blds[e] = ((c >> 2) * BK + k) * 64 + (c & 3) * 16;
+      bkk[e] = k;
     }
   }
   // k-bound: a KMAJOR chunk at k >= K still lies inside the resource (it reads the next row), so the test is
@@ -232,7 +242,25 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
     for (int d = 0; d < 4; ++d) r[d] = (2 * d + 1 < n) ? r[d] : (2 * d < n ? (r[d] & 0xFFFFu) : 0u);
     return r;
   };
-  u32x4 ra[ACH], rb[BCH];
+  u32x4 ra[DMA ? 1 : ACH], rb[DMA ? 1 : BCH];
+  auto dma = [&](uint32_t k0, int buf) {   // tile at k0 -> stage buf (DMA only)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    char *abase = smem + buf * STAGE + wave * (ACH * 1024), *bbase = smem + buf * STAGE + ATILE + wave * (BCH * 1024);
+#pragma unroll
+    for (int e = 0; e < ACH; ++e) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ares, (lds_ptr)(abase + e * 1024), 16, k0 + akk[e] < g.K ? aoff[e] : OOB, 0, 0, 0);
+#endif
+      aoff[e] = __builtin_elementwise_add_sat(aoff[e], akm ? (uint32_t)BK * 2 : (uint32_t)BK * ldA2);
+    }
+#pragma unroll
+    for (int e = 0; e < BCH; ++e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bres, (lds_ptr)(bbase + e * 1024), 16, k0 + bkk[e] < g.K ? boff[e] : OOB, 0, 0, 0);
+#endif
+      boff[e] = __builtin_elementwise_add_sat(boff[e], bkm ? (uint32_t)BK * 2 : (uint32_t)BK * ldB2);
+    }
+  };
   auto gload = [&](uint32_t k0) {
     const bool tail = k0 + BK > g.K && (g.K & 7) != 0;   // wave-uniform: only the last k tile of a ragged K
 #pragma unroll
@@ -281,6 +309,40 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + 4 * 64));
     return __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
   };
+  // DMA mode reads its fragments through inline asm: behind an LDS-DMA in flight hipcc puts s_waitcnt vmcnt(0) in
+  // front of every LDS read it cannot prove disjoint from the DMA's destination (all transposing reads), which
+  // drains the prefetch of the next tile.  The asm reads are invisible to that pass; their own completion is
+  // awaited by frag_wait below (an asm whose operands are the fragments, so no consumer can move above it).
+  auto lds_addr = [](const char *p) { return (uint32_t)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char *)p; };
+  auto fragment_asm = [&](const char *img, bool kmajor, int x0, int s) -> v8 {
+    if (kmajor) {
+      const int x = x0 + i, c = 2 * s + hi;
+      u32x4 r;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds_addr(img + x * 128 + ((c ^ ((x >> 1) & 7)) * 16))));
+      return __builtin_bit_cast(v8, r);
+    }
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t a = lds_addr(img + ((x0 >> 5) * BK + 16 * s) * 64 + tr_lane);
+    u32x2 lo, hi2;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi2) : "v"(a));
+    return __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi2, 0, 1, 2, 3));
+  };
+  constexpr int FRAG_OPS = MT * (AKM ? 1 : 2) + NT * (BKM ? 1 : 2);   // LDS instructions per k-step of fragment reads
+  static_assert(MT == 4 && NT == 2 || !DMA, "frag_wait lists the fragments of a 4 x 2 wave tile");
+  auto frag_wait = [&](v8 (&a)[MT], v8 (&b)[NT], bool more_in_flight) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 r0 = __builtin_bit_cast(u4, a[0]), r1 = __builtin_bit_cast(u4, a[1]), r2 = __builtin_bit_cast(u4, a[MT > 2 ? 2 : 0]),
+       r3 = __builtin_bit_cast(u4, a[MT > 3 ? 3 : 0]), r4 = __builtin_bit_cast(u4, b[0]), r5 = __builtin_bit_cast(u4, b[1]);
+    if (more_in_flight)   // the next step's reads were issued after these: LDS returns in order
+      asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) : "n"(FRAG_OPS));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5));
+    a[0] = __builtin_bit_cast(v8, r0); a[1] = __builtin_bit_cast(v8, r1);
+    if (MT > 2) a[2] = __builtin_bit_cast(v8, r2);
+    if (MT > 3) a[3] = __builtin_bit_cast(v8, r3);
+    b[0] = __builtin_bit_cast(v8, r4); b[1] = __builtin_bit_cast(v8, r5);
+  };
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -291,29 +353,43 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
 
   const uint32_t nk = (g.K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  if constexpr (DMA) {
+    dma(0, 0);
+  } else {
+    gload(0);
+    lstore(0);
+    __syncthreads();
+  }
   for (uint32_t kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if constexpr (DMA) {
+      // tile kt has had a whole iteration to land; behind the barrier nobody reads the other stage any more
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      __syncthreads();
+      if (kt + 1 < nk) dma((kt + 1) * BK, buf ^ 1);
+    } else {
+      if (kt + 1 < nk) gload((kt + 1) * BK);
+    }
     const char *Ai = smem + buf * STAGE, *Bi = Ai + ATILE;
     v8 fa[2][MT], fb[2][NT];   // fragments of k-step s + 1 are requested before the matrix instructions of step s
 #pragma unroll
-    for (int t = 0; t < MT; ++t) fa[0][t] = fragment(Ai, akm, wm + 32 * t, 0);
+    for (int t = 0; t < MT; ++t) fa[0][t] = DMA ? fragment_asm(Ai, akm, wm + 32 * t, 0) : fragment(Ai, akm, wm + 32 * t, 0);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) fb[0][t] = fragment(Bi, bkm, wn + 32 * t, 0);
+    for (int t = 0; t < NT; ++t) fb[0][t] = DMA ? fragment_asm(Bi, bkm, wn + 32 * t, 0) : fragment(Bi, bkm, wn + 32 * t, 0);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       v8 (&a)[MT] = fa[s & 1];
       v8 (&b)[NT] = fb[s & 1];
       if (s + 1 < BK / 16) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) fa[(s + 1) & 1][t] = fragment(Ai, akm, wm + 32 * t, s + 1);
+        for (int t = 0; t < MT; ++t)
+          fa[(s + 1) & 1][t] = DMA ? fragment_asm(Ai, akm, wm + 32 * t, s + 1) : fragment(Ai, akm, wm + 32 * t, s + 1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) fb[(s + 1) & 1][t] = fragment(Bi, bkm, wn + 32 * t, s + 1);
+        for (int t = 0; t < NT; ++t)
+          fb[(s + 1) & 1][t] = DMA ? fragment_asm(Bi, bkm, wn + 32 * t, s + 1) : fragment(Bi, bkm, wn + 32 * t, s + 1);
         __builtin_amdgcn_sched_barrier(0x406);   // LDS and matrix instructions keep this order; vector / scalar work may move
       }
+      if constexpr (DMA) frag_wait(a, b, s + 1 < BK / 16);
       // The staging writes of the next k tile go between the matrix instructions of the last k-step instead of
       // one burst in front of the barrier (a wide LDS store occupies the store path for ~13 cycles and loads do
       // not overlap it).  The other stage has no readers in this iteration; past the last tile the registers hold
@@ -322,7 +398,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
       for (int mb = 0; mb < MT; ++mb)
 #pragma unroll
         for (int nb = 0; nb < NT; ++nb) {
-          if (s == BK / 16 - 1) {
+          if (!DMA && s == BK / 16 - 1) {
             constexpr int PER = (ACH + BCH) / (MT * NT);
             static_assert((ACH + BCH) % (MT * NT) == 0, "staging chunks must spread evenly over the last k-step");
 #pragma unroll
@@ -331,7 +407,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
           acc[mb][nb] = F::mfma(a[mb], b[nb], acc[mb][nb]);
         }
     }
-    __syncthreads();
+    if constexpr (!DMA) __syncthreads();
   }
   gemm_store<MT, NT>(g, C, acc, bm + wm, bn + wn, lane);
 }

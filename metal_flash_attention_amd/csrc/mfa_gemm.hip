@@ -5,6 +5,7 @@
 #include "gemm_kernels.h"
 #include "mfa_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -153,7 +154,16 @@ template <typename K> static hipError_t enable_lds(K kernel, int bytes) {
 template <typename T, bool AKM, bool BKM>
 static hipError_t launch16(bool big, const GemmArgs &g, dim3 grid, hipStream_t s) {
   hipError_t e;
-  if (big) {
+  // LDS-DMA staging for launches made of whole, 16-byte aligned chunks (MFA_GEMM_IMPL=vgpr: developer knob that
+  // forces the register-staged kernel, which also serves every other launch)
+  static const bool dmaKnob = !(std::getenv("MFA_GEMM_IMPL") && std::strcmp(std::getenv("MFA_GEMM_IMPL"), "vgpr") == 0);
+  const bool aligned = (g.K & 7) == 0 && (g.ldA & 7) == 0 && (g.ldB & 7) == 0 && (g.bsA & 7) == 0 && (g.bsB & 7) == 0 &&
+                       ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;
+  if (big && dmaKnob && aligned) {
+    constexpr int LDS = gemm16_lds_bytes<2, 4, 4, 2>();
+    e = enable_lds(gemm_16<T, 2, 4, 4, 2, AKM, BKM, true>, LDS);
+    if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<T, 2, 4, 4, 2, AKM, BKM, true>), grid, dim3(512), LDS, s, g);
+  } else if (big) {
     constexpr int LDS = gemm16_lds_bytes<2, 4, 4, 2>();
     e = enable_lds(gemm_16<T, 2, 4, 4, 2, AKM, BKM>, LDS);
     if (e == hipSuccess) hipLaunchKernelGGL((gemm_16<T, 2, 4, 4, 2, AKM, BKM>), grid, dim3(512), LDS, s, g);

@@ -15,6 +15,9 @@ def main():
     ap.add_argument("--sizes", default="4096,8192")
     ap.add_argument("--dtypes", default="bf16,f32")
     ap.add_argument("--odd", action="store_true", help="also n-1 and n+1 (misaligned problem sizes)")
+    ap.add_argument("--vendor", action="store_true",
+                    help="also time torch.matmul (hipBLASLt) on the same operands: a calibration of what a tuned "
+                         "library reaches on this box with random data, not part of the product")
     args = ap.parse_args()
     import torch
     from metal_flash_attention_amd import GEMMDescriptor, GEMMKernel, GEMMKernelDescriptor, GEMMOperandPrecision as P
@@ -44,6 +47,22 @@ def main():
                     extra = f"  {tf / sustained[dt] * 100:5.1f} % of sustained" if sustained[dt] else ""
                     print(f"{dt:4s} n={n:5d} {'A^T' if tA else 'A  '} {'B^T' if tB else 'B  '} {k.variant:32s} {best:8.3f} ms "
                           f"{tf:8.1f} TFLOP/s  {tf / peak[dt] * 100:5.1f} % of spec{extra}  rel err {err:.1e}")
+                    if args.vendor:
+                        am, bm = (a.T if tA else a), (b.T if tB else b)
+                        out = torch.empty((n, n), device="cuda", dtype=tdt)
+                        for _ in range(2):
+                            torch.matmul(am, bm, out=out)
+                        vbest = float("inf")
+                        for _ in range(3):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            for _ in range(iters):
+                                torch.matmul(am, bm, out=out)
+                            e1.record()
+                            torch.cuda.synchronize()
+                            vbest = min(vbest, e0.elapsed_time(e1) / iters)
+                        print(f"{dt:4s} n={n:5d} {'A^T' if tA else 'A  '} {'B^T' if tB else 'B  '} {'torch.matmul (hipBLASLt), ' + dt + ' C':32s} "
+                              f"{vbest:8.3f} ms {2.0 * n ** 3 / vbest / 1e9:8.1f} TFLOP/s")
 
 
 if __name__ == "__main__":

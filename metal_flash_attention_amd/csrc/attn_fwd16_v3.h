@@ -27,6 +27,36 @@ namespace mfa {
 //   2 = K rows padded by 16 bytes in LDS instead of XOR-swizzled: equally conflict-free for ds_read_b128
 //       (row stride = 16 mod 256 bytes), and the eight fragment addresses of a lane become ONE register
 //       plus immediates instead of eight registers each needing a v_add_u32 with the stage base.
+// LDS reads as inline asm (LDMA schedule): hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it cannot
+// prove disjoint from the destination of an LDS-DMA in flight (all transposing reads), which would drain the
+// prefetch of the next tile.  The asm reads are invisible to that pass; lds_wait<N> (an asm whose in/out operands
+// are the fragments, so no consumer can be scheduled above it) waits until at most N younger LDS reads are pending
+// -- LDS returns in order, and asm volatile statements keep their order.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const char *p) {
+  return (uint32_t)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char *)p;
+}
+__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_tr16_pair(uint32_t addr) {   // rows +0 and +8 of a 16-key group
+  u32x2_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 8 * 64));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+}
+template <int N> __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));   // 4-bit counter
+}
+template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false,
           bool CAUSAL = false, int VD = 0, bool SPARSE = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
@@ -37,6 +67,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   constexpr bool KPAD = (VD & 2) != 0;
   constexpr bool VPIPE = (VD & 4) != 0;   // V^T fragments double-buffered in groups of four MFMAs (see step)
   constexpr bool WSPREAD = (VD & 8) != 0; // staging writes of the next tile issued between the matrix instructions of step A
+  // LDMA: tiles go global -> LDS directly (buffer_load_dwordx4 ... lds): instruction i of wave w fills the 1 KiB of an
+  // image at 16-byte positions (w * NCH + i) * 64 + lane, so each lane fetches the chunk that BELONGS at its position
+  // (K swizzle and V sub-tiling applied on the source address).  No staging registers, no ds_write_b128.  Needs
+  // 16-byte aligned rows (the host checks) and reads its fragments through the asm helpers above.
+  constexpr bool LDMA = (VD & 32) != 0;
+  static_assert(!LDMA || (VPIPE && RING == 3 && PRE >= 1 && !KPAD && !SPARSE && RB == 1 && NKS % 4 == 0),
+                "LDMA: grouped-read schedule on the 3-stage ring");
   constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
@@ -105,6 +142,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const bool valid = c * 8 < Dr;
     koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
     voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
+    if constexpr (LDMA) {   // 16-byte position p of the image -> the chunk stored there
+      const int p = (wave * NCH + i) * 64 + lane;
+      const int krow = p / CPR, kc = (p % CPR) ^ kswz_mask<D>(krow);
+      const int vkey = (p >> 2) % BC, vc = (p / (BC * 4)) * 4 + (p & 3);
+      koff[i] = (kc * 8 < Dr) ? (tile0 * BC + krow) * ldk2 + kc * 16 : OOB;
+      voff[i] = (vc * 8 < Dr) ? (tile0 * BC + vkey) * ldv2 + vc * 16 : OOB;
+    }
     klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
     vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
     if constexpr (SPARSE) {
@@ -112,37 +156,56 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
     }
   }
-  u32x4 kreg[NCH], vreg[NCH];
-  auto issue_loads = [&]() {
+  u32x4 kreg[LDMA ? 1 : NCH], vreg[LDMA ? 1 : NCH];
+  auto issue_dma = [&](int stage) {   // LDMA: the next tile in sequence -> `stage` (zeros past the end)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    char *base = smem + stage * STAGE + wave * (NCH * 1024);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
-      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(kres, (lds_ptr)(base + i * 1024), 16, koff[i], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + KTILE + i * 1024), 16, voff[i], 0, 0, 0);
+#endif
       koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
       voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+    }
+  };
+  auto issue_loads = [&]() {
+    if constexpr (!LDMA) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+        koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+        voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+      }
     }
   };
   auto stage_part = [&](int stage, int i0, int i1) {   // write chunks [i0, i1) of tile j+1, then request them for tile j+2
-    char *base = smem + stage * STAGE;
+    if constexpr (!LDMA) {
+      char *base = smem + stage * STAGE;
 #pragma unroll
-    for (int i = i0; i < i1; ++i) {
-      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
-      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
-    }
+      for (int i = i0; i < i1; ++i) {
+        *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+        *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+      }
 #pragma unroll
-    for (int i = i0; i < i1; ++i) {
-      kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
-      vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
-      koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
-      voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+      for (int i = i0; i < i1; ++i) {
+        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
+        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+        koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+        voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
+      }
     }
   };
   auto write_tiles = [&](int stage) {
-    char *base = smem + stage * STAGE;
+    if constexpr (!LDMA) {
+      char *base = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
-      *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+      for (int i = 0; i < NCH; ++i) {
+        *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
+        *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+      }
     }
   };
   const int n16 = lane & 15;
@@ -368,6 +431,57 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf1[db], pf[b][1], o[b][db]);
   };
 
+  // LDMA pipeline step: the same order as the grouped step above with every LDS read issued through asm -- K fragments
+  // of the next 32 keys and the first group of V^T fragments up front, one group of four V^T fragments requested
+  // while the previous four are multiplied.
+  auto step_dma = [&](f32x16 (&s_cur)[RB], f32x16 (&s_next)[RB], int k_stage, int k_kb, int v_stage, int v_kb) {
+    if constexpr (LDMA) {
+      constexpr int G = 4, NG = 2 * NDB / G;
+      const uint32_t ka = lds_addr(smem + k_stage * STAGE + k_kb * 32 * ROWB);
+      const uint32_t va = lds_addr(smem + v_stage * STAGE + vtr_off + v_kb * 32 * 64);
+      u32x4 kf[NKS], vg[2][G];
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) kf[t] = lds_read_b128(ka + kread[t]);
+      auto load_group = [&](auto gc, u32x4 (&vf)[G]) {
+        constexpr int g = decltype(gc)::value;
+        static_for<G>([&](auto ic) {
+          constexpr int idx = g * G + decltype(ic)::value, u = idx / NDB, db = idx % NDB;
+          vf[decltype(ic)::value] = lds_read_tr16_pair<(db * BC + 16 * u) * 64>(va);
+        });
+      };
+      load_group(std::integral_constant<int, 0>{}, vg[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      exponentiate(s_cur, pf);
+#pragma unroll
+      for (int t = 0; t < NKS; t += 4)   // 2 G transposing reads were issued after the K fragments (in-order return)
+        lds_wait<2 * G>(kf[t], kf[t + 1], kf[t + 2], kf[t + 3]);
+#pragma unroll
+      for (int t = 0; t < NKS; ++t) {
+        if (t == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_next[0][r] = 0.f;
+        }
+        s_next[0] = F::mfma(__builtin_bit_cast(v8, kf[t]), qf[0][t], s_next[0]);
+      }
+      // sched_barrier(0x406): matrix instructions and the asm reads / waits keep this order, VALU / SALU /
+      // transcendental work (the exponentiation above, the block maximum that follows) may move across
+      __builtin_amdgcn_sched_barrier(0x406);
+      static_for<NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, vg[(g + 1) & 1]);
+        u32x4 (&vf)[G] = vg[g & 1];
+        lds_wait<(g + 1 < NG) ? 2 * G : 0>(vf[0], vf[1], vf[2], vf[3]);
+        __builtin_amdgcn_sched_barrier(0x406);
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+          const int idx = g * G + i, u = idx / NDB, db = idx % NDB;
+          o[0][db] = F::mfma(__builtin_bit_cast(v8, vf[i]), pf[0][u], o[0][db]);
+        }
+        __builtin_amdgcn_sched_barrier(0x406);
+      });
+    }
+  };
+
   static_assert(!(SPARSE && SPLIT), "block-sparse launches are row-parallel");
   // One contiguous run of key tiles [tile0, tile1): prologue, pipelined loop, tail.  Dense launches make one
   // call; block-sparse launches one per run of active tiles, the online-softmax state (m, l, O) carried
@@ -383,9 +497,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- prologue
   const int ntiles = tile1 - tile0;
   const bool ragged = (C & (BC - 1)) != 0 && tile1 == tiles_total;   // only the globally last tile is partial
-  issue_loads();
-  write_tiles(0);
-  issue_loads();
+  if constexpr (LDMA) {
+    issue_dma(0);      // first tile of the range -> stage 0
+    issue_dma(1);      // second tile -> stage 1 (zeros past the end)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");   // the first tile (and the Q fragments) have landed
+  } else {
+    issue_loads();
+    write_tiles(0);
+    issue_loads();
+  }
   __syncthreads();
   f32x16 s0[RB], s1[RB];   // half score tiles (keys 0-31 / 32-63 of a tile); roles alternate
   float m_new[RB];
@@ -403,6 +523,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // with a second barrier before step B reads it.
   auto iteration = [&](int j, bool next_is_last, int st_cur, int st_next) {
     rescale_if_needed(m_new);
+    if constexpr (LDMA) {
+      // this wave's part of tile j+1 has had a whole iteration to land; behind the barrier every part is visible
+      // and nobody reads tile j-1 any more, so its stage takes tile j+2
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+      __syncthreads();
+      issue_dma(3 - st_cur - st_next);
+      step_dma(s0, s1, st_cur, 1, st_cur, 0);
+      mask_causal(s1, (tile0 + j) * BC + 32);
+      block_max(s1, m_new);
+      rescale_if_needed(m_new);
+      step_dma(s1, s0, st_next, 0, st_cur, 1);
+      if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
+      mask_causal(s0, (tile0 + j + 1) * BC);
+      block_max(s0, m_new);
+      return;
+    }
     if constexpr (WSPREAD && RING == 3) {
       // tile j+1 is only read from step B on: stage it in the middle of step A, behind this wave's own K fragment
       // reads, and publish it with the barrier between the two steps (every wave past the previous iteration's
@@ -531,6 +667,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- epilogue: O /= l (+Source.swift:165-171), L = m + log2(l) (+Caching.swift:373-377).
   // SPLIT launches instead publish the un-normalised (O, m, l) of their key range; attn_fwd_combine
   // merges the pieces (no atomics: every piece has its own slab, like the reference's dQ / dK-dV split).
+  if constexpr (LDMA) __builtin_amdgcn_s_waitcnt(0x0F70);   // the run-ahead DMAs (zeros past the end) must not land in the epilogue's buffer
   __syncthreads();   // every wave is done with the ring
   constexpr int OLD = D + 4;
   float *Os = reinterpret_cast<float *>(smem) + wave * (RB * 32 * OLD);

@@ -51,13 +51,14 @@ static void launch_v3_sparse(dim3 grid, hipStream_t stream, const KernelArgs &ar
                        dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
 }
 
-// product variants: the dense code object plus its causal, block-sparse and column-parallel siblings
-template <typename T, int D, int NW, int RB, int THR, int PRE, int RING = 3, int VD = 0>
+// product variants: the dense code object plus its causal, block-sparse and column-parallel siblings (VDS: schedule
+// bits of the block-sparse pair, which restarts its pipeline per run of active tiles and keeps register staging)
+template <typename T, int D, int NW, int RB, int THR, int PRE, int RING = 3, int VD = 0, int PRES = PRE, int VDS = VD>
 static void fill_with_split(VariantInfo *v, const char *name) {
   fill<T, D, NW, RB, THR, PRE, 0, RING, VD>(v, name);
-  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRE, RING, VD>;
-  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, VD, true>);
-  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD, true>);
+  v->launchSparse = &launch_v3_sparse<T, D, NW, RB, THR, PRES, RING, VDS>;
+  v->funcSparse = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRES, 0, RING, false, false, VDS, true>);
+  v->funcSparseCausal = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRES, 0, RING, false, true, VDS, true>);
   v->launchSplit = &launch_v3_split<T, D, NW, RB, THR, PRE, 0, RING, VD>;
   v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, true, false, VD>);
   v->launchCausal = &launch_v3_causal<T, D, NW, RB, THR, PRE, RING, VD>;
@@ -65,22 +66,28 @@ static void fill_with_split(VariantInfo *v, const char *name) {
   v->causal = true;
 }
 
-// impl 0: product schedule -- D <= 128: 8 waves x 32 rows, 3-stage ring (two waves per SIMD hide the LDS latency:
-// hoisting fragment reads measured +-0); D = 256: 4 waves x 32 rows (one per SIMD, 512 registers), 2-stage ring,
-// K fragments hoisted (+11 % measured: nothing else hides the latency), V^T fragments double-buffered in groups
-// of four MFMAs and the staging writes of the next tile spread between those groups instead of one burst behind the
-// barrier (+11 % measured: 64 KiB of ds_write_b128 per tile kept the LDS busy while no wave had work).
-// Developer schedules (MFA_FWD16_IMPL=v3:<n>): 1 / 2 = K / K + first V fragments hoisted (D = 256: 2 = the previous
-// product without grouped reads / spread writes, 3 = grouped reads only); 3 / 4 / 5 at D = 128 = grouped reads /
-// + spread writes / writes in the middle of step A (all within +-1 % with two waves per SIMD); 41 = K rows padded
-// instead of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind the decomposition in DESIGN.md 4.2.
+// impl 0: product schedule.
+//   D = 128: 8 waves x 32 rows, 3-stage ring filled by LDS-DMA (buffer_load_dwordx4 ... lds, no staging registers, no
+//     ds_write_b128), LDS reads through inline asm with counted waits, V^T fragments in groups of four MFMAs: +3 %
+//     over the register-staged schedule (impl 7), bit-identical results.  The block-sparse pair keeps impl 7's schedule.
+//   D = 64 / 32: register-staged, fragment reads left to hipcc (two waves per SIMD hide the LDS latency; the
+//     LDS-DMA schedule measured -8 % at D = 64, which is VALU-bound).
+//   D = 256: 4 waves x 32 rows (one per SIMD, 512 registers), 2-stage ring, K fragments hoisted (+11 %), V^T
+//     fragments double-buffered in groups of four MFMAs and the staging writes of the next tile spread between those
+//     groups instead of one burst behind the barrier (+11 %: 64 KiB of ds_write_b128 per tile kept the LDS busy while
+//     no wave had work).
+// Developer schedules (MFA_FWD16_IMPL=v3:<n>): 1 / 2 = K / K + first V fragments hoisted (D = 256: 2 = no grouped
+// reads / spread writes, 3 = grouped reads only); D = 128: 3 / 4 / 5 = grouped reads / + spread writes / writes in
+// the middle of step A (all within +-1 %), 7 = register-staged previous product, 8 at D = 64 = LDS-DMA; 41 = K rows
+// padded instead of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind DESIGN.md 4.2.
 // Schedules that were measured and removed (numbers in DESIGN.md 4.2, profiles/ab*.txt): 4 waves x 64 rows with
-// asm-placed QK MFMAs, row sum on the matrix pipe, split QK accumulator, LDS-DMA staging, sched_group_barrier
-// interleave, static wave priority, packed-VALU softmax; at D = 64, 64 rows per wave with two waves per SIMD (+-0:
-// that size is VALU-bound, not LDS-bound).
+// asm-placed QK MFMAs, row sum on the matrix pipe, split QK accumulator, sched_group_barrier interleave, static wave
+// priority, packed-VALU softmax, K fragments requested one step ahead on top of LDS-DMA (+0.5 %); at D = 64, 64
+// rows per wave with two waves per SIMD (+-0).
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
-    if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
+    if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 1, 3, 36, 0, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"); return true; }
+    if (D == 128 && impl == 7) { fill<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
     if (D == 128 && impl == 1) { fill<__bf16, 128, 8, 1, 8, 1>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek"); return true; }
     if (D == 128 && impl == 2) { fill<__bf16, 128, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prekv"); return true; }
     if (D == 128 && impl == 41) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_kpad"); return true; }
@@ -101,10 +108,11 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 4) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 12>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe_wspread"); return true; }
     if (D == 128 && impl == 5) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, 8>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_wmid"); return true; }
     if (D == 64 && impl == 5) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 8>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_wmid"); return true; }
+    if (D == 64 && impl == 8) { fill<__bf16, 64, 8, 1, 8, 1, 0, 3, 36>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_ldsdma"); return true; }
     if (D == 128 && impl == 3) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe"); return true; }
   }
   if (precision == PREC_FP16) {
-    if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8"); return true; }
+    if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 1, 3, 36, 0, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8_ldsdma"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
     if (D == 32 && impl == 0) { fill_with_split<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill_with_split<_Float16, 256, 4, 1, 8, 1, 2, 12>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_spread"); return true; }

@@ -279,6 +279,27 @@ def test_forward_16bit_forced_rescale(impl, monkeypatch):
     assert np.abs(got["L"] - ref["L"]).max() < 2e-3
 
 
+@pytest.mark.parametrize("impl", ["v3:0", "v3:7", "v3:4"])
+def test_forward_16bit_forced_rescale_d128(impl, monkeypatch):
+    """The same forced-rescale construction at D = 128, where the product schedule stages through LDS-DMA and
+    reads its fragments through inline asm (v3:0); v3:7 is the register-staged schedule it replaced."""
+    monkeypatch.setenv("MFA_FWD16_IMPL", impl)
+    R, C, D = 300, 1000, 128
+    net = Network(NetworkDescriptor(R, C, D), seed=22)
+    net.K[450] = net.Q[5] * 4.0
+    net.K[900] = net.Q[270] * 1.2
+    net.invalidate()
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net, run_backward=False)
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(backward=False)
+    assert np.isfinite(got["O"]).all()
+    assert np.abs(got["O"] - ref["O"]).max() < 2e-2, run.kernels[AttentionKernelType.forward].variant
+    assert np.abs(got["L"] - ref["L"]).max() < 2e-3
+    assert all(run.tails_ok.values())
+
+
 # ---- BASELINE.json configurations at FULL size ------------------------------------------------
 def _full_size(R, D, low, in_type=P.BF16, backward=False, seed=0):
     net = Network(NetworkDescriptor(R, R, D), seed=seed)

@@ -34,7 +34,9 @@ SUSTAINED_TFLOPS_RANDOM = {"bf16": 1560.0, "f16": 1560.0}
 # process): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes
 # for wide coalesced reads on gfx950.  Keyed by (workload, kernel variant); null when not profiled.
 MEASURED_TRAFFIC_BYTES = {
-    ("fwd_bf16_d128", "attn_fwd16v3_bf16_d128_w8x32_thr8"):
+    ("fwd_bf16_d128", "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"):
+        {"bytes": (2 * 393335.2 + 528384.0) * 1024, "source": "profiles/r01_fwd_bf16_d128_v3_ldsdma_summary.txt"},
+    ("fwd_bf16_d128", "attn_fwd16v3_bf16_d128_w8x32_thr8"):   # register-staged schedule (MFA_FWD16_IMPL=v3:7)
         {"bytes": (2 * 393354.6 + 528384.0) * 1024, "source": "profiles/r01_fwd_bf16_d128_v3_summary.txt"},
 }
 
@@ -86,7 +88,10 @@ def main():
         # RCCL first; if it cannot initialise on this node fall back to gloo rather than lose the run.
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MFA_BENCH_BACKEND", "nccl")
+        # (RCCL hangs instead of failing when two ranks share one device -- the 1-GPU test box -- so that case
+        # goes straight to gloo.)
+        shared_device = world > max(1, torch.cuda.device_count())
+        backend = os.environ.get("MFA_BENCH_BACKEND", "gloo" if shared_device else "nccl")
         try:
             dist.init_process_group(backend, rank=rank, world_size=world)
             if backend == "nccl":

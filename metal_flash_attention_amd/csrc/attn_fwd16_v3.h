@@ -1,32 +1,36 @@
-// attn_fwd16_v3.h -- forward attention, 16-bit matrix cores, ONE wave per SIMD owning 64 query rows.
+// attn_fwd16_v3.h -- forward attention on the 16-bit matrix cores: the product kernel for bf16 / fp16 Q, K, V.
 //
-// Same math / fragment maps / LDS images as attn_fwd16.h and the same ring, loads, deferred rescale
-// and epilogue as attn_fwd16_v2.h.  What is re-derived here is the register blocking, for gfx950's
-// 512-register lanes (the reference blocks for Apple's ~208 B/thread,
-// AttentionDescriptor+Parameters.swift:77-285):
-//   * a wave owns RB = 2 blocks of 32 query rows: every K fragment (ds_read_b128) and every V^T
-//     fragment (2 x ds_read_b64_tr_b16) read from LDS feeds TWO MFMAs, halving LDS traffic per flop;
-//     4 waves per workgroup = one wave per SIMD, each with the whole 512-entry register file
-//     (O accumulators 128, Q fragments 64, two live half score tiles 64, staging 32, ...).
-//   * the pipeline step is HALF a K/V tile (32 keys): S^T of the next 32 keys is produced by the
-//     matrix pipe while the VALU exponentiates the current 32, then O^T += V^T P^T for the current
-//     32 while the VALU reduces the next block's maximum.  The two half score tiles swap roles every
-//     step, so no register copies are needed, and only 64 score registers are live.
-//   * per step and wave: 32 MFMAs against 8 + 16 LDS reads and ~110 VALU instructions.
+// Same math / fragment maps / LDS images as attn_fwd16.h and the same ring, deferred rescale and epilogue as
+// attn_fwd16_v2.h.  What is specific to this kernel:
+//   * the pipeline step is HALF a K/V tile (32 keys): S^T of the next 32 keys is produced by the matrix pipe
+//     while the VALU exponentiates the current 32, then O^T += V^T P^T for the current 32 while the VALU
+//     reduces the next block's maximum.  The two half score tiles swap roles every step, so no register copies
+//     are needed and only two half tiles of scores are live;
+//   * geometry by template: NW waves x RB blocks of 32 query rows.  Product: D <= 128 -> 8 waves x 32 rows (two
+//     waves per SIMD, <= 256 registers each); D = 256 -> 4 waves x 32 rows (one per SIMD, 512 registers).  RB = 2
+//     (every K / V^T fragment feeds two MFMAs) was measured and lost;
+//   * RING: 3 stages with one barrier per tile, or 2 stages with two barriers (D = 256: three would not fit);
+//   * PRE: 0 = fragment reads placed by hipcc, 1 / 2 = K / K + first V^T fragments requested before the
+//     exponentiation;
+//   * SPLIT / CAUSAL / SPARSE: column-parallel pieces through the caller's workspace, causal mask, block mask --
+//     separate code objects, so the dense kernel carries none of their code.
 #pragma once
 #include "attn_fwd16_v2.h"
 #include <type_traits>
 
 namespace mfa {
 
-// VD (bit mask; tools/probe_valu.hip shows that ONE wave issues at most one VALU instruction per ~7.3
-// cycles whatever its kind, so the NUMBER of instructions per wave is what could matter):
-//   1 = (removed) softmax arithmetic on register pairs through inline-asm v_pk_fma_f32 / v_pk_add_f32:
-//       -23 % VALU instructions, no measurable gain, and the asm consumers of v_exp_f32 results escape
-//       hipcc's trans-use hazard handling;
-//   2 = K rows padded by 16 bytes in LDS instead of XOR-swizzled: equally conflict-free for ds_read_b128
-//       (row stride = 16 mod 256 bytes), and the eight fragment addresses of a lane become ONE register
-//       plus immediates instead of eight registers each needing a v_add_u32 with the stage base.
+// VD (bit mask of schedule options):
+//    2 = KPAD: K rows padded by 16 bytes in LDS instead of XOR-swizzled (equally conflict-free for ds_read_b128;
+//        the eight fragment addresses of a lane become one register plus immediates): +-0, developer knob;
+//    4 = VPIPE: V^T fragments double-buffered in groups of four MFMAs (needs PRE >= 1);
+//    8 = WSPREAD: the ds_write_b128 of the next tile issued between those groups (with VPIPE) or in the middle
+//        of step A, instead of one burst at the barrier -- +11 % at D = 256 (one wave per SIMD), +-1 % otherwise;
+//   32 = LDMA: tiles staged by LDS-DMA, every LDS read of the loop issued through the asm helpers below
+//        (needs VPIPE, RING = 3) -- the D = 128 product.
+//   (1 was softmax arithmetic on register pairs through inline-asm v_pk_fma_f32 / v_pk_add_f32: -23 % VALU
+//   instructions, no measurable gain, and asm consumers of v_exp_f32 results escape hipcc's trans-use hazard
+//   handling; 16 was the row sum on the matrix pipe: -2.5 %.  Both removed.)
 // LDS reads as inline asm (LDMA schedule): hipcc puts s_waitcnt vmcnt(0) in front of every LDS read it cannot
 // prove disjoint from the destination of an LDS-DMA in flight (all transposing reads), which would drain the
 // prefetch of the next tile.  The asm reads are invisible to that pass; lds_wait<N> (an asm whose in/out operands

@@ -76,10 +76,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // (K swizzle and V sub-tiling applied on the source address).  No staging registers, no ds_write_b128.  Needs
   // 16-byte aligned rows (the host checks) and reads its fragments through the asm helpers above.
   constexpr bool LDMA = (VD & 32) != 0;
-  static_assert(!LDMA || (VPIPE && RING == 3 && PRE >= 1 && !KPAD && !SPARSE && RB == 1 && NKS % 4 == 0),
-                "LDMA: grouped-read schedule on the 3-stage ring");
+  // LDMA with RING == 2 (D = 256, where three whole stages do not fit): the K images form a ring of THREE and the
+  // V images a ring of TWO (3 x 32 + 2 x 32 KiB = all 160 KiB).  K(j+2) and V(j+1) are requested right behind the
+  // barrier of iteration j: both have a whole iteration to land, and the second barrier of the register-staged
+  // 2-stage ring (which published the tile written during step A) is not needed.
+  constexpr bool KV32 = LDMA && RING == 2;
+  static_assert(!LDMA || (VPIPE && (RING == 3 || RING == 2) && PRE >= 1 && !KPAD && !SPARSE && RB == 1 && NKS % 4 == 0),
+                "LDMA: grouped-read schedule");
   constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
+  // byte offset of K image `stage`; of the stage base the V addressing (which includes + KTILE) starts from
+  auto koffs = [](int stage) { return KV32 ? stage * KTILE : stage * STAGE; };
+  auto voffs = [](int stage) { return KV32 ? 2 * KTILE + stage * TILE : stage * STAGE; };
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
   // ABL: timing-only ablations (WRONG RESULTS): 2 = exp2 replaced by an FMA, 3 = one K fragment address, 8 = no
   // per-tile barrier, 20 = no fragment reads from LDS in the loop, 21 = no softmax arithmetic, 22 = 20 + 21
@@ -161,19 +169,28 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     }
   }
   u32x4 kreg[LDMA ? 1 : NCH], vreg[LDMA ? 1 : NCH];
-  auto issue_dma = [&](int stage) {   // LDMA: the next tile in sequence -> `stage` (zeros past the end)
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    char *base = smem + stage * STAGE + wave * (NCH * 1024);
+  typedef __attribute__((address_space(3))) void *lds_ptr;
+  auto issue_dma_k = [&](int stage) {   // LDMA: the next K tile in sequence -> K image `stage` (zeros past the end)
+    char *base = smem + koffs(stage) + wave * (NCH * 1024);
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
       __builtin_amdgcn_raw_ptr_buffer_load_lds(kres, (lds_ptr)(base + i * 1024), 16, koff[i], 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + KTILE + i * 1024), 16, voff[i], 0, 0, 0);
 #endif
       koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
+    }
+  };
+  auto issue_dma_v = [&](int stage) {
+    char *base = smem + voffs(stage) + KTILE + wave * (NCH * 1024);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vres, (lds_ptr)(base + i * 1024), 16, voff[i], 0, 0, 0);
+#endif
       voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
     }
   };
+  auto issue_dma = [&](int stage) { issue_dma_k(stage); issue_dma_v(stage); };
   auto issue_loads = [&]() {
     if constexpr (!LDMA) {
 #pragma unroll
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 
   // S^T for the 32 keys of half `kb` of the tile in `stage`: one K fragment feeds RB MFMAs
   auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
-    const char *Ks = smem + stage * STAGE + kb * 32 * ROWB;
+    const char *Ks = smem + koffs(stage) + kb * 32 * ROWB;
 #pragma unroll
     for (int t = 0; t < NKS; ++t) {
       const v8 kf = NOLDS ? qf[0][(t + 1) % NKS] : *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   };
   // O^T += V^T P^T for the 32 keys of half `kb`: one V^T fragment feeds RB MFMAs
   auto pv = [&](int stage, int kb, const v8 (&pf)[RB][2]) {
-    const char *Vs = smem + stage * STAGE + vtr_off + kb * 32 * 64;
+    const char *Vs = smem + voffs(stage) + vtr_off + kb * 32 * 64;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -441,8 +458,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto step_dma = [&](f32x16 (&s_cur)[RB], f32x16 (&s_next)[RB], int k_stage, int k_kb, int v_stage, int v_kb) {
     if constexpr (LDMA) {
       constexpr int G = 4, NG = 2 * NDB / G;
-      const uint32_t ka = lds_addr(smem + k_stage * STAGE + k_kb * 32 * ROWB);
-      const uint32_t va = lds_addr(smem + v_stage * STAGE + vtr_off + v_kb * 32 * 64);
+      const uint32_t ka = lds_addr(smem + koffs(k_stage) + k_kb * 32 * ROWB);
+      const uint32_t va = lds_addr(smem + voffs(v_stage) + vtr_off + v_kb * 32 * 64);
       u32x4 kf[NKS], vg[2][G];
 #pragma unroll
       for (int t = 0; t < NKS; ++t) kf[t] = lds_read_b128(ka + kread[t]);
@@ -501,7 +518,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- prologue
   const int ntiles = tile1 - tile0;
   const bool ragged = (C & (BC - 1)) != 0 && tile1 == tiles_total;   // only the globally last tile is partial
-  if constexpr (LDMA) {
+  if constexpr (KV32) {
+    issue_dma_k(0);
+    issue_dma_v(0);
+    issue_dma_k(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NCH) : "memory");       // K(0), V(0) (and the Q fragments) have landed
+  } else if constexpr (LDMA) {
     issue_dma(0);      // first tile of the range -> stage 0
     issue_dma(1);      // second tile -> stage 1 (zeros past the end)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NCH) : "memory");   // the first tile (and the Q fragments) have landed
@@ -519,6 +541,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   block_max(s0, m_new);
 
   int st_cur_rt = 0, st_next_rt = 1;
+  int k_cur_rt = 0;   // KV32: position of K(j) in the ring of three K images (st_cur is V(j)'s in the ring of two)
   // iteration j: s0 = S(tile j, keys 0-31) and its block maximum are ready on entry
   // RING == 3: tile j+1 replaces tile j-2, whose last reader finished before the barrier of the
   // previous iteration, so one barrier per tile suffices.  RING == 2 (head dimensions whose three
@@ -532,12 +555,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       // and nobody reads tile j-1 any more, so its stage takes tile j+2
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
       __syncthreads();
-      issue_dma(3 - st_cur - st_next);
-      step_dma(s0, s1, st_cur, 1, st_cur, 0);
+      const int k_cur = KV32 ? k_cur_rt : st_cur, k_next = KV32 ? (k_cur_rt == 2 ? 0 : k_cur_rt + 1) : st_next;
+      if constexpr (KV32) {
+        issue_dma_k(k_cur == 0 ? 2 : k_cur - 1);   // K(j+2) replaces K(j-1)
+        issue_dma_v(st_next);                      // V(j+1) replaces V(j-1)
+      } else {
+        issue_dma(3 - st_cur - st_next);
+      }
+      step_dma(s0, s1, k_cur, 1, st_cur, 0);
       mask_causal(s1, (tile0 + j) * BC + 32);
       block_max(s1, m_new);
       rescale_if_needed(m_new);
-      step_dma(s1, s0, st_next, 0, st_cur, 1);
+      step_dma(s1, s0, k_next, 0, st_cur, 1);
       if (next_is_last && ragged) mask_edge(s0, (tile0 + j + 1) * BC);
       mask_causal(s0, (tile0 + j + 1) * BC);
       block_max(s0, m_new);
@@ -625,6 +654,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto advance = [&]() {
     st_cur_rt = st_next_rt;
     st_next_rt = (st_next_rt == RING - 1) ? 0 : st_next_rt + 1;
+    k_cur_rt = (k_cur_rt == 2) ? 0 : k_cur_rt + 1;
   };
   int j = 0;
   for (; j + 2 < ntiles; ++j) { iteration(j, false, st_cur_rt, st_next_rt); advance(); }
@@ -632,7 +662,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   const int st_cur = st_cur_rt;
   // last tile (j = ntiles-1): both halves, no successor
   rescale_if_needed(m_new);
-  qk(st_cur, 1, s1);
+  if constexpr (KV32) {   // V of the last tile was requested in the last iteration: not yet awaited / published
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+  qk(KV32 ? k_cur_rt : st_cur, 1, s1);
   exponentiate(s0, pf);
   pv(st_cur, 0, pf);
   if (ragged) mask_edge(s1, (tile0 + j) * BC + 32);

@@ -4,18 +4,24 @@
 
 namespace mfa {
 
+// LDS bytes of a schedule: the LDS-DMA schedule on the 2-stage ring keeps three K and two V images (all 160 KiB)
+template <int D, int NW, int RB, int RING, int VD> constexpr int fwd16v3_lds_bytes() {
+  if ((VD & 32) && RING == 2) return 5 * 64 * D * 2;
+  return fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>();
+}
+
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, int VD = 0>
 static void launch_v3(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
   hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, false, VD>), dim3(grid.x * grid.y * grid.z), dim3(NW * 64),
-                     (fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>()), stream, args, g);
+                     (fwd16v3_lds_bytes<D, NW, RB, RING, VD>()), stream, args, g);
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, int VD = 0>
 static void launch_v3_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
   hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, true, false, VD>), dim3(grid.x * grid.y * grid.z * splits),
-                     dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
+                     dim3(NW * 64), (fwd16v3_lds_bytes<D, NW, RB, RING, VD>()), stream, args, g);
   const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
   hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
 }
@@ -28,7 +34,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->traversal = 64;
   v->headBlock = D;
   v->threads = NW * 64;
-  v->ldsBytes = fwd16v2_lds_bytes<D, NW, RB, RING, (VD & 2) ? 16 : 0>();
+  v->ldsBytes = fwd16v3_lds_bytes<D, NW, RB, RING, VD>();
   v->cacheLeft = true;
   v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, VD>;
 }
@@ -37,7 +43,7 @@ template <typename T, int D, int NW, int RB, int THR, int PRE, int RING, int VD>
 static void launch_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
   hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD>), dim3(grid.x * grid.y * grid.z),
-                     dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
+                     dim3(NW * 64), (fwd16v3_lds_bytes<D, NW, RB, RING, VD>()), stream, args, g);
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE, int RING, int VD>
@@ -45,10 +51,10 @@ static void launch_v3_sparse(dim3 grid, hipStream_t stream, const KernelArgs &ar
   Fwd16Grid g{grid.x, grid.y, grid.z};
   if (args.causal)
     hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, true, VD, true>), dim3(grid.x * grid.y * grid.z),
-                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
+                       dim3(NW * 64), (fwd16v3_lds_bytes<D, NW, RB, RING, VD>()), stream, args, g);
   else
     hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, RB, THR, PRE, 0, RING, false, false, VD, true>), dim3(grid.x * grid.y * grid.z),
-                       dim3(NW * 64), (fwd16v2_lds_bytes<D, NW, RB, RING>()), stream, args, g);
+                       dim3(NW * 64), (fwd16v3_lds_bytes<D, NW, RB, RING, VD>()), stream, args, g);
 }
 
 // product variants: the dense code object plus its causal, block-sparse and column-parallel siblings (VDS: schedule
@@ -78,7 +84,8 @@ static void fill_with_split(VariantInfo *v, const char *name) {
 //     no wave had work).
 // Developer schedules (MFA_FWD16_IMPL=v3:<n>): 1 / 2 = K / K + first V fragments hoisted (D = 256: 2 = no grouped
 // reads / spread writes, 3 = grouped reads only); D = 128: 3 / 4 / 5 = grouped reads / + spread writes / writes in
-// the middle of step A (all within +-1 %), 7 = register-staged previous product, 8 at D = 64 = LDS-DMA; 41 = K rows
+// the middle of step A (all within +-1 %), 7 = register-staged previous product, 8 at D = 64 / 256 = LDS-DMA
+// (-8 % / -1.7 %; D = 256 with three K and two V images and one barrier per tile); 41 = K rows
 // padded instead of swizzled; 11, 12, 14, 50-52 = timing-only ablations (WRONG RESULTS) behind DESIGN.md 4.2.
 // Schedules that were measured and removed (numbers in DESIGN.md 4.2, profiles/ab*.txt): 4 waves x 64 rows with
 // asm-placed QK MFMAs, row sum on the matrix pipe, split QK accumulator, sched_group_barrier interleave, static wave
@@ -102,6 +109,7 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
     if (D == 32 && impl == 0) { fill_with_split<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill_with_split<__bf16, 256, 4, 1, 8, 1, 2, 12>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_spread"); return true; }
+    if (D == 256 && impl == 8) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2, 36>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ldsdma_k3v2"); return true; }
     if (D == 256 && impl == 2) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
     if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
     if (D == 256 && impl == 3) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2, 4>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek_vpipe"); return true; }

@@ -228,7 +228,7 @@ def test_16bit_matrix_core_path(shape, precision, transpose):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("transpose", [(False, False), (False, True), (True, False), (True, True)])
-@pytest.mark.parametrize("shape", [(255, 257, 251), (127, 129, 77), (1, 1, 1), (33, 70, 9)])
+@pytest.mark.parametrize("shape", [(255, 257, 251), (127, 129, 77), (1, 1, 1), (33, 70, 9), (3100, 3300, 251)])
 def test_16bit_path_with_unaligned_rows_and_ragged_k(shape, transpose):
     """Odd leading dimensions (rows start at 2-byte alignment) and K % 8 != 0 still run on the 16-bit matrix
     cores: unaligned 16-byte loads, the chunk that straddles K keeps only its first K - k elements.  The

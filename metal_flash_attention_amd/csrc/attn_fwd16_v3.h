@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // barrier of iteration j: both have a whole iteration to land, and the second barrier of the register-staged
   // 2-stage ring (which published the tile written during step A) is not needed.
   constexpr bool KV32 = LDMA && RING == 2;
-  static_assert(!LDMA || (VPIPE && (RING == 3 || RING == 2) && PRE >= 1 && !KPAD && !SPARSE && RB == 1 && NKS % 4 == 0),
+  static_assert(!LDMA || (VPIPE && (RING == 3 || RING == 2) && PRE >= 1 && !KPAD && RB == 1 && NKS % 4 == 0),
                 "LDMA: grouped-read schedule");
   constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
@@ -166,6 +166,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     if constexpr (SPARSE) {
       kbase0[i] = valid ? row * ldk2 + c * 16 : OOB;
       vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
+      if constexpr (LDMA) {
+        const int p = (wave * NCH + i) * 64 + lane;
+        const int krow = p / CPR, kc = (p % CPR) ^ kswz_mask<D>(krow);
+        const int vkey = (p >> 2) % BC, vc = (p / (BC * 4)) * 4 + (p & 3);
+        kbase0[i] = (kc * 8 < Dr) ? krow * ldk2 + kc * 16 : OOB;
+        vbase0[i] = (vc * 8 < Dr) ? vkey * ldv2 + vc * 16 : OOB;
+      }
     }
   }
   u32x4 kreg[LDMA ? 1 : NCH], vreg[LDMA ? 1 : NCH];

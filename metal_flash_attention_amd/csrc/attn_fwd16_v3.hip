@@ -75,7 +75,8 @@ static void fill_with_split(VariantInfo *v, const char *name) {
 // impl 0: product schedule.
 //   D = 128: 8 waves x 32 rows, 3-stage ring filled by LDS-DMA (buffer_load_dwordx4 ... lds, no staging registers, no
 //     ds_write_b128), LDS reads through inline asm with counted waits, V^T fragments in groups of four MFMAs: +3 %
-//     over the register-staged schedule (impl 7), bit-identical results.  The block-sparse pair keeps impl 7's schedule.
+//     over the register-staged schedule (impl 7), bit-identical results; the causal, column-parallel and block-sparse
+//     siblings use the same schedule (block-sparse: the DMA prologue restarts per run of active tiles).
 //   D = 64 / 32: register-staged, fragment reads left to hipcc (two waves per SIMD hide the LDS latency; the
 //     LDS-DMA schedule measured -8 % at D = 64, which is VALU-bound).
 //   D = 256: 4 waves x 32 rows (one per SIMD, 512 registers), 2-stage ring, K fragments hoisted (+11 %), V^T
@@ -93,7 +94,7 @@ static void fill_with_split(VariantInfo *v, const char *name) {
 // rows per wave with two waves per SIMD (+-0).
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
-    if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 1, 3, 36, 0, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"); return true; }
+    if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 1, 3, 36>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"); return true; }
     if (D == 128 && impl == 7) { fill<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
     if (D == 128 && impl == 1) { fill<__bf16, 128, 8, 1, 8, 1>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek"); return true; }
     if (D == 128 && impl == 2) { fill<__bf16, 128, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prekv"); return true; }
@@ -120,7 +121,7 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 3) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe"); return true; }
   }
   if (precision == PREC_FP16) {
-    if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 1, 3, 36, 0, 0>(out, "attn_fwd16v3_f16_d128_w8x32_thr8_ldsdma"); return true; }
+    if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 1, 3, 36>(out, "attn_fwd16v3_f16_d128_w8x32_thr8_ldsdma"); return true; }
     if (D == 64 && impl == 0) { fill_with_split<_Float16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_f16_d64_w8x32_thr8"); return true; }
     if (D == 32 && impl == 0) { fill_with_split<_Float16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_f16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill_with_split<_Float16, 256, 4, 1, 8, 1, 2, 12>(out, "attn_fwd16v3_f16_d256_w4x32_thr8_ring2_spread"); return true; }

@@ -45,15 +45,23 @@ __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
   return r;
 }
-template <int OFF> __device__ __forceinline__ u32x4 lds_read_tr16_pair(uint32_t addr) {   // rows +0 and +8 of a 16-key group
-  u32x2_t lo, hi;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(OFF));
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(OFF + 8 * 64));
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
+struct TrPair { u32x2_t lo, hi; };   // the two halves stay separate values until lds_wait has seen them: nothing but
+                                     // the awaited registers themselves may sit between a read and its wait
+template <int OFF> __device__ __forceinline__ TrPair lds_read_tr16_pair(uint32_t addr) {   // rows +0 and +8 of a 16-key group
+  TrPair r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r.lo) : "v"(addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r.hi) : "v"(addr), "n"(OFF + 8 * 64));
+  return r;
 }
 template <int N> __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c, u32x4 &d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N < 15 ? N : 15));   // 4-bit counter
 }
+template <int N> __device__ __forceinline__ void lds_wait(TrPair &a, TrPair &b, TrPair &c, TrPair &d) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi)
+               : "n"(N < 15 ? N : 15));
+}
+__device__ __forceinline__ u32x4 tr_join(const TrPair &p) { return __builtin_shufflevector(p.lo, p.hi, 0, 1, 2, 3); }
 template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) {
   if constexpr (N > 0) {
     static_for<N - 1>(f);
@@ -467,10 +475,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       constexpr int G = 4, NG = 2 * NDB / G;
       const uint32_t ka = lds_addr(smem + koffs(k_stage) + k_kb * 32 * ROWB);
       const uint32_t va = lds_addr(smem + voffs(v_stage) + vtr_off + v_kb * 32 * 64);
-      u32x4 kf[NKS], vg[2][G];
+      u32x4 kf[NKS];
+      TrPair vg[2][G];
 #pragma unroll
       for (int t = 0; t < NKS; ++t) kf[t] = lds_read_b128(ka + kread[t]);
-      auto load_group = [&](auto gc, u32x4 (&vf)[G]) {
+      auto load_group = [&](auto gc, TrPair (&vf)[G]) {
         constexpr int g = decltype(gc)::value;
         static_for<G>([&](auto ic) {
           constexpr int idx = g * G + decltype(ic)::value, u = idx / NDB, db = idx % NDB;
@@ -497,13 +506,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       static_for<NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value;
         if constexpr (g + 1 < NG) load_group(std::integral_constant<int, g + 1>{}, vg[(g + 1) & 1]);
-        u32x4 (&vf)[G] = vg[g & 1];
+        TrPair (&vf)[G] = vg[g & 1];
         lds_wait<(g + 1 < NG) ? 2 * G : 0>(vf[0], vf[1], vf[2], vf[3]);
         __builtin_amdgcn_sched_barrier(0x406);
 #pragma unroll
         for (int i = 0; i < G; ++i) {
           const int idx = g * G + i, u = idx / NDB, db = idx % NDB;
-          o[0][db] = F::mfma(__builtin_bit_cast(v8, vf[i]), pf[0][u], o[0][db]);
+          o[0][db] = F::mfma(__builtin_bit_cast(v8, tr_join(vf[i])), pf[0][u], o[0][db]);
         }
         __builtin_amdgcn_sched_barrier(0x406);
       });

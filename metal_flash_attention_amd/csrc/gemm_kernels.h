@@ -22,6 +22,7 @@
 // are all FP16, GEMMDescriptor.swift:188-193; fp32 is at least as accurate), then add the previous C if
 // asked and store with the reference's rounding: FP16 round-to-nearest, BF16 truncation.
 #pragma once
+#include <type_traits>
 #include "attn_fwd16.h"
 
 namespace mfa {
@@ -314,34 +315,41 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
   // drains the prefetch of the next tile.  The asm reads are invisible to that pass; their own completion is
   // awaited by frag_wait below (an asm whose operands are the fragments, so no consumer can move above it).
   auto lds_addr = [](const char *p) { return (uint32_t)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char *)p; };
-  auto fragment_asm = [&](const char *img, bool kmajor, int x0, int s) -> v8 {
-    if (kmajor) {
+  // An asm fragment stays in the registers its read(s) named until frag_wait has listed them: a k-major fragment
+  // is one 128-bit value, a transposed one two 64-bit halves that are joined only afterwards (nothing but the
+  // awaited registers themselves may sit between a read and its wait).
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  struct AsmFrag { u32x4 q; u32x2 lo, hi; };
+  auto fragment_asm = [&](const char *img, auto kmajor, int x0, int s) -> AsmFrag {
+    AsmFrag f;
+    if constexpr (decltype(kmajor)::value) {
       const int x = x0 + i, c = 2 * s + hi;
-      u32x4 r;
-      asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds_addr(img + x * 128 + ((c ^ ((x >> 1) & 7)) * 16))));
-      return __builtin_bit_cast(v8, r);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(f.q) : "v"(lds_addr(img + x * 128 + ((c ^ ((x >> 1) & 7)) * 16))));
+    } else {
+      const uint32_t a = lds_addr(img + ((x0 >> 5) * BK + 16 * s) * 64 + tr_lane);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.lo) : "v"(a));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(f.hi) : "v"(a));
     }
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const uint32_t a = lds_addr(img + ((x0 >> 5) * BK + 16 * s) * 64 + tr_lane);
-    u32x2 lo, hi2;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi2) : "v"(a));
-    return __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi2, 0, 1, 2, 3));
+    return f;
+  };
+  auto frag_value = [&](const AsmFrag &f, auto kmajor) -> v8 {
+    if constexpr (decltype(kmajor)::value) return __builtin_bit_cast(v8, f.q);
+    else return __builtin_bit_cast(v8, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3));
   };
   constexpr int FRAG_OPS = MT * (AKM ? 1 : 2) + NT * (BKM ? 1 : 2);   // LDS instructions per k-step of fragment reads
   static_assert(MT == 4 && NT == 2 || !DMA, "frag_wait lists the fragments of a 4 x 2 wave tile");
-  auto frag_wait = [&](v8 (&a)[MT], v8 (&b)[NT], bool more_in_flight) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    u4 r0 = __builtin_bit_cast(u4, a[0]), r1 = __builtin_bit_cast(u4, a[1]), r2 = __builtin_bit_cast(u4, a[MT > 2 ? 2 : 0]),
-       r3 = __builtin_bit_cast(u4, a[MT > 3 ? 3 : 0]), r4 = __builtin_bit_cast(u4, b[0]), r5 = __builtin_bit_cast(u4, b[1]);
-    if (more_in_flight)   // the next step's reads were issued after these: LDS returns in order
-      asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5) : "n"(FRAG_OPS));
+  // s_waitcnt with the A fragments as in/out operands, then an empty asm that lists the B fragments (asm volatile
+  // statements keep their order): no consumer of either can be scheduled above the wait
+  auto frag_wait = [&](AsmFrag (&a)[MT], AsmFrag (&b)[NT], auto more) {
+    constexpr int N = decltype(more)::value ? FRAG_OPS : 0;   // the next step's reads were issued after these: LDS returns in order
+    if constexpr (AKM)
+      asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a[0].q), "+v"(a[1].q), "+v"(a[2].q), "+v"(a[3].q) : "n"(N < 15 ? N : 15));
     else
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5));
-    a[0] = __builtin_bit_cast(v8, r0); a[1] = __builtin_bit_cast(v8, r1);
-    if (MT > 2) a[2] = __builtin_bit_cast(v8, r2);
-    if (MT > 3) a[3] = __builtin_bit_cast(v8, r3);
-    b[0] = __builtin_bit_cast(v8, r4); b[1] = __builtin_bit_cast(v8, r5);
+      asm volatile("s_waitcnt lgkmcnt(%8)"
+                   : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(a[2].lo), "+v"(a[2].hi), "+v"(a[3].lo), "+v"(a[3].hi)
+                   : "n"(N < 15 ? N : 15));
+    if constexpr (BKM) asm volatile("" : "+v"(b[0].q), "+v"(b[1].q));
+    else asm volatile("" : "+v"(b[0].lo), "+v"(b[0].hi), "+v"(b[1].lo), "+v"(b[1].hi));
   };
 
   f32x16 acc[MT][NT];
@@ -372,24 +380,44 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
     }
     const char *Ai = smem + buf * STAGE, *Bi = Ai + ATILE;
     v8 fa[2][MT], fb[2][NT];   // fragments of k-step s + 1 are requested before the matrix instructions of step s
+    AsmFrag ga[2][DMA ? MT : 1], gb[2][DMA ? NT : 1];   // (DMA: as asm fragments)
+    constexpr std::integral_constant<bool, AKM> akc{};
+    constexpr std::integral_constant<bool, BKM> bkc{};
 #pragma unroll
-    for (int t = 0; t < MT; ++t) fa[0][t] = DMA ? fragment_asm(Ai, akm, wm + 32 * t, 0) : fragment(Ai, akm, wm + 32 * t, 0);
+    for (int t = 0; t < MT; ++t) {
+      if constexpr (DMA) ga[0][t] = fragment_asm(Ai, akc, wm + 32 * t, 0);
+      else fa[0][t] = fragment(Ai, akm, wm + 32 * t, 0);
+    }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) fb[0][t] = DMA ? fragment_asm(Bi, bkm, wn + 32 * t, 0) : fragment(Bi, bkm, wn + 32 * t, 0);
+    for (int t = 0; t < NT; ++t) {
+      if constexpr (DMA) gb[0][t] = fragment_asm(Bi, bkc, wn + 32 * t, 0);
+      else fb[0][t] = fragment(Bi, bkm, wn + 32 * t, 0);
+    }
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       v8 (&a)[MT] = fa[s & 1];
       v8 (&b)[NT] = fb[s & 1];
       if (s + 1 < BK / 16) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-          fa[(s + 1) & 1][t] = DMA ? fragment_asm(Ai, akm, wm + 32 * t, s + 1) : fragment(Ai, akm, wm + 32 * t, s + 1);
+        for (int t = 0; t < MT; ++t) {
+          if constexpr (DMA) ga[(s + 1) & 1][t] = fragment_asm(Ai, akc, wm + 32 * t, s + 1);
+          else fa[(s + 1) & 1][t] = fragment(Ai, akm, wm + 32 * t, s + 1);
+        }
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          fb[(s + 1) & 1][t] = DMA ? fragment_asm(Bi, bkm, wn + 32 * t, s + 1) : fragment(Bi, bkm, wn + 32 * t, s + 1);
+        for (int t = 0; t < NT; ++t) {
+          if constexpr (DMA) gb[(s + 1) & 1][t] = fragment_asm(Bi, bkc, wn + 32 * t, s + 1);
+          else fb[(s + 1) & 1][t] = fragment(Bi, bkm, wn + 32 * t, s + 1);
+        }
         __builtin_amdgcn_sched_barrier(0x406);   // LDS and matrix instructions keep this order; vector / scalar work may move
       }
-      if constexpr (DMA) frag_wait(a, b, s + 1 < BK / 16);
+      if constexpr (DMA) {
+        if (s + 1 < BK / 16) frag_wait(ga[s & 1], gb[s & 1], std::true_type{});
+        else frag_wait(ga[s & 1], gb[s & 1], std::false_type{});
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[t] = frag_value(ga[s & 1][t], akc);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = frag_value(gb[s & 1][t], bkc);
+      }
       // The staging writes of the next k tile go between the matrix instructions of the last k-step instead of
       // one burst in front of the barrier (a wide LDS store occupies the store path for ~13 cycles and loads do
       // not overlap it).  The other stage has no readers in this iteration; past the last tile the registers hold

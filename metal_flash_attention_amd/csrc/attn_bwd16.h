@@ -237,12 +237,20 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
       // the two accumulation chains are independent: alternating them keeps consecutive MFMAs off
       // the same accumulator (a non-MFMA instruction between two dependent MFMAs costs ~43 cycles)
+      // the fragments of k-step t + 1 are requested before the matrix instructions of step t; sched_barrier(0x406)
+      // holds that order (LDS and matrix instructions stay, vector / scalar work may move)
+      v8 kfa[2], vfa[2];
+      kfa[0] = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfread[0]);
+      vfa[0] = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + fread[0]);
 #pragma unroll
       for (int t = 0; t < NKS; ++t) {
-        const v8 kf = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfread[t]);
-        const v8 vf = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + fread[t]);
-        s = F::mfma(kf, qf[t], s);
-        dp = F::mfma(vf, gf[t], dp);
+        if (t + 1 < NKS) {
+          kfa[(t + 1) & 1] = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfread[t + 1]);
+          vfa[(t + 1) & 1] = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + fread[t + 1]);
+          __builtin_amdgcn_sched_barrier(0x406);
+        }
+        s = F::mfma(kfa[t & 1], qf[t], s);
+        dp = F::mfma(vfa[t & 1], gf[t], dp);
       }
       // P = exp2(S*scale2 - L); dS = P (dP*scale - D).  Keys past C have zero K and V rows, so their
       // dS multiplies zero K rows below: no mask needed (as in the reference, +Accumulate.swift:330-346).
@@ -266,17 +274,22 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       // barrier they keep the LDS busy for ~800 cycles (D = 256) during which no wave has anything to run.  The
       // other stage has no readers in this iteration; past the last tile the registers hold stale data that
       // nobody reads.
+      // The transposed fragment of product idx + 1 is requested before the matrix instruction of product idx.
+      auto read_kt = [&](int idx) -> v8 {   // idx = u * NDB + db
+        const char *kp = st + ((idx % NDB) * BC + 32 * kb + 16 * (idx / NDB)) * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr0));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr1));
+        return __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+      };
+      v8 ktf[2];
+      ktf[0] = read_kt(0);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-          if (kb == 1 && (u * NDB + db) % WEVERY == 0) write_chunk(stage ^ 1, (u * NDB + db) / WEVERY);
-          const char *kp = st + (db * BC + 32 * kb + 16 * u) * 64;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr0));
-          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + tr1));
-          const v8 ktf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
-          dq[db] = F::mfma(ktf, dsf[u], dq[db]);
-        }
+      for (int idx = 0; idx < 2 * NDB; ++idx) {
+        if (idx + 1 < 2 * NDB) ktf[(idx + 1) & 1] = read_kt(idx + 1);
+        if (kb == 1 && idx % WEVERY == 0) write_chunk(stage ^ 1, idx / WEVERY);
+        __builtin_amdgcn_sched_barrier(0x406);
+        dq[idx % NDB] = F::mfma(ktf[idx & 1], dsf[idx / NDB], dq[idx % NDB]);
+      }
     }
     __syncthreads();
     stage ^= 1;

@@ -44,9 +44,7 @@ template <int D> constexpr int dkv16rs_lds_bytes() {
 }
 
 // ABL: timing-only ablations (WRONG RESULTS): 1 = no global loads in the loop, 2 = no staging at all,
-// 3 = no barrier, 4 = no L/D/P LDS traffic in the arithmetic.  5 = schedule variant with CORRECT results (developer
-// knob MFA_DKV16_IMPL=rs:5, not yet measured): the second half of the transposed fragments is requested before the
-// first half's matrix instructions instead of where hipcc puts it (one MFMA ahead of its consumer).
+// 3 = no barrier, 4 = no L/D/P LDS traffic in the arithmetic
 // SPLIT: traversal-parallel launch (see attn_dq16): the row blocks are cut into grid.splits pieces, partial dV and
 // dK go to fp32 slabs of the caller's workspace (dV slabs first, then dK slabs), attn_bwd_combine adds them.
 template <typename T, int D, typename TG = T, bool CAUSAL = false, int ABL = 0, bool SPARSE = false, bool SPLIT = false>
@@ -271,13 +269,9 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
     };
     auto second_product = [&](int cur, const v8 (&tf0)[NDB], const v8 (&frag)[2]) {
       v8 tf1[NDB];
-      if constexpr (ABL == 5) {
-        load_tr(cur & 3, 1, tf1);
-        __builtin_amdgcn_sched_barrier(0x406);   // LDS and matrix instructions keep this order
-      }
 #pragma unroll
       for (int db = 0; db < NDB; ++db) acc[db] = F::mfma(tf0[db], frag[0], acc[db]);
-      if constexpr (ABL != 5) load_tr(cur & 3, 1, tf1);
+      load_tr(cur & 3, 1, tf1);
 #pragma unroll
       for (int db = 0; db < NDB; ++db) acc[db] = F::mfma(tf1[db], frag[1], acc[db]);
     };

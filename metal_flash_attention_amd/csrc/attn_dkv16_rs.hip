@@ -70,16 +70,6 @@ bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInf
     }
     return true;
   }
-  if (impl == 5 && precision == PREC_BF16 && gprecision == PREC_BF16 && D == 128) {   // schedule knob, correct results
-    // (the same schedule at D = 256 needs 32 more registers than a lane has: 88 bytes of scratch, not instantiated)
-    fill<__bf16, 128>(out, "attn_dkv16rs_bf16_d128_p4x32_tf1_early");
-    out->launchCausal = nullptr; out->funcCausal = nullptr; out->causal = false;
-    out->launchSparse = nullptr; out->funcSparse = nullptr; out->funcSparseCausal = nullptr;
-    out->launchSplit = nullptr; out->funcSplit = nullptr; out->funcSplitCausal = nullptr;
-    out->func = reinterpret_cast<const void *>(&attn_dkv16_rs<__bf16, 128, __bf16, false, 5>);
-    out->launch = &launch_rs<__bf16, 128, __bf16, false, 5>;
-    return true;
-  }
   if (precision == PREC_FP16 && gprecision == PREC_BF16) {
     if (D == 128) { fill<_Float16, 128, __bf16>(out, "attn_dkv16rs_f16_dObf16_d128_p4x32"); return true; }
     if (D == 64) { fill<_Float16, 64, __bf16>(out, "attn_dkv16rs_f16_dObf16_d64_p4x32"); return true; }

@@ -9,11 +9,17 @@ A "step" is one forward dispatch over this rank's shard of batch x head (synthet
 resident in HBM).  The reference benchmarks a single head and raises N until the GPU is full
 (SquareAttentionTest.swift:159-165); a single N=4096 head is 16 workgroups on a 256-CU chip, so
 the throughput number is taken with a batch x head grid (B=8, H=32 per GPU), the sharding axis of
-BASELINE config 5.  Multi-GPU: one process per GPU, heads sharded, NO data-path collective
-(attention heads are independent); torch.distributed is used only for the barrier and the
-max-over-ranks of the elapsed time.
+BASELINE config 5.  Multi-GPU: one process per GPU, heads sharded, NO data-path collective and no RCCL
+(attention heads are independent); torch.distributed's gloo backend carries the one barrier and the
+max-over-ranks of the elapsed time.  `python bench.py --gpus N` starts its own N ranks when it was not launched by
+torch.distributed.run (ranks beyond the device count share devices round-robin, which is how the N > 1 path is
+exercised on a 1-GPU box).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload fwd_bf16_d128|...]
+
+Workloads: fwd_bf16_d128 = the headline (BASELINE config 4's dtype at the metric's N and D); fwd_bf16_d128_n16k =
+BASELINE config 5's per-GPU shard (32 heads of N=16384 per GPU: `--gpus 8 --workload fwd_bf16_d128_n16k` is the
+B=8 H=32 job); c1_cpu = BASELINE config 1 (N=128, D=64, fp32, the CPU oracle only: one thread and all cores).
 """
 import argparse
 import json
@@ -30,15 +36,27 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}  # /opt/skills/guide
 # ~1.50 GHz instead of 2.4 GHz (zero operands: 2451 TF at 2.35 GHz).  Reported next to the spec peak.
 SUSTAINED_TFLOPS_RANDOM = {"bf16": 1560.0, "f16": 1560.0}
 
-# HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
-# process): (2 x FETCH_SIZE + WRITE_SIZE) KiB, FETCH_SIZE doubled as MI355X_MICROARCH.md "HBM" prescribes
-# for wide coalesced reads on gfx950.  Keyed by (workload, kernel variant); null when not profiled.
-MEASURED_TRAFFIC_BYTES = {
-    ("fwd_bf16_d128", "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"):
-        {"bytes": (2 * 393335.2 + 528384.0) * 1024, "source": "profiles/r01_fwd_bf16_d128_v3_ldsdma_summary.txt"},
-    ("fwd_bf16_d128", "attn_fwd16v3_bf16_d128_w8x32_thr8"):   # register-staged schedule (MFA_FWD16_IMPL=v3:7)
-        {"bytes": (2 * 393354.6 + 528384.0) * 1024, "source": "profiles/r01_fwd_bf16_d128_v3_summary.txt"},
-}
+# HBM bytes per launch come from rocprofv3 PMC passes (it cannot run inside this process): tools/profile_pmc.sh writes
+# profiles/traffic.json with the SHA-256 of the libmfa_hip.so it profiled; the bench line carries a number only when
+# that hash is the hash of the library loaded NOW and the kernel variant matches -- otherwise null (never stale).
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(workload, variant):
+    import hashlib
+    try:
+        with open(TRAFFIC_JSON) as f:
+            table = json.load(f)
+        from metal_flash_attention_amd import _abi
+        with open(_abi.library_path(), "rb") as f:
+            digest = hashlib.sha256(f.read()).hexdigest()
+    except Exception:  # noqa: BLE001
+        return None, None
+    for row in table.get("entries", []):
+        if row.get("workload") == workload and row.get("variant") == variant and row.get("lib_sha256") == digest:
+            return row.get("bytes_per_launch"), row.get("source")
+    return None, None
+
 
 WORKLOADS = {
     # name: (kernel types, N, D, dtype, batch, heads)
@@ -54,6 +72,7 @@ WORKLOADS = {
     "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
                                     types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_n16k": dict(N=16384, D=128, dtype="bf16", batch=1, heads=32, types=("forward",)),  # config 5 shard
+    "c1_cpu": dict(N=128, D=64, dtype="f32", batch=1, heads=1, types=("forward",)),                   # config 1, CPU only
 }
 OPS_PER_N2 = {"forward": lambda D: 2 * D + 5, "backwardQuery": lambda D: 3 * D + 5,
               "backwardKeyValue": lambda D: 4 * D + 5}       # README.md:108-124
@@ -71,6 +90,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
     args = ap.parse_args()
 
+    if args.workload == "c1_cpu":
+        print(json.dumps(c1_cpu_line(args)))
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import numpy as np
     import torch
 
@@ -78,34 +103,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))   # ranks share a GPU only in tests
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % ndev)   # ranks share a device only when there are fewer devices than ranks
     dist = None
-    ctl_device = "cuda"
+    ctl_device = "cpu"
     if world > 1:
-        # control plane only (barrier + max of one scalar; attention heads need no data-path collective).
-        # RCCL first; if it cannot initialise on this node fall back to gloo rather than lose the run.
+        # control plane only (one barrier + max of one scalar), always gloo: attention heads need no data-path
+        # collective and this path must not depend on RCCL (north_star: "no RCCL")
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # (RCCL hangs instead of failing when two ranks share one device -- the 1-GPU test box -- so that case
-        # goes straight to gloo.)
-        shared_device = world > max(1, torch.cuda.device_count())
-        backend = os.environ.get("MFA_BENCH_BACKEND", "gloo" if shared_device else "nccl")
-        try:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-            if backend == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                ctl_device = "cpu"
-        except Exception as exc:  # noqa: BLE001
-            if rank == 0:
-                print(f"[bench] {backend} control plane failed ({exc!r}); using gloo", file=sys.stderr)
-            if dist.is_initialized():
-                dist.destroy_process_group()
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            ctl_device = "cpu"
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
                                            AttentionOperand as Op, GEMMOperandPrecision as P)
@@ -192,6 +201,7 @@ def main():
     achieved_tflops = flops_launch_rank / (launch_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[w["dtype"]]
 
+    traffic_bytes, traffic_source = measured_traffic(args.workload, kernels[types[0]].variant)
     out = {
         "metric": "GINSTR/s forward attention N=4096 D=128 bf16" if args.workload == "fwd_bf16_d128"
         else f"GINSTR/s {args.workload}",
@@ -209,16 +219,16 @@ def main():
         "config": {"workload": f"attention {'+'.join(w['types'])} N={N} D={D} {w['dtype']} Q/K/V, fp32 O/L; "
                                f"B={B} H={H} heads per GPU, batch x head sharded across GPUs, no collectives",
                    "kernel_variants": [kernels[t].variant for t in types],
-                   "split_kv_workspace_bytes": ws_bytes},
+                   "split_kv_workspace_bytes": ws_bytes,
+                   "control_plane": "gloo" if world > 1 else "none", "devices_visible": ndev,
+                   "per_gpu_roofline_frac": round(achieved_tflops / peak, 4)},
         "mfma_tflops": round(achieved_tflops * world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4),
                      "sustained_peak_random_operands": SUSTAINED_TFLOPS_RANDOM.get(w["dtype"]),
                      "frac_of_sustained": (round(achieved_tflops / SUSTAINED_TFLOPS_RANDOM[w["dtype"]], 4)
                                            if w["dtype"] in SUSTAINED_TFLOPS_RANDOM else None),
-                     "traffic": (MEASURED_TRAFFIC_BYTES.get((args.workload, kernels[types[0]].variant)) or {}).get("bytes"),
-                     "traffic_unit": "bytes/launch (HBM, PMC)",
-                     "traffic_source": (MEASURED_TRAFFIC_BYTES.get((args.workload, kernels[types[0]].variant)) or {}).get("source"),
+                     "traffic": traffic_bytes, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_source,
                      "algorithmic_bytes": (3 * N * D * (2 if low else 4) + N * D * 4 + N * 4) * B * H if not backward else None,
                      "kernel": "+".join(kernels[t].variant for t in types), "launch_ms": round(launch_ms, 4)},
     }
@@ -229,6 +239,55 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks of this script (one per GPU; round-robin
+    over the visible devices when there are fewer), rendezvous on 127.0.0.1 over gloo.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def c1_cpu_line(args):
+    """BASELINE config 1: forward, one head, N=128, D=64, fp32, through the naive CPU reference -- here its C restatement
+    (oracle/network.c).  No GPU is touched.  `value` = all host threads; the single-thread rate (the analogue of the
+    unparallelised Swift loop) is reported next to it, both checked against the committed fixture."""
+    import numpy as np
+    from oracle import Network, NetworkDescriptor, max_threads
+    w = WORKLOADS["c1_cpu"]
+    N, D = w["N"], w["D"]
+    ops = OPS_PER_N2["forward"](D) * N * N
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "network_golden.npz"))
+
+    def rate(threads):
+        net = Network(NetworkDescriptor(N, N, D), seed=10, threads=threads)
+        res = net.run(backward=False)
+        assert np.array_equal(res["O"], golden["s10_O"]) and np.array_equal(res["L"], golden["s10_L"])
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            net.run(backward=False)
+            reps += 1
+        return ops * reps / (time.perf_counter() - t0) / 1e9
+
+    one, many = rate(1), rate(0)
+    return {"metric": "GINSTR/s c1_cpu", "value": round(many, 3), "unit": "GINSTR/s", "n_gpus": 0, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ops / many / 1e6, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "attention forward N=128 D=64 fp32, one head, CPU oracle only (BASELINE config 1)"},
+            "cpu_baseline": {"value": round(many, 3), "unit": "GINSTR/s", "cores": max_threads(), "kind": "port",
+                             "single_thread_value": round(one, 3),
+                             "sample": "the whole workload, repeated for 1 s per thread count; O and L equal the committed "
+                                       "fixture tests/golden/network_golden.npz bit for bit"}}
 
 
 def cpu_baseline(np, torch, w, bufs, Op, target_seconds, backward):

@@ -195,6 +195,7 @@ SYMBOLS = [
 ]
 
 _lib = None
+EXPECTED_ABI = 4   # MFA_ABI_VERSION of include/mfa.h this file mirrors
 
 
 class MFAError(RuntimeError):
@@ -225,8 +226,17 @@ def lib() -> ctypes.CDLL:
         fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
         fn.restype = restype
         fn.argtypes = argtypes
+    got = int(handle.mfa_abi_version())
+    if got != EXPECTED_ABI:   # the struct mirrors above describe exactly one layout of mfa_launch_params & co.
+        raise ImportError(f"{LIB_PATH} reports ABI version {got}, these bindings were written for {EXPECTED_ABI}: "
+                          f"rebuild the library (make -C metal_flash_attention_amd/csrc)")
     _lib = handle
     return handle
+
+
+def library_path() -> str:
+    """Path of the C-ABI library these bindings load (bench.py hashes it to tie a PMC profile to a build)."""
+    return LIB_PATH
 
 
 def check(status: int) -> None:

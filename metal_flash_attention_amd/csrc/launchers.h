@@ -44,6 +44,8 @@ bool fwd16_variant(int precision, int D, VariantInfo *out);
 bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 // one wave per SIMD, 64 query rows per wave, half-tile pipeline (see attn_fwd16_v3.h)
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
+// four waves x 64 rows, one wave per SIMD, hand-placed instruction stream (attn_fwd16_p4.h); D <= 128 only
+bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out);
 // 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)
 bool fwd16_v4_variant(int precision, int D, int impl, VariantInfo *out);
 

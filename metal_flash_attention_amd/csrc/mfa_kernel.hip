@@ -104,7 +104,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       if (knob && std::strncmp(knob, "v2:", 3) == 0) fast = fwd16_v2_variant(pq, bucket, std::atoi(knob + 3), &variant);
       else if (knob && std::strncmp(knob, "v3:", 3) == 0) fast = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &variant);
       else if (knob && std::strncmp(knob, "v4:", 3) == 0) fast = fwd16_v4_variant(pq, bucket, std::atoi(knob + 3), &variant);
-      else if (!wantV1) fast = fwd16_v3_variant(pq, bucket, 0, &variant);
+      else if (knob && std::strncmp(knob, "p4:", 3) == 0) {
+        fast = fwd16_v3_variant(pq, bucket, 0, &variant) && fwd16_p4_variant(pq, bucket, std::atoi(knob + 3), &variant);
+      }
+      else if (!wantV1) {
+        fast = fwd16_v3_variant(pq, bucket, 0, &variant);
+        if (fast && bucket == 128) fwd16_p4_variant(pq, bucket, 0, &variant);   // keeps v3's split / sparse siblings
+      }
       if (!fast) fast = fwd16_variant(pq, bucket, &variant);
     }
   }

@@ -19,6 +19,7 @@ from oracle import Network, NetworkDescriptor  # noqa: E402
 CASES = [  # (seed, R, C, D): small members of SquareAttentionTest.swift:6-25 + rectangular ones
     (0, 10, 10, 3), (1, 8, 8, 2), (2, 23, 23, 2), (3, 4, 4, 1), (4, 32, 32, 64), (5, 64, 64, 40),
     (6, 7, 33, 5), (7, 40, 9, 17), (8, 1, 128, 16), (9, 48, 31, 32),
+    (10, 128, 128, 64),   # BASELINE config 1: forward single-head N=128 D=64 fp32 (CPU plumbing)
 ]
 
 

@@ -1,0 +1,100 @@
+"""CPU checks of the hand-placed instruction stream of attn_fwd16_p4 (tools/p4gen.py) on the lane-exact model in
+tools/p4sim.py: the stream that is compiled into libmfa_hip.so is executed instruction by instruction for one
+256-row block and compared with a float64 attention (the formulas of the reference's Network.swift:134-200 in
+matrix form).  No GPU, no oracle library needed."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import p4gen  # noqa: E402
+import p4sim  # noqa: E402
+
+
+def _check(R, C, rblk=0, causal=False, cfg=None, dma_mode="late", order=(0, 1, 2, 3), seed=0, spike=None, tol_o=4e-3, tol_l=2e-5):
+    rng = np.random.default_rng(seed)
+    q, k, v = p4sim.rand_bf16((R, 128), rng), p4sim.rand_bf16((C, 128), rng), p4sim.rand_bf16((C, 128), rng)
+    if spike is not None:   # one key row aligned with one query row: forces the deferred rescale at a chosen tile
+        qrow, krow, gain = spike
+        qf = p4sim.bf16_to_f32(q[qrow].astype(np.uint32))
+        k[krow] = p4sim.f32_to_bf16_rne((qf * gain).astype(np.float32)).astype(np.uint16)
+    O, L, wg = p4sim.run_block(q, k, v, rblk, cfg=cfg, causal=causal, dma_mode=dma_mode, order=order)
+    Oref, Lref = p4sim.reference(q, k, v, causal=causal)
+    rows = np.arange(rblk * 256, min(R, rblk * 256 + 256))
+    dO = np.abs(O[: len(rows)] - Oref[rows]).max()
+    dL = np.abs(L[: len(rows)] - Lref[rows]).max()
+    assert dO < tol_o, (dO, dL)
+    assert dL < tol_l * max(1.0, np.abs(Lref[rows]).max()), (dO, dL)
+    return wg
+
+
+@pytest.mark.parametrize("C", [64, 128, 192, 256, 320])
+def test_tile_counts(C):
+    _check(256, C)
+
+
+@pytest.mark.parametrize("R,C", [(256, 100), (200, 130), (256, 200), (70, 1)])
+def test_ragged(R, C):
+    _check(R, C, seed=1)
+
+
+@pytest.mark.parametrize("R,C,rblk", [(256, 256, 0), (512, 512, 1), (300, 400, 1), (256, 320, 0)])
+def test_causal(R, C, rblk):
+    _check(R, C, rblk=rblk, causal=True, seed=2)
+
+
+@pytest.mark.parametrize("dma_mode", ["early", "late"])
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 2, 1, 0)])
+def test_ring_discipline(dma_mode, order):
+    # DMA data landing as early / as late as the waits allow, waves running ahead of / behind each other
+    _check(256, 448, dma_mode=dma_mode, order=order, seed=3)
+
+
+@pytest.mark.parametrize("thr", [0.0, 8.0])
+def test_deferred_rescale_spike(thr):
+    # cdna_hip_programming.md T13: a score far above the row's others at a late tile must rescale O, l and the
+    # pending P exactly once
+    cfg = p4gen.Cfg("bf16", thr, 0)
+    wg = _check(256, 320, cfg=cfg, spike=(5, 200, 3.0), seed=4, tol_o=1.2e-2)
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 256   # the rescale section ran more than once
+    _check(256, 320, cfg=cfg, spike=(40, 300, 4.0), seed=5, tol_o=1.2e-2)
+
+
+@pytest.mark.parametrize("name", sorted(p4gen.VARIANTS))
+def test_every_compiled_variant(name):
+    cfg = p4gen.VARIANTS[name]
+    if cfg.dtype != "bf16":
+        cfg = p4gen.Cfg("bf16", cfg.thr, cfg.xe, cfg.order_a, cfg.pad)   # the model multiplies bf16; f16 differs by mnemonics only
+    _check(256, 256, cfg=cfg, seed=6)
+
+
+def test_stream_file_is_current():
+    """csrc/attn_fwd16_p4_stream.inc is what tools/p4gen.py generates"""
+    path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4_stream.inc")
+    import tempfile
+    with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:
+        p4gen.write_inc(tmp.name)
+        assert open(path).read() == open(tmp.name).read(), "run python tools/p4gen.py"
+
+
+def test_filler_budget():
+    """at most 7 filler instructions in any gap of the steady-state phases, ~5.5 on average"""
+    ins = p4gen.Stream(p4gen.VARIANTS["BF16_THR8"]).build()
+    names = [i.op for i in ins]
+    loop = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("LOOP"))
+    end = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("ENDEVEN"))
+    gaps, cur = [], None
+    for x in ins[loop:end]:
+        if x.op.startswith("v_mfma"):
+            if cur is not None:
+                gaps.append(cur)
+            cur = 0
+        elif cur is not None and x.op not in ("label",):
+            cur += 1
+    assert len(gaps) >= 127
+    first = gaps[:64]                      # one tile: phase A gaps 0..31 (31 = the seam with the barrier), phase B 32..63
+    inner = first[:31] + first[32:63]      # the two phase seams carry waits, barrier, loop control (and the skipped mask code)
+    assert max(inner) <= 7, max(inner)
+    assert sum(inner) / len(inner) < 5.8, sum(inner) / len(inner)

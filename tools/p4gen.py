@@ -1,0 +1,590 @@
+#!/usr/bin/env python3
+"""Generator of the hand-placed instruction stream of attn_fwd16_p4 (csrc/attn_fwd16_p4.h).
+
+The forward kernel for D <= 128 keeps the whole tile traversal of a 256-row block in ONE inline-asm statement:
+four waves x 64 query rows, one wave per SIMD, matrix operands in the accumulator half of the register file.
+hipcc cannot place fillers between hand-written matrix instructions without a wait state per asm boundary, and it
+cannot index sub-registers of an asm operand, so the stream is emitted here with a fixed register map:
+
+    a[0:127]   O accumulators   (rb, db) -> 16 (4 rb + db)
+    a[128:191] Q fragments      (rb, ks) -> 128 + 4 (8 rb + ks)
+    a[192:255] K fragments      (kb, ks) -> 192 + 4 (8 kb + ks)          the 64-key tile being multiplied
+    v[32:95]   score tile of even tiles,  v[96:159] of odd tiles  (rb, kb) -> 16 (2 rb + kb)
+    v[160:191] P^T fragments    (rb, u)  -> 160 + 4 (4 rb + u)
+    v[192:223] V^T fragment ring, eight slots: fragment f = 4 u + db lives in slot f % 8
+    v[224:255] addresses and softmax temporaries
+    v[0:31]    left to hipcc (operands of the statement, its own values)
+
+Per 64-key tile j (parity = j & 1), two phases of 32 matrix instructions, one barrier between them:
+    A(j): S(j) = K(j) Q^T        | exp2 / row sum / 16-bit pack of tile j-1, first half of the V^T(j-1) fragment reads
+    B(j): O += V^T(j-1) P^T(j-1) | row max of S(j), deferred-rescale decision, s * scale2 - m, K(j+1) fragments,
+                                   second half of the V^T(j-1) reads, LDS-DMA of K(j+2) and V(j+1)
+Fillers are dealt out per gap between two matrix instructions (tables below).
+
+The same instruction list is rendered as the asm template (render) and executed by tools/p4sim.py, a lane-exact
+model of the subset of gfx950 instructions used here, which checks the result against a float64 attention on CPU
+(tests/test_p4_stream.py) -- register map, waits and ring discipline are verified without a GPU.
+
+Usage: python tools/p4gen.py   (rewrites metal_flash_attention_amd/csrc/attn_fwd16_p4_stream.inc)
+"""
+import os
+import sys
+
+# ---------------------------------------------------------------- register map
+O_BASE, Q_BASE, K_BASE = 0, 128, 192
+S_BASE = (32, 96)
+P_BASE, VF_BASE = 160, 192
+T_KADDR = 224          # 8: K fragment address per ks
+T_VADDR = 232          # V^T read base of the tile being read
+T_MX = 233             # 4: running block maxima (rb, kb) -> 2 rb + kb
+T_MN = 237             # 2: new row maximum per rb
+T_SW = 239             # 2: half-swap temporaries
+T_CORR = 241           # 2
+T_LB = 243             # 2: second partial row sum per rb
+T_MASKV = 245
+T_TL = 246             # 2: mask limits relative to the tile
+T_THR = 248            # 2: m + THR
+T_RS = 248             # 8: rescale temporaries (v248..v255)
+FIRST_OWNED_VGPR = 32
+
+KSLOT, VBASE, VSLOT, VRING = 16384, 32768, 16384, 3
+
+# named operands of the asm statement (see attn_fwd16_p4.h); order = operand order
+OUT_V = ["m0", "m1", "l0", "l1", "koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3"]
+TMP_S = ["j", "vrd", "vwr", "pend", "t0", "t1"]          # "=&s" 32-bit temporaries
+TMP_S64 = ["sv"]                                       # "=&s" 64-bit temporary
+IN_V = ["kbase", "vbase", "lim0", "lim1"]
+IN_S = ["kres", "vres", "nt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "maskfrom"]
+
+
+class Cfg:
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0):
+        self.dtype, self.thr, self.xe, self.order_a, self.pad = dtype, float(thr), xe, order_a, pad
+
+
+# ---------------------------------------------------------------- tiny IR
+def V(n, cnt=1):
+    return ("v", n, cnt)
+
+
+def A(n, cnt=1):
+    return ("a", n, cnt)
+
+
+def VN(name):
+    return ("V", name)
+
+
+def SN(name, cnt=1):
+    return ("S", name, cnt)
+
+
+def I(v):
+    return ("i", int(v))
+
+
+def F(v):
+    return ("f", float(v))
+
+
+VCC, M0 = ("vcc",), ("m0",)
+
+
+class Ins:
+    __slots__ = ("op", "d", "s", "mod", "note")
+
+    def __init__(self, op, d=None, s=(), mod=None, note=""):
+        self.op, self.d, self.s, self.mod, self.note = op, d, tuple(s), dict(mod or {}), note
+
+
+def s_elem(par, rb, kb, r):
+    return V(S_BASE[par] + 16 * (2 * rb + kb) + r)
+
+
+def s_blk(par, rb, kb):
+    return V(S_BASE[par] + 16 * (2 * rb + kb), 16)
+
+
+def p_word(rb, u, w):
+    return V(P_BASE + 4 * (4 * rb + u) + w)
+
+
+def p_frag(rb, u):
+    return V(P_BASE + 4 * (4 * rb + u), 4)
+
+
+def vf_frag(f):
+    return V(VF_BASE + 4 * (f % 8), 4)
+
+
+def vf_half(f, h):
+    return V(VF_BASE + 4 * (f % 8) + 2 * h, 2)
+
+
+def o_acc(rb, db):
+    return A(O_BASE + 16 * (4 * rb + db), 16)
+
+
+def q_frag(rb, ks):
+    return A(Q_BASE + 4 * (8 * rb + ks), 4)
+
+
+def k_frag(kb, ks):
+    return A(K_BASE + 4 * (8 * kb + ks), 4)
+
+
+# element e (0..63) of a score tile: blocks in the order (rb0,kb0) (rb1,kb0) (rb0,kb1) (rb1,kb1), register e % 16
+def elem(e):
+    blk, r = divmod(e, 16)
+    return blk & 1, blk >> 1, r   # rb, kb, r
+
+
+class Stream:
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.ins = []
+        self.uid = 0
+        # LDS queue bookkeeping for counted waits: ids of issued LDS reads in order, index of the last one known complete
+        self.lds_issued = 0
+        self.lds_done = 0
+
+    def emit(self, op, d=None, s=(), note="", **mod):
+        self.ins.append(Ins(op, d, s, mod, note))
+
+    def label(self, name):
+        self.ins.append(Ins("label", None, (), {"name": name}))
+
+    def newlabel(self, stem):
+        self.uid += 1
+        return "%s_%d" % (stem, self.uid)
+
+    # ---- LDS reads with exact wait counting (LDS returns in order)
+    def lds_read(self, op, d, addr, offset, note=""):
+        self.emit(op, d, [addr], note=note, offset=offset)
+        self.lds_issued += 1
+        return self.lds_issued      # id = position in issue order (1-based)
+
+    def lds_need(self, rid):
+        """make sure LDS read `rid` has returned"""
+        if rid <= self.lds_done:
+            return
+        younger = self.lds_issued - rid
+        n = min(younger, 15)
+        self.emit("s_waitcnt", None, [], lgkmcnt=n)
+        self.lds_done = self.lds_issued - n
+
+    def lds_flush(self):
+        if self.lds_done < self.lds_issued:
+            self.emit("s_waitcnt", None, [], lgkmcnt=0)
+            self.lds_done = self.lds_issued
+
+    # ---- matrix instructions
+    def mfma(self, d, a, b, c):
+        self.emit("v_mfma_f32_32x32x16_" + self.cfg.dtype, d, [a, b, c])
+
+    def qk_order(self):
+        if self.cfg.order_a == "kb":      # kb-major: the kb = 0 blocks complete after 16 instructions
+            return [(g // 16, g % 2, (g % 16) // 2) for g in range(32)]          # (kb, rb, ks)
+        return [((g % 4) // 2, g % 2, g // 4) for g in range(32)]                # four accumulators in rotation
+
+    # ------------------------------------------------------------ phase A
+    def phase_a(self, par, mfma, softmax, zero_o):
+        """A(j), par = j & 1: S[par] = K Q^T | finish-softmax of S[par ^ 1] | V^T reads of fragments 0..7"""
+        cfg = self.cfg
+        prev = par ^ 1
+        vids = {}
+        if softmax:
+            self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of tile j-1")
+        order = self.qk_order()
+        pending_pack = None
+        for g in range(32):
+            if mfma:
+                kb, rb, ks = order[g]
+                c = I(0) if ks == 0 else s_blk(par, rb, kb)
+                self.mfma(s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), c)
+            if zero_o:
+                for i in range(4):
+                    self.emit("v_accvgpr_write_b32", A(O_BASE + 4 * g + i), [I(0)])
+            if softmax:
+                for e in (2 * g, 2 * g + 1):
+                    if e >= cfg.xe:
+                        rb_, kb_, r_ = elem(e)
+                        x = s_elem(prev, rb_, kb_, r_)
+                        self.emit("v_exp_f32", x, [x])
+                if pending_pack is not None:
+                    self.sum_pack(prev, pending_pack)
+                pending_pack = 2 * g
+                # V^T fragments 0..7 (16 reads) in gaps 12..27: they land before the barrier
+                if 12 <= g < 28:
+                    i = g - 12
+                    vids[i] = self.v_read(i)
+        if softmax:
+            self.sum_pack(prev, pending_pack)
+        return vids
+
+    def sum_pack(self, prev, e):
+        rb, kb, r = elem(e)
+        x0, x1 = s_elem(prev, rb, kb, r), s_elem(prev, rb, kb, r + 1)
+        self.emit("v_add_f32", VN("l%d" % rb), [x0, VN("l%d" % rb)])
+        self.emit("v_add_f32", V(T_LB + rb), [x1, V(T_LB + rb)])
+        # MFMA step u (16 keys) of key block kb uses registers 8 (u & 1) .. + 7
+        self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, p_word(rb, 2 * kb + r // 8, (r % 8) // 2), [x0, x1])
+
+    def v_read(self, i):
+        """V^T read i (0..31): fragment f = i // 2 = 4 u + db, half i % 2 (keys +0..3 / +8..11 of the 16-key group)"""
+        f, h = divmod(i, 2)
+        u, db = divmod(f, 4)
+        off = (db * 64 + 16 * u) * 64 + h * 8 * 64
+        return self.lds_read("ds_read_b64_tr_b16", vf_half(f, h), V(T_VADDR), off, note="V^T f%d.%d" % (f, h))
+
+    # ------------------------------------------------------------ phase B
+    def phase_b(self, par, mfma, softmax, vids):
+        """B(j): O += V^T(j-1) P^T(j-1) | start-softmax of S[par], K(j+1) fragments, V^T fragments 8..15, DMA"""
+        cfg = self.cfg
+        if not mfma and softmax:
+            self.emit("s_nop", None, [I(15)], note="S(0) is still leaving the matrix pipe")
+        if softmax:
+            self.mask_section(par, after_mfma=mfma)
+        fill = [[] for _ in range(32)]   # closures per gap
+
+        def at(g, fn):
+            fill[g].append(fn)
+
+        if mfma:
+            # V^T fragments 8..15: fragment f reuses the slot of f-8, free once the two MFMAs of f-8 (gaps 2(f-8), +1) are issued
+            for f in range(8, 16):
+                g0 = 2 * (f - 8) + 2
+                at(g0, lambda f=f: vids.__setitem__(2 * f, self.v_read(2 * f)))
+                at(g0 + 1, lambda f=f: vids.__setitem__(2 * f + 1, self.v_read(2 * f + 1)))
+        if softmax:
+            for i in range(32):                      # row maxima: gaps 0..7
+                at(i // 4, lambda i=i: self.max_op(par, i))
+            at(8, lambda: self.decide_1())
+            at(9, lambda: self.decide_2())
+            at(10, lambda: self.decide_3())
+            dec_lbl = self.newlabel("DEC")
+            at(11, lambda: self.decide_4(dec_lbl))
+            # s * scale2 - m : 64 over gaps 12..31 (4 per gap in 12..15, then 3)
+            e = 0
+            for g in range(12, 32):
+                n = 4 if g < 16 else 3
+                for _ in range(n):
+                    if e < 64:
+                        at(g, lambda e=e: self.fma_op(par, e))
+                        e += 1
+            assert e == 64
+            # K(j+1) fragments -> a[192:255], one per gap 12..27
+            for i in range(16):
+                at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
+            # LDS-DMA: K(j+2) pieces in gaps 20..23, V(j+1) pieces 24..27; their offsets advance in gaps 28..31
+            for i in range(4):
+                at(20 + i, lambda i=i: self.dma_piece("k", par, i))
+                at(24 + i, lambda i=i: self.dma_piece("v", par, i))
+                at(28 + i, lambda i=i: self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1))
+                at(28 + i, lambda i=i: self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1))
+            at(0, lambda: self.vwr_update())
+            at(1, lambda: self.vrd_advance())
+        for g in range(32):
+            if mfma:
+                u, db, rb = g // 8, (g % 8) // 2, g % 2
+                f = 4 * u + db
+                if rb == 0 and f % 2 == 0:
+                    self.lds_need(vids[2 * f + 3])   # both halves of fragments f and f + 1 have returned
+                self.mfma(o_acc(rb, db), vf_frag(f), p_frag(rb, u), o_acc(rb, db))
+            for fn in fill[g]:
+                fn()
+        while self.xe_pending:
+            y = self.xe_pending.pop(0)
+            self.emit("v_exp_f32", y, [y])
+        self.lds_flush()
+        if softmax:
+            # apply a pending rescale (rare)
+            resc, back = self.newlabel("RESC"), self.newlabel("RESCBACK")
+            self.emit("s_cmp_eq_u32", None, [SN("pend"), I(0)])
+            self.emit("s_cbranch_scc0", None, [], target=resc)
+            self.label(back)
+            self.outofline.append(("resc", resc, back))
+            self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK"))
+
+    def max_op(self, par, i):
+        # op i: block i // 8 in the order (rb0,kb0) (rb1,kb0) (rb0,kb1) (rb1,kb1); step i % 8 covers 3, 2, ..., 2, 1 values
+        blk, st = divmod(i, 8)
+        rb, kb = blk & 1, blk >> 1
+        mx = V(T_MX + 2 * rb + kb)
+        if st == 0:
+            self.emit("v_max3_f32", mx, [s_elem(par, rb, kb, 0), s_elem(par, rb, kb, 1), s_elem(par, rb, kb, 2)])
+        elif st < 7:
+            self.emit("v_max3_f32", mx, [mx, s_elem(par, rb, kb, 2 * st + 1), s_elem(par, rb, kb, 2 * st + 2)])
+        else:
+            self.emit("v_max_f32", mx, [mx, s_elem(par, rb, kb, 15)])
+
+    def decide_1(self):   # onlineReduceMaximum across the two key blocks, copies for the half swap
+        for rb in range(2):
+            self.emit("v_max_f32", V(T_MN + rb), [V(T_MX + 2 * rb), V(T_MX + 2 * rb + 1)])
+        for rb in range(2):
+            self.emit("v_mov_b32", V(T_SW + rb), [V(T_MN + rb)])
+
+    def decide_2(self):   # lanes l and l ^ 32 hold the two halves of a row's keys
+        self.emit("s_nop", None, [I(1)], note="VALU write -> permlane read")
+        for rb in range(2):
+            self.emit("v_permlane32_swap_b32", V(T_SW + rb), [V(T_MN + rb)], swap=1)
+        for rb in range(2):
+            self.emit("v_max_f32", V(T_MN + rb), [V(T_SW + rb), V(T_MN + rb)])
+
+    def decide_3(self):
+        for rb in range(2):
+            self.emit("v_mul_f32", V(T_MN + rb), [SN("scale2"), V(T_MN + rb)])
+        for rb in range(2):
+            self.emit("v_add_f32", V(T_THR + rb), [F(self.cfg.thr), VN("m%d" % rb)])
+
+    def decide_4(self, lbl):   # any row whose block maximum exceeds m + THR -> raise m (out of line)
+        self.emit("v_cmp_gt_f32", VCC, [V(T_MN), V(T_THR)])
+        self.emit("s_mov_b64", SN("sv", 2), [VCC])
+        self.emit("v_cmp_gt_f32", VCC, [V(T_MN + 1), V(T_THR + 1)])
+        self.emit("s_or_b64", VCC, [VCC, SN("sv", 2)])
+        self.emit("s_cbranch_vccnz", None, [], target=lbl)
+        self.label(lbl + "_BACK")
+
+    def fma_op(self, par, e):
+        rb, kb, r = elem(e)
+        x = s_elem(par, rb, kb, r)
+        self.emit("v_fma_f32", x, [x, SN("scale2"), VN("m%d" % rb)], neg2=1)
+        if e < self.cfg.xe:   # exp2 already in phase B, two elements behind its own fma
+            self.xe_pending.append(x)
+        if len(self.xe_pending) > 2:
+            y = self.xe_pending.pop(0)
+            self.emit("v_exp_f32", y, [y])
+
+    def k_read(self, slot, i):
+        kb, ks = divmod(i, 8)
+        self.lds_read("ds_read_b128", k_frag(kb, ks), V(T_KADDR + ks), slot * KSLOT + kb * 8192, note="K(%d,%d)" % (kb, ks))
+
+    def vrd_advance(self):   # the V^T read base of this tile is already in T_VADDR
+        self.emit("s_add_u32", SN("vrd"), [SN("vrd"), I(VSLOT)])
+        self.emit("s_cmp_ge_u32", None, [SN("vrd"), I(VRING * VSLOT)])
+        self.emit("s_cselect_b32", SN("vrd"), [I(0), SN("vrd")])
+
+    def vwr_update(self):   # V(j+1) goes to the image after the one V(j) went to ("vwr" includes this wave's LDS base)
+        self.emit("s_add_u32", SN("vwr"), [SN("vwr"), I(VSLOT)])
+        self.emit("s_cmp_ge_u32", None, [SN("vwr"), SN("t1")])
+        self.emit("s_cselect_b32", SN("vwr"), [SN("ldsv"), SN("vwr")])
+
+    def dma_piece(self, which, par, i):
+        if which == "k":   # K(j+2) -> K image j & 1
+            self.emit("s_add_u32", M0, [SN("ldsk"), I(par * KSLOT + i * 1024)])
+            self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), SN("kres", 4)])
+        else:              # V(j+1) -> V image (j + 1) % 3
+            self.emit("s_add_u32", M0, [SN("vwr"), I(i * 1024)])
+            self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), SN("vres", 4)])
+
+    def mask_section(self, par, after_mfma):
+        """edge masks on the fresh score tile: key c of row r is visible iff c <= lim[r] (lim = min(C - 1, causal limit))"""
+        skip = self.newlabel("NOMASK")
+        self.emit("s_cmp_lt_i32", None, [SN("j"), SN("maskfrom")])
+        self.emit("s_cbranch_scc1", None, [], target=skip)
+        if after_mfma:
+            self.emit("s_nop", None, [I(15)], note="S(j) is still leaving the matrix pipe")
+        self.emit("s_lshl_b32", SN("t0"), [SN("j"), I(6)])
+        for rb in range(2):
+            self.emit("v_subrev_u32", V(T_TL + rb), [SN("t0"), VN("lim%d" % rb)])   # lim - 4 hi - 64 j
+        self.emit("v_mov_b32", V(T_MASKV), [F(-(0.875 / 1.44269504089) * 3.402823466e+38)])   # +Softmax.swift:242-243
+        for rb in range(2):
+            for kb in range(2):
+                for r in range(16):
+                    c = kb * 32 + (r & 3) + 8 * (r >> 2)
+                    x = s_elem(par, rb, kb, r)
+                    self.emit("v_cmp_gt_i32", VCC, [I(c), V(T_TL + rb)])
+                    self.emit("v_cndmask_b32", x, [x, V(T_MASKV), VCC])
+        self.label(skip)
+
+    # ------------------------------------------------------------ out-of-line sections
+    def emit_outofline(self):
+        for kind, lbl, back in self.outofline:
+            self.label(lbl)
+            if kind == "dec":   # onlineCorrectO factors (+Softmax.swift:290-301): m_up = max(m, m_new), corr = 2^(m - m_up)
+                for rb in range(2):
+                    self.emit("v_max_f32", V(T_THR + rb), [VN("m%d" % rb), V(T_MN + rb)])
+                for rb in range(2):
+                    self.emit("v_sub_f32", V(T_CORR + rb), [VN("m%d" % rb), V(T_THR + rb)])
+                for rb in range(2):
+                    self.emit("v_mov_b32", VN("m%d" % rb), [V(T_THR + rb)])
+                for rb in range(2):
+                    self.emit("v_exp_f32", V(T_CORR + rb), [V(T_CORR + rb)])
+                self.emit("s_mov_b32", SN("pend"), [I(1)])
+                self.emit("s_branch", None, [], target=back)
+            else:               # O, l *= corr once every matrix instruction that accumulates P(j-1) has been issued
+                self.emit("s_nop", None, [I(15)])
+                self.emit("s_nop", None, [I(7)])
+                for rb in range(2):
+                    for i0 in range(0, 64, 8):
+                        for t in range(8):
+                            self.emit("v_accvgpr_read_b32", V(T_RS + t), [A(O_BASE + 64 * rb + i0 + t)])
+                        for t in range(8):
+                            self.emit("v_mul_f32", V(T_RS + t), [V(T_CORR + rb), V(T_RS + t)])
+                        for t in range(8):
+                            self.emit("v_accvgpr_write_b32", A(O_BASE + 64 * rb + i0 + t), [V(T_RS + t)])
+                    self.emit("v_mul_f32", VN("l%d" % rb), [V(T_CORR + rb), VN("l%d" % rb)])
+                    self.emit("v_mul_f32", V(T_LB + rb), [V(T_CORR + rb), V(T_LB + rb)])
+                self.emit("s_mov_b32", SN("pend"), [I(0)])
+                self.emit("s_nop", None, [I(4)], note="accvgpr write -> MFMA SrcC")
+                self.emit("s_branch", None, [], target=back)
+
+    # ------------------------------------------------------------ whole traversal
+    def build(self):
+        self.outofline = []
+        self.xe_pending = []
+        if self.cfg.pad:
+            self.emit("s_nop", None, [I(0)], note="code placement pad")
+        # ---- prologue: K(0), V(0) landed (K(1) may be in flight): 12 DMA pieces were issued by the caller
+        self.emit("s_waitcnt", None, [], vmcnt=4)
+        self.emit("s_barrier")
+        for ks in range(8):
+            self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
+        for rb in range(2):
+            self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
+            self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
+        self.emit("s_mov_b32", SN("pend"), [I(0)])
+        self.emit("s_mov_b32", SN("j"), [I(0)])
+        self.emit("s_mov_b32", SN("vrd"), [I(2 * VSLOT)])    # "image of V(-1)"
+        self.emit("s_mov_b32", SN("vwr"), [SN("ldsv")])      # V(0) went to image 0: V(1) goes to image 1
+        self.emit("s_add_u32", SN("t1"), [SN("ldsv"), I(VRING * VSLOT)])
+        for i in range(16):
+            self.k_read(0, i)
+        self.lds_flush()
+        self.phase_a(0, mfma=True, softmax=False, zero_o=True)
+        self.emit("s_waitcnt", None, [], vmcnt=0)            # K(1)
+        self.emit("s_barrier")
+        self.phase_b(0, mfma=False, softmax=True, vids={})
+        self.emit("s_mov_b32", SN("j"), [I(1)])
+        loop, end_even, end_odd, done, fin = (self.newlabel(x) for x in ("LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN"))
+        self.label(loop)
+        for par, endl in ((1, end_even), (0, end_odd)):
+            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
+            self.emit("s_cbranch_scc1", None, [], target=endl)
+            vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
+            self.lds_flush()
+            self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j)
+            self.emit("s_barrier")
+            self.phase_b(par, mfma=True, softmax=True, vids=vids)
+            self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
+        self.emit("s_branch", None, [], target=loop)
+        # tails: finish tile nt-1 (its scores are in S[last parity])
+        for lastpar, lbl in ((0, end_even), (1, end_odd)):
+            self.label(lbl)
+            vids = self.phase_a(lastpar ^ 1, mfma=False, softmax=True, zero_o=False)
+            self.lds_flush()
+            self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
+            self.phase_b(lastpar ^ 1, mfma=True, softmax=False, vids=vids)
+            self.emit("s_branch", None, [], target=done)
+        self.label(done)
+        for rb in range(2):
+            self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
+        self.emit("s_branch", None, [], target=fin)
+        self.emit_outofline()
+        self.label(fin)
+        return self.ins
+
+
+# ---------------------------------------------------------------- rendering
+def fmt(o):
+    k = o[0]
+    if k in ("v", "a"):
+        return "%s%d" % (k, o[1]) if o[2] == 1 else "%s[%d:%d]" % (k, o[1], o[1] + o[2] - 1)
+    if k == "V":
+        return "%%[%s]" % o[1]
+    if k == "S":
+        return "%%[%s]" % o[1]
+    if k == "i":
+        return str(o[1]) if -16 <= o[1] <= 64 else hex(o[1] & 0xFFFFFFFF)
+    if k == "f":
+        import struct
+        v = o[1]
+        inline = {0.0: "0", 0.5: "0.5", 1.0: "1.0", 2.0: "2.0", 4.0: "4.0", -0.5: "-0.5", -1.0: "-1.0", -2.0: "-2.0", -4.0: "-4.0"}
+        if v in inline:
+            return inline[v]
+        return hex(struct.unpack("<I", struct.pack("<f", v))[0])
+    if k == "vcc":
+        return "vcc"
+    if k == "m0":
+        return "m0"
+    raise ValueError(o)
+
+
+def render_one(ins, suffix="%="):
+    op, m = ins.op, ins.mod
+    if op == "label":
+        return "%s_%s:" % (m["name"], suffix)
+    if op == "s_waitcnt":
+        parts = []
+        if "vmcnt" in m:
+            parts.append("vmcnt(%d)" % m["vmcnt"])
+        if "lgkmcnt" in m:
+            parts.append("lgkmcnt(%d)" % m["lgkmcnt"])
+        return "s_waitcnt " + " ".join(parts)
+    if op == "s_barrier":
+        return "s_barrier"
+    if op in ("s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccnz", "s_branch"):
+        return "%s %s_%s" % (op, m["target"], suffix)
+    if op == "buffer_load_dwordx4_lds":
+        return "buffer_load_dwordx4 %s, %s, 0 offen lds" % (fmt(ins.s[0]), fmt(ins.s[1]))
+    if op in ("ds_read_b128", "ds_read_b64_tr_b16"):
+        return "%s %s, %s offset:%d" % (op, fmt(ins.d), fmt(ins.s[0]), m["offset"])
+    if op == "v_fma_f32":
+        return "v_fma_f32 %s, %s, %s, -%s" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
+    if op == "v_add_u32_e64":
+        return "v_add_u32_e64 %s, %s, %s clamp" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
+    if op == "v_permlane32_swap_b32":
+        return "v_permlane32_swap_b32 %s, %s" % (fmt(ins.d), fmt(ins.s[0]))
+    if op in ("s_cmp_lt_i32", "s_cmp_ge_i32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_nop"):
+        return "%s %s" % (op, ", ".join(fmt(x) for x in ins.s))
+    if op in ("v_cmp_gt_f32", "v_cmp_gt_i32"):
+        return "%s_e32 vcc, %s, %s" % (op, fmt(ins.s[0]), fmt(ins.s[1]))
+    if op == "v_cndmask_b32":
+        return "v_cndmask_b32_e32 %s, %s, %s, vcc" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
+    ops = [fmt(ins.d)] if ins.d is not None else []
+    ops += [fmt(x) for x in ins.s]
+    return "%s %s" % (op, ", ".join(ops))
+
+
+def render(instrs):
+    return [render_one(i) for i in instrs]
+
+
+def write_inc(path):
+    lines = ["// GENERATED by tools/p4gen.py -- do not edit.  Instruction streams of attn_fwd16_p4 (see the generator's",
+             "// header for the register map and the phase tables).", "#pragma once", ""]
+    vregs = ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256))
+    lines.append("#define MFA_P4_OWNED_VGPRS " + vregs)
+    lines.append("")
+    for name, cfg in VARIANTS.items():
+        st = Stream(cfg)
+        ins = st.build()
+        txt = render(ins)
+        n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
+        lines.append("// %s: dtype=%s thr=%g xe=%d order_a=%s pad=%d -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, len(txt), n_mfma))
+        lines.append("#define MFA_P4_STREAM_%s \\" % name)
+        for t in txt:
+            lines.append('  "%s\\n\\t" \\' % t)
+        lines.append('  ""')
+        lines.append("")
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
+VARIANTS = {
+    "BF16_THR8": Cfg("bf16", 8, 0),
+    "BF16_THR0": Cfg("bf16", 0, 0),
+    "F16_THR8": Cfg("f16", 8, 0),
+    "BF16_THR8_XE16": Cfg("bf16", 8, 16),
+    "BF16_THR8_ROT": Cfg("bf16", 8, 0, order_a="rot4"),
+    "BF16_THR8_PAD": Cfg("bf16", 8, 0, pad=1),
+}
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4_stream.inc")
+    write_inc(out)
+    st = Stream(VARIANTS["BF16_THR8"])
+    ins = st.build()
+    print("wrote", os.path.normpath(out), "-", len(ins), "instructions in the default stream")

@@ -36,6 +36,7 @@ bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out) {
     if (impl == 2) { fill_p4<__bf16, p4::S_BF16_THR8_XE16>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_xe16"); return true; }
     if (impl == 3) { fill_p4<__bf16, p4::S_BF16_THR8_ROT>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_rot4"); return true; }
     if (impl == 4) { fill_p4<__bf16, p4::S_BF16_THR8_PAD>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_pad"); return true; }
+    if (impl == 5) { fill_p4<__bf16, p4::S_BF16_THR8_PROF>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_PROF_CLOBBERS_O"); return true; }
   }
   if (precision == PREC_FP16) {
     if (impl == 0) { fill_p4<_Float16, p4::S_F16_THR8>(out, "attn_fwd16p4_f16_d128_w4x64_thr8"); return true; }

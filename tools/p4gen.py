@@ -51,15 +51,15 @@ KSLOT, VBASE, VSLOT, VRING = 16384, 32768, 16384, 3
 
 # named operands of the asm statement (see attn_fwd16_p4.h); order = operand order
 OUT_V = ["m0", "m1", "l0", "l1", "koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3"]
-TMP_S = ["j", "vrd", "vwr", "pend", "t0", "t1"]          # "=&s" 32-bit temporaries
-TMP_S64 = ["sv"]                                       # "=&s" 64-bit temporary
+TMP_S = ["j", "vrd", "vwr", "pend", "t0", "t1", "pa", "pw", "pb", "plast"]   # "=&s" 32-bit temporaries (p*: PROF streams)
+TMP_S64 = ["sv", "ptime"]                              # "=&s" 64-bit temporaries
 IN_V = ["kbase", "vbase", "lim0", "lim1"]
 IN_S = ["kres", "vres", "nt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "maskfrom"]
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0):
-        self.dtype, self.thr, self.xe, self.order_a, self.pad = dtype, float(thr), xe, order_a, pad
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0):
+        self.dtype, self.thr, self.xe, self.order_a, self.pad, self.prof = dtype, float(thr), xe, order_a, pad, prof
 
 
 # ---------------------------------------------------------------- tiny IR
@@ -87,7 +87,7 @@ def F(v):
     return ("f", float(v))
 
 
-VCC, M0 = ("vcc",), ("m0",)
+VCC, M0, VCC_LO = ("vcc",), ("m0",), ("vcc_lo",)
 
 
 class Ins:
@@ -177,6 +177,19 @@ class Stream:
         if self.lds_done < self.lds_issued:
             self.emit("s_waitcnt", None, [], lgkmcnt=0)
             self.lds_done = self.lds_issued
+
+    def stamp(self, acc):
+        """PROF streams: add the shader-clock time since the previous stamp to accumulator `acc` (s_memtime returns through
+        lgkmcnt, so a stamp sits only where no LDS read may be in flight afterwards: it waits lgkmcnt(0) itself)"""
+        if not self.cfg.prof:
+            return
+        self.emit("s_memtime", SN("ptime", 2))
+        self.emit("s_waitcnt", None, [], lgkmcnt=0)
+        self.lds_done = self.lds_issued
+        self.emit("s_mov_b64", VCC, [SN("ptime", 2)])       # vcc_lo names the low dword (vcc is dead at a phase seam)
+        self.emit("s_sub_u32", SN("t0"), [VCC_LO, SN("plast")])
+        self.emit("s_add_u32", SN(acc), [SN(acc), SN("t0")])
+        self.emit("s_mov_b32", SN("plast"), [VCC_LO])
 
     # ---- matrix instructions
     def mfma(self, d, a, b, c):
@@ -456,16 +469,26 @@ class Stream:
         self.emit("s_barrier")
         self.phase_b(0, mfma=False, softmax=True, vids={})
         self.emit("s_mov_b32", SN("j"), [I(1)])
+        for acc in ("pa", "pw", "pb"):
+            self.emit("s_mov_b32", SN(acc), [I(0)])
+        if self.cfg.prof:
+            self.emit("s_memtime", SN("ptime", 2))
+            self.emit("s_waitcnt", None, [], lgkmcnt=0)
+            self.emit("s_mov_b64", VCC, [SN("ptime", 2)])
+            self.emit("s_mov_b32", SN("plast"), [VCC_LO])
         loop, end_even, end_odd, done, fin = (self.newlabel(x) for x in ("LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN"))
         self.label(loop)
         for par, endl in ((1, end_even), (0, end_odd)):
             self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
             self.emit("s_cbranch_scc1", None, [], target=endl)
             vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
+            self.stamp("pa")
             self.lds_flush()
             self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j)
             self.emit("s_barrier")
+            self.stamp("pw")
             self.phase_b(par, mfma=True, softmax=True, vids=vids)
+            self.stamp("pb")
             self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_branch", None, [], target=loop)
         # tails: finish tile nt-1 (its scores are in S[last parity])
@@ -494,6 +517,8 @@ def fmt(o):
         return "%%[%s]" % o[1]
     if k == "S":
         return "%%[%s]" % o[1]
+    if k == "vcc_lo":
+        return "vcc_lo"
     if k == "i":
         return str(o[1]) if -16 <= o[1] <= 64 else hex(o[1] & 0xFFFFFFFF)
     if k == "f":
@@ -579,6 +604,7 @@ VARIANTS = {
     "BF16_THR8_XE16": Cfg("bf16", 8, 16),
     "BF16_THR8_ROT": Cfg("bf16", 8, 0, order_a="rot4"),
     "BF16_THR8_PAD": Cfg("bf16", 8, 0, pad=1),
+    "BF16_THR8_PROF": Cfg("bf16", 8, 0, prof=1),
 }
 
 if __name__ == "__main__":

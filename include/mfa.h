@@ -12,6 +12,25 @@
  * passed as void* = hipStream_t).  Every function returns an mfa_status; nothing aborts the
  * process (the reference uses fatalError).  The library never allocates device memory and
  * keeps no hidden workspace: the caller owns all ten operand buffers, as in the reference.
+ *
+ * Numerics contract (where this target departs from the reference's arithmetic):
+ *   - Inputs must be finite.  The 16-bit matrix-core forward kernels are compiled with -ffinite-math-only (the softmax
+ *     path itself never creates Inf / NaN: finite mask value, finite running-maximum start); an Inf or NaN in Q, K or V
+ *     is undefined behaviour there, not propagated.  The fp32-arithmetic (general) kernels propagate them.
+ *   - Deferred rescale.  The 16-bit forward kernels raise the running row maximum m -- and rescale O and l -- only
+ *     when a block maximum exceeds m by more than 8 (log2 units); until then P = 2^(S - m) may reach 2^8 before it is
+ *     rounded to 16 bits.  The reference corrects whenever the maximum grows (+Softmax.swift:290-301).  L = m + log2 l
+ *     is unaffected; measured |dO| against the reference's rule: 7e-4 at N = 4096.
+ *   - P and dS are rounded to the inputs' 16-bit type in every 16-bit matrix-core kernel (they are MFMA operands),
+ *     also when lowPrecisionIntermediates is 0 and the reference would keep them in FP32 registers
+ *     (+Precisions.swift:201-205).  S, the accumulators, L and D arithmetic are fp32.
+ *   - lowPrecisionIntermediates = 1 (the reference then holds P, and with FP16 also S, in 16-bit registers) lets the
+ *     D <= 128 forward kernel multiply Q by log2(e)/sqrt(D) once, rounded to the inputs' type, instead of scaling every
+ *     score in fp32: L moves by up to ~2e-3 (BF16) / 2e-4 (FP16) natural-log units.  With the flag clear the scale is
+ *     applied in fp32 per score.
+ *   - Head dimensions: D <= 384 (the reference's tables end there, +Parameters.swift:77-285).  16-bit matrix-core code
+ *     objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic kernels whatever the storage type.
+ *     Accumulators stay in registers at every D; larger D is MFA_ERR_UNSUPPORTED.
  */
 #ifndef MFA_H
 #define MFA_H
@@ -94,7 +113,11 @@ typedef struct mfa_attention_kernel_descriptor {
   int8_t preferAsyncCache;                        /* (:21)  -1 / 0 / 1 */
   int8_t preferAsyncLoad;                         /* (:24) */
   int8_t type;                                    /* (:44)  -1 or mfa_kernel_type */
-  int8_t reserved;
+  /* Extension.  In the reference blockDimensions and cacheState ARE the kernel (AttentionKernel.swift:27-50); a
+   * pre-compiled suite can only honour tuples that exist.  0 (default): mfa_attention_kernel_create takes the nearest
+   * compiled variant and mfa_attention_kernel_effective_descriptor reports it.  Non-zero: a tuple no code object
+   * implements is MFA_ERR_UNSUPPORTED (the message lists the compiled tuples). */
+  int8_t strictBlockDimensions;
 } mfa_attention_kernel_descriptor;
 void mfa_attention_kernel_descriptor_init(mfa_attention_kernel_descriptor *kdesc);
 

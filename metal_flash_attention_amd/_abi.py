@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfa_hip.so")
+# MFA_LIBRARY: developer tools (tools/ab_*.py) point this at libmfa_hip_dev.so, the -DMFA_DEV_VARIANTS build that carries
+# the A/B knobs; it only chooses WHICH build of the same C ABI is loaded -- there is no fallback either way.
+LIB_PATH = os.environ.get("MFA_LIBRARY") or os.path.join(_HERE, "libmfa_hip.so")
 
 MFA_OPERAND_COUNT = 14
 MFA_BUFFER_SLOTS = 10
@@ -59,7 +61,7 @@ class mfa_attention_kernel_descriptor(ctypes.Structure):
         ("preferAsyncCache", ctypes.c_int8),
         ("preferAsyncLoad", ctypes.c_int8),
         ("type", ctypes.c_int8),
-        ("reserved", ctypes.c_int8),
+        ("strictBlockDimensions", ctypes.c_int8),
     ]
 
 

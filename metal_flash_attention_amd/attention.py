@@ -108,6 +108,8 @@ class AttentionKernelDescriptor:
         self.registerPrecisions: Dict[AttentionOperand, GEMMOperandPrecision] = {}
         self.transposeState: Dict[AttentionOperand, bool] = {}
         self.type: Optional[AttentionKernelType] = None
+        # extension: True = block dimensions / cache state no compiled variant implements are an error
+        self.strictBlockDimensions: bool = False
 
     def _to_c(self) -> _abi.mfa_attention_kernel_descriptor:
         c = _abi.mfa_attention_kernel_descriptor()
@@ -125,6 +127,7 @@ class AttentionKernelDescriptor:
         c.preferAsyncCache = -1 if self.preferAsyncCache is None else int(bool(self.preferAsyncCache))
         c.preferAsyncLoad = -1 if self.preferAsyncLoad is None else int(bool(self.preferAsyncLoad))
         c.type = -1 if self.type is None else int(self.type)
+        c.strictBlockDimensions = int(bool(self.strictBlockDimensions))
         return c
 
     @classmethod

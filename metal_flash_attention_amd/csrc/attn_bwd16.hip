@@ -62,6 +62,7 @@ static void fill_dq(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = dq16_lds_bytes<D, NW>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_dq16<T, D, NW, TG>;
   v->launchCausal = &launch_dq16_causal<T, D, NW, TG>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dq16<T, D, NW, TG, true>);
@@ -83,6 +84,7 @@ static void fill_dkv(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = dkv16_lds_bytes<D, NW>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_dkv16<T, D, NW, PRE, TG>;
   v->launchCausal = &launch_dkv16_causal<T, D, NW, PRE, TG>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16<T, D, NW, PRE, TG, true>);
@@ -118,10 +120,12 @@ bool dkv16_variant(int precision, int gprecision, int D, VariantInfo *out) {
     return false;
   }
   if (precision != gprecision) return false;
+#ifdef MFA_DEV_VARIANTS
   const char *knob = std::getenv("MFA_DKV16_IMPL");   // developer A/B knob: "0" = compiler-placed LDS reads
   if (knob && knob[0] == '0' && precision == PREC_BF16 && D == 128) {
     fill_dkv<__bf16, 128, 4, 0>(out, "attn_dkv16_bf16_d128_w4x32_nopre"); return true;
   }
+#endif
   if (precision == PREC_BF16) {
     if (D == 128) { fill_dkv<__bf16, 128, 4>(out, "attn_dkv16_bf16_d128_w4x32"); return true; }
     if (D == 64) { fill_dkv<__bf16, 64, 4>(out, "attn_dkv16_bf16_d64_w4x32"); return true; }

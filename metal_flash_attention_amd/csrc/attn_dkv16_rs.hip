@@ -44,6 +44,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = dkv16rs_pairs<D>() * 128;
   v->ldsBytes = dkv16rs_lds_bytes<D>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_rs<T, D, TG, false>;
   v->launchCausal = &launch_rs<T, D, TG, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16_rs<T, D, TG, true>);
@@ -57,6 +58,7 @@ static void fill(VariantInfo *v, const char *name) {
 }
 
 bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
+#ifdef MFA_DEV_VARIANTS
   if (impl >= 1 && impl <= 4 && precision == PREC_BF16 && gprecision == PREC_BF16 && D == 128) {   // timing-only ablations
     fill<__bf16, 128>(out, "ablate_dkv16rs_WRONG_RESULTS");
     out->launchCausal = nullptr; out->funcCausal = nullptr; out->causal = false;
@@ -70,6 +72,7 @@ bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInf
     }
     return true;
   }
+#endif
   if (precision == PREC_FP16 && gprecision == PREC_BF16) {
     if (D == 128) { fill<_Float16, 128, __bf16>(out, "attn_dkv16rs_f16_dObf16_d128_p4x32"); return true; }
     if (D == 64) { fill<_Float16, 64, __bf16>(out, "attn_dkv16rs_f16_dObf16_d64_p4x32"); return true; }

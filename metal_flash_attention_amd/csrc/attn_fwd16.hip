@@ -22,6 +22,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = fwd16_lds_bytes<D>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_fwd16<T, D, NW, RB>;
 }
 

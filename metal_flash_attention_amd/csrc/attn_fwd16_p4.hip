@@ -19,27 +19,41 @@ template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char
   v->threads = 256;
   v->ldsBytes = v->ldsBytes > (uint32_t)p4::LDS_BYTES ? v->ldsBytes : (uint32_t)p4::LDS_BYTES;   // (siblings of the 8 x 32 kernel keep theirs)
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_p4<T, STREAM, false>;
   v->launchCausal = &launch_p4<T, STREAM, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, true>);
   v->causal = true;
 }
 
-// impl 0: product stream (deferred rescale THR = 8).  1: THR = 0, the reference's rule (+Softmax.swift:290-301).
-// Developer streams (only reachable with MFA_DEV_VARIANTS builds): 2 = 16 exp2 per tile moved into phase B, 3 = QK
-// accumulators in rotation, 4 = code placement pad.
+template <typename T, int STREAM> static void fill_p4_dev(VariantInfo *v, const char *name) {   // dense launches only
+  fill_p4<T, p4::S_BF16_THR8>(v, name);
+  v->func = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false>);
+  v->launch = &launch_p4<T, STREAM, false>;
+  v->launchCausal = nullptr; v->funcCausal = nullptr; v->causal = false;
+}
+
+// Product streams: impl 0 = scale applied in fp32 (exact S; selected when the descriptor keeps the attention matrix in
+// FP32 registers), impl 10 = FOLD (Q pre-multiplied by the softmax scale in the 16-bit type, the running maximum
+// subtracted inside the matrix pipe; selected with lowPrecisionIntermediates, where the reference itself holds P -- and
+// for FP16 also S -- in 16 bits), impl 1 = THR = 0 (the reference's rescale rule, +Softmax.swift:290-301, instead of the
+// deferred one).  Everything else is a developer stream (libmfa_hip_dev.so only): MFA_FWD16_IMPL=p4:<1000 + stream index>
+// for A/B placements, phase-clock stamps and timing-only ablations (tools/p4_prof.py lists the indices).
 bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out) {
   if (D != 128) return false;
   if (precision == PREC_BF16) {
     if (impl == 0) { fill_p4<__bf16, p4::S_BF16_THR8>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8"); return true; }
     if (impl == 1) { fill_p4<__bf16, p4::S_BF16_THR0>(out, "attn_fwd16p4_bf16_d128_w4x64_thr0"); return true; }
-    if (impl == 2) { fill_p4<__bf16, p4::S_BF16_THR8_XE16>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_xe16"); return true; }
-    if (impl == 3) { fill_p4<__bf16, p4::S_BF16_THR8_ROT>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_rot4"); return true; }
-    if (impl == 4) { fill_p4<__bf16, p4::S_BF16_THR8_PAD>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_pad"); return true; }
-    if (impl == 5) { fill_p4<__bf16, p4::S_BF16_THR8_PROF>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_PROF_CLOBBERS_O"); return true; }
+    if (impl == 10) { fill_p4<__bf16, p4::S_BF16_FOLD>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_fold"); return true; }
+#ifdef MFA_DEV_VARIANTS
+#define MFA_P4_DEV(name) if (impl == 1000 + p4::S_##name) { fill_p4_dev<__bf16, p4::S_##name>(out, "attn_fwd16p4_DEV_" #name); return true; }
+    MFA_P4_DEV_STREAM_LIST(MFA_P4_DEV)
+#undef MFA_P4_DEV
+#endif
   }
   if (precision == PREC_FP16) {
     if (impl == 0) { fill_p4<_Float16, p4::S_F16_THR8>(out, "attn_fwd16p4_f16_d128_w4x64_thr8"); return true; }
+    if (impl == 10) { fill_p4<_Float16, p4::S_F16_FOLD>(out, "attn_fwd16p4_f16_d128_w4x64_thr8_fold"); return true; }
   }
   return false;
 }

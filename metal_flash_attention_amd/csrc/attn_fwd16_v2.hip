@@ -21,6 +21,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = fwd16v2_lds_bytes<D, NW, RB>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_v2<T, D, NW, RB, THR, MSUM>;
 }
 

@@ -31,11 +31,12 @@ static void fill(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, RB, THR, PRE, ABL, RING, false, false, VD>);
   v->name = name;
   v->parallelization = NW * RB * 32;
-  v->traversal = 64;
+  v->traversal = 32;   // pipeline step: half a 64-key LDS tile (attn_fwd16_v3.h)
   v->headBlock = D;
   v->threads = NW * 64;
   v->ldsBytes = fwd16v3_lds_bytes<D, NW, RB, RING, VD>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_v3<T, D, NW, RB, THR, PRE, ABL, RING, VD>;
 }
 
@@ -95,6 +96,7 @@ static void fill_with_split(VariantInfo *v, const char *name) {
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   if (precision == PREC_BF16) {
     if (D == 128 && impl == 0) { fill_with_split<__bf16, 128, 8, 1, 8, 1, 3, 36>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"); return true; }
+#ifdef MFA_DEV_VARIANTS
     if (D == 128 && impl == 7) { fill<__bf16, 128, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8"); return true; }
     if (D == 128 && impl == 1) { fill<__bf16, 128, 8, 1, 8, 1>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek"); return true; }
     if (D == 128 && impl == 2) { fill<__bf16, 128, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prekv"); return true; }
@@ -105,11 +107,15 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 50) { fill<__bf16, 128, 8, 1, 8, 0, 20>(out, "ablate_no_lds_reads_WRONG_RESULTS"); return true; }
     if (D == 128 && impl == 51) { fill<__bf16, 128, 8, 1, 8, 0, 21>(out, "ablate_no_softmax_WRONG_RESULTS"); return true; }
     if (D == 128 && impl == 52) { fill<__bf16, 128, 8, 1, 8, 0, 22>(out, "ablate_no_lds_reads_no_softmax_WRONG_RESULTS"); return true; }
+#endif
     if (D == 64 && impl == 0) { fill_with_split<__bf16, 64, 8, 1, 8, 0>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8"); return true; }
+#ifdef MFA_DEV_VARIANTS
     if (D == 64 && impl == 2) { fill<__bf16, 64, 8, 1, 8, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_prekv"); return true; }
     if (D == 64 && impl == 41) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 2>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_kpad"); return true; }
+#endif
     if (D == 32 && impl == 0) { fill_with_split<__bf16, 32, 4, 1, 8, 0>(out, "attn_fwd16v3_bf16_d32_w4x32_thr8"); return true; }
     if (D == 256 && impl == 0) { fill_with_split<__bf16, 256, 4, 1, 8, 1, 2, 12>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_spread"); return true; }
+#ifdef MFA_DEV_VARIANTS
     if (D == 256 && impl == 8) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2, 36>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ldsdma_k3v2"); return true; }
     if (D == 256 && impl == 2) { fill<__bf16, 256, 4, 1, 8, 1, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2_prek"); return true; }
     if (D == 256 && impl == 1) { fill<__bf16, 256, 4, 1, 8, 0, 0, 2>(out, "attn_fwd16v3_bf16_d256_w4x32_thr8_ring2"); return true; }
@@ -119,6 +125,7 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 64 && impl == 5) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 8>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_wmid"); return true; }
     if (D == 64 && impl == 8) { fill<__bf16, 64, 8, 1, 8, 1, 0, 3, 36>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_ldsdma"); return true; }
     if (D == 128 && impl == 3) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 4>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe"); return true; }
+#endif
   }
   if (precision == PREC_FP16) {
     if (D == 128 && impl == 0) { fill_with_split<_Float16, 128, 8, 1, 8, 1, 3, 36>(out, "attn_fwd16v3_f16_d128_w8x32_thr8_ldsdma"); return true; }

@@ -35,6 +35,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = 512;
   v->ldsBytes = fwd16v2_lds_bytes<D, 8, 1, RING>();
   v->cacheLeft = true;
+  v->cacheSecond = true;
   v->launch = &launch_v4<T, D, THR, OPT, RING>;
   if constexpr (FULL) {
     v->launchSplit = &launch_v4_split<T, D, THR, OPT, RING>;

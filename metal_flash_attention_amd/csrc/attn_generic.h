@@ -194,11 +194,13 @@ constexpr int generic_max(int a, int b) { return a > b ? a : b; }
 template <int DP, int NW, bool CACHE> constexpr int generic_fwd_lds_floats() {
   return CACHE ? generic_max(NW * 32, 64) * (DP + 1) : (NW * 32 + 64) * (DP + 1);
 }
-template <int DP, int NW, bool CACHE> constexpr int generic_dq_lds_floats() {
-  return CACHE ? generic_max(NW * 32, 64) * (DP + 1) : (2 * NW * 32 + 64) * (DP + 1);
+// QONLY (dQ): Q cached in registers, dO left in LDS; SEQ (dK/dV): Q and dO tiles share ONE LDS buffer (staged in turn) --
+// the two arrangements that let a 32-row block of a 384-wide head fit the 160 KiB of LDS and the 512 registers
+template <int DP, int NW, bool CACHE, bool QONLY = false> constexpr int generic_dq_lds_floats() {
+  return CACHE ? generic_max(NW * 32, 64) * (DP + 1) : QONLY ? (NW * 32 + 64) * (DP + 1) : (2 * NW * 32 + 64) * (DP + 1);
 }
-template <int DP, int NW, bool CACHE> constexpr int generic_dkv_lds_floats() {
-  return (CACHE ? generic_max(NW * 32, 64) * (DP + 1) : (2 * NW * 32 + 64) * (DP + 1)) + 64;
+template <int DP, int NW, bool CACHE, bool SEQ = false> constexpr int generic_dkv_lds_floats() {
+  return (CACHE ? generic_max(NW * 32, 64) * (DP + 1) : SEQ ? (2 * NW * 32 + 32) * (DP + 1) : (2 * NW * 32 + 64) * (DP + 1)) + 64;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -348,8 +350,9 @@ __global__ __launch_bounds__(NW * 64, (DP <= 128 ? 2 : 1)) void attn_generic_fwd
 // ----------------------------------------------------------------------------------------------
 // backward dQ: D = rowsum(dO*O)/sqrt(D); dQ = sum_c dS K                (+Source.swift:202-242)
 // ----------------------------------------------------------------------------------------------
-template <int DP, int NW, bool CACHE, bool MASKED = false>
+template <int DP, int NW, bool CACHE, bool MASKED = false, bool QONLY = false>
 __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
+  static_assert(!(CACHE && QONLY), "QONLY: Q cached, dO streamed from LDS");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1, BR = NW * 32, BC = 32, NT = NW * 64, NDB = DP / 32, NS = DP / 2;
   const int tid = threadIdx.x;
@@ -362,17 +365,18 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   batch_lengths(a, batch, R, C);
   const int64_t row = r0 + wave * 32 + q;
 
+  constexpr bool QC = CACHE || QONLY;   // Q fragments live in registers
   float *Qs = smem;
-  float *dOs = CACHE ? smem : smem + BR * LD;
-  float *Ks = CACHE ? smem : smem + 2 * BR * LD;
+  float *dOs = QC ? smem : smem + BR * LD;                           // QONLY: dO takes the place of Q once Q is cached
+  float *Ks = CACHE ? smem : QONLY ? smem + BR * LD : smem + 2 * BR * LD;
   float *Vs = Ks + BC * LD;
 
-  float qf[CACHE ? NS : 1], gf[CACHE ? NS : 1];
+  float qf[QC ? NS : 1], gf[CACHE ? NS : 1];
   const float *qrow = Qs + (wave * 32 + q) * LD + hi;
   const float *grow = dOs + (wave * 32 + q) * LD + hi;
   stage_tile<BR, DP, NT>(Qs, a.op[SLOT_Q], operand_base(a.op[SLOT_Q], head, batch), r0, R, D, tid);
   __syncthreads();
-  if constexpr (CACHE) {
+  if constexpr (QC) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) qf[s] = qrow[2 * s];
     __syncthreads();
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
     const float *krow = Ks + q * LD + hi;
     const float *vrow = Vs + q * LD + hi;
 #pragma unroll
-    for (int t = 0; t < NS; ++t) s = mfma_f32(krow[2 * t], CACHE ? qf[t] : qrow[2 * t], s);      // S^T = K Q^T
+    for (int t = 0; t < NS; ++t) s = mfma_f32(krow[2 * t], QC ? qf[t] : qrow[2 * t], s);         // S^T = K Q^T
 #pragma unroll
     for (int t = 0; t < NS; ++t) dp = mfma_f32(vrow[2 * t], CACHE ? gf[t] : grow[2 * t], dp);    // dP^T = V dO^T
     // P = exp2(S*scale2 - L); dS = P * (dP*scale - D)     (+Softmax.swift:409-427)
@@ -485,8 +489,9 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
 //                                                                      (+Source.swift:244-293)
 // grid = (ceil(C / (32*NW)), heads, batches)
 // ----------------------------------------------------------------------------------------------
-template <int DP, int NW, bool CACHE, bool MASKED = false>
+template <int DP, int NW, bool CACHE, bool MASKED = false, bool SEQ = false>
 __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) {
+  static_assert(!(CACHE && SEQ), "SEQ: K and V stay in LDS, Q and dO tiles take turns in one buffer");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DP + 1, BCOL = NW * 32, BRW = 32, NT = NW * 64, NDB = DP / 32, NS = DP / 2;
   const int tid = threadIdx.x;
@@ -501,8 +506,8 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   float *Kst = smem;                                  // [BCOL][LD]
   float *Vst = CACHE ? smem : smem + BCOL * LD;       // [BCOL][LD]
   float *Qs = CACHE ? smem : smem + 2 * BCOL * LD;    // [32][LD]
-  float *dOs = Qs + BRW * LD;                         // [32][LD]
-  float *LDs = smem + generic_dkv_lds_floats<DP, NW, CACHE>() - 64;  // L[32], D[32]
+  float *dOs = SEQ ? Qs : Qs + BRW * LD;              // [32][LD]  (SEQ: the same buffer, staged in turn)
+  float *LDs = smem + generic_dkv_lds_floats<DP, NW, CACHE, SEQ>() - 64;  // L[32], D[32]
 
   float kf[CACHE ? NS : 1], vf[CACHE ? NS : 1];
   const float *krow = Kst + (wave * 32 + kc) * LD + hi;
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   // causal extension: rows above the workgroup's first column minus the offset see none of its columns
   const int coff = C - R;
   const int rstart = a.causal ? (int)(max((int64_t)0, c0 - coff) / BRW) * BRW : 0;
-  constexpr bool CAN_PREFETCH = (DP <= 128);
+  constexpr bool CAN_PREFETCH = (DP <= 128) && !SEQ;
   const uint32_t *mbase = MASKED ? mask_base(a, head, batch) : nullptr;
   const bool prefetch = !MASKED && CAN_PREFETCH && f32_fast_path(a.op[SLOT_Q], qbase, D) && f32_fast_path(a.op[SLOT_dO], gbase, D);
   TileRegsF32<BRW, DP, NT> qregs, gregs;
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
       tile_store_f32<BRW, DP, NT>(dOs, gregs, tid);
     } else {
       stage_tile<BRW, DP, NT>(Qs, a.op[SLOT_Q], qbase, r0, R, D, tid);
-      stage_tile<BRW, DP, NT>(dOs, a.op[SLOT_dO], gbase, r0, R, D, tid);
+      if constexpr (!SEQ) stage_tile<BRW, DP, NT>(dOs, a.op[SLOT_dO], gbase, r0, R, D, tid);
     }
     if (tid < 64) { // L and D slices along the traversal dimension (+Softmax.swift:356-381, :472-503)
       const int rr = tid & 31;
@@ -575,6 +580,11 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
     const float *gr = dOs + kc * LD + hi;
 #pragma unroll
     for (int t = 0; t < NS; ++t) s = mfma_f32(qr[2 * t], CACHE ? kf[t] : krow[2 * t], s);
+    if constexpr (SEQ) {   // Q has been multiplied: dO takes its place in the shared buffer
+      __syncthreads();
+      stage_tile<BRW, DP, NT>(dOs, a.op[SLOT_dO], gbase, r0, R, D, tid);
+      __syncthreads();
+    }
 #pragma unroll
     for (int t = 0; t < NS; ++t) dp = mfma_f32(gr[2 * t], CACHE ? vf[t] : vrow[2 * t], dp);   // dP = dO V^T
     f32x16 p;
@@ -587,14 +597,32 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
       s[r] = p[r] * (dp[r] * a.scale - Dr);
     }
     // dV^T += dO^T P ; dK^T += Q^T dS   (row index permuted; padded rows of Q/dO are zero)
+    if constexpr (!SEQ) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const float *g2 = dOs + crow(t, hi) * LD + kc;
-      const float *q2 = Qs + crow(t, hi) * LD + kc;
+      for (int t = 0; t < 16; ++t) {
+        const float *g2 = dOs + crow(t, hi) * LD + kc;
+        const float *q2 = Qs + crow(t, hi) * LD + kc;
 #pragma unroll
-      for (int db = 0; db < NDB; ++db) {
-        dv[db] = mfma_f32(g2[32 * db], p[t], dv[db]);
-        dk[db] = mfma_f32(q2[32 * db], s[t], dk[db]);
+        for (int db = 0; db < NDB; ++db) {
+          dv[db] = mfma_f32(g2[32 * db], p[t], dv[db]);
+          dk[db] = mfma_f32(q2[32 * db], s[t], dk[db]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float *g2 = dOs + crow(t, hi) * LD + kc;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) dv[db] = mfma_f32(g2[32 * db], p[t], dv[db]);
+      }
+      __syncthreads();   // dO has been multiplied: Q returns for the dK product
+      stage_tile<BRW, DP, NT>(Qs, a.op[SLOT_Q], qbase, r0, R, D, tid);
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float *q2 = Qs + crow(t, hi) * LD + kc;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) dk[db] = mfma_f32(q2[32 * db], s[t], dk[db]);
       }
     }
     __syncthreads();

@@ -5,32 +5,33 @@
 
 namespace mfa {
 
-template <int DP, int NW, bool CACHE>
+template <int DP, int NW, bool CACHE, bool X = false>
 static void launch_dkv(dim3 grid, hipStream_t stream, const KernelArgs &args) {
-  constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
-  hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE>), grid, dim3(NW * 64), lds, stream, args);
+  constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE, X>() * sizeof(float);
+  hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE, false, X>), grid, dim3(NW * 64), lds, stream, args);
 }
 
-template <int DP, int NW, bool CACHE>
+template <int DP, int NW, bool CACHE, bool X = false>
 static void launch_dkv_masked(dim3 grid, hipStream_t stream, const KernelArgs &args) {
-  constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
-  hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE, true>), grid, dim3(NW * 64), lds, stream, args);
+  constexpr uint32_t lds = generic_dkv_lds_floats<DP, NW, CACHE, X>() * sizeof(float);
+  hipLaunchKernelGGL((attn_generic_dkv<DP, NW, CACHE, true, X>), grid, dim3(NW * 64), lds, stream, args);
 }
 
-template <int DP, int NW, bool CACHE>
+template <int DP, int NW, bool CACHE, bool X = false>
 static void fill(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_generic_dkv<DP, NW, CACHE>);
+  v->func = reinterpret_cast<const void *>(&attn_generic_dkv<DP, NW, CACHE, false, X>);
   v->name = name;
   v->parallelization = NW * 32;
   v->traversal = 32;
   v->headBlock = DP;
   v->threads = NW * 64;
-  v->ldsBytes = generic_dkv_lds_floats<DP, NW, CACHE>() * sizeof(float);
+  v->ldsBytes = generic_dkv_lds_floats<DP, NW, CACHE, X>() * sizeof(float);
   v->cacheLeft = CACHE;
+  v->cacheSecond = CACHE;
   v->causal = true;
-  v->launchSparse = &launch_dkv_masked<DP, NW, CACHE>;   // block mask: own code objects
-  v->funcSparse = reinterpret_cast<const void *>(&attn_generic_dkv<DP, NW, CACHE, true>);
-  v->launch = &launch_dkv<DP, NW, CACHE>;
+  v->launchSparse = &launch_dkv_masked<DP, NW, CACHE, X>;   // block mask: own code objects
+  v->funcSparse = reinterpret_cast<const void *>(&attn_generic_dkv<DP, NW, CACHE, true, X>);
+  v->launch = &launch_dkv<DP, NW, CACHE, X>;
 }
 
 bool generic_dkv_variant(int DP, VariantInfo *out) {
@@ -39,6 +40,7 @@ bool generic_dkv_variant(int DP, VariantInfo *out) {
     case 64:  fill<64, 4, true>(out, "attn_generic_dkv_f32mfma_d64_w4_cached"); return true;
     case 128: fill<128, 4, true>(out, "attn_generic_dkv_f32mfma_d128_w4_cached"); return true;   // (2 waves per workgroup, i.e. half the LDS and twice the workgroups per CU: 10-15 % slower, measured)
     case 256: fill<256, 4, true>(out, "attn_generic_dkv_f32mfma_d256_w4_cached"); return true;
+    case 384: fill<384, 1, false, true>(out, "attn_generic_dkv_f32mfma_d384_w1_streamed"); return true;
     default: return false;
   }
 }

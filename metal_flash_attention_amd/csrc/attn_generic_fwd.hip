@@ -27,6 +27,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->threads = NW * 64;
   v->ldsBytes = generic_fwd_lds_floats<DP, NW, CACHE>() * sizeof(float);
   v->cacheLeft = CACHE;
+  v->cacheSecond = CACHE;
   v->causal = true;
   v->launchSparse = &launch_fwd_masked<DP, NW, CACHE>;   // block mask: own code objects
   v->funcSparse = reinterpret_cast<const void *>(&attn_generic_fwd<DP, NW, CACHE, true>);
@@ -39,6 +40,8 @@ bool generic_fwd_variant(int DP, VariantInfo *out) {
     case 64:  fill<64, 4, true>(out, "attn_generic_fwd_f32mfma_d64_w4_cached"); return true;
     case 128: fill<128, 4, true>(out, "attn_generic_fwd_f32mfma_d128_w4_cached"); return true;   // (2 waves per workgroup, i.e. half the LDS and twice the workgroups per CU: 10-15 % slower, measured)
     case 256: fill<256, 4, true>(out, "attn_generic_fwd_f32mfma_d256_w4_cached"); return true;
+    // D <= 384: two waves per workgroup (64 rows x 385 floats of LDS staging), 192 registers of O and 192 of Q per lane
+    case 384: fill<384, 2, true>(out, "attn_generic_fwd_f32mfma_d384_w2_cached"); return true;
     default: return false;
   }
 }

@@ -13,6 +13,7 @@ struct VariantInfo {
   uint32_t threads = 0;         // work-items per workgroup
   uint32_t ldsBytes = 0;        // dynamic LDS
   bool cacheLeft = false;       // left-hand operands cached in VGPRs (Q / Q,dO / K,V)
+  bool cacheSecond = false;     // the second of them alone (dO / V); fill code sets it = cacheLeft unless a variant splits the pair
   bool causal = false;          // the code object implements the causal mask itself (general kernels: always)
   void (*launch)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
   // forward only: column-parallel launch (key range cut into `splits` pieces, partial results in the

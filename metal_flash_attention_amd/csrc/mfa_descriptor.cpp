@@ -33,38 +33,53 @@ mfa_status fail(mfa_status status, const std::string &message) {
 // gfx950 parameter tables.  Columns (AttentionDescriptor+Parameters.swift:106-148):
 //   | max D | parallelization | traversal | head | cached operands |
 // parallelization = rows (fwd, dQ) / columns (dK/dV) per workgroup; a multiple of 32 because one
-// wave owns one 32x32 MFMA tile.  traversal = columns (rows) consumed per main-loop step.
-// head = width of the head-dimension block the inner loops are unrolled over.
-// "FP32" tables drive the fp32-MFMA kernels; "mixed" tables drive the 16-bit MFMA kernels.
+// wave owns one 32x32 MFMA tile.  traversal = columns (rows) consumed per main-loop (pipeline) step.
+// head = head-dimension block the code object is unrolled over.  "FP32" tables list the fp32-arithmetic
+// kernels (attn_generic.h), "mixed" tables the 16-bit matrix-core kernels (attn_fwd16_p4.h, attn_fwd16_v3.h,
+// attn_bwd16.h, attn_dkv16_rs.h).  Every row below IS a compiled code object: mfa_attention_kernel_create matches
+// the row against the variants (tests/test_host_api.py::test_default_table_rows_are_compiled_variants keeps the two
+// from drifting apart); a row no variant implements falls back to the nearest one, or fails with
+// strictBlockDimensions.  Accumulators stay in registers at every supported D (512 registers per lane); the 384 rows are
+// the gfx950 form of the reference's large-D rows (+Parameters.swift:77-285): what gets evicted first there -- the
+// left-hand operands -- is what leaves the registers here too (dO, then K and V), the accumulators never do.
 // ---------------------------------------------------------------------------------------------
 static const char *kDefaultTables[3][2] = {
     {// forward, FP32
      "| 32  | 128 | 32 | 32  | Q, O |\n"
      "| 64  | 128 | 32 | 64  | Q, O |\n"
      "| 128 | 128 | 32 | 128 | Q, O |\n"
-     "| 256 | 128 | 32 | 256 | Q, O |\n",
-     // forward, mixed
-     "| 64  | 256 | 64 | 64  | Q, O |\n"
+     "| 256 | 128 | 32 | 256 | Q, O |\n"
+     "| 384 | 64  | 32 | 384 | Q, O |\n",
+     // forward, mixed: D <= 128 -> 4 waves x 64 rows, 64-key steps (attn_fwd16_p4.h); | 128 | 256 | 32 | 128 | selects the
+     // 8 waves x 32 rows kernel with 32-key pipeline steps (attn_fwd16_v3.h), which also serves the other buckets
+     "| 32  | 128 | 32 | 32  | Q, O |\n"
+     "| 64  | 256 | 32 | 64  | Q, O |\n"
      "| 128 | 256 | 64 | 128 | Q, O |\n"
-     "| 256 | 128 | 64 | 64  | O    |\n"},
+     "| 256 | 128 | 32 | 256 | Q, O |\n"
+     "| 384 | 64  | 32 | 384 | Q, O |\n"},
     {// backwardQuery, FP32
      "| 32  | 128 | 32 | 32  | Q, dO, dQ |\n"
      "| 64  | 128 | 32 | 64  | Q, dO, dQ |\n"
      "| 128 | 128 | 32 | 128 | Q, dO, dQ |\n"
-     "| 256 | 32  | 32 | 256 | dQ        |\n",
+     "| 256 | 128 | 32 | 256 | Q, dO, dQ |\n"
+     "| 384 | 32  | 32 | 384 | Q, dQ     |\n",
      // backwardQuery, mixed
-     "| 64  | 128 | 64 | 64  | Q, dO, dQ |\n"
-     "| 128 | 128 | 64 | 128 | Q, dO, dQ |\n"
-     "| 256 | 64  | 64 | 64  | dQ        |\n"},
+     "| 64  | 256 | 64 | 64  | Q, dO, dQ |\n"
+     "| 128 | 256 | 64 | 128 | Q, dO, dQ |\n"
+     "| 256 | 128 | 64 | 256 | Q, dO, dQ |\n"
+     "| 384 | 32  | 32 | 384 | Q, dQ     |\n"},
     {// backwardKeyValue, FP32
      "| 32  | 128 | 32 | 32  | K, V, dV, dK |\n"
      "| 64  | 128 | 32 | 64  | K, V, dV, dK |\n"
      "| 128 | 128 | 32 | 128 | K, V, dV, dK |\n"
-     "| 256 | 32  | 32 | 256 | dV, dK       |\n",
-     // backwardKeyValue, mixed
-     "| 64  | 128 | 64 | 64  | K, V, dV, dK |\n"
-     "| 128 | 128 | 64 | 128 | K, V, dV, dK |\n"
-     "| 256 | 64  | 64 | 64  | dV, dK       |\n"}};
+     "| 256 | 128 | 32 | 256 | K, V, dV, dK |\n"
+     "| 384 | 32  | 32 | 384 | dV, dK       |\n",
+     // backwardKeyValue, mixed: role-split wave pairs (attn_dkv16_rs.h); | 128 | 128 | 64 | 128 | selects the one-wave-per-
+     // key-block kernel (attn_bwd16.h)
+     "| 64  | 128 | 32 | 64  | K, V, dV, dK |\n"
+     "| 128 | 128 | 32 | 128 | K, V, dV, dK |\n"
+     "| 256 | 64  | 32 | 256 | K, V, dV, dK |\n"
+     "| 384 | 32  | 32 | 384 | dV, dK       |\n"}};
 
 static std::mutex g_table_mutex;
 static std::string g_tables[3][2];
@@ -352,12 +367,16 @@ mfa_status mfa_attention_descriptor_kernel_descriptor(const mfa_attention_descri
   if (desc->row == 0 || desc->column == 0 || desc->head == 0)
     return fail(MFA_ERR_INVALID_ARGUMENT, "matrixDimensions must be non-zero");
 
-  // parameterFile(type:) -- mixed tables only when BOTH flags are set (+Parameters.swift:16)
+  // parameterFile(type:).  The reference takes its mixed tables only when BOTH flags are set (+Parameters.swift:16):
+  // there the tables follow the REGISTER footprint, which FP16 intermediates halve.  On gfx950 S, P and every
+  // accumulator are fp32 registers whatever the flags say (MFMA results), and what changes the kernel -- 16-bit
+  // matrix-core code objects instead of the fp32-arithmetic ones -- is the storage type of Q, K, V: the mixed tables
+  // list the block dimensions of the 16-bit code objects, so they are taken whenever the inputs are 16-bit.
   std::string file;
   {
     std::lock_guard<std::mutex> lock(g_table_mutex);
     ensure_tables();
-    const int mixed = (desc->lowPrecisionInputs && desc->lowPrecisionIntermediates) ? 1 : 0;
+    const int mixed = desc->lowPrecisionInputs ? 1 : 0;
     file = g_tables[type][mixed];
   }
   mfa_parameter_row row;

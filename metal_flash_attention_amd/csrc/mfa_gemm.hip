@@ -156,7 +156,11 @@ static hipError_t launch16(bool big, const GemmArgs &g, dim3 grid, hipStream_t s
   hipError_t e;
   // LDS-DMA staging for launches made of whole, 16-byte aligned chunks (MFA_GEMM_IMPL=vgpr: developer knob that
   // forces the register-staged kernel, which also serves every other launch)
+#ifdef MFA_DEV_VARIANTS
   static const bool dmaKnob = !(std::getenv("MFA_GEMM_IMPL") && std::strcmp(std::getenv("MFA_GEMM_IMPL"), "vgpr") == 0);
+#else
+  constexpr bool dmaKnob = true;
+#endif
   const bool aligned = (g.K & 7) == 0 && (g.ldA & 7) == 0 && (g.ldB & 7) == 0 && (g.bsA & 7) == 0 && (g.bsB & 7) == 0 &&
                        ((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0;
   if (big && dmaKnob && aligned) {

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "launchers.h"
 #include "mfa_internal.h"
@@ -48,7 +49,7 @@ static bool slot_used(int type, int slot) {
 }
 
 static int generic_bucket(int D) {
-  static const int buckets[] = {32, 64, 128, 256};
+  static const int buckets[] = {32, 64, 128, 256, 384};
   for (int b : buckets)
     if (D <= b) return b;
   return -1;
@@ -77,8 +78,12 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       return fail(MFA_ERR_INCOMPLETE_DESCRIPTOR, std::string("Transpose state of ") + mfa_operand_name(op) + " was not specified.");
   }
 
-  VariantInfo variant, general;
-  bool found = false, fast = false;
+  // ---- candidates: every compiled code object that can serve this descriptor.  The general (fp32-arithmetic) kernel
+  // of the head-dimension bucket always can; the matrix-core kernels need Q, K, V (and dO) in ONE 16-bit type, nothing
+  // transposed, outputs in FP32 or the inputs' type, and a head dimension that is a multiple of 8 (16-byte chunks).
+  VariantInfo general;
+  std::vector<VariantInfo> candidates;   // matrix-core candidates, the product default first
+  bool found = false;
   const int D = kdesc->headDimension;
   const int bucket = generic_bucket(D);
   if (bucket > 0) {
@@ -88,63 +93,118 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       default: found = generic_dkv_variant(bucket, &general); break;
     }
   }
-  // 16-bit matrix-core path: Q, K, V stored in ONE 16-bit type, nothing transposed, O in FP32,
-  // head dimension a multiple of 8 (16-byte chunks).
-  if (found && type == MFA_FORWARD) {
-    const int pq = kdesc->memoryPrecisions[MFA_Q];
-    const bool same = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
-    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
-                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
-    const int po = kdesc->memoryPrecisions[MFA_O];   // FP32, or the inputs' 16-bit type (fused output cast)
-    if (same && rowMajor && (po == MFA_FP32 || po == pq) && (D % 8) == 0) {
-      // MFA_FWD16_IMPL (developer knob for A/B runs): "v1" = unpipelined kernel, "v2:<n>" = full-tile
-      // pipeline schedule n, "v3:<n>" = half-tile pipeline schedule n.  Default: v3 schedule 0.
-      const char *knob = std::getenv("MFA_FWD16_IMPL");
-      bool wantV1 = knob && std::strcmp(knob, "v1") == 0;
-      if (knob && std::strncmp(knob, "v2:", 3) == 0) fast = fwd16_v2_variant(pq, bucket, std::atoi(knob + 3), &variant);
-      else if (knob && std::strncmp(knob, "v3:", 3) == 0) fast = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &variant);
-      else if (knob && std::strncmp(knob, "v4:", 3) == 0) fast = fwd16_v4_variant(pq, bucket, std::atoi(knob + 3), &variant);
-      else if (knob && std::strncmp(knob, "p4:", 3) == 0) {
-        fast = fwd16_v3_variant(pq, bucket, 0, &variant) && fwd16_p4_variant(pq, bucket, std::atoi(knob + 3), &variant);
-      }
-      else if (!wantV1) {
-        fast = fwd16_v3_variant(pq, bucket, 0, &variant);
-        if (fast && bucket == 128) fwd16_p4_variant(pq, bucket, 0, &variant);   // keeps v3's split / sparse siblings
-      }
-      if (!fast) fast = fwd16_variant(pq, bucket, &variant);
-    }
-  }
-  // 16-bit matrix-core backward kernels: additionally dO in the same 16-bit type and FP32 outputs
-  if (found && type != MFA_FORWARD && std::getenv("MFA_BWD16_DISABLE") == nullptr) {
-    const int pq = kdesc->memoryPrecisions[MFA_Q];
-    const int pg = kdesc->memoryPrecisions[MFA_dO];
-    const bool same = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] &&
-                      pq == kdesc->memoryPrecisions[MFA_V] && pg != MFA_FP32;
-    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
-                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
-    if (same && rowMajor && (D % 8) == 0) {
-      const int bucket16 = bucket < 64 ? 64 : bucket;   // the backward pair starts at D = 64 (smaller heads are zero-padded)
-      auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
-      if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ) &&
-          !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
-        fast = dq16_variant(pq, pg, bucket16, &variant);
-      if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
-          kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV] &&
-          !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV])
-      {
-        // MFA_DKV16_IMPL (developer knob for A/B runs): "w4" = one wave per key block (attn_dkv16), "rs:<n>" =
-        // role-split wave pairs, ablation n.  Default: role-split wave pairs (attn_dkv16_rs).
-        const char *knob = std::getenv("MFA_DKV16_IMPL");
-        const bool wantW4 = knob && (std::strcmp(knob, "w4") == 0 || knob[0] == '0');
-        if (!wantW4) fast = dkv16_rs_variant(pq, pg, bucket16, (knob && std::strncmp(knob, "rs:", 3) == 0) ? std::atoi(knob + 3) : 0, &variant);
-        if (!fast) fast = dkv16_variant(pq, pg, bucket16, &variant);
-      }
-    }
-  }
-  if (found && !fast) variant = general;
   if (!found)
     return fail(MFA_ERR_UNSUPPORTED, "no gfx950 code object for head dimension " + std::to_string(D) +
-                                         " (this build supports D <= 256)");
+                                         " (this build supports D <= 384)");
+  const int pq = kdesc->memoryPrecisions[MFA_Q];
+  const bool same16 = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
+  auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
+  auto add = [&](bool ok, const VariantInfo &v) { if (ok) candidates.push_back(v); };
+  VariantInfo v;
+  if (type == MFA_FORWARD) {
+    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
+                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
+    if (same16 && rowMajor && f32_or_inputs(MFA_O) && (D % 8) == 0) {
+      VariantInfo v3;
+      const bool have3 = fwd16_v3_variant(pq, bucket, 0, &v3);
+      if (have3 && bucket == 128) {
+        // four waves x 64 rows, hand-placed stream (attn_fwd16_p4.h); split / block-sparse launches keep the siblings of
+        // the 8 x 32 kernel.  A descriptor that holds the attention matrix in 16-bit registers (the reference's
+        // lowPrecisionIntermediates: P, and for FP16 also S, +Precisions.swift:149-215) selects the stream that
+        // pre-multiplies Q by the softmax scale in the 16-bit type; otherwise the scale is applied in fp32 per score
+        const bool lowS = kdesc->registerPrecisions[MFA_P] > MFA_FP32;
+        v = v3;
+        add(fwd16_p4_variant(pq, bucket, lowS ? 10 : 0, &v), v);
+      }
+      add(have3, v3);
+    }
+  } else {
+    const int pg = kdesc->memoryPrecisions[MFA_dO];
+    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
+                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
+    if (same16 && pg != MFA_FP32 && rowMajor && (D % 8) == 0) {
+      const int bucket16 = bucket < 64 ? 64 : bucket;   // the backward pair starts at D = 64 (smaller heads are zero-padded)
+      if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ) &&
+          !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
+        add(dq16_variant(pq, pg, bucket16, &v), v);
+      if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
+          kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV] &&
+          !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV]) {
+        add(dkv16_rs_variant(pq, pg, bucket16, 0, &v), v);   // role-split wave pairs (attn_dkv16_rs.h)
+        add(dkv16_variant(pq, pg, bucket16, &v), v);          // one wave per key block (attn_bwd16.h)
+      }
+    }
+  }
+#ifdef MFA_DEV_VARIANTS
+  // Developer builds only (make DEV=1 -> libmfa_hip_dev.so): environment knobs for A/B runs and timing-only ablations.
+  // The product library contains neither this code nor the code objects it selects.
+  {
+    VariantInfo dev;
+    bool have = false;
+    const char *knob = std::getenv("MFA_FWD16_IMPL");
+    if (type == MFA_FORWARD && knob && !candidates.empty()) {
+      if (std::strcmp(knob, "v1") == 0) have = fwd16_variant(pq, bucket, &dev);
+      else if (std::strncmp(knob, "v2:", 3) == 0) have = fwd16_v2_variant(pq, bucket, std::atoi(knob + 3), &dev);
+      else if (std::strncmp(knob, "v3:", 3) == 0) have = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &dev);
+      else if (std::strncmp(knob, "v4:", 3) == 0) have = fwd16_v4_variant(pq, bucket, std::atoi(knob + 3), &dev);
+      else if (std::strncmp(knob, "p4:", 3) == 0) have = fwd16_v3_variant(pq, bucket, 0, &dev) && fwd16_p4_variant(pq, bucket, std::atoi(knob + 3), &dev);
+    }
+    knob = std::getenv("MFA_DKV16_IMPL");
+    if (type == MFA_BACKWARD_KEY_VALUE && knob && !candidates.empty()) {
+      const int pg = kdesc->memoryPrecisions[MFA_dO], bucket16 = bucket < 64 ? 64 : bucket;
+      if (std::strcmp(knob, "w4") == 0) have = dkv16_variant(pq, pg, bucket16, &dev);
+      else if (std::strncmp(knob, "rs:", 3) == 0) have = dkv16_rs_variant(pq, pg, bucket16, std::atoi(knob + 3), &dev);
+    }
+    if (type != MFA_FORWARD && std::getenv("MFA_BWD16_DISABLE")) candidates.clear();
+    if (have) { candidates.clear(); candidates.push_back(dev); }
+  }
+#endif
+
+  // ---- the parameter-table row decides among the candidates (AttentionDescriptor.swift:37-54 ->
+  // AttentionKernel.swift:27-50: in the reference blockDimensions and cacheState ARE the kernel).  Exact match on
+  // (parallelization, traversal, head block, cached left-hand operands) wins; otherwise the nearest candidate serves
+  // the launch and mfa_attention_kernel_effective_descriptor reports what it really does -- unless the descriptor
+  // asks for strictBlockDimensions, in which case an unmatched row is an error.
+  // (the general kernel is not a candidate next to matrix-core variants: its block dimensions coincide with some of theirs,
+  // and a table edit must not silently move a 16-bit problem onto fp32 arithmetic; it serves the launches they cannot)
+  const bool fast = !candidates.empty();
+  if (!fast) candidates.push_back(general);
+  uint16_t wantHead = 0;   // the smallest compiled head block that holds the requested one
+  for (const VariantInfo &c : candidates)
+    if (c.headBlock >= kdesc->headBlock && (wantHead == 0 || c.headBlock < wantHead)) wantHead = c.headBlock;
+  // left-hand operands of the kernel type: (first, second) = (Q, -) / (Q, dO) / (K, V)
+  const int firstLeft = type == MFA_BACKWARD_KEY_VALUE ? MFA_K : MFA_Q;
+  const int secondLeft = type == MFA_FORWARD ? MFA_Q : type == MFA_BACKWARD_QUERY ? MFA_dO : MFA_V;
+  auto accumulators_cached_requested = [&]() {
+    switch (type) {
+      case MFA_FORWARD: return kdesc->cacheState[MFA_O] != 0;
+      case MFA_BACKWARD_QUERY: return kdesc->cacheState[MFA_dQ] != 0;
+      default: return kdesc->cacheState[MFA_dK] != 0 && kdesc->cacheState[MFA_dV] != 0;
+    }
+  };
+  auto distance = [&](const VariantInfo &c) {
+    int d = 0;
+    if (c.headBlock != wantHead) d += 8;
+    if (c.parallelization != kdesc->parallelization) d += 4;
+    if (c.traversal != kdesc->traversal) d += 2;
+    if (c.cacheLeft != (kdesc->cacheState[firstLeft] != 0)) d += 1;
+    if (type != MFA_FORWARD && c.cacheSecond != (kdesc->cacheState[secondLeft] != 0)) d += 1;
+    if (!accumulators_cached_requested()) d += 1;   // accumulators never leave the registers on gfx950 (D <= 256)
+    return d;
+  };
+  size_t best = 0;
+  for (size_t i = 1; i < candidates.size(); ++i)
+    if (distance(candidates[i]) < distance(candidates[best])) best = i;
+  if (kdesc->strictBlockDimensions && distance(candidates[best]) != 0) {
+    std::string have;
+    for (const VariantInfo &c : candidates)
+      have += " (" + std::to_string(c.parallelization) + ", " + std::to_string(c.traversal) + ", " + std::to_string(c.headBlock) +
+              (c.cacheLeft ? ", left operands cached)" : ", left operands streamed)");
+    return fail(MFA_ERR_UNSUPPORTED, "no code object implements block dimensions (" + std::to_string(kdesc->parallelization) + ", " +
+                                         std::to_string(kdesc->traversal) + ", " + std::to_string(kdesc->headBlock) +
+                                         ") with the requested cache state; compiled (parallelization, traversal, head):" + have);
+  }
+  const VariantInfo variant = candidates[best];
 
   mfa_attention_kernel *kernel = new mfa_attention_kernel();
   kernel->desc = *kdesc;
@@ -162,11 +222,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       kernel->effective.cacheState[MFA_O] = 1;
       break;
     case MFA_BACKWARD_QUERY:
-      kernel->effective.cacheState[MFA_Q] = kernel->effective.cacheState[MFA_dO] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_Q] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_dO] = variant.cacheSecond;
       kernel->effective.cacheState[MFA_dQ] = 1;
       break;
     default:
-      kernel->effective.cacheState[MFA_K] = kernel->effective.cacheState[MFA_V] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_K] = variant.cacheLeft;
+      kernel->effective.cacheState[MFA_V] = variant.cacheSecond;
       kernel->effective.cacheState[MFA_dK] = kernel->effective.cacheState[MFA_dV] = 1;
       break;
   }

@@ -25,7 +25,9 @@ _KERNELS: Dict[Tuple, AttentionKernel] = {}
 
 
 def _kernel(dtype: torch.dtype, R: int, C: int, D: int, kind: AttentionKernelType) -> AttentionKernel:
-    key = (dtype, R, C, D, kind)
+    # a kernel object depends on (precisions, head dimension, type) only -- the sequence lengths are launch parameters
+    # (mfa_launch_params.row / .column), so the cache is bounded by the handful of head dimensions a model uses
+    key = (dtype, D, kind)
     k = _KERNELS.get(key)
     if k is None:
         desc = AttentionDescriptor()
@@ -47,6 +49,18 @@ def _check(q, k, v):
         raise TypeError("flash_attention: q, k, v must share one of bfloat16 / float16 / float32")
     if q.dim() != 4 or k.dim() != 4 or v.shape != k.shape or q.shape[:2] != k.shape[:2] or q.shape[3] != k.shape[3]:
         raise ValueError("flash_attention: expected q [B, H, R, D] and k, v [B, H, C, D]")
+    if k.device != q.device or v.device != q.device:
+        raise RuntimeError(f"flash_attention: q, k, v must live on one device (got {q.device}, {k.device}, {v.device})")
+
+
+def _check_block_mask(block_mask, R, C):
+    """bitmap rows cover every 256-row block, words cover every 128-key block (the kernels index it unchecked)"""
+    if block_mask.dim() != 2:
+        raise ValueError("flash_attention: block_mask must be [ceil(R / 256)][words] (pack_block_mask)")
+    rows_needed, words_needed = (R + 255) // 256, ((C + 127) // 128 + 31) // 32
+    if block_mask.shape[0] < rows_needed or block_mask.shape[1] < words_needed:
+        raise ValueError(f"flash_attention: block_mask is {tuple(block_mask.shape)}, needs at least "
+                         f"({rows_needed}, {words_needed}) for R={R}, C={C}")
 
 
 def _strides(B, H, R, C, D):
@@ -70,6 +84,7 @@ class _FlashAttention(torch.autograd.Function):
         lengths = q_lengths is not None or k_lengths is not None
         mask_kw = {}
         if block_mask is not None:   # int32 [ceil(R / 256)][words]: bit b of word w = column block 32 w + b (128 keys each)
+            _check_block_mask(block_mask, R, C)
             block_mask = block_mask.to(device=q.device, dtype=torch.int32).contiguous()
             mask_kw = dict(blockMask=block_mask, blockMaskWords=int(block_mask.shape[-1]))
         if lengths:   # padding rows of the outputs are not written by the kernels: define them as zero
@@ -78,9 +93,11 @@ class _FlashAttention(torch.autograd.Function):
             q_lengths = None if q_lengths is None else q_lengths.to(device=q.device, dtype=torch.int32).contiguous()
             k_lengths = None if k_lengths is None else k_lengths.to(device=q.device, dtype=torch.int32).contiguous()
         ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal and not lengths and not mask_kw else None
-        kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
-                        headStrides=hs, batchStrides=bs, stream=torch.cuda.current_stream().cuda_stream,
-                        workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
+        # the C side launches on the CURRENT device (hipGetDevice) and this stream: make both the tensors' device
+        with torch.cuda.device(q.device):
+            kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
+                            headStrides=hs, batchStrides=bs, stream=torch.cuda.current_stream(q.device).cuda_stream,
+                            workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
         ctx.save_for_backward(q, k, v, o, l)
         ctx.causal = causal
         ctx.lengths = (q_lengths, k_lengths)
@@ -102,11 +119,12 @@ class _FlashAttention(torch.autograd.Function):
         dterm = alloc((B, H, R), dtype=torch.float32, device=q.device)
         bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
         hs, bs = _strides(B, H, R, C, D)
-        stream = torch.cuda.current_stream().cuda_stream
-        for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
-            _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
-                                                     batchStrides=bs, stream=stream, causal=ctx.causal,
-                                                     rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1], **ctx.mask_kw)
+        with torch.cuda.device(q.device):
+            stream = torch.cuda.current_stream(q.device).cuda_stream
+            for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
+                _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
+                                                         batchStrides=bs, stream=stream, causal=ctx.causal,
+                                                         rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1], **ctx.mask_kw)
         return dq, dk, dv, None, None, None, None
 
 

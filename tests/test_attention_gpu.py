@@ -2,6 +2,8 @@
 against the CPU oracle on the same seeded inputs.  Shapes, dtype packing, canaries and tolerances
 follow the reference's tests (SquareAttentionTest.swift:5-26, :397-554;
 RectangularAttentionTest.swift:7-35, :451-472); unlike the reference these tests ASSERT."""
+import os
+
 import numpy as np
 import pytest
 
@@ -24,6 +26,32 @@ def make_desc(R, C, D, low_in=False, low_mid=False, tr=(False,) * 4, in_type=P.F
     d.transposeState = tuple(tr)
     d.lowPrecisionInputType = in_type
     return d
+
+
+import contextlib
+
+import metal_flash_attention_amd as mfa
+from metal_flash_attention_amd import _abi
+
+DEV_LIBRARY = "libmfa_hip_dev" in os.path.basename(_abi.library_path()) if hasattr(_abi, "library_path") else False
+needs_dev_library = pytest.mark.skipif(
+    not DEV_LIBRARY, reason="developer schedule: run with MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_dev.so (make DEV=1)")
+
+
+@contextlib.contextmanager
+def parameter_rows(*rows):
+    """Install parameter-table rows (type, mixed, text) for the duration of a test: the product library selects code objects
+    through the table (AttentionDescriptor.swift:37-54), not through environment knobs."""
+    try:
+        for t, mixed, text in rows:
+            mfa.setParameterFile(t, mixed, text)
+        yield
+    finally:
+        mfa.resetParameterFiles()
+
+
+FWD_8x32 = (AttentionKernelType.forward, True, "| 32 | 128 | 32 | 32 | Q, O |\n| 64 | 256 | 32 | 64 | Q, O |\n| 128 | 256 | 32 | 128 | Q, O |\n| 256 | 128 | 32 | 256 | Q, O |\n")
+DKV_W4 = (AttentionKernelType.backwardKeyValue, True, "| 64 | 128 | 64 | 64 | K, V, dV, dK |\n| 128 | 128 | 64 | 128 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
 
 
 def round_inputs(net, desc):
@@ -256,14 +284,16 @@ def test_forward_16bit_unaligned_launch_falls_back_to_general_kernel():
     assert np.abs(bufs[Op.O].cpu().numpy() - ref["O"]).max() < 5e-5
 
 
-@pytest.mark.parametrize("impl", ["v1", "v2:0", "v2:1", "v2:2", "v3:0", "v3:1", "v3:2", "v3:41", "v4:0", "v4:1", "v4:2", "v4:4", "v4:8", "v4:16"])
+@pytest.mark.parametrize("impl", ["product"] + [pytest.param(i, marks=needs_dev_library) for i in
+                                                ["v1", "v2:0", "v2:1", "v2:2", "v3:0", "v3:1", "v3:2", "v3:41", "v4:0", "v4:1", "v4:2", "v4:4", "v4:8", "v4:16"]])
 def test_forward_16bit_forced_rescale(impl, monkeypatch):
     """The deferred-rescale branch of the pipelined kernel is rare on random data, so force it
     (guide rule: a rare data-dependent branch needs its own test): one key far along the traversal
     dominates some rows by much more than the threshold, another grows the maximum only slightly.
     All schedules -- THR=0 (the reference's rule), THR=8 and the unpipelined kernel -- must agree
     with the full-tensor oracle."""
-    monkeypatch.setenv("MFA_FWD16_IMPL", impl)
+    if impl != "product":
+        monkeypatch.setenv("MFA_FWD16_IMPL", impl)
     R, C, D = 128, 640, 64
     net = Network(NetworkDescriptor(R, C, D), seed=21)
     net.K[300] = net.Q[5] * 6.0      # huge score for row 5 (and large for correlated rows) at tile 4
@@ -279,24 +309,37 @@ def test_forward_16bit_forced_rescale(impl, monkeypatch):
     assert np.abs(got["L"] - ref["L"]).max() < 2e-3
 
 
-@pytest.mark.parametrize("impl", ["v3:0", "v3:7", "v3:4"])
-def test_forward_16bit_forced_rescale_d128(impl, monkeypatch):
-    """The same forced-rescale construction at D = 128, where the product schedule stages through LDS-DMA and
-    reads its fragments through inline asm (v3:0); v3:7 is the register-staged schedule it replaced."""
-    monkeypatch.setenv("MFA_FWD16_IMPL", impl)
+@pytest.mark.parametrize("which", ["p4_exact", "p4_fold", "v3_8x32", pytest.param("dev:v3:7", marks=needs_dev_library),
+                                   pytest.param("dev:p4:1", marks=needs_dev_library)])
+def test_forward_16bit_forced_rescale_d128(which, monkeypatch):
+    """The same forced-rescale construction at D = 128 for every product code object: the four-wave hand-placed stream with the
+    scale applied in fp32 (default row), its FOLD stream (lowPrecisionIntermediates), and the eight-wave kernel (32-key row)."""
+    rows = [FWD_8x32] if which == "v3_8x32" else []
+    if which.startswith("dev:"):
+        monkeypatch.setenv("MFA_FWD16_IMPL", which[4:])
+    with parameter_rows(*rows):
+        _forced_rescale_d128(which)
+
+
+def _forced_rescale_d128(which):
     R, C, D = 300, 1000, 128
     net = Network(NetworkDescriptor(R, C, D), seed=22)
     net.K[450] = net.Q[5] * 4.0
     net.K[900] = net.Q[270] * 1.2
     net.invalidate()
-    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
+    desc = make_desc(R, C, D, low_in=True, low_mid=(which == "p4_fold"), in_type=P.BF16)
     run = harness.DeviceRun(desc, net, run_backward=False)
+    variant = run.kernels[AttentionKernelType.forward].variant
+    expect = {"p4_exact": "attn_fwd16p4_bf16_d128_w4x64_thr8", "p4_fold": "attn_fwd16p4_bf16_d128_w4x64_thr8_fold",
+              "v3_8x32": "attn_fwd16v3_bf16_d128_w8x32_thr8_ldsdma"}.get(which)
+    assert expect is None or variant == expect, variant
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run(backward=False)
     assert np.isfinite(got["O"]).all()
-    assert np.abs(got["O"] - ref["O"]).max() < 2e-2, run.kernels[AttentionKernelType.forward].variant
-    assert np.abs(got["L"] - ref["L"]).max() < 2e-3
+    assert np.abs(got["O"] - ref["O"]).max() < 2e-2, variant
+    # FOLD: Q * scale rounded to bf16 (8-bit mantissa) moves L by ~2e-3; L itself is stored in FP16 with low intermediates
+    assert np.abs(got["L"] - ref["L"]).max() < (2e-2 if which == "p4_fold" else 2e-3), variant
     assert all(run.tails_ok.values())
 
 
@@ -390,13 +433,13 @@ def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
     tolerances of the oracle fed with the rounded inputs, and within a tighter bound (2e-2 absolute on
     the gradients, whose dS is rounded to BF16 like the reference's register precision for dS,
     AttentionDescriptor+Precisions.swift:199-200)."""
-    monkeypatch.setenv("MFA_DKV16_IMPL", dkv_impl)
     R, C, D = shape
     if dkv_impl == "w4" and D > 128:
         pytest.skip("the one-wave-per-key-block kernel stops at D = 128")
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
-    run = harness.DeviceRun(desc, net)
+    with parameter_rows(*([DKV_W4] if dkv_impl == "w4" else [])):   # 64-row steps = the one-wave-per-key-block kernel
+        run = harness.DeviceRun(desc, net)
     variants = {t.name: k.variant for t, k in run.kernels.items()}
     assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
     assert ("attn_dkv16rs" in variants["backwardKeyValue"]) == (dkv_impl == "rs"), variants
@@ -411,14 +454,13 @@ def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
 
 
 def test_backward_16bit_matches_general_kernels(monkeypatch):
-    """Same inputs through the fp32-arithmetic general kernels (MFA_BWD16_DISABLE) and the 16-bit
-    matrix-core kernels: gradients agree to the 16-bit rounding of P and dS."""
+    """Same inputs through the fp32-arithmetic general kernels (reached through a layout the matrix-core kernels do not take:
+    V and dV stored transposed) and the 16-bit matrix-core kernels: gradients agree to the 16-bit rounding of P and dS."""
     R, C, D = 384, 448, 128
     net = Network(NetworkDescriptor(R, C, D), seed=31)
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
     fast = harness.DeviceRun(desc, net).execute()
-    monkeypatch.setenv("MFA_BWD16_DISABLE", "1")
-    run = harness.DeviceRun(desc, net)
+    run = harness.DeviceRun(make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=(False, False, True, False)), net)
     assert all("generic" in k.variant for t, k in run.kernels.items() if t != AttentionKernelType.forward)
     slow = run.execute()
     for name in ("D", "dQ", "dK", "dV"):
@@ -582,6 +624,7 @@ V4_SHAPES = [(256, 256, 128), (300, 300, 128), (1, 64, 128), (257, 130, 120), (9
              (255, 257, 64), (64, 1, 64), (129, 77, 40), (2048, 2048, 64)]
 
 
+@needs_dev_library
 @pytest.mark.parametrize("impl", ["v4:0", "v4:16", "v3:41"])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("shape", V4_SHAPES)
@@ -800,3 +843,36 @@ def test_backward_split_matches_unsplit_and_oracle(shape, causal):
     failures, report = harness.compare(ref, got, dict(D=5e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
     assert not failures, failures
     assert all(run.tails_ok.values())
+
+
+# ---- head dimensions above 256 (the reference's large-D rows, +Parameters.swift:77-285; accumulator paging of
+# +Accumulate.swift:449-467 re-derived: accumulators stay in the 512 registers, the left-hand operands leave them) ----
+@pytest.mark.parametrize("shape", [(200, 200, 320), (130, 130, 384), (77, 150, 384), (33, 260, 264), (100, 64, 352)])
+def test_large_head_dimension_fp32(shape):
+    report, run = run_case(*shape, seed=sum(shape), tolerances={k: 5e-5 for k in TOL_FP32})
+    assert all("d384" in k.variant for k in run.kernels.values()), [k.variant for k in run.kernels.values()]
+
+
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+@pytest.mark.parametrize("shape", [(150, 170, 320), (64, 300, 384)])
+def test_large_head_dimension_16bit_inputs(shape, in_type):
+    """16-bit storage at D > 256 runs on the fp32-arithmetic kernels (no 16-bit code object above 256): with the oracle
+    fed the rounded inputs the results agree to fp32 accuracy."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=5 + D)
+    desc = make_desc(R, C, D, low_in=True, in_type=in_type)
+    run = harness.DeviceRun(desc, net)
+    assert all("generic" in k.variant and "d384" in k.variant for k in run.kernels.values())
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run()
+    failures, report = harness.compare(ref, got, dict(O=1e-4, L=1e-4, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+    assert not failures, failures
+    assert all(run.tails_ok.values())
+
+
+def test_head_dimension_limit_is_reported():
+    from metal_flash_attention_amd import MFAError
+    with pytest.raises(MFAError) as e:
+        AttentionKernel(make_desc(64, 64, 392).kernelDescriptor(AttentionKernelType.forward))
+    assert e.value.status == 3 and "D <= 384" in str(e.value)

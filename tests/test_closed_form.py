@@ -27,9 +27,14 @@ def _oracle(inputs, threads=0, causal=False):
     return net.run(backward=True, causal=causal)
 
 
-def _assert_close(got, exp, tol, what):
+def _assert_close(got, exp, tol, what, inputs=None):
     for name, e in exp.items():
         scale = max(1.0, float(np.abs(e).max()))
+        if inputs is not None and name in ("dQ", "dK"):
+            # dQ = dS K / sqrt(D) (dK = dS^T Q / sqrt(D)): the rounding of dS = P (dP - D) is multiplied by the largest key
+            # (query) entry -- the dominant-key case has a key of length 60 sqrt(D) / 4 by construction
+            other = inputs["K" if name == "dQ" else "Q"]
+            scale *= max(1.0, float(np.abs(other).max()) / np.sqrt(other.shape[1]))
         if name in ("dK", "dQ", "dV"):
             # sums of R (or C) fp32 terms that cancel (dS = P (dP - D) with |dP|, |D| ~ sqrt(D)): the rounding floor grows
             # with the square root of the number of terms -- the reference's 2e-5 was set on N <= 777 random problems
@@ -98,7 +103,7 @@ def test_hip_fp32_reproduces_closed_forms(case, shape):
     inputs, exp = closed_form.build(case, *shape, seed=21)
     R, D = inputs["Q"].shape
     got, variants = _device(inputs, R, inputs["K"].shape[0], D)
-    _assert_close(got, exp, FP32_TOL, f"HIP fp32 {case} {shape} {variants}")
+    _assert_close(got, exp, FP32_TOL, f"HIP fp32 {case} {shape} {variants}", inputs)
 
 
 @pytest.mark.gpu
@@ -107,7 +112,7 @@ def test_hip_fp32_closed_forms_at_c3_shape(case):
     """BASELINE config 3 (forward + backward, N=4096, D=128, fp32)"""
     inputs, exp = closed_form.build(case, 4096, 4096, 128, seed=22)
     got, variants = _device(inputs, 4096, 4096, 128)
-    _assert_close(got, exp, 1e-4, f"HIP fp32 {case} C3 {variants}")
+    _assert_close(got, exp, 1e-4, f"HIP fp32 {case} C3 {variants}", inputs)
 
 
 @pytest.mark.gpu

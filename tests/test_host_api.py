@@ -191,3 +191,78 @@ def test_oversized_slices_route_to_general_kernels_without_a_gpu():
     k = AttentionKernel(d.kernelDescriptor(T.forward))
     assert k.variant.startswith("attn_fwd16")
     assert k.workspaceSize(row=4096, column=4096) > 0
+
+
+# ---- the parameter table drives kernel selection (AttentionDescriptor.swift:37-54 -> AttentionKernel.swift:27-50) ----
+def _low(dims, in_type=P.BF16, low_mid=False):
+    d = _desc(dims=dims, low_in=True, low_mid=low_mid)
+    d.lowPrecisionInputType = in_type
+    return d
+
+
+def test_default_table_rows_are_compiled_variants():
+    """every row of every built-in table is (parallelization, traversal, head, cached operands) of a code object that
+    exists: creating the kernel with strictBlockDimensions succeeds and the effective descriptor equals the request"""
+    for t in T:
+        for mixed in (False, True):
+            rows = [r for r in mfa.parameterFile(t, mixed).split("\n") if r.strip()]
+            for r in rows:
+                max_d = int(r.split("|")[1])
+                for D in {max_d, max(8, max_d - 8)}:
+                    d = _low((512, 512, D)) if mixed else _desc(dims=(512, 512, D))
+                    kd = d.kernelDescriptor(t)
+                    kd.strictBlockDimensions = True
+                    k = AttentionKernel(kd)     # MFAError (status 3) if no variant implements the row
+                    eff = k.effectiveDescriptor
+                    assert eff.blockDimensions[:2] == kd.blockDimensions[:2], (t, mixed, D, k.variant)
+                    assert eff.blockDimensions[2] >= kd.blockDimensions[2]
+                    assert eff.cacheState == kd.cacheState, (t, mixed, D, k.variant)
+
+
+def test_parameter_table_row_selects_the_code_object():
+    """forward, 16-bit inputs, D = 128: the default row (256, 64, 128) is the four-wave hand-placed kernel; a row with 32-key
+    steps selects the eight-wave kernel; a tuple nothing implements falls back (reported) or fails (strict)"""
+    try:
+        d = _low((4096, 4096, 128))
+        assert AttentionKernel(d.kernelDescriptor(T.forward)).variant.startswith("attn_fwd16p4_bf16_d128_w4x64")
+        mfa.setParameterFile(T.forward, True, "| 64 | 256 | 32 | 64 | Q, O |\n| 128 | 256 | 32 | 128 | Q, O |\n| 256 | 128 | 32 | 256 | Q, O |\n")
+        k = AttentionKernel(d.kernelDescriptor(T.forward))
+        assert k.variant.startswith("attn_fwd16v3_bf16_d128_w8x32") and k.blockDimensions == (256, 32, 128)
+        mfa.setParameterFile(T.backwardKeyValue, True, "| 128 | 128 | 64 | 128 | K, V, dV, dK |\n")
+        assert AttentionKernel(d.kernelDescriptor(T.backwardKeyValue)).variant.startswith("attn_dkv16_bf16_d128_w4x32")
+        mfa.resetParameterFiles()
+        assert AttentionKernel(d.kernelDescriptor(T.backwardKeyValue)).variant.startswith("attn_dkv16rs_bf16_d128")
+        # nothing implements 64 rows x 128 keys with Q streamed: nearest variant + report, or an error when strict
+        mfa.setParameterFile(T.forward, True, "| 384 | 64 | 128 | 32 | O |\n")
+        kd = d.kernelDescriptor(T.forward)
+        k = AttentionKernel(kd)
+        assert k.effectiveDescriptor.blockDimensions != kd.blockDimensions and k.effectiveDescriptor.cacheState[Op.Q] is True
+        kd.strictBlockDimensions = True
+        with pytest.raises(MFAError) as e:
+            AttentionKernel(kd)
+        assert e.value.status == 3 and "compiled (parallelization, traversal, head)" in str(e.value)
+    finally:
+        mfa.resetParameterFiles()
+
+
+def test_low_precision_intermediates_select_the_folded_scale_stream():
+    """S and P in FP32 registers (lowPrecisionIntermediates = false): the scale is applied in fp32 per score; with
+    lowPrecisionIntermediates the reference itself keeps S / P in 16 bits (+Precisions.swift:149-215) and the kernel may
+    pre-multiply Q by the scale in the 16-bit type"""
+    exact = AttentionKernel(_low((4096, 4096, 128)).kernelDescriptor(T.forward)).variant
+    folded = AttentionKernel(_low((4096, 4096, 128), low_mid=True).kernelDescriptor(T.forward)).variant
+    assert "fold" not in exact and folded.endswith("_fold"), (exact, folded)
+
+
+def test_product_library_carries_no_developer_knobs():
+    """no environment knob, no superseded kernel, no timing-only ablation in libmfa_hip.so (they live in the -DMFA_DEV_VARIANTS
+    build libmfa_hip_dev.so used by tools/ab_*.py)"""
+    import os
+    import re
+    from metal_flash_attention_amd import _abi
+    path = os.path.join(os.path.dirname(_abi.__file__), "libmfa_hip.so")
+    blob = open(path, "rb").read()
+    for needle in (b"WRONG_RESULTS", b"MFA_FWD16_IMPL", b"MFA_DKV16_IMPL", b"MFA_BWD16_DISABLE", b"MFA_GEMM_IMPL", b"PROF_CLOBBERS_O",
+                   b"attn_fwd16_v2", b"attn_fwd16_v4"):
+        assert needle not in blob, needle
+    assert re.search(rb"getenv", blob) is None

@@ -15,13 +15,16 @@ import p4sim  # noqa: E402
 
 def _check(R, C, rblk=0, causal=False, cfg=None, dma_mode="late", order=(0, 1, 2, 3), seed=0, spike=None, tol_o=4e-3, tol_l=2e-5):
     rng = np.random.default_rng(seed)
-    q, k, v = p4sim.rand_bf16((R, 128), rng), p4sim.rand_bf16((C, 128), rng), p4sim.rand_bf16((C, 128), rng)
+    f16 = cfg is not None and cfg.dtype == "f16"
+    if cfg is not None and cfg.fold:
+        tol_l = max(tol_l, 6e-4 if f16 else 5e-3)   # Q * scale2 rounded to the 16-bit type (11 / 8 bit mantissa)
+    q, k, v = (p4sim.rand_bf16(s, rng, f16=f16) for s in ((R, 128), (C, 128), (C, 128)))
     if spike is not None:   # one key row aligned with one query row: forces the deferred rescale at a chosen tile
         qrow, krow, gain = spike
         qf = p4sim.bf16_to_f32(q[qrow].astype(np.uint32))
         k[krow] = p4sim.f32_to_bf16_rne((qf * gain).astype(np.float32)).astype(np.uint16)
     O, L, wg = p4sim.run_block(q, k, v, rblk, cfg=cfg, causal=causal, dma_mode=dma_mode, order=order)
-    Oref, Lref = p4sim.reference(q, k, v, causal=causal)
+    Oref, Lref = p4sim.reference(q, k, v, causal=causal, f16=f16)
     rows = np.arange(rblk * 256, min(R, rblk * 256 + 256))
     dO = np.abs(O[: len(rows)] - Oref[rows]).max()
     dL = np.abs(L[: len(rows)] - Lref[rows]).max()
@@ -62,13 +65,46 @@ def test_deferred_rescale_spike(thr):
     _check(256, 320, cfg=cfg, spike=(40, 300, 4.0), seed=5, tol_o=1.2e-2)
 
 
-@pytest.mark.parametrize("name", sorted(p4gen.VARIANTS))
+@pytest.mark.parametrize("name", sorted(n for n, c in p4gen.VARIANTS.items() if not c.abl))   # (ablations: timing only)
 def test_every_compiled_variant(name):
     cfg = p4gen.VARIANTS[name]
-    if cfg.dtype != "bf16" or cfg.prof:
-        # the model multiplies bf16 (f16 differs by mnemonics only) and has no shader clock (PROF adds stamps only)
-        cfg = p4gen.Cfg("bf16", cfg.thr, cfg.xe, cfg.order_a, cfg.pad)
+    if cfg.prof:   # the model has no shader clock (PROF adds stamps only)
+        cfg = p4gen.Cfg(cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, 0, cfg.fold, cfg.xb, cfg.dma, cfg.abl)
     _check(256, 256, cfg=cfg, seed=6)
+
+
+FOLD = p4gen.VARIANTS["BF16_FOLD"]
+
+
+@pytest.mark.parametrize("R,C,rblk,causal", [(256, 64, 0, False), (256, 130, 0, False), (200, 449, 0, False), (512, 512, 1, True),
+                                             (300, 400, 1, True), (70, 1, 0, False)])
+def test_fold_stream_shapes(R, C, rblk, causal):
+    _check(R, C, rblk=rblk, causal=causal, cfg=FOLD, seed=8)
+
+
+@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3))])
+def test_fold_stream_ring_and_spike(dma_mode, order):
+    wg = _check(256, 448, cfg=FOLD, dma_mode=dma_mode, order=order, spike=(5, 300, 3.0), seed=9, tol_o=1.2e-2)
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 256   # first tile + the spike
+
+
+@pytest.mark.parametrize("name", ["BF16_THR8_DMAA", "BF16_FOLD_DMAA"])
+@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3)), ("early", (0, 1, 2, 3))])
+def test_dma_in_phase_a_ring_discipline(name, dma_mode, order):
+    _check(256, 448 + 64, cfg=p4gen.VARIANTS[name], dma_mode=dma_mode, order=order, seed=10)
+    _check(200, 130, cfg=p4gen.VARIANTS[name], dma_mode=dma_mode, order=order, seed=11)
+    _check(256, 64, cfg=p4gen.VARIANTS[name], dma_mode=dma_mode, order=order, seed=12)
+
+
+def test_fold_stream_very_negative_scores():
+    """every score far below zero: the first tile must still set m to the true maximum (m starts at 0 in FOLD streams)"""
+    rng = np.random.default_rng(3)
+    q = p4sim.rand_bf16((256, 128), rng)
+    k = p4sim.f32_to_bf16_rne((-3.0 * p4sim.bf16_to_f32(q[:192].astype(np.uint32))).astype(np.float32).reshape(-1)).astype(np.uint16).reshape(192, 128)
+    v = p4sim.rand_bf16((192, 128), rng)
+    O, L, _ = p4sim.run_block(q, k, v, 0, cfg=FOLD)
+    Oref, Lref = p4sim.reference(q, k, v)
+    assert np.isfinite(O).all() and np.abs(O - Oref).max() < 2e-2 and np.abs(L - Lref).max() < 0.2
 
 
 def test_stream_file_is_current():

@@ -69,3 +69,44 @@ def test_two_rank_gloo_sharding_matches_single_process():
     for unit in range(total_heads):
         ref = Network(NetworkDescriptor(24, 40, 16), seed=unit, threads=1).run(backward=False)["O"]
         assert covered[unit] == ref.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_rank_shards_of_real_device_buffers_equal_the_unsharded_launch(world):
+    """The multi-GPU structure on one device: `world` ranks each launch the HIP kernels on THEIR contiguous range of the
+    flattened batch x head axis of the same device buffers (exactly what bench.py does with one rank per GPU); together
+    they must reproduce the single launch over all heads bit for bit -- no head skipped, none computed twice."""
+    import torch
+    from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
+                                           AttentionOperand as Op, GEMMOperandPrecision as P)
+    B, H, N, D = 2, 5, 384, 128
+    desc = AttentionDescriptor()
+    desc.lowPrecisionInputs = True
+    desc.lowPrecisionInputType = P.BF16
+    desc.matrixDimensions = (N, N, D)
+    desc.transposeState = (False,) * 4
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    q, k, v = (torch.randn((B * H, N, D), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+    hs = {Op.Q: N * D, Op.K: N * D, Op.V: N * D, Op.O: N * D, Op.L: N}
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(lo, hi, o, l):
+        kernel.dispatch({Op.Q: q[lo:hi], Op.K: k[lo:hi], Op.V: v[lo:hi], Op.O: o[lo:hi], Op.L: l[lo:hi]}, row=N, column=N,
+                        heads=hi - lo, headStrides=hs, stream=stream)
+
+    o_all = torch.full((B * H, N, D), float("nan"), device="cuda")
+    l_all = torch.full((B * H, N), float("nan"), device="cuda")
+    run(0, B * H, o_all, l_all)
+    o_sh, l_sh = torch.full_like(o_all, float("nan")), torch.full_like(l_all, float("nan"))
+    covered = []
+    for rank in range(world):
+        lo, hi = shard_range(B * H, world, rank)
+        covered += list(range(lo, hi))
+        if hi > lo:
+            run(lo, hi, o_sh, l_sh)
+    torch.cuda.synchronize()
+    assert covered == list(range(B * H))
+    assert not torch.isnan(o_sh).any() and torch.equal(o_sh, o_all) and torch.equal(l_sh, l_all)

@@ -11,14 +11,20 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the MFA_*_IMPL knobs exist only in the developer build of the library (make -C metal_flash_attention_amd/csrc DEV=1)
+os.environ.setdefault("MFA_LIBRARY", os.path.join(ROOT, "metal_flash_attention_amd", "libmfa_hip_dev.so"))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--heads", type=int, default=256)
-    ap.add_argument("--impl", default="p4:5")
+    ap.add_argument("--impl", default="BF16_FOLD_PROF", help="p4:<n>, or the name of a PROF stream of tools/p4gen.py")
     args = ap.parse_args()
+    if not args.impl.startswith("p4:"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import p4gen
+        args.impl = "p4:%d" % (1000 + list(p4gen.VARIANTS).index(args.impl))
     import torch
     from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
                                            AttentionOperand as Op, GEMMOperandPrecision as P)

@@ -43,9 +43,11 @@ T_CORR = 241           # 2
 T_LB = 243             # 2: second partial row sum per rb
 T_MASKV = 245
 T_TL = 246             # 2: mask limits relative to the tile
-T_THR = 248            # 2: m + THR
-T_RS = 248             # 8: rescale temporaries (v248..v255)
-FIRST_OWNED_VGPR = 32
+T_THR = 248            # 2: m + THR                      (exact-scale streams)
+T_RS = 248             # 8: rescale temporaries v248..v255 (exact-scale streams; FOLD streams borrow V^T ring slots 0, 1)
+T_ONES = 248           # 4: FOLD streams: A operand of the extra k-step (-1.0 in k-slots 0, 1)
+T_MF = (252, 28)       # 4 each: FOLD streams: B operand of the extra k-step per rb (m_hi, m_lo in k-slots 0, 1)
+FIRST_OWNED_VGPR = 28
 
 KSLOT, VBASE, VSLOT, VRING = 16384, 32768, 16384, 3
 
@@ -53,13 +55,22 @@ KSLOT, VBASE, VSLOT, VRING = 16384, 32768, 16384, 3
 OUT_V = ["m0", "m1", "l0", "l1", "koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3"]
 TMP_S = ["j", "vrd", "vwr", "pend", "t0", "t1", "pa", "pw", "pb", "plast"]   # "=&s" 32-bit temporaries (p*: PROF streams)
 TMP_S64 = ["sv", "ptime"]                              # "=&s" 64-bit temporaries
-IN_V = ["kbase", "vbase", "lim0", "lim1"]
+IN_V = ["kbase", "vbase", "lim0", "lim1", "onesw"]
 IN_S = ["kres", "vres", "nt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "maskfrom"]
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0):
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=()):
+        """fold: Q arrives pre-multiplied by log2(e)/sqrt(D) and the running maximum is subtracted INSIDE the matrix pipe (an
+        extra k-step whose A operand is -1.0 and whose B operand carries m as a bf16/f16 pair): no s * scale2 - m per
+        score; xb = scores per tile exponentiated in phase B already (FOLD streams only)."""
         self.dtype, self.thr, self.xe, self.order_a, self.pad, self.prof = dtype, float(thr), xe, order_a, pad, prof
+        self.fold, self.xb = fold, (xb if fold else 0)
+        # dma = "b": K(j+2), V(j+1) requested in phase B(j) beside the K fragment reads; "a": K(j+1), V(j) requested in the
+        # first gaps of phase A(j), where only VALU work is placed (an LDS-DMA issue next to LDS reads costs 2-3x as much)
+        self.dma = dma
+        # timing-only ablations (WRONG RESULTS; developer builds): fillers left out of the steady-state phases
+        self.abl = frozenset(abl)
 
 
 # ---------------------------------------------------------------- tiny IR
@@ -201,6 +212,22 @@ class Stream:
         return [((g % 4) // 2, g % 2, g // 4) for g in range(32)]                # four accumulators in rotation
 
     # ------------------------------------------------------------ phase A
+    def qk_list(self, par):
+        """matrix instructions of phase A as (dst, a, b, c) tuples"""
+        out = []
+        if not self.cfg.fold:
+            for kb, rb, ks in self.qk_order():
+                c = I(0) if ks == 0 else s_blk(par, rb, kb)
+                out.append((s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), c))
+            return out
+        for kb in range(2):   # FOLD: S' = (-1) * m + K Q'^T: the block starts from the extra k-step
+            for rb in range(2):
+                out.append((s_blk(par, rb, kb), V(T_ONES, 4), V(T_MF[rb], 4), I(0)))
+            for ks in range(8):
+                for rb in range(2):
+                    out.append((s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), s_blk(par, rb, kb)))
+        return out
+
     def phase_a(self, par, mfma, softmax, zero_o):
         """A(j), par = j & 1: S[par] = K Q^T | finish-softmax of S[par ^ 1] | V^T reads of fragments 0..7"""
         cfg = self.cfg
@@ -208,38 +235,56 @@ class Stream:
         vids = {}
         if softmax:
             self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of tile j-1")
-        order = self.qk_order()
+        mlist = self.qk_list(par)
+        ng = len(mlist)
+        g0 = (ng - 32) // 2          # element pair i is exponentiated in gap g0 + i and packed one gap later
+        v0 = g0 + 12                 # V^T fragments 0..7 (16 reads) in gaps v0 .. v0 + 15: they land before the barrier
         pending_pack = None
-        for g in range(32):
+        for g in range(ng):
             if mfma:
-                kb, rb, ks = order[g]
-                c = I(0) if ks == 0 else s_blk(par, rb, kb)
-                self.mfma(s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), c)
-            if zero_o:
+                self.mfma(*mlist[g])
+            if zero_o and g < 32:
                 for i in range(4):
                     self.emit("v_accvgpr_write_b32", A(O_BASE + 4 * g + i), [I(0)])
             if softmax:
-                for e in (2 * g, 2 * g + 1):
-                    if e >= cfg.xe:
-                        rb_, kb_, r_ = elem(e)
-                        x = s_elem(prev, rb_, kb_, r_)
-                        self.emit("v_exp_f32", x, [x])
                 if pending_pack is not None:
-                    self.sum_pack(prev, pending_pack)
-                pending_pack = 2 * g
-                # V^T fragments 0..7 (16 reads) in gaps 12..27: they land before the barrier
-                if 12 <= g < 28:
-                    i = g - 12
-                    vids[i] = self.v_read(i)
-        if softmax:
-            self.sum_pack(prev, pending_pack)
+                    self.sum_pack(prev, pending_pack, mfma)
+                    pending_pack = None
+                i = g - g0
+                if 0 <= i < 32:
+                    for e in (2 * i, 2 * i + 1):
+                        if e >= max(cfg.xe, cfg.xb) and not (mfma and "expa" in cfg.abl):
+                            rb_, kb_, r_ = elem(e)
+                            x = s_elem(prev, rb_, kb_, r_)
+                            self.emit("v_exp_f32", x, [x])
+                    pending_pack = 2 * i
+                if v0 <= g < v0 + 16 and not (mfma and "vreada" in cfg.abl):
+                    vids[g - v0] = self.v_read(g - v0)
+                elif v0 <= g < v0 + 16:
+                    vids[g - v0] = 0
+            if mfma and softmax and cfg.dma == "a":   # steady state only: K(j+1) -> K image (j+1) & 1, V(j) -> V image j % 3
+                if g == 0:
+                    self.vwr_update()
+                if 2 <= g < 6:
+                    self.dma_piece("k", par ^ 1, g - 2)
+                elif 6 <= g < 10:
+                    self.dma_piece("v", par, g - 6)
+                if 4 <= g < 8:
+                    self.emit("v_add_u32_e64", VN("koff%d" % (g - 4)), [VN("koff%d" % (g - 4)), SN("kinc")], clamp=1)
+                elif 8 <= g < 12:
+                    self.emit("v_add_u32_e64", VN("voff%d" % (g - 8)), [VN("voff%d" % (g - 8)), SN("vinc")], clamp=1)
+        if softmax and pending_pack is not None:
+            self.sum_pack(prev, pending_pack, mfma)
         return vids
 
-    def sum_pack(self, prev, e):
+    def sum_pack(self, prev, e, steady=False):
         rb, kb, r = elem(e)
         x0, x1 = s_elem(prev, rb, kb, r), s_elem(prev, rb, kb, r + 1)
-        self.emit("v_add_f32", VN("l%d" % rb), [x0, VN("l%d" % rb)])
-        self.emit("v_add_f32", V(T_LB + rb), [x1, V(T_LB + rb)])
+        if not (steady and "sum" in self.cfg.abl):
+            self.emit("v_add_f32", VN("l%d" % rb), [x0, VN("l%d" % rb)])
+            self.emit("v_add_f32", V(T_LB + rb), [x1, V(T_LB + rb)])
+        if steady and "pack" in self.cfg.abl:
+            return
         # MFMA step u (16 keys) of key block kb uses registers 8 (u & 1) .. + 7
         self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, p_word(rb, 2 * kb + r // 8, (r % 8) // 2), [x0, x1])
 
@@ -267,35 +312,48 @@ class Stream:
             # V^T fragments 8..15: fragment f reuses the slot of f-8, free once the two MFMAs of f-8 (gaps 2(f-8), +1) are issued
             for f in range(8, 16):
                 g0 = 2 * (f - 8) + 2
+                if softmax and "vreadb" in cfg.abl:
+                    vids[2 * f] = vids[2 * f + 1] = 0
+                    continue
                 at(g0, lambda f=f: vids.__setitem__(2 * f, self.v_read(2 * f)))
                 at(g0 + 1, lambda f=f: vids.__setitem__(2 * f + 1, self.v_read(2 * f + 1)))
         if softmax:
             for i in range(32):                      # row maxima: gaps 0..7
-                at(i // 4, lambda i=i: self.max_op(par, i))
+                if not (mfma and "max" in cfg.abl):
+                    at(i // 4, lambda i=i: self.max_op(par, i))
             at(8, lambda: self.decide_1())
             at(9, lambda: self.decide_2())
-            at(10, lambda: self.decide_3())
             dec_lbl = self.newlabel("DEC")
-            at(11, lambda: self.decide_4(dec_lbl))
-            # s * scale2 - m : 64 over gaps 12..31 (4 per gap in 12..15, then 3)
-            e = 0
-            for g in range(12, 32):
-                n = 4 if g < 16 else 3
-                for _ in range(n):
-                    if e < 64:
-                        at(g, lambda e=e: self.fma_op(par, e))
-                        e += 1
-            assert e == 64
+            first = not mfma           # B'(0): the first tile always sets m (the reference starts from the true maximum)
+            if cfg.fold:
+                at(10, lambda: self.decide_4_fold(dec_lbl, first))
+                for e in range(cfg.xb):          # exp2 of the first xb scores right here: S' needs no further arithmetic
+                    if not (mfma and "expb" in cfg.abl):
+                        at(12 + e // 2, lambda e=e: self.exp_in_b(par, e))
+            else:
+                at(10, lambda: self.decide_3())
+                at(11, lambda: self.decide_4(dec_lbl))
+                # s * scale2 - m : 64 over gaps 12..31 (4 per gap in 12..15, then 3)
+                e = 0
+                for g in range(12, 32):
+                    n = 4 if g < 16 else 3
+                    for _ in range(n):
+                        if e < 64:
+                            at(g, lambda e=e: self.fma_op(par, e))
+                            e += 1
+                assert e == 64
             # K(j+1) fragments -> a[192:255], one per gap 12..27
             for i in range(16):
-                at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
+                if not (mfma and "kread" in cfg.abl):
+                    at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
             # LDS-DMA: K(j+2) pieces in gaps 20..23, V(j+1) pieces 24..27; their offsets advance in gaps 28..31
-            for i in range(4):
+            for i in range(4 if cfg.dma == "b" and not (mfma and "dma" in cfg.abl) else 0):
                 at(20 + i, lambda i=i: self.dma_piece("k", par, i))
                 at(24 + i, lambda i=i: self.dma_piece("v", par, i))
                 at(28 + i, lambda i=i: self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1))
                 at(28 + i, lambda i=i: self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1))
-            at(0, lambda: self.vwr_update())
+            if cfg.dma == "b":
+                at(0, lambda: self.vwr_update())
             at(1, lambda: self.vrd_advance())
         for g in range(32):
             if mfma:
@@ -316,8 +374,8 @@ class Stream:
             self.emit("s_cmp_eq_u32", None, [SN("pend"), I(0)])
             self.emit("s_cbranch_scc0", None, [], target=resc)
             self.label(back)
-            self.outofline.append(("resc", resc, back))
-            self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK"))
+            self.outofline.append(("resc", resc, back, par, False))
+            self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK", par, not mfma))
 
     def max_op(self, par, i):
         # op i: block i // 8 in the order (rb0,kb0) (rb1,kb0) (rb0,kb1) (rb1,kb1); step i % 8 covers 3, 2, ..., 2, 1 values
@@ -357,6 +415,22 @@ class Stream:
         self.emit("s_or_b64", VCC, [VCC, SN("sv", 2)])
         self.emit("s_cbranch_vccnz", None, [], target=lbl)
         self.label(lbl + "_BACK")
+
+    def decide_4_fold(self, lbl, first):   # the scores are already relative to m: any block maximum above THR raises m
+        if first:
+            self.emit("s_branch", None, [], target=lbl)
+        else:
+            self.emit("v_cmp_lt_f32", VCC, [F(self.cfg.thr), V(T_MN)])
+            self.emit("s_mov_b64", SN("sv", 2), [VCC])
+            self.emit("v_cmp_lt_f32", VCC, [F(self.cfg.thr), V(T_MN + 1)])
+            self.emit("s_or_b64", VCC, [VCC, SN("sv", 2)])
+            self.emit("s_cbranch_vccnz", None, [], target=lbl)
+        self.label(lbl + "_BACK")
+
+    def exp_in_b(self, par, e):
+        rb, kb, r = elem(e)
+        x = s_elem(par, rb, kb, r)
+        self.emit("v_exp_f32", x, [x])
 
     def fma_op(self, par, e):
         rb, kb, r = elem(e)
@@ -412,9 +486,35 @@ class Stream:
 
     # ------------------------------------------------------------ out-of-line sections
     def emit_outofline(self):
-        for kind, lbl, back in self.outofline:
+        cfg = self.cfg
+        rs = VF_BASE if cfg.fold else T_RS      # rescale temporaries (FOLD: V^T ring slots 0, 1 are idle at the end of phase B)
+        for kind, lbl, back, par, first in self.outofline:
             self.label(lbl)
-            if kind == "dec":   # onlineCorrectO factors (+Softmax.swift:290-301): m_up = max(m, m_new), corr = 2^(m - m_up)
+            if kind == "dec" and cfg.fold:
+                # m_up = m + max(mx', 0) (first tile: m + mx'); kept as the exact sum of a 16-bit pair (hi, lo) so that the
+                # extra k-step subtracts EXACTLY the m that L = m + log2 l reports; shift = m_new - m_old re-bases this
+                # tile's scores, corr = 2^-shift re-bases O and l at the end of phase B (+Softmax.swift:290-301)
+                ta, tb = V(T_SW), V(T_SW + 1)
+                for rb in range(2):
+                    mn, m = V(T_MN + rb), VN("m%d" % rb)
+                    if not first:
+                        self.emit("v_max_f32", mn, [I(0), mn])
+                    self.emit("v_add_f32", ta, [m, mn])
+                    self.to16_f32(tb, ta)                     # hi = m_up cut to the 16-bit type's mantissa
+                    self.emit("v_sub_f32", ta, [ta, tb])
+                    self.to16_f32(ta, ta)                     # lo
+                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(T_MF[rb]), [tb, ta])   # (+hi, +lo): the A operand is -1.0
+                    self.emit("v_add_f32", ta, [tb, ta])      # m_new = hi + lo (exact in fp32)
+                    self.emit("v_sub_f32", tb, [ta, m])       # shift
+                    self.emit("v_mov_b32", m, [ta])
+                    self.emit("v_exp_f32", V(T_CORR + rb), [tb], neg0=1)
+                    for kb in range(2):
+                        for r in range(16):
+                            x = s_elem(par, rb, kb, r)
+                            self.emit("v_sub_f32", x, [x, tb])
+                self.emit("s_mov_b32", SN("pend"), [I(1)])
+                self.emit("s_branch", None, [], target=back)
+            elif kind == "dec":   # onlineCorrectO factors (+Softmax.swift:290-301): m_up = max(m, m_new), corr = 2^(m - m_up)
                 for rb in range(2):
                     self.emit("v_max_f32", V(T_THR + rb), [VN("m%d" % rb), V(T_MN + rb)])
                 for rb in range(2):
@@ -431,16 +531,22 @@ class Stream:
                 for rb in range(2):
                     for i0 in range(0, 64, 8):
                         for t in range(8):
-                            self.emit("v_accvgpr_read_b32", V(T_RS + t), [A(O_BASE + 64 * rb + i0 + t)])
+                            self.emit("v_accvgpr_read_b32", V(rs + t), [A(O_BASE + 64 * rb + i0 + t)])
                         for t in range(8):
-                            self.emit("v_mul_f32", V(T_RS + t), [V(T_CORR + rb), V(T_RS + t)])
+                            self.emit("v_mul_f32", V(rs + t), [V(T_CORR + rb), V(rs + t)])
                         for t in range(8):
-                            self.emit("v_accvgpr_write_b32", A(O_BASE + 64 * rb + i0 + t), [V(T_RS + t)])
+                            self.emit("v_accvgpr_write_b32", A(O_BASE + 64 * rb + i0 + t), [V(rs + t)])
                     self.emit("v_mul_f32", VN("l%d" % rb), [V(T_CORR + rb), VN("l%d" % rb)])
                     self.emit("v_mul_f32", V(T_LB + rb), [V(T_CORR + rb), V(T_LB + rb)])
                 self.emit("s_mov_b32", SN("pend"), [I(0)])
                 self.emit("s_nop", None, [I(4)], note="accvgpr write -> MFMA SrcC")
                 self.emit("s_branch", None, [], target=back)
+
+    def to16_f32(self, d, x):
+        """d = x truncated to the mantissa width of the stream's 16-bit type (still an fp32 value): 8 significant bits for
+        bf16, 11 for f16 -- converting d to that type is then exact (x within the type's normal range, which scores in
+        log2 units are).  One AND instead of a conversion round trip."""
+        self.emit("v_and_b32", d, [I(0xFFFF0000 if self.cfg.dtype == "bf16" else 0xFFFFE000), x])
 
     # ------------------------------------------------------------ whole traversal
     def build(self):
@@ -456,6 +562,10 @@ class Stream:
         for rb in range(2):
             self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
+        if self.cfg.fold:
+            self.emit("v_mov_b32", V(T_ONES), [VN("onesw")])
+            for r in list(range(T_ONES + 1, T_ONES + 4)) + [T_MF[0] + i for i in range(4)] + [T_MF[1] + i for i in range(4)]:
+                self.emit("v_mov_b32", V(r), [I(0)])
         self.emit("s_mov_b32", SN("pend"), [I(0)])
         self.emit("s_mov_b32", SN("j"), [I(0)])
         self.emit("s_mov_b32", SN("vrd"), [I(2 * VSLOT)])    # "image of V(-1)"
@@ -562,6 +672,12 @@ def render_one(ins, suffix="%="):
         return "v_permlane32_swap_b32 %s, %s" % (fmt(ins.d), fmt(ins.s[0]))
     if op in ("s_cmp_lt_i32", "s_cmp_ge_i32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_nop"):
         return "%s %s" % (op, ", ".join(fmt(x) for x in ins.s))
+    if op in ("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32") and (m.get("neg0") or m.get("neg1")):
+        return "%s %s, %s%s, %s%s" % (op, fmt(ins.d), "-" if m.get("neg0") else "", fmt(ins.s[0]), "-" if m.get("neg1") else "", fmt(ins.s[1]))
+    if op == "v_exp_f32" and m.get("neg0"):
+        return "v_exp_f32_e64 %s, -%s" % (fmt(ins.d), fmt(ins.s[0]))
+    if op == "v_cmp_lt_f32":
+        return "v_cmp_lt_f32_e32 vcc, %s, %s" % (fmt(ins.s[0]), fmt(ins.s[1]))
     if op in ("v_cmp_gt_f32", "v_cmp_gt_i32"):
         return "%s_e32 vcc, %s, %s" % (op, fmt(ins.s[0]), fmt(ins.s[1]))
     if op == "v_cndmask_b32":
@@ -581,13 +697,25 @@ def write_inc(path):
     vregs = ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256))
     lines.append("#define MFA_P4_OWNED_VGPRS " + vregs)
     lines.append("")
+    lines.append("// X(name, folds Q scale and running maximum into the matrix pipe, stamps the shader clock)")
+    lines.append("#define MFA_P4_STREAM_LIST(X) \\")
+    for name, cfg in VARIANTS.items():
+        lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.prof))
+    lines.append("")
+    lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates: MFA_FWD16_IMPL=p4:<1000 + index>")
+    lines.append("#define MFA_P4_DEV_STREAM_LIST(X) \\")
+    for name, cfg in VARIANTS.items():
+        if name not in PRODUCT_STREAMS and cfg.dtype == "bf16":
+            lines.append("  X(%s) \\" % name)
+    lines.append("")
+    lines.append("")
     for name, cfg in VARIANTS.items():
         st = Stream(cfg)
         ins = st.build()
         txt = render(ins)
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
-        lines.append("// %s: dtype=%s thr=%g xe=%d order_a=%s pad=%d -- %d instructions, %d matrix instructions"
-                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, len(txt), n_mfma))
+        lines.append("// %s: dtype=%s thr=%g xe=%d order_a=%s pad=%d prof=%d fold=%d xb=%d dma=%s -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, cfg.prof, cfg.fold, cfg.xb, cfg.dma, len(txt), n_mfma))
         lines.append("#define MFA_P4_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)
@@ -605,7 +733,28 @@ VARIANTS = {
     "BF16_THR8_ROT": Cfg("bf16", 8, 0, order_a="rot4"),
     "BF16_THR8_PAD": Cfg("bf16", 8, 0, pad=1),
     "BF16_THR8_PROF": Cfg("bf16", 8, 0, prof=1),
+    "BF16_FOLD": Cfg("bf16", 8, fold=1, xb=40),
+    "F16_FOLD": Cfg("f16", 8, fold=1, xb=40),
+    "BF16_FOLD_XB24": Cfg("bf16", 8, fold=1, xb=24),
+    "BF16_FOLD_PROF": Cfg("bf16", 8, fold=1, xb=40, prof=1),
+    "ABL_EXPA": Cfg("bf16", 8, fold=1, prof=1, abl=("expa",)),
+    "ABL_SUMPACK": Cfg("bf16", 8, fold=1, prof=1, abl=("sum", "pack")),
+    "ABL_VREADA": Cfg("bf16", 8, fold=1, prof=1, abl=("vreada",)),
+    "ABL_VREADB": Cfg("bf16", 8, fold=1, prof=1, abl=("vreadb",)),
+    "ABL_KREAD": Cfg("bf16", 8, fold=1, prof=1, abl=("kread",)),
+    "ABL_MAX": Cfg("bf16", 8, fold=1, prof=1, abl=("max",)),
+    "ABL_EXPB": Cfg("bf16", 8, fold=1, prof=1, abl=("expb",)),
+    "ABL_DMA": Cfg("bf16", 8, fold=1, prof=1, abl=("dma",)),
+    "ABL_ALLB": Cfg("bf16", 8, fold=1, prof=1, abl=("vreadb", "kread", "max", "expb", "dma")),
+    "ABL_ALLA": Cfg("bf16", 8, fold=1, prof=1, abl=("expa", "sum", "pack", "vreada")),
+    "BF16_THR8_DMAA": Cfg("bf16", 8, dma="a"),
+    "F16_THR8_DMAA": Cfg("f16", 8, dma="a"),
+    "BF16_FOLD_DMAA": Cfg("bf16", 8, fold=1, xb=40, dma="a"),
+    "F16_FOLD_DMAA": Cfg("f16", 8, fold=1, xb=40, dma="a"),
+    "BF16_FOLD_DMAA_PROF": Cfg("bf16", 8, fold=1, xb=40, dma="a", prof=1),
 }
+
+PRODUCT_STREAMS = ("BF16_THR8", "F16_THR8", "BF16_THR0", "BF16_FOLD", "F16_FOLD")
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

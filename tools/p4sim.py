@@ -140,10 +140,18 @@ def frag16(regs4):
     return out
 
 
-def frag16_fast(regs4):
+def h16_to_f32(h, f16):
+    return h.astype(np.uint16).view(np.float16).astype(np.float32) if f16 else bf16_to_f32(h)
+
+
+def f32_to_h16(x, f16):
+    return x.astype(np.float16).view(np.uint16).astype(np.uint32) if f16 else f32_to_bf16_rne(x)
+
+
+def frag16_fast(regs4, f16=False):
     r = np.asarray(regs4)                       # [4][64]
-    lo = bf16_to_f32(r & 0xFFFF)                # element 2 w
-    hi = bf16_to_f32(r >> 16)                   # element 2 w + 1
+    lo = h16_to_f32(r & 0xFFFF, f16)            # element 2 w
+    hi = h16_to_f32(r >> 16, f16)               # element 2 w + 1
     out = np.zeros((32, 16), np.float32)
     for h in range(2):
         for w in range(4):
@@ -196,8 +204,9 @@ class Workgroup:
     def execute(self, w, ins):
         op, d, s, m = ins.op, ins.d, ins.s, ins.mod
         if op.startswith("v_mfma"):
-            A = frag16_fast(w.rd_multi(s[0]))     # [i][k]
-            B = frag16_fast(w.rd_multi(s[1]))     # [j][k]
+            f16 = op.endswith("_f16")
+            A = frag16_fast(w.rd_multi(s[0]), f16)     # [i][k]
+            B = frag16_fast(w.rd_multi(s[1]), f16)     # [j][k]
             acc = np.zeros((32, 32), np.float32)
             if s[2][0] != "i":
                 c = w.rd_multi(s[2]).view(np.float32)     # [16][64]
@@ -255,8 +264,11 @@ class Workgroup:
             else:
                 w.vm_q.append((addrs, data))
         elif op == "v_exp_f32":
+            x = w.rdf(s[0]).astype(np.float64)
+            if m.get("neg0"):
+                x = -x
             with np.errstate(over="ignore", under="ignore"):
-                w.wr(d, np.exp2(w.rdf(s[0]).astype(np.float64)).astype(np.float32))
+                w.wr(d, np.exp2(x).astype(np.float32))
         elif op == "v_fma_f32":
             a, b, c = w.rdf(s[0]).astype(np.float64), w.rdf(s[1]).astype(np.float64), w.rdf(s[2]).astype(np.float64)
             if m.get("neg2"):
@@ -270,11 +282,29 @@ class Workgroup:
             w.wr(d, r.astype(np.float32))
         elif op == "v_max3_f32":
             w.wr(d, np.maximum(np.maximum(w.rdf(s[0]), w.rdf(s[1])), w.rdf(s[2])))
-        elif op == "v_cvt_pk_bf16_f32":
-            lo, hi = f32_to_bf16_rne(w.rdf(s[0]).copy()), f32_to_bf16_rne(w.rdf(s[1]).copy())
+        elif op in ("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"):
+            f16 = op == "v_cvt_pk_f16_f32"
+            x0, x1 = w.rdf(s[0]).copy(), w.rdf(s[1]).copy()
+            if m.get("neg0"):
+                x0 = -x0
+            if m.get("neg1"):
+                x1 = -x1
+            with np.errstate(over="ignore"):
+                lo, hi = f32_to_h16(x0, f16), f32_to_h16(x1, f16)
             w.wr(d, lo | (hi << 16))
+        elif op == "v_cvt_f16_f32":
+            with np.errstate(over="ignore"):
+                w.wr(d, f32_to_h16(w.rdf(s[0]).copy(), True))
+        elif op == "v_cvt_f32_f16":
+            w.wr(d, h16_to_f32(w.rd(s[0]) & 0xFFFF, True))
+        elif op == "v_lshlrev_b32":
+            w.wr(d, (w.rd(s[1]).astype(np.uint64) << int(s[0][1])) & 0xFFFFFFFF)
+        elif op == "v_cmp_lt_f32":
+            w.vcc = w.rdf(s[0]) < w.rdf(s[1])
         elif op == "v_mov_b32":
             w.wr(d, w.rd(s[0]).copy())
+        elif op == "v_and_b32":
+            w.wr(d, w.rd(s[0]) & w.rd(s[1]))
         elif op == "v_xor_b32":
             w.wr(d, w.rd(s[0]) ^ w.rd(s[1]))
         elif op == "v_add_u32":
@@ -351,6 +381,7 @@ class Workgroup:
 def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 1, 2, 3), scale=None, stream=None):
     """One 256-row block: q [R][128], k / v [C][128] as uint16 bf16 bit patterns.  Returns O [256][128] f32, L [256]."""
     cfg = cfg or Cfg()
+    f16 = cfg.dtype == "f16"
     R, C, D = q.shape[0], k.shape[0], 128
     assert q.shape[1] == D
     instrs = stream if stream is not None else Stream(cfg).build()
@@ -367,6 +398,10 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
     scale = scale if scale is not None else 1.0 / np.sqrt(np.float32(D))
     scale2 = float(np.float32(1.44269504089) * np.float32(scale))
     OOB = 0xFFFFFF00
+    if cfg.fold:   # the C++ prologue of FOLD streams stores Q * scale2, rounded to the 16-bit type, in a[128:191]
+        qf = h16_to_f32(q.astype(np.uint32).reshape(-1), f16).reshape(q.shape)
+        q = f32_to_h16((qf * np.float32(scale2)).astype(np.float32).reshape(-1), f16).astype(np.uint16).reshape(q.shape)
+        qb = q.reshape(-1).view(np.uint8)
     for w in wg.waves:
         wave = w.id
         r0 = rblk * 256 + wave * 64
@@ -414,7 +449,9 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         w.vm_q = [(None, None)] * 12
         n16 = lane & 15
         w.vn.update({
-            "m0": np.full(64, -FLT_MAX, np.float32).view(np.uint32), "m1": np.full(64, -FLT_MAX, np.float32).view(np.uint32),
+            "m0": np.full(64, 0.0 if cfg.fold else -FLT_MAX, np.float32).view(np.uint32),
+            "m1": np.full(64, 0.0 if cfg.fold else -FLT_MAX, np.float32).view(np.uint32),
+            "onesw": np.where(lane < 32, 0xBC00BC00 if f16 else 0xBF80BF80, 0).astype(np.uint32),
             "l0": np.zeros(64, np.uint32), "l1": np.zeros(64, np.uint32),
             "kbase": (qq * 256 + ((hi ^ (qq & 15)) << 4)).astype(np.uint32),
             "vbase": (VBASE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32),
@@ -448,9 +485,9 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
     return O, L, wg
 
 
-def reference(q, k, v, causal=False):
-    """float64 attention on the bf16 inputs; returns O, L (base-2 log-sum-exp of the scaled scores)"""
-    qf, kf, vf = (bf16_to_f32(x.astype(np.uint32)).astype(np.float64) for x in (q, k, v))
+def reference(q, k, v, causal=False, f16=False):
+    """float64 attention on the 16-bit inputs; returns O, L (base-2 log-sum-exp of the scaled scores)"""
+    qf, kf, vf = (h16_to_f32(x.astype(np.uint32).reshape(-1), f16).reshape(x.shape).astype(np.float64) for x in (q, k, v))
     R, C = qf.shape[0], kf.shape[0]
     s = qf @ kf.T / np.sqrt(qf.shape[1])
     if causal:
@@ -462,9 +499,9 @@ def reference(q, k, v, causal=False):
     return (p @ vf) / lsum, (mx[:, 0] + np.log(lsum[:, 0])) * 1.44269504089
 
 
-def rand_bf16(shape, rng, scale=1.0):
+def rand_bf16(shape, rng, scale=1.0, f16=False):
     x = (rng.standard_normal(shape) * scale).astype(np.float32)
-    return f32_to_bf16_rne(x).astype(np.uint16)
+    return f32_to_h16(x.reshape(-1), f16).astype(np.uint16).reshape(shape)
 
 
 if __name__ == "__main__":

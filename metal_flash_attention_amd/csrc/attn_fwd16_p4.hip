@@ -7,7 +7,8 @@ namespace mfa {
 template <typename T, int STREAM, bool CAUSAL>
 static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, CAUSAL>), dim3(grid.x * grid.y * grid.z), dim3(256), p4::LDS_BYTES, stream, args, g);
+  const uint32_t groups = CAUSAL ? (grid.x + 1) / 2 : grid.x;   // causal: one workgroup per pair of row blocks (last - i, i)
+  hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, CAUSAL>), dim3(groups * grid.y * grid.z), dim3(256), p4::LDS_BYTES, stream, args, g);
 }
 
 template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char *name) {

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
     const float l_tot = half_swap_add(l[b]) + 1.401298464e-45f;
-    const float inv = SPLIT ? 1.0f : ((SPARSE && !(l_tot > 1e-30f)) ? 0.f : 1.0f / l_tot);   // SPARSE: a row may see no key at all
+    const float inv = SPLIT ? 1.0f : (l_tot > 1e-30f ? 1.0f / l_tot : 0.f);   // a row may see no key at all (block mask, empty batch entry)
     float *orow = Os + (b * 32 + q) * OLD;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)

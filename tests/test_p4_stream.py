@@ -61,7 +61,7 @@ def test_deferred_rescale_spike(thr):
     # pending P exactly once
     cfg = p4gen.Cfg("bf16", thr, 0)
     wg = _check(256, 320, cfg=cfg, spike=(5, 200, 3.0), seed=4, tol_o=1.2e-2)
-    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 256   # the rescale section ran more than once
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 128   # the rescale section ran (the first tile needs none: O = 0)
     _check(256, 320, cfg=cfg, spike=(40, 300, 4.0), seed=5, tol_o=1.2e-2)
 
 
@@ -85,15 +85,19 @@ def test_fold_stream_shapes(R, C, rblk, causal):
 @pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3))])
 def test_fold_stream_ring_and_spike(dma_mode, order):
     wg = _check(256, 448, cfg=FOLD, dma_mode=dma_mode, order=order, spike=(5, 300, 3.0), seed=9, tol_o=1.2e-2)
-    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 256   # first tile + the spike
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 128   # the spike (the first tile re-bases nothing: O = 0)
 
 
-@pytest.mark.parametrize("name", ["BF16_THR8_DMAA", "BF16_FOLD_DMAA"])
-@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3)), ("early", (0, 1, 2, 3))])
-def test_dma_in_phase_a_ring_discipline(name, dma_mode, order):
-    _check(256, 448 + 64, cfg=p4gen.VARIANTS[name], dma_mode=dma_mode, order=order, seed=10)
-    _check(200, 130, cfg=p4gen.VARIANTS[name], dma_mode=dma_mode, order=order, seed=11)
-    _check(256, 64, cfg=p4gen.VARIANTS[name], dma_mode=dma_mode, order=order, seed=12)
+@pytest.mark.parametrize("name", ["BF16_THR8", "BF16_FOLD"])
+@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3)), ("early", (0, 1, 2, 3)), ("late", (3, 2, 1, 0))])
+def test_causal_per_wave_bounds_and_skip_loop(name, dma_mode, order):
+    """causal: a wave stops multiplying at the diagonal of ITS rows and then only keeps the barriers and its LDS-DMA share
+    going for the others; waves running ahead / behind, DMA landing early / late"""
+    cfg = p4gen.VARIANTS[name]
+    for R, C, rblk in ((512, 512, 1), (256, 256, 0), (700, 1000, 2), (300, 300, 1)):
+        wg = _check(R, C, rblk=rblk, causal=True, cfg=cfg, dma_mode=dma_mode, order=order, seed=13)
+    counts = [w.count.get("v_mfma_f32_32x32x16_bf16", 0) for w in wg.waves]
+    assert len(set(w.count["s_barrier"] for w in wg.waves)) == 1
 
 
 def test_fold_stream_very_negative_scores():

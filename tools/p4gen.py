@@ -56,7 +56,7 @@ OUT_V = ["m0", "m1", "l0", "l1", "koff0", "koff1", "koff2", "koff3", "voff0", "v
 TMP_S = ["j", "vrd", "vwr", "pend", "t0", "t1", "pa", "pw", "pb", "plast"]   # "=&s" 32-bit temporaries (p*: PROF streams)
 TMP_S64 = ["sv", "ptime"]                              # "=&s" 64-bit temporaries
 IN_V = ["kbase", "vbase", "lim0", "lim1", "onesw"]
-IN_S = ["kres", "vres", "nt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "maskfrom"]
+IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "maskfrom"]
 
 
 class Cfg:
@@ -512,7 +512,7 @@ class Stream:
                         for r in range(16):
                             x = s_elem(par, rb, kb, r)
                             self.emit("v_sub_f32", x, [x, tb])
-                self.emit("s_mov_b32", SN("pend"), [I(1)])
+                self.emit("s_mov_b32", SN("pend"), [I(0 if first else 1)])   # first tile: O and l are still zero, nothing to re-base
                 self.emit("s_branch", None, [], target=back)
             elif kind == "dec":   # onlineCorrectO factors (+Softmax.swift:290-301): m_up = max(m, m_new), corr = 2^(m - m_up)
                 for rb in range(2):
@@ -523,7 +523,7 @@ class Stream:
                     self.emit("v_mov_b32", VN("m%d" % rb), [V(T_THR + rb)])
                 for rb in range(2):
                     self.emit("v_exp_f32", V(T_CORR + rb), [V(T_CORR + rb)])
-                self.emit("s_mov_b32", SN("pend"), [I(1)])
+                self.emit("s_mov_b32", SN("pend"), [I(0 if first else 1)])   # first tile: O and l are still zero
                 self.emit("s_branch", None, [], target=back)
             else:               # O, l *= corr once every matrix instruction that accumulates P(j-1) has been issued
                 self.emit("s_nop", None, [I(15)])
@@ -586,10 +586,12 @@ class Stream:
             self.emit("s_waitcnt", None, [], lgkmcnt=0)
             self.emit("s_mov_b64", VCC, [SN("ptime", 2)])
             self.emit("s_mov_b32", SN("plast"), [VCC_LO])
-        loop, end_even, end_odd, done, fin = (self.newlabel(x) for x in ("LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN"))
+        loop, end_even, end_odd, done, fin, skip_odd, skip_even = (
+            self.newlabel(x) for x in ("LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN", "SKIPODD", "SKIPEVEN"))
         self.label(loop)
+        # wnt = key tiles THIS WAVE needs (causal: up to the diagonal of its own last row; otherwise = nt)
         for par, endl in ((1, end_even), (0, end_odd)):
-            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
+            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("wnt")])
             self.emit("s_cbranch_scc1", None, [], target=endl)
             vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
             self.stamp("pa")
@@ -601,14 +603,34 @@ class Stream:
             self.stamp("pb")
             self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_branch", None, [], target=loop)
-        # tails: finish tile nt-1 (its scores are in S[last parity])
-        for lastpar, lbl in ((0, end_even), (1, end_odd)):
+        # tails: finish tile wnt-1 (its scores are in S[last parity]), then keep the other waves company
+        for lastpar, lbl, nxt in ((0, end_even, skip_odd), (1, end_odd, skip_even)):
             self.label(lbl)
             vids = self.phase_a(lastpar ^ 1, mfma=False, softmax=True, zero_o=False)
             self.lds_flush()
             self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
             self.phase_b(lastpar ^ 1, mfma=True, softmax=False, vids=vids)
-            self.emit("s_branch", None, [], target=done)
+            self.emit("s_branch", None, [], target=nxt)
+        # A wave whose rows are done before the workgroup's last tile (causal) still owes the others its barriers and its
+        # share of the LDS-DMA pieces: tiles j = wnt .. nt-1 without arithmetic
+        for par, lbl in ((1, skip_odd), (0, skip_even)):
+            self.label(lbl)
+            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
+            self.emit("s_cbranch_scc1", None, [], target=done)
+            self.emit("s_waitcnt", None, [], vmcnt=0)
+            self.emit("s_barrier")
+            if self.cfg.dma == "b":
+                self.vwr_update()
+                for i in range(4):
+                    self.dma_piece("k", par, i)
+                for i in range(4):
+                    self.dma_piece("v", par, i)
+                for i in range(4):
+                    self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1)
+                    self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1)
+            self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
+            if par == 0:
+                self.emit("s_branch", None, [], target=skip_odd)
         self.label(done)
         for rb in range(2):
             self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
@@ -747,11 +769,6 @@ VARIANTS = {
     "ABL_DMA": Cfg("bf16", 8, fold=1, prof=1, abl=("dma",)),
     "ABL_ALLB": Cfg("bf16", 8, fold=1, prof=1, abl=("vreadb", "kread", "max", "expb", "dma")),
     "ABL_ALLA": Cfg("bf16", 8, fold=1, prof=1, abl=("expa", "sum", "pack", "vreada")),
-    "BF16_THR8_DMAA": Cfg("bf16", 8, dma="a"),
-    "F16_THR8_DMAA": Cfg("f16", 8, dma="a"),
-    "BF16_FOLD_DMAA": Cfg("bf16", 8, fold=1, xb=40, dma="a"),
-    "F16_FOLD_DMAA": Cfg("f16", 8, fold=1, xb=40, dma="a"),
-    "BF16_FOLD_DMAA_PROF": Cfg("bf16", 8, fold=1, xb=40, dma="a", prof=1),
 }
 
 PRODUCT_STREAMS = ("BF16_THR8", "F16_THR8", "BF16_THR0", "BF16_FOLD", "F16_FOLD")

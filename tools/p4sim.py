@@ -464,7 +464,11 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             w.vn["lim%d" % b] = (lim - 4 * hi).astype(np.int64).astype(np.uint32)
         minlim = min(C - 1, r0 + coff) if causal else C - 1
         maskfrom = (minlim + 1) // 64 if (causal or ragged) else nt
-        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
+        wnt = nt
+        if causal:   # tiles this wave's own rows can see
+            wlast = min(R, r0 + 64) - 1
+            wnt = max(1, min(nt, (wlast + coff) // 64 + 1)) if wlast >= r0 else 1
+        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
                      "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "maskfrom": maskfrom})
     wg.run(order)
     O = np.zeros((256, D), np.float32)

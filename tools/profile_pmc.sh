@@ -16,5 +16,14 @@ rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$REPO/$OUT/pmc3" -o pmc3 -- python "$REPO/bench.py" $ARGS > "$REPO/$OUT/pmc3.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$REPO/$OUT/pmc4" -o pmc4 -- python "$REPO/bench.py" $ARGS > "$REPO/$OUT/pmc4.log" 2>&1
 cd "$REPO"
-python tools/summarize_prof.py "$OUT" "bench.py $ARGS" > "$OUT/summary.txt" 2>&1
+# workload and kernel variant of the profiled command, for profiles/traffic.json (bench.py reads it back, hash-checked)
+WORKLOAD=$(python - <<PY
+import shlex
+a = shlex.split("$ARGS")
+print(a[a.index("--workload") + 1] if "--workload" in a else "fwd_bf16_d128")
+PY
+)
+export MFA_PROFILED_VARIANT=$(python bench.py $ARGS 2>/dev/null | tail -n 1 | python -c "import json,sys; print(json.load(sys.stdin)['config']['kernel_variants'][0])")
+python tools/summarize_prof.py "$OUT" "bench.py $ARGS" "$WORKLOAD" > "$OUT/summary.txt" 2>&1
+cp "$OUT/summary.txt" "profiles/r02_${WORKLOAD}_summary.txt"
 cat "$OUT/summary.txt"

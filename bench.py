@@ -60,7 +60,12 @@ def measured_traffic(workload, variant):
 
 WORKLOADS = {
     # name: (kernel types, N, D, dtype, batch, heads)
-    "fwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",)),   # headline
+    # headline: the reference's MIXED-PRECISION mode (lowPrecisionInputs + lowPrecisionIntermediates, the mode its own
+    # headline numbers are quoted in, README.md:15 / BASELINE.md) with BF16 storage
+    "fwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), low_mid=True),
+    # same shape with the attention matrix kept in FP32 registers (lowPrecisionIntermediates = false): the scale is applied
+    # in fp32 per score instead of being folded into Q
+    "fwd_bf16_d128_fp32mid": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",)),
     "fwd_bf16_d64": dict(N=4096, D=64, dtype="bf16", batch=8, heads=32, types=("forward",)),     # config 2, batched
     "fwd_bf16_d64_1head": dict(N=4096, D=64, dtype="bf16", batch=1, heads=1, types=("forward",)),  # config 2 as written
     "fwd_bf16_d256": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",)),   # config 4, batched
@@ -132,7 +137,7 @@ def main():
     low = w["dtype"] != "f32"
     desc = AttentionDescriptor()
     desc.lowPrecisionInputs = low
-    desc.lowPrecisionIntermediates = False
+    desc.lowPrecisionIntermediates = bool(w.get("low_mid", False))
     desc.lowPrecisionInputType = P.BF16 if w["dtype"] == "bf16" else P.FP16
     desc.matrixDimensions = (N, N, D)
     desc.transposeState = (False, False, False, False)
@@ -147,14 +152,16 @@ def main():
     bufs = {}
     for op in (Op.Q, Op.K, Op.V):
         bufs[op] = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32).to(tdtype)
-    bufs[Op.O] = torch.empty(shape, device="cuda", dtype=torch.float32)
-    bufs[Op.L] = torch.empty((B, H, N), device="cuda", dtype=torch.float32)
+    mem = desc.memoryPrecisions   # L is FP16 and D BF16 in the reference's mixed-precision mode (+Precisions.swift:82-83)
+    tprec = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
+    bufs[Op.O] = torch.empty(shape, device="cuda", dtype=tprec[mem[Op.O]])
+    bufs[Op.L] = torch.empty((B, H, N), device="cuda", dtype=tprec[mem[Op.L]])
     backward = len(types) > 1
     if backward:
         # the reference stores dO as BF16 in low-precision mode (+Precisions.swift:17)
         bufs[Op.dO] = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32).to(
             torch.bfloat16 if low else torch.float32)
-        bufs[Op.D] = torch.empty((B, H, N), device="cuda", dtype=torch.float32)
+        bufs[Op.D] = torch.empty((B, H, N), device="cuda", dtype=tprec[mem[Op.D]])
         for op in (Op.dQ, Op.dK, Op.dV):
             bufs[op] = torch.empty(shape, device="cuda", dtype=torch.float32)
     hs = {op: (N if op in (Op.L, Op.D) else N * D) for op in bufs}
@@ -229,8 +236,11 @@ def main():
         "vs_baseline": None,
         "dtype": w["dtype"],
         "data": "synthetic",
-        "config": {"workload": f"attention {'+'.join(w['types'])} N={N} D={D} {w['dtype']} Q/K/V, fp32 O/L; "
+        "config": {"workload": f"attention {'+'.join(w['types'])} N={N} D={D} {w['dtype']} Q/K/V, fp32 O, {mem[Op.L].name} L; "
                                f"B={B} H={H} heads per GPU, batch x head sharded across GPUs, no collectives",
+                   "precision_mode": ("mixed: lowPrecisionInputs + lowPrecisionIntermediates (the reference's mixed-precision "
+                                      "benchmark mode, README.md:15)" if w.get("low_mid") else
+                                      ("lowPrecisionInputs only (attention matrix in FP32 registers)" if low else "FP32")),
                    "kernel_variants": [kernels[t].variant for t in types],
                    "split_kv_workspace_bytes": ws_bytes,
                    "control_plane": "gloo" if world > 1 else "none", "devices_visible": ndev,

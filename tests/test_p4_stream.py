@@ -69,7 +69,7 @@ def test_deferred_rescale_spike(thr):
 def test_every_compiled_variant(name):
     cfg = p4gen.VARIANTS[name]
     if cfg.prof:   # the model has no shader clock (PROF adds stamps only)
-        cfg = p4gen.Cfg(cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, 0, cfg.fold, cfg.xb, cfg.dma, cfg.abl)
+        cfg = p4gen.Cfg(cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, 0, cfg.fold, cfg.xb, cfg.dma, cfg.abl, cfg.xf)
     _check(256, 256, cfg=cfg, seed=6)
 
 

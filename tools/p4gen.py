@@ -60,12 +60,16 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=()):
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64):
         """fold: Q arrives pre-multiplied by log2(e)/sqrt(D) and the running maximum is subtracted INSIDE the matrix pipe (an
         extra k-step whose A operand is -1.0 and whose B operand carries m as a bf16/f16 pair): no s * scale2 - m per
         score; xb = scores per tile exponentiated in phase B already (FOLD streams only)."""
         self.dtype, self.thr, self.xe, self.order_a, self.pad, self.prof = dtype, float(thr), xe, order_a, pad, prof
         self.fold, self.xb = fold, (xb if fold else 0)
+        # exact-scale streams: scores e < xe are exponentiated in phase B (behind their s * scale2 - m), scores e >= xf get
+        # that multiply-subtract in phase A(j+1) in front of their exp2 instead of in phase B(j).  xe = xf = 32 keeps the
+        # filler COUNT of both phases and moves transcendentals to phase B, where they are cheaper (ablation table, DESIGN.md)
+        self.xf = xf
         # dma = "b": K(j+2), V(j+1) requested in phase B(j) beside the K fragment reads; "a": K(j+1), V(j) requested in the
         # first gaps of phase A(j), where only VALU work is placed (an LDS-DMA issue next to LDS reads costs 2-3x as much)
         self.dma = dma
@@ -251,6 +255,10 @@ class Stream:
                     self.sum_pack(prev, pending_pack, mfma)
                     pending_pack = None
                 i = g - g0
+                if not cfg.fold and 0 <= i + 1 < 32:      # s * scale2 - m of the pair exponentiated in the NEXT gap
+                    for e in (2 * i + 2, 2 * i + 3):
+                        if e >= cfg.xf:
+                            self.fma_only(prev, e)
                 if 0 <= i < 32:
                     for e in (2 * i, 2 * i + 1):
                         if e >= max(cfg.xe, cfg.xb) and not (mfma and "expa" in cfg.abl):
@@ -329,7 +337,7 @@ class Stream:
                 at(10, lambda: self.decide_4_fold(dec_lbl, first))
                 for e in range(cfg.xb):          # exp2 of the first xb scores right here: S' needs no further arithmetic
                     if not (mfma and "expb" in cfg.abl):
-                        at(12 + e // 2, lambda e=e: self.exp_in_b(par, e))
+                        at(12 + e // 2 if cfg.xb <= 40 else 11 + (e * 21) // cfg.xb, lambda e=e: self.exp_in_b(par, e))
             else:
                 at(10, lambda: self.decide_3())
                 at(11, lambda: self.decide_4(dec_lbl))
@@ -432,7 +440,14 @@ class Stream:
         x = s_elem(par, rb, kb, r)
         self.emit("v_exp_f32", x, [x])
 
+    def fma_only(self, par, e):
+        rb, kb, r = elem(e)
+        x = s_elem(par, rb, kb, r)
+        self.emit("v_fma_f32", x, [x, SN("scale2"), VN("m%d" % rb)], neg2=1)
+
     def fma_op(self, par, e):
+        if e >= self.cfg.xf:
+            return          # done in phase A of the next tile
         rb, kb, r = elem(e)
         x = s_elem(par, rb, kb, r)
         self.emit("v_fma_f32", x, [x, SN("scale2"), VN("m%d" % rb)], neg2=1)
@@ -736,8 +751,8 @@ def write_inc(path):
         ins = st.build()
         txt = render(ins)
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
-        lines.append("// %s: dtype=%s thr=%g xe=%d order_a=%s pad=%d prof=%d fold=%d xb=%d dma=%s -- %d instructions, %d matrix instructions"
-                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.order_a, cfg.pad, cfg.prof, cfg.fold, cfg.xb, cfg.dma, len(txt), n_mfma))
+        lines.append("// %s: dtype=%s thr=%g xe=%d xf=%d order_a=%s pad=%d prof=%d fold=%d xb=%d dma=%s -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.xf, cfg.order_a, cfg.pad, cfg.prof, cfg.fold, cfg.xb, cfg.dma, len(txt), n_mfma))
         lines.append("#define MFA_P4_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)

@@ -26,4 +26,5 @@ PY
 export MFA_PROFILED_VARIANT=$(python bench.py $ARGS 2>/dev/null | tail -n 1 | python -c "import json,sys; print(json.load(sys.stdin)['config']['kernel_variants'][0])")
 python tools/summarize_prof.py "$OUT" "bench.py $ARGS" "$WORKLOAD" > "$OUT/summary.txt" 2>&1
 cp "$OUT/summary.txt" "profiles/r02_${WORKLOAD}_summary.txt"
+cp profiles/traffic.json "$OUT/traffic.json"   # gpurun merges only gpurun_out/ back: copy it into profiles/ after the call
 cat "$OUT/summary.txt"

@@ -83,9 +83,10 @@ __device__ __forceinline__ void store_block_rows(const float *Os, char *base, in
 // 16-byte chunk index swizzle of the row-major K image (ds_read_b128 is conflict-free when the 16
 // rows of a lane group land on 16 distinct 16-B slots of the 256-B bank row)
 template <int D> __device__ __forceinline__ int kswz(int row, int chunk) {
-  if constexpr (D >= 128) return chunk ^ (row & 15);
+  if constexpr (D >= 128 && (D & (D - 1)) == 0) return chunk ^ (row & 15);
   else if constexpr (D == 64) return chunk ^ ((row >> 1) & 7);
-  else return chunk ^ ((row >> 2) & 3);  // D == 32
+  else return chunk ^ ((row >> 2) & 3);  // D == 32, and the buckets whose row is not a power of two (96, 160, 192 elements:
+                                         // the XOR must stay inside the row, chunks per row are a multiple of four)
 }
 
 // the row-dependent XOR mask of kswz (kswz(row, c) == c ^ kswz_mask(row)); the swizzle is an involution

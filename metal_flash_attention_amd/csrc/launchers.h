@@ -57,4 +57,15 @@ bool dkv16_variant(int precision, int gprecision, int D, VariantInfo *out);
 // role-split wave pairs: one wave of a SIMD accumulates dV, its partner dK (see attn_dkv16_rs.h)
 bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInfo *out);
 
+// head-dimension buckets 160 / 192 of the 16-bit trio and 96 of the dK/dV kernel (one translation unit per kernel type and
+// bucket).  Measured at N = 4096, 64 heads (profiles/r02_bucket_perf.txt): the 96-wide forward and dQ objects LOSE to the 128
+// objects run on zero-padded chunks (0.576 vs 0.499 ms, 0.885 vs 0.781 ms) and are not built; dK/dV wins at 96 (1.02 vs 1.18 ms)
+bool fwd16_v3_variant_d160(int precision, VariantInfo *out);
+bool fwd16_v3_variant_d192(int precision, VariantInfo *out);
+bool dq16_variant_d160(int precision, int gprecision, VariantInfo *out);
+bool dq16_variant_d192(int precision, int gprecision, VariantInfo *out);
+bool dkv16_rs_variant_d96(int precision, int gprecision, VariantInfo *out);
+bool dkv16_rs_variant_d160(int precision, int gprecision, VariantInfo *out);
+bool dkv16_rs_variant_d192(int precision, int gprecision, VariantInfo *out);
+
 } // namespace mfa

@@ -55,6 +55,8 @@ static const char *kDefaultTables[3][2] = {
      "| 32  | 128 | 32 | 32  | Q, O |\n"
      "| 64  | 256 | 32 | 64  | Q, O |\n"
      "| 128 | 256 | 64 | 128 | Q, O |\n"
+     "| 160 | 128 | 32 | 160 | Q, O |\n"
+     "| 192 | 128 | 32 | 192 | Q, O |\n"
      "| 256 | 128 | 32 | 256 | Q, O |\n"
      "| 384 | 64  | 32 | 384 | Q, O |\n"},
     {// backwardQuery, FP32
@@ -66,6 +68,8 @@ static const char *kDefaultTables[3][2] = {
      // backwardQuery, mixed
      "| 64  | 256 | 64 | 64  | Q, dO, dQ |\n"
      "| 128 | 256 | 64 | 128 | Q, dO, dQ |\n"
+     "| 160 | 128 | 64 | 160 | Q, dO, dQ |\n"
+     "| 192 | 128 | 64 | 192 | Q, dO, dQ |\n"
      "| 256 | 128 | 64 | 256 | Q, dO, dQ |\n"
      "| 384 | 32  | 32 | 384 | Q, dQ     |\n"},
     {// backwardKeyValue, FP32
@@ -77,7 +81,10 @@ static const char *kDefaultTables[3][2] = {
      // backwardKeyValue, mixed: role-split wave pairs (attn_dkv16_rs.h); | 128 | 128 | 64 | 128 | selects the one-wave-per-
      // key-block kernel (attn_bwd16.h)
      "| 64  | 128 | 32 | 64  | K, V, dV, dK |\n"
+     "| 96  | 128 | 32 | 96  | K, V, dV, dK |\n"
      "| 128 | 128 | 32 | 128 | K, V, dV, dK |\n"
+     "| 160 | 64  | 32 | 160 | K, V, dV, dK |\n"
+     "| 192 | 64  | 32 | 192 | K, V, dV, dK |\n"
      "| 256 | 64  | 32 | 256 | K, V, dV, dK |\n"
      "| 384 | 32  | 32 | 384 | dV, dK       |\n"}};
 

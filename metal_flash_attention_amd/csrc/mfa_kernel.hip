@@ -48,6 +48,19 @@ static bool slot_used(int type, int slot) {
   }
 }
 
+// head-dimension buckets of the 16-bit matrix-core code objects (the forward has a D = 32 object, the backward pair starts
+// at 64 and runs smaller heads zero-padded); 0 = none (D > 256: fp32-arithmetic kernels)
+enum { B16_FORWARD, B16_DQ, B16_DKV };
+static int bucket16(int D, int kind) {
+  static const int buckets[] = {32, 64, 96, 128, 160, 192, 256};
+  for (int b : buckets) {
+    if (b == 32 && kind != B16_FORWARD) continue;
+    if (b == 96 && kind != B16_DKV) continue;   // forward and dQ: the 128 objects are faster on D <= 96 than 96-wide ones
+    if (D <= b) return b;
+  }
+  return 0;
+}
+
 static int generic_bucket(int D) {
   static const int buckets[] = {32, 64, 128, 256, 384};
   for (int b : buckets)
@@ -104,17 +117,23 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   if (type == MFA_FORWARD) {
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
-    if (same16 && rowMajor && f32_or_inputs(MFA_O) && (D % 8) == 0) {
+    const int b16 = bucket16(D, B16_FORWARD);
+    if (same16 && rowMajor && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
       VariantInfo v3;
-      const bool have3 = fwd16_v3_variant(pq, bucket, 0, &v3);
-      if (have3 && bucket == 128) {
+      bool have3 = false;
+      switch (b16) {
+        case 160: have3 = fwd16_v3_variant_d160(pq, &v3); break;
+        case 192: have3 = fwd16_v3_variant_d192(pq, &v3); break;
+        default: have3 = fwd16_v3_variant(pq, b16, 0, &v3); break;
+      }
+      if (have3 && b16 == 128) {
         // four waves x 64 rows, hand-placed stream (attn_fwd16_p4.h); split / block-sparse launches keep the siblings of
         // the 8 x 32 kernel.  A descriptor that holds the attention matrix in 16-bit registers (the reference's
         // lowPrecisionIntermediates: P, and for FP16 also S, +Precisions.swift:149-215) selects the stream that
         // pre-multiplies Q by the softmax scale in the 16-bit type; otherwise the scale is applied in fp32 per score
         const bool lowS = kdesc->registerPrecisions[MFA_P] > MFA_FP32;
         v = v3;
-        add(fwd16_p4_variant(pq, bucket, lowS ? 10 : 0, &v), v);
+        add(fwd16_p4_variant(pq, 128, lowS ? 10 : 0, &v), v);
       }
       add(have3, v3);
     }
@@ -122,16 +141,26 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const int pg = kdesc->memoryPrecisions[MFA_dO];
     const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
                           !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
-    if (same16 && pg != MFA_FP32 && rowMajor && (D % 8) == 0) {
-      const int bucket16 = bucket < 64 ? 64 : bucket;   // the backward pair starts at D = 64 (smaller heads are zero-padded)
+    const int b16 = bucket16(D, type == MFA_BACKWARD_QUERY ? B16_DQ : B16_DKV);
+    if (same16 && pg != MFA_FP32 && rowMajor && (D % 8) == 0 && b16 > 0) {
       if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ) &&
-          !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ])
-        add(dq16_variant(pq, pg, bucket16, &v), v);
+          !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ]) {
+        switch (b16) {
+          case 160: add(dq16_variant_d160(pq, pg, &v), v); break;
+          case 192: add(dq16_variant_d192(pq, pg, &v), v); break;
+          default: add(dq16_variant(pq, pg, b16, &v), v); break;
+        }
+      }
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
           kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV] &&
           !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV]) {
-        add(dkv16_rs_variant(pq, pg, bucket16, 0, &v), v);   // role-split wave pairs (attn_dkv16_rs.h)
-        add(dkv16_variant(pq, pg, bucket16, &v), v);          // one wave per key block (attn_bwd16.h)
+        switch (b16) {   // role-split wave pairs (attn_dkv16_rs.h)
+          case 96: add(dkv16_rs_variant_d96(pq, pg, &v), v); break;
+          case 160: add(dkv16_rs_variant_d160(pq, pg, &v), v); break;
+          case 192: add(dkv16_rs_variant_d192(pq, pg, &v), v); break;
+          default: add(dkv16_rs_variant(pq, pg, b16, 0, &v), v); break;
+        }
+        add(dkv16_variant(pq, pg, b16, &v), v);          // one wave per key block (attn_bwd16.h; D = 64, 128 only)
       }
     }
   }
@@ -151,9 +180,9 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     }
     knob = std::getenv("MFA_DKV16_IMPL");
     if (type == MFA_BACKWARD_KEY_VALUE && knob && !candidates.empty()) {
-      const int pg = kdesc->memoryPrecisions[MFA_dO], bucket16 = bucket < 64 ? 64 : bucket;
-      if (std::strcmp(knob, "w4") == 0) have = dkv16_variant(pq, pg, bucket16, &dev);
-      else if (std::strncmp(knob, "rs:", 3) == 0) have = dkv16_rs_variant(pq, pg, bucket16, std::atoi(knob + 3), &dev);
+      const int pg = kdesc->memoryPrecisions[MFA_dO], bk = bucket < 64 ? 64 : bucket;
+      if (std::strcmp(knob, "w4") == 0) have = dkv16_variant(pq, pg, bk, &dev);
+      else if (std::strncmp(knob, "rs:", 3) == 0) have = dkv16_rs_variant(pq, pg, bk, std::atoi(knob + 3), &dev);
     }
     if (type != MFA_FORWARD && std::getenv("MFA_BWD16_DISABLE")) candidates.clear();
     if (have) { candidates.clear(); candidates.push_back(dev); }
@@ -212,6 +241,15 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   kernel->fallback = general;
   kernel->hasFallback = fast;
   kernel->effective = *kdesc;
+  // register precisions the code object REALLY uses (AttentionDescriptor+Precisions.swift:149-215 describes Apple's choices):
+  // the matrix-core kernels feed P (forward, dK/dV) and dS (backward) to the MFMA in the inputs' 16-bit type whatever
+  // lowPrecisionIntermediates says; S, dP, the accumulators, L and D terms are fp32 registers in every kernel
+  if (fast) {
+    kernel->effective.registerPrecisions[MFA_P] = (int8_t)pq;
+    if (type != MFA_FORWARD) kernel->effective.registerPrecisions[MFA_dS] = (int8_t)pq;
+    kernel->effective.registerPrecisions[MFA_S] = MFA_FP32;
+    if (type != MFA_FORWARD) kernel->effective.registerPrecisions[MFA_dP] = MFA_FP32;
+  }
   kernel->effective.parallelization = variant.parallelization;
   kernel->effective.traversal = variant.traversal;
   kernel->effective.headBlock = variant.headBlock;

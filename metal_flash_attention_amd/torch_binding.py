@@ -69,17 +69,39 @@ def _strides(B, H, R, C, D):
     return hs, {op: s * H for op, s in hs.items()}
 
 
+def _as_strided_operand(t):
+    """A [B, H, N, D] VIEW whose last dimension is contiguous (e.g. a permuted [B, N, H, D] tensor, a slice of a fused QKV
+    projection) is handed to the kernels as it is: the C ABI takes a leading dimension and head / batch strides per operand
+    (mfa_launch_params), so no copy is made.  Anything else is made contiguous first."""
+    if t.stride(-1) != 1 or any(st < 0 for st in t.stride()) or (t.shape[2] > 1 and t.stride(2) < t.shape[3]):
+        t = t.contiguous()
+    return t, int(t.stride(2)) if t.shape[2] > 1 else int(t.shape[3]), int(t.stride(1)), int(t.stride(0))
+
+
+def _apply_layouts(hs, bs, lds, **operands):
+    """overwrite the packed strides of the given operands (name -> tensor) with their real ones"""
+    out = {}
+    for name, t in operands.items():
+        t, ld, head, batch = _as_strided_operand(t)
+        op = getattr(Op, name)
+        lds[op], hs[op], bs[op] = ld, head, batch
+        out[name] = t
+    return out
+
+
 class _FlashAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, causal: bool, q_lengths=None, k_lengths=None, block_mask=None):
         _check(q, k, v)
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         B, H, R, D = q.shape
         C = k.shape[2]
+        hs, bs = _strides(B, H, R, C, D)
+        lds = {}
+        views = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v)
+        q, k, v = views["Q"], views["K"], views["V"]
         o = torch.empty((B, H, R, D), dtype=q.dtype, device=q.device)      # fused output cast: no fp32 copy of O
         l = torch.empty((B, H, R), dtype=torch.float32, device=q.device)
         kernel = _kernel(q.dtype, R, C, D, AttentionKernelType.forward)
-        hs, bs = _strides(B, H, R, C, D)
         need = kernel.workspaceSize(row=R, column=C, heads=H, batches=B)
         lengths = q_lengths is not None or k_lengths is not None
         mask_kw = {}
@@ -96,8 +118,8 @@ class _FlashAttention(torch.autograd.Function):
         # the C side launches on the CURRENT device (hipGetDevice) and this stream: make both the tensors' device
         with torch.cuda.device(q.device):
             kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
-                            headStrides=hs, batchStrides=bs, stream=torch.cuda.current_stream(q.device).cuda_stream,
-                            workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
+                            headStrides=hs, batchStrides=bs, leadingDimensions=lds,
+                            stream=torch.cuda.current_stream(q.device).cuda_stream, workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
         ctx.save_for_backward(q, k, v, o, l)
         ctx.causal = causal
         ctx.lengths = (q_lengths, k_lengths)
@@ -119,11 +141,13 @@ class _FlashAttention(torch.autograd.Function):
         dterm = alloc((B, H, R), dtype=torch.float32, device=q.device)
         bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
         hs, bs = _strides(B, H, R, C, D)
+        lds = {}
+        _apply_layouts(hs, bs, lds, Q=q, K=k, V=v)   # saved as the (possibly strided) views the forward used
         with torch.cuda.device(q.device):
             stream = torch.cuda.current_stream(q.device).cuda_stream
             for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
                 _kernel(q.dtype, R, C, D, kind).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
-                                                         batchStrides=bs, stream=stream, causal=ctx.causal,
+                                                         batchStrides=bs, leadingDimensions=lds, stream=stream, causal=ctx.causal,
                                                          rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1], **ctx.mask_kw)
         return dq, dk, dv, None, None, None, None
 

@@ -204,6 +204,8 @@ FWD16_SHAPES = [
     # (R, C, D): D buckets 32/64/128/256, D below a bucket (multiple of 8), ragged R and C
     (256, 256, 128), (512, 512, 64), (300, 300, 128), (255, 257, 64), (33, 65, 32), (64, 1, 64),
     (1, 64, 128), (100, 1000, 256), (257, 130, 200), (129, 77, 40), (96, 640, 80), (1024, 1024, 128),
+    # buckets 96 / 160 / 192 (round 2) and head dimensions just below them
+    (300, 333, 96), (257, 130, 88), (200, 449, 160), (129, 300, 152), (256, 320, 192), (100, 1000, 176),
 ]
 
 
@@ -422,7 +424,8 @@ def test_size_independent_properties_at_full_size():
 
 # ---- 16-bit matrix-core backward kernels (attn_dq16 / attn_dkv16) -----------------------------
 BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), (1, 100, 128), (100, 1, 64),
-                (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64), (256, 256, 256), (300, 333, 200), (65, 700, 256)]
+                (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64), (256, 256, 256), (300, 333, 200), (65, 700, 256),
+                (300, 333, 96), (257, 130, 88), (200, 449, 160), (129, 300, 152), (256, 320, 192), (100, 1000, 176)]
 
 
 @pytest.mark.parametrize("dkv_impl", ["w4", "rs"])
@@ -434,8 +437,8 @@ def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
     the gradients, whose dS is rounded to BF16 like the reference's register precision for dS,
     AttentionDescriptor+Precisions.swift:199-200)."""
     R, C, D = shape
-    if dkv_impl == "w4" and D > 128:
-        pytest.skip("the one-wave-per-key-block kernel stops at D = 128")
+    if dkv_impl == "w4" and (D > 128 or 64 < D <= 96):
+        pytest.skip("the one-wave-per-key-block kernel exists for the 64 and 128 buckets only")
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
     with parameter_rows(*([DKV_W4] if dkv_impl == "w4" else [])):   # 64-row steps = the one-wave-per-key-block kernel

@@ -254,6 +254,21 @@ def test_low_precision_intermediates_select_the_folded_scale_stream():
     assert "fold" not in exact and folded.endswith("_fold"), (exact, folded)
 
 
+def test_effective_descriptor_reports_the_register_precisions_really_used():
+    """matrix-core kernels round P (and dS) to the inputs' 16-bit type also when the descriptor asks for FP32 intermediates
+    (+Precisions.swift:201-205): the effective descriptor says so instead of echoing the request"""
+    d = _low((512, 512, 128))
+    for t in T:
+        kd = d.kernelDescriptor(t)
+        assert kd.registerPrecisions[Op.P] == P.FP32
+        eff = AttentionKernel(kd).effectiveDescriptor
+        assert eff.registerPrecisions[Op.P] == P.BF16 and eff.registerPrecisions[Op.S] == P.FP32, t
+        if t != T.forward:
+            assert eff.registerPrecisions[Op.dS] == P.BF16
+    eff = AttentionKernel(_desc(dims=(512, 512, 128)).kernelDescriptor(T.forward)).effectiveDescriptor   # fp32 kernels: as requested
+    assert eff.registerPrecisions[Op.P] == P.FP32
+
+
 def test_product_library_carries_no_developer_knobs():
     """no environment knob, no superseded kernel, no timing-only ablation in libmfa_hip.so (they live in the -DMFA_DEV_VARIANTS
     build libmfa_hip_dev.so used by tools/ab_*.py)"""

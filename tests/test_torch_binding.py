@@ -98,3 +98,32 @@ def test_block_mask_through_the_binding():
     assert (o.float() - ref).abs().max().item() < 3e-2
     for got, want in ((q.grad, qr.grad), (k.grad, kr.grad), (v.grad, vr.grad)):
         assert (got.float() - want).abs().max().item() < 6e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_strided_views_are_passed_without_a_copy(dtype, monkeypatch):
+    """[B, N, H, D] storage viewed as [B, H, N, D] and slices of one fused QKV tensor: the binding hands the kernels the real
+    leading dimension / head / batch strides instead of calling .contiguous()"""
+    from metal_flash_attention_amd import torch_binding as tb
+    B, H, N, D = 2, 4, 200, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    qkv = torch.randn(B, N, 3, H, D, generator=g, device="cuda").to(dtype)          # fused projection output
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3).requires_grad_(False) for i in range(3))
+    assert not q.is_contiguous()
+    calls = []
+    real = torch.Tensor.contiguous
+    monkeypatch.setattr(torch.Tensor, "contiguous", lambda self, *a, **kw: (calls.append(tuple(self.shape)), real(self, *a, **kw))[1])
+    o = tb.flash_attention(q, k, v, causal=True)
+    monkeypatch.undo()
+    assert (B, H, N, D) not in calls, "a [B, H, N, D] view with a contiguous last dimension must not be copied"
+    _, _, _, ref = reference(q, k, v, True)
+    assert (o.float() - ref).abs().max().item() < (3e-2 if dtype != torch.float32 else 2e-5)
+    qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))   # gradients through strided saved views
+    q2 = qkv.detach().clone().requires_grad_(True)
+    o2 = tb.flash_attention(*(q2[:, :, i].permute(0, 2, 1, 3) for i in range(3)), causal=False)
+    o2.sum().backward()
+    qr, kr, vr, orf = reference(q, k, v, False)
+    orf.sum().backward()
+    got = q2.grad[:, :, 0].permute(0, 2, 1, 3).float()
+    assert (got - qr.grad).abs().max().item() < (6e-2 if dtype != torch.float32 else 5e-5)

@@ -73,6 +73,21 @@ WORKLOADS = {
                             types=("forward", "backwardQuery", "backwardKeyValue")),             # config 3, batched
     "fwdbwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16,
                              types=("forward", "backwardQuery", "backwardKeyValue")),
+    # one backward kernel timed alone (forward and backwardQuery run once, untimed, so that L and D hold real values)
+    "dkv_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, timed=("backwardKeyValue",),
+                          types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dkv_bf16_d128_fp32mid": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, timed=("backwardKeyValue",),
+                                  types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dkv_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, causal=True,
+                                 timed=("backwardKeyValue",), types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dq_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, timed=("backwardQuery",),
+                         types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dq_bf16_d128_fp32mid": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, timed=("backwardQuery",),
+                                 types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dq_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, causal=True,
+                                timed=("backwardQuery",), types=("forward", "backwardQuery", "backwardKeyValue")),
+    "fwdbwd_bf16_d128_mixed": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True,
+                                   types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),
     "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
                                     types=("forward", "backwardQuery", "backwardKeyValue")),
@@ -172,10 +187,15 @@ def main():
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if ws_bytes else None
 
     def step():
-        for t in types:
+        for t in timed:
             kernels[t].dispatch(bufs, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                                 stream=stream, workspace=workspace if t.name == "forward" else None,
                                 causal=bool(w.get("causal", False)))
+
+    timed = types
+    step()                            # every kernel once: L, D (and O) hold real values for a kernel timed alone
+    timed = [t for t in types if t.name in w.get("timed", w["types"])]
+    types = timed                     # rates and rooflines below count the timed kernels only
 
     def sync_all():
         torch.cuda.synchronize()
@@ -236,7 +256,7 @@ def main():
         "vs_baseline": None,
         "dtype": w["dtype"],
         "data": "synthetic",
-        "config": {"workload": f"attention {'+'.join(w['types'])} N={N} D={D} {w['dtype']} Q/K/V, fp32 O, {mem[Op.L].name} L; "
+        "config": {"workload": f"attention {'+'.join(w.get('timed', w['types']))} N={N} D={D} {w['dtype']} Q/K/V, fp32 O, {mem[Op.L].name} L; "
                                f"B={B} H={H} heads per GPU, batch x head sharded across GPUs, no collectives",
                    "precision_mode": ("mixed: lowPrecisionInputs + lowPrecisionIntermediates (the reference's mixed-precision "
                                       "benchmark mode, README.md:15)" if w.get("low_mid") else

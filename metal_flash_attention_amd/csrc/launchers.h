@@ -8,6 +8,7 @@ struct VariantInfo {
   const void *func = nullptr;   // __global__ function address (for hipFuncSetAttribute)
   const char *name = "";
   uint16_t parallelization = 0; // rows (fwd, dQ) or columns (dK/dV) per workgroup
+  uint16_t siblingParallelization = 0;   // the same for launchSparse / launchSplit when they belong to another kernel (0: equal)
   uint16_t traversal = 0;       // columns (fwd, dQ) or rows (dK/dV) per main-loop step
   uint16_t headBlock = 0;       // padded head dimension the code object is unrolled for
   uint32_t threads = 0;         // work-items per workgroup
@@ -47,6 +48,11 @@ bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
 // four waves x 64 rows, one wave per SIMD, hand-placed instruction stream (attn_fwd16_p4.h); D <= 128 only
 bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out);
+// backwardKeyValue counterpart: four waves x 64 keys (attn_dkv16_p4.h); `out` arrives filled by dkv16_rs_variant, whose
+// split / block-sparse launchers it keeps.  lprec / dprec: storage types of L and D (fixed per instruction stream)
+bool dkv16_p4_variant(int precision, int lprec, int dprec, int D, int impl, VariantInfo *out);
+// backwardQuery counterpart: four waves x 64 rows (attn_dq16_p4.h); `out` arrives filled by dq16_variant
+bool dq16_p4_variant(int precision, int D, int impl, VariantInfo *out);
 // 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)
 bool fwd16_v4_variant(int precision, int D, int impl, VariantInfo *out);
 

@@ -148,7 +148,15 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         switch (b16) {
           case 160: add(dq16_variant_d160(pq, pg, &v), v); break;
           case 192: add(dq16_variant_d192(pq, pg, &v), v); break;
-          default: add(dq16_variant(pq, pg, b16, &v), v); break;
+          default: {
+            const bool w8 = dq16_variant(pq, pg, b16, &v);
+            if (w8 && b16 == 128 && pq == pg) {   // four waves x 64 rows, hand-placed stream (attn_dq16_p4.h): the same block
+              VariantInfo v4 = v;                 // dimensions as the 8 x 32 kernel, which keeps the launches this one lacks
+              add(dq16_p4_variant(pq, 128, kdesc->registerPrecisions[MFA_P] > MFA_FP32 ? 10 : 0, &v4), v4);
+            }
+            add(w8, v);
+            break;
+          }
         }
       }
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
@@ -158,7 +166,15 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           case 96: add(dkv16_rs_variant_d96(pq, pg, &v), v); break;
           case 160: add(dkv16_rs_variant_d160(pq, pg, &v), v); break;
           case 192: add(dkv16_rs_variant_d192(pq, pg, &v), v); break;
-          default: add(dkv16_rs_variant(pq, pg, b16, 0, &v), v); break;
+          default: {
+            const bool rs = dkv16_rs_variant(pq, pg, b16, 0, &v);
+            if (rs && b16 == 128 && pq == pg) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
+              VariantInfo v4 = v;
+              add(dkv16_p4_variant(pq, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], 128, 0, &v4), v4);
+            }
+            add(rs, v);
+            break;
+          }
         }
         add(dkv16_variant(pq, pg, b16, &v), v);          // one wave per key block (attn_bwd16.h; D = 64, 128 only)
       }
@@ -408,7 +424,12 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
   // (SquareAttentionTest.swift:355-367)
   const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? p->column : p->row;
-  const uint32_t blocks = (par + plan->variant->parallelization - 1) / plan->variant->parallelization;
+  uint32_t blocks = (par + plan->variant->parallelization - 1) / plan->variant->parallelization;
+  // block-sparse and split launches may belong to a sibling kernel with its own workgroup shape (attn_dkv16_p4 keeps those of
+  // attn_dkv16_rs)
+  const uint32_t sibPar = plan->variant->siblingParallelization ? plan->variant->siblingParallelization : plan->variant->parallelization;
+  const uint32_t sibBlocks = (par + sibPar - 1) / sibPar;
+  if (args->mask && plan->variant->launchSparse && !plan->useFallback) blocks = sibBlocks;
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
   plan->splits = 1;
@@ -418,12 +439,13 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   const bool splittable = !plan->useFallback && plan->variant->launchSplit && !args->rowLen && !args->colLen && !args->mask &&
                           (type != MFA_FORWARD || !args->causal);
   if (splittable) {
-    const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column);
+    const uint32_t s = choose_splits((uint64_t)sibBlocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column);
     if (s > 1) {
       plan->workspaceNeeded = split_workspace_bytes(type, s, heads, batches, p->row, p->column, D);
       if (p->workspace && p->workspaceBytes >= plan->workspaceNeeded &&
           (reinterpret_cast<uintptr_t>(p->workspace) & 15) == 0 && (D % 4) == 0 &&
-          (uint64_t)blocks * heads * batches * s <= 0x7FFFFFFFull) {
+          (uint64_t)sibBlocks * heads * batches * s <= 0x7FFFFFFFull) {
+        plan->grid = dim3(sibBlocks, heads, batches);
         plan->splits = s;
         plan->wsO = static_cast<float *>(p->workspace);
         plan->wsML = plan->wsO + (uint64_t)s * heads * batches * p->row * D;   // forward only
@@ -483,7 +505,8 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
   if (params->rowLengths || params->columnLengths || params->blockMask || (type == MFA_FORWARD && params->causal)) return MFA_OK;
   const uint32_t heads = params->heads ? params->heads : 1, batches = params->batches ? params->batches : 1;
   const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? params->column : params->row;
-  const uint32_t blocks = (par + kernel->variant.parallelization - 1) / kernel->variant.parallelization;
+  const uint32_t wgPar = kernel->variant.siblingParallelization ? kernel->variant.siblingParallelization : kernel->variant.parallelization;
+  const uint32_t blocks = (par + wgPar - 1) / wgPar;
   const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? params->row : params->column);
   if (s > 1) *bytes = split_workspace_bytes(type, s, heads, batches, params->row, params->column, kernel->desc.headDimension);
   return MFA_OK;

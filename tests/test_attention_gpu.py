@@ -51,6 +51,8 @@ def parameter_rows(*rows):
 
 
 FWD_8x32 = (AttentionKernelType.forward, True, "| 32 | 128 | 32 | 32 | Q, O |\n| 64 | 256 | 32 | 64 | Q, O |\n| 128 | 256 | 32 | 128 | Q, O |\n| 256 | 128 | 32 | 256 | Q, O |\n")
+DKV_RS = (AttentionKernelType.backwardKeyValue, True, "| 64 | 128 | 32 | 64 | K, V, dV, dK |\n| 96 | 128 | 32 | 96 | K, V, dV, dK |\n| 128 | 128 | 32 | 128 | K, V, dV, dK |\n"
+          "| 160 | 64 | 32 | 160 | K, V, dV, dK |\n| 192 | 64 | 32 | 192 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
 DKV_W4 = (AttentionKernelType.backwardKeyValue, True, "| 64 | 128 | 64 | 64 | K, V, dV, dK |\n| 128 | 128 | 64 | 128 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
 
 
@@ -428,10 +430,13 @@ BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), 
                 (300, 333, 96), (257, 130, 88), (200, 449, 160), (129, 300, 152), (256, 320, 192), (100, 1000, 176)]
 
 
-@pytest.mark.parametrize("dkv_impl", ["w4", "rs"])
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("dkv_impl", ["w4", "rs", "p4"])
 @pytest.mark.parametrize("shape", BWD16_SHAPES)
-def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
-    """dkv_impl: one wave per key block / role-split wave pairs (attn_dkv16_rs.h).
+def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
+    """dkv_impl: one wave per key block / role-split wave pairs (attn_dkv16_rs.h) / four waves x 64 keys, hand-placed
+    (attn_dkv16_p4.h: the default row for D in (96, 128]; low_mid selects its stream with K pre-multiplied by the softmax
+    scale, FP16 L, BF16 D).
     All three kernels on the BF16 matrix cores (Q, K, V, dO BF16): within the reference's mixed
     tolerances of the oracle fed with the rounded inputs, and within a tighter bound (2e-2 absolute on
     the gradients, whose dS is rounded to BF16 like the reference's register precision for dS,
@@ -439,20 +444,26 @@ def test_backward_16bit_mfma(shape, dkv_impl, monkeypatch):
     R, C, D = shape
     if dkv_impl == "w4" and (D > 128 or 64 < D <= 96):
         pytest.skip("the one-wave-per-key-block kernel exists for the 64 and 128 buckets only")
+    if dkv_impl == "p4" and not 96 < D <= 128:
+        pytest.skip("the four-wave kernel exists for the 128 bucket only")
+    if low_mid and dkv_impl == "w4":
+        pytest.skip("covered with FP32 intermediates")
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
-    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
-    with parameter_rows(*([DKV_W4] if dkv_impl == "w4" else [])):   # 64-row steps = the one-wave-per-key-block kernel
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16, low_mid=low_mid)
+    with parameter_rows(*({"w4": [DKV_W4], "rs": [DKV_RS], "p4": []}[dkv_impl])):
         run = harness.DeviceRun(desc, net)
     variants = {t.name: k.variant for t, k in run.kernels.items()}
     assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
     assert ("attn_dkv16rs" in variants["backwardKeyValue"]) == (dkv_impl == "rs"), variants
+    assert ("attn_dkv16p4" in variants["backwardKeyValue"]) == (dkv_impl == "p4"), variants
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run()
     failures, report = harness.compare(ref, got, TOL_MIXED_SHORT if C <= 20 else TOL_MIXED)
     assert not failures, (failures, variants)
-    tight, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
-    assert not tight, (tight, variants)
+    if not low_mid:   # FP16 L and BF16 D (mixed mode) alone cost more than this bound
+        tight, report = harness.compare(ref, got, dict(O=1.5e-2, L=1e-3, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+        assert not tight, (tight, variants)
     assert all(run.tails_ok.values()), run.tails_ok
 
 
@@ -839,8 +850,11 @@ def test_backward_split_matches_unsplit_and_oracle(shape, causal):
         k.dispatch(run.buffers, row=R, column=C, stream=stream, causal=causal, workspace=ws)
     torch.cuda.synchronize()
     got = run.results()
+    # the unsplit launch of the 128 bucket is the four-wave hand-placed kernel, the split one its 8 x 32 / role-split sibling:
+    # P and dS are rounded to BF16 at different values of the same expression (both within the oracle bounds below)
+    other_kernel = any("p4" in run.kernels[t].variant for t in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue))
     for name in ("dQ", "dK", "dV", "D"):
-        assert np.abs(got[name] - base[name]).max() < 2e-3, name
+        assert np.abs(got[name] - base[name]).max() < (1.5e-2 if other_kernel and name != "D" else 2e-3), name
     round_inputs(net, desc)
     ref = net.run(causal=causal)
     failures, report = harness.compare(ref, got, dict(D=5e-2, dV=2e-2, dK=2e-2, dQ=2e-2))

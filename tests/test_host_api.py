@@ -230,8 +230,12 @@ def test_parameter_table_row_selects_the_code_object():
         assert k.variant.startswith("attn_fwd16v3_bf16_d128_w8x32") and k.blockDimensions == (256, 32, 128)
         mfa.setParameterFile(T.backwardKeyValue, True, "| 128 | 128 | 64 | 128 | K, V, dV, dK |\n")
         assert AttentionKernel(d.kernelDescriptor(T.backwardKeyValue)).variant.startswith("attn_dkv16_bf16_d128_w4x32")
-        mfa.resetParameterFiles()
+        mfa.setParameterFile(T.backwardKeyValue, True, "| 128 | 128 | 32 | 128 | K, V, dV, dK |\n")
         assert AttentionKernel(d.kernelDescriptor(T.backwardKeyValue)).variant.startswith("attn_dkv16rs_bf16_d128")
+        mfa.resetParameterFiles()   # default row (256, 32, 128): four waves x 64 keys; the stream follows the types of L and D
+        assert AttentionKernel(d.kernelDescriptor(T.backwardKeyValue)).variant == "attn_dkv16p4_bf16_d128_w4x64_exact"
+        dm = _low((4096, 4096, 128), low_mid=True)
+        assert AttentionKernel(dm.kernelDescriptor(T.backwardKeyValue)).variant == "attn_dkv16p4_bf16_d128_w4x64"
         # nothing implements 64 rows x 128 keys with Q streamed: nearest variant + report, or an error when strict
         mfa.setParameterFile(T.forward, True, "| 384 | 64 | 128 | 32 | O |\n")
         kd = d.kernelDescriptor(T.forward)

@@ -124,7 +124,10 @@ class Wave:
     def retire_vm(self, keep):
         while len(self.vm_q) > keep:
             addrs, data = self.vm_q.pop(0)
-            if addrs is not None:
+            if isinstance(addrs, tuple):                 # plain buffer load: (kind, idx) <- data
+                (self.v if addrs[0] == "v" else self.a)[addrs[1]] = data
+                self.poison.discard(addrs)
+            elif addrs is not None:
                 self.wg.lds_write16(addrs, data)
 
 
@@ -263,6 +266,18 @@ class Workgroup:
                 w.vm_q.append((None, None))
             else:
                 w.vm_q.append((addrs, data))
+        elif op in ("buffer_load_dword", "buffer_load_ushort"):
+            off = w.rd(s[0]).astype(np.int64)
+            buf, nrec = w.sn[s[1][1]]
+            n = 4 if op == "buffer_load_dword" else 2
+            data = np.zeros(64, np.uint32)
+            for l in range(64):
+                o = int(off[l])
+                if o + n <= nrec:
+                    data[l] = int.from_bytes(bytes(buf[o:o + n]), "little")
+            dest = (d[0], d[1])
+            w.poison.add(dest)
+            w.vm_q.append((dest, data))
         elif op == "v_exp_f32":
             x = w.rdf(s[0]).astype(np.float64)
             if m.get("neg0"):
@@ -280,6 +295,11 @@ class Workgroup:
             with np.errstate(over="ignore", invalid="ignore"):
                 r = {"v_add_f32": a + b, "v_sub_f32": a - b, "v_mul_f32": a * b, "v_max_f32": np.maximum(a, b)}[op]
             w.wr(d, r.astype(np.float32))
+        elif op == "v_pk_mul_f32":
+            x, y = w.rd_multi(s[0]).view(np.float32), (w.rd_multi(s[1]) if s[1][0] != "S" else np.stack([w.rd(("S", s[1][1]))] * 2)).view(np.float32)
+            res = (x * y).astype(np.float32).view(np.uint32)
+            for (kind, idx), row in zip(w.regs(d), res):
+                (w.v if kind == "v" else w.a)[idx] = row
         elif op == "v_max3_f32":
             w.wr(d, np.maximum(np.maximum(w.rdf(s[0]), w.rdf(s[1])), w.rdf(s[2])))
         elif op in ("v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32"):
@@ -315,6 +335,8 @@ class Workgroup:
             w.wr(d, (w.rd(s[1]).astype(np.int64) - w.rd(s[0]).astype(np.int64)) & 0xFFFFFFFF)
         elif op == "v_cmp_gt_f32":
             w.vcc = w.rdf(s[0]) > w.rdf(s[1])
+        elif op == "v_cmp_lt_i32":
+            w.vcc = w.rd(s[0]).view(np.int32) < w.rd(s[1]).view(np.int32)
         elif op == "v_cmp_gt_i32":
             w.vcc = w.rd(s[0]).view(np.int32) > w.rd(s[1]).view(np.int32)
         elif op == "v_cndmask_b32":
@@ -335,6 +357,8 @@ class Workgroup:
         elif op in ("s_add_u32", "s_sub_u32"):
             a, b = w.srd(s[0]), w.srd(s[1])
             w.swr(d, a + b if op == "s_add_u32" else a - b)
+        elif op == "s_and_b32":
+            w.swr(d, w.srd(s[0]) & w.srd(s[1]))
         elif op == "s_lshl_b32":
             w.swr(d, w.srd(s[0]) << w.srd(s[1]))
         elif op in ("s_cmp_lt_i32", "s_cmp_ge_i32"):

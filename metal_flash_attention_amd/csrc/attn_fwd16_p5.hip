@@ -1,0 +1,49 @@
+// attn_fwd16_p5.hip -- instantiations of the four-wave, 64-rows-per-wave forward kernel for 128 < D <= 256 (attn_fwd16_p5.h).
+#include "attn_fwd16_p5.h"
+#include "launchers.h"
+
+namespace mfa {
+
+template <typename T, int STREAM, bool CAUSAL>
+static void launch_p5(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  const uint32_t groups = CAUSAL ? (grid.x + 1) / 2 : grid.x;   // causal: one workgroup per pair of row blocks (last - i, i)
+  hipLaunchKernelGGL((attn_fwd16_p5<T, STREAM, CAUSAL>), dim3(groups * grid.y * grid.z), dim3(256), p5::LDS_BYTES, stream, args, g);
+}
+
+// `v` arrives filled by fwd16_v3_variant (D = 256: four waves x 32 rows): split and block-sparse launches keep its code objects
+template <typename T, int STREAM> static void fill_p5(VariantInfo *v, const char *name) {
+  v->func = reinterpret_cast<const void *>(&attn_fwd16_p5<T, STREAM, false>);
+  v->name = name;
+  v->siblingParallelization = v->parallelization;
+  v->parallelization = 256;
+  v->traversal = 32;
+  v->headBlock = 256;
+  v->threads = 256;
+  v->ldsBytes = v->ldsBytes > (uint32_t)p5::LDS_BYTES ? v->ldsBytes : (uint32_t)p5::LDS_BYTES;
+  v->cacheLeft = true;
+  v->cacheSecond = true;
+  v->launch = &launch_p5<T, STREAM, false>;
+  v->launchCausal = &launch_p5<T, STREAM, true>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_p5<T, STREAM, true>);
+  v->causal = true;
+}
+
+// impl 0 = scale applied in fp32; impl 10 = FOLD (see attn_fwd16_p4.hip); 1000 + stream index: developer streams
+bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out) {
+  if (D != 256) return false;
+  if (precision == PREC_BF16) {
+    if (impl == 0) { fill_p5<__bf16, p5::S_BF16_THR8>(out, "attn_fwd16p5_bf16_d256_w4x64_thr8"); return true; }
+    if (impl == 10) { fill_p5<__bf16, p5::S_BF16_FOLD>(out, "attn_fwd16p5_bf16_d256_w4x64_thr8_fold"); return true; }
+#ifdef MFA_DEV_VARIANTS
+    if (impl == 1000 + p5::S_BF16_FOLD_PROF) { fill_p5<__bf16, p5::S_BF16_FOLD_PROF>(out, "attn_fwd16p5_DEV_BF16_FOLD_PROF"); return true; }
+#endif
+  }
+  if (precision == PREC_FP16) {
+    if (impl == 0) { fill_p5<_Float16, p5::S_F16_THR8>(out, "attn_fwd16p5_f16_d256_w4x64_thr8"); return true; }
+    if (impl == 10) { fill_p5<_Float16, p5::S_F16_FOLD>(out, "attn_fwd16p5_f16_d256_w4x64_thr8_fold"); return true; }
+  }
+  return false;
+}
+
+} // namespace mfa

@@ -48,6 +48,8 @@ bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
 // four waves x 64 rows, one wave per SIMD, hand-placed instruction stream (attn_fwd16_p4.h); D <= 128 only
 bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out);
+// 128 < D <= 256: four waves x 64 rows, 32-key steps (attn_fwd16_p5.h); `out` arrives filled by fwd16_v3_variant
+bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out);
 // backwardKeyValue counterpart: four waves x 64 keys (attn_dkv16_p4.h); `out` arrives filled by dkv16_rs_variant, whose
 // split / block-sparse launchers it keeps.  lprec / dprec: storage types of L and D (fixed per instruction stream)
 bool dkv16_p4_variant(int precision, int lprec, int dprec, int D, int impl, VariantInfo *out);

@@ -135,6 +135,11 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         v = v3;
         add(fwd16_p4_variant(pq, 128, lowS ? 10 : 0, &v), v);
       }
+      if (have3 && b16 == 256) {   // four waves x 64 rows, 32-key steps (attn_fwd16_p5.h)
+        const bool lowS = kdesc->registerPrecisions[MFA_P] > MFA_FP32;
+        v = v3;
+        add(fwd16_p5_variant(pq, 256, lowS ? 10 : 0, &v), v);
+      }
       add(have3, v3);
     }
   } else {
@@ -199,6 +204,14 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       const int pg = kdesc->memoryPrecisions[MFA_dO], bk = bucket < 64 ? 64 : bucket;
       if (std::strcmp(knob, "w4") == 0) have = dkv16_variant(pq, pg, bk, &dev);
       else if (std::strncmp(knob, "rs:", 3) == 0) have = dkv16_rs_variant(pq, pg, bk, std::atoi(knob + 3), &dev);
+      else if (std::strncmp(knob, "p4:", 3) == 0)
+        have = dkv16_rs_variant(pq, pg, bk, 0, &dev) &&
+               dkv16_p4_variant(pq, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], bk, std::atoi(knob + 3), &dev);
+    }
+    knob = std::getenv("MFA_DQ16_IMPL");
+    if (type == MFA_BACKWARD_QUERY && knob && !candidates.empty() && std::strncmp(knob, "p4:", 3) == 0) {
+      const int pg = kdesc->memoryPrecisions[MFA_dO];
+      have = dq16_variant(pq, pg, bucket, &dev) && dq16_p4_variant(pq, bucket, std::atoi(knob + 3), &dev);
     }
     if (type != MFA_FORWARD && std::getenv("MFA_BWD16_DISABLE")) candidates.clear();
     if (have) { candidates.clear(); candidates.push_back(dev); }

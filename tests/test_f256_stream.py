@@ -1,0 +1,66 @@
+"""CPU checks of the hand-placed instruction stream of attn_fwd16_p5 (tools/f256gen.py; forward, 128 < D <= 256) on the
+lane-exact model in tools/p4sim.py: the stream that is compiled into libmfa_hip.so is executed instruction by instruction
+for one 256-row block and compared with a float64 attention.  No GPU, no oracle library needed."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import f256gen  # noqa: E402
+import f256sim  # noqa: E402
+
+V = f256gen.VARIANTS
+
+
+def _check(R, C, rblk=0, causal=False, cfg=None, seed=0, tol_o=4e-3, tol_l=2e-5, **kw):
+    cfg = cfg or V["BF16_THR8"]
+    if cfg.fold:
+        tol_l = max(tol_l, 6e-4 if cfg.dtype == "f16" else 5e-3)   # Q * scale2 rounded to the 16-bit type
+    dO, dL, wg = f256sim.check(R=R, C=C, rblk=rblk, causal=causal, cfg=cfg, seed=seed, **kw)
+    assert dO < tol_o and dL < tol_l * 12, (dO, dL)
+    return wg
+
+
+@pytest.mark.parametrize("C", [32, 64, 96, 160, 288])      # 288 keys = 9 steps: the four-stage ring wraps twice
+def test_step_counts(C):
+    _check(256, C)
+
+
+@pytest.mark.parametrize("R,C,rblk", [(256, 100, 0), (200, 130, 0), (300, 70, 1), (70, 1, 0)])
+def test_ragged(R, C, rblk):
+    _check(R, C, rblk=rblk, seed=1)
+
+
+@pytest.mark.parametrize("R,C,rblk", [(256, 256, 0), (512, 512, 1), (300, 400, 1)])
+def test_causal_per_wave_bounds_and_skip_loop(R, C, rblk):
+    _check(R, C, rblk=rblk, causal=True, seed=2)
+
+
+@pytest.mark.parametrize("dma_mode", ["early", "late"])
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 2, 1, 0)])
+def test_ring_discipline(dma_mode, order):
+    _check(256, 224, dma_mode=dma_mode, order=order, seed=3)
+
+
+@pytest.mark.parametrize("name", ["BF16_THR8", "BF16_FOLD"])
+def test_deferred_rescale_spike(name):
+    # a score far above the row's others at a late step must rescale O, l after every P^T V^T product of the step before
+    wg = _check(256, 192, cfg=V[name], seed=4, spike=(5, 150, 3.0), tol_o=8e-3, tol_l=2e-3)
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 256
+
+
+@pytest.mark.parametrize("name", [n for n, c in V.items() if not c.prof])
+def test_every_compiled_variant(name):
+    _check(256, 160, cfg=V[name], seed=5)
+    _check(256, 320, cfg=V[name], causal=True, seed=6)
+
+
+def test_stream_file_is_current():
+    """csrc/attn_fwd16_p5_stream.inc is what tools/f256gen.py generates"""
+    path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p5_stream.inc")
+    with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:
+        f256gen.write_inc(tmp.name)
+        assert open(path).read() == open(tmp.name).read(), "run python tools/f256gen.py"

@@ -335,6 +335,8 @@ class Workgroup:
             w.wr(d, (w.rd(s[1]).astype(np.int64) - w.rd(s[0]).astype(np.int64)) & 0xFFFFFFFF)
         elif op == "v_cmp_gt_f32":
             w.vcc = w.rdf(s[0]) > w.rdf(s[1])
+        elif op == "v_cmp_le_i32":
+            w.vcc = w.rd(s[0]).view(np.int32) <= w.rd(s[1]).view(np.int32)
         elif op == "v_cmp_lt_i32":
             w.vcc = w.rd(s[0]).view(np.int32) < w.rd(s[1]).view(np.int32)
         elif op == "v_cmp_gt_i32":

@@ -117,6 +117,7 @@ def frag_first(i):
     return (2 if i < 8 else 4) + 2 * i          # 2 + 2i (S), 20 + 2 (i - 8) (dP), 36 + 2 (i - 16) (dV), 52 + 2 (i - 24) (dK)
 
 
+PACKED_MUL = int(os.environ.get('MFA_GEN_PACKED_MUL', '0'))   # v_pk_mul_f32 for dS' = P * dP': no faster on gfx950 (dQ 1.5 % slower), see DESIGN.md
 N_MFMA = 68
 
 
@@ -211,8 +212,13 @@ class Stream(_P4Stream):
         self.emit("v_pk_mul_f32", x, [x, SN("scale2x2", 2)])
 
     def mul_op(self, kb, r):     # dS' = P * dP', two at a time
-        x = V(DPB + 16 * kb + r, 2)
-        self.emit("v_pk_mul_f32", x, [V(SP + 16 * kb + r, 2), x])
+        if PACKED_MUL:
+            x = V(DPB + 16 * kb + r, 2)
+            self.emit("v_pk_mul_f32", x, [V(SP + 16 * kb + r, 2), x])
+        else:
+            for t in range(2):
+                x = V(DPB + 16 * kb + r + t)
+                self.emit("v_mul_f32", x, [V(SP + 16 * kb + r + t), x])
 
     def packds_op(self, kb, u, w):
         r = 8 * u + 2 * w
@@ -294,8 +300,8 @@ class Stream(_P4Stream):
         slots = {("mul", 0): (38, 40), ("mul", 1): (42, 48), ("pack", 0): (44, 46), ("pack", 1): (52, 54)}
         for u in range(2):
             for kb in range(2):
-                for r in range(8 * u, 8 * u + 8, 2):
-                    at(slots[("mul", u)][kb], lambda kb=kb, r=r: self.mul_op(kb, r))
+                for n, r in enumerate(range(8 * u, 8 * u + 8, 2)):
+                    at(slots[("mul", u)][kb] + (0 if PACKED_MUL else n // 2), lambda kb=kb, r=r: self.mul_op(kb, r))
                 for w in range(4):
                     at(slots[("pack", u)][kb], lambda kb=kb, u=u, w=w: self.packds_op(kb, u, w))
         # ---- the seam to the next step (gap 60): own DMA pieces of step t+1 and its L / D have landed; barrier; then the

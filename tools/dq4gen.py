@@ -46,6 +46,7 @@ T_TL, T_MASKV = 232, 234
 FIRST_OWNED_VGPR = 24
 
 STAGE, VIMG, RING = 32768, 16384, 4
+PACKED_MUL = int(os.environ.get('MFA_GEN_PACKED_MUL', '0'))   # v_pk_mul_f32 for dS' = P * dP': no faster on gfx950 (dQ 1.5 % slower), see DESIGN.md
 N_MFMA = 96
 
 INOUT_V = ["koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3", "ka0", "ka1", "ta0", "ta1"]
@@ -149,8 +150,13 @@ class Stream(_P4Stream):
         self.emit("v_exp_f32", x, [x])
 
     def mul_op(self, rb, kb, r):
-        x = V(DP + 16 * (2 * kb + rb) + r, 2)
-        self.emit("v_pk_mul_f32", x, [V(ST + 16 * (2 * kb + rb) + r, 2), x])
+        if PACKED_MUL:
+            x = V(DP + 16 * (2 * kb + rb) + r, 2)
+            self.emit("v_pk_mul_f32", x, [V(ST + 16 * (2 * kb + rb) + r, 2), x])
+        else:
+            for t in range(2):
+                x = V(DP + 16 * (2 * kb + rb) + r + t)
+                self.emit("v_mul_f32", x, [V(ST + 16 * (2 * kb + rb) + r + t), x])
 
     def pack_op(self, rb, kb, u, w):
         r = 8 * u + 2 * w
@@ -218,8 +224,16 @@ class Stream(_P4Stream):
             for rb in range(2):
                 for u in range(2):
                     seq += [lambda rb=rb, kb=kb, u=u, w=w: self.pack_op(rb, kb, u, w) for w in range(4)]
-            for n, fn in enumerate(seq):
-                at(g1 + 2 + (n * 14) // len(seq), fn)
+            # even gaps take more of them: the odd ones carry the fragment reads (two per gap beside Q(0)) and their waits
+            g, used = g1 + 2, 0
+            for fn in seq:
+                quota = (5 if len(seq) > 32 else 3) if g % 2 == 0 else 2
+                if used == quota:
+                    g, used = g + 1, 0
+                    quota = (5 if len(seq) > 32 else 3) if g % 2 == 0 else 2
+                assert g < g1 + 16
+                at(g, fn)
+                used += 1
 
         # ---- seam (gap 88): own DMA pieces of tile j+1 have landed; barrier; first fragments of tile j+1
         def seam():

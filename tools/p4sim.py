@@ -295,9 +295,10 @@ class Workgroup:
             with np.errstate(over="ignore", invalid="ignore"):
                 r = {"v_add_f32": a + b, "v_sub_f32": a - b, "v_mul_f32": a * b, "v_max_f32": np.maximum(a, b)}[op]
             w.wr(d, r.astype(np.float32))
-        elif op == "v_pk_mul_f32":
+        elif op in ("v_pk_mul_f32", "v_pk_add_f32"):
             x, y = w.rd_multi(s[0]).view(np.float32), (w.rd_multi(s[1]) if s[1][0] != "S" else np.stack([w.rd(("S", s[1][1]))] * 2)).view(np.float32)
-            res = (x * y).astype(np.float32).view(np.uint32)
+            with np.errstate(over="ignore", invalid="ignore"):
+                res = ((x * y) if op == "v_pk_mul_f32" else (x + y)).astype(np.float32).view(np.uint32)
             for (kind, idx), row in zip(w.regs(d), res):
                 (w.v if kind == "v" else w.a)[idx] = row
         elif op == "v_max3_f32":

@@ -88,6 +88,10 @@ WORKLOADS = {
                                 timed=("backwardQuery",), types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwdbwd_bf16_d128_mixed": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True,
                                    types=("forward", "backwardQuery", "backwardKeyValue")),
+    # the headline shape with Q, K, V, O stored transposed ([D][N]): with a workspace the launch re-lays them out (an
+    # HBM-bound pass per operand) and runs the same matrix-core kernel
+    "fwd_bf16_d128_transposed": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), low_mid=True,
+                                     tr=(True, True, True, True)),
     "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),
     "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
                                     types=("forward", "backwardQuery", "backwardKeyValue")),
@@ -155,7 +159,7 @@ def main():
     desc.lowPrecisionIntermediates = bool(w.get("low_mid", False))
     desc.lowPrecisionInputType = P.BF16 if w["dtype"] == "bf16" else P.FP16
     desc.matrixDimensions = (N, N, D)
-    desc.transposeState = (False, False, False, False)
+    desc.transposeState = tuple(w.get("tr", (False, False, False, False)))
     types = [AttentionKernelType[t] for t in w["types"]]
     kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in types}
 
@@ -183,13 +187,15 @@ def main():
     bs = {op: v * H for op, v in hs.items()}
     stream = torch.cuda.current_stream().cuda_stream
     # caller-owned scratch: lets a launch with too few row blocks (single head) run column-parallel
-    ws_bytes = kernels[types[0]].workspaceSize(row=N, column=N, heads=H, batches=B) if types[0].name == "forward" else 0
+    relayout = any(w.get("tr", ()))      # transposed operands: every kernel type gets its re-layout scratch
+    ws_bytes = max(kernels[t].workspaceSize(row=N, column=N, heads=H, batches=B) if (t.name == "forward" or relayout) else 0
+                   for t in types)
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if ws_bytes else None
 
     def step():
         for t in timed:
             kernels[t].dispatch(bufs, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs,
-                                stream=stream, workspace=workspace if t.name == "forward" else None,
+                                stream=stream, workspace=workspace if (t.name == "forward" or relayout) else None,
                                 causal=bool(w.get("causal", False)))
 
     timed = types

@@ -168,6 +168,15 @@ uint32_t mfa_attention_kernel_threadgroup_size(const mfa_attention_kernel *kerne
 uint32_t mfa_attention_kernel_threadgroup_memory_allocation(const mfa_attention_kernel *kernel);
 /* name of the selected HIP kernel variant, e.g. "attn_fwd_bf16_d128_r256" (diagnostics) */
 const char *mfa_attention_kernel_variant(const mfa_attention_kernel *kernel);
+/* name of the general (fp32-arithmetic) code object that serves the launches the selected variant cannot take (misaligned
+ * pointers or strides, transposed operands without a workspace ...); "" if the selected variant is the general one */
+const char *mfa_attention_kernel_fallback_variant(const mfa_attention_kernel *kernel);
+/* Transposed operands (transposeState, AttentionKernelDescriptor.swift:30-41) and the 16-bit matrix-core kernels: those
+ * read row-major tiles, so a launch with `workspace` first re-lays every transposed operand out into the workspace (one
+ * HBM-bound pass per operand, 2 x sequence x D x size bytes; transposed outputs are written back the same way) and then
+ * runs the matrix-core code object; without a workspace the general kernel reads the transposed operands in place.
+ * Non-zero = this kernel is in that situation (size the workspace with mfa_attention_kernel_workspace_size). */
+int mfa_attention_kernel_needs_workspace_for_fast_path(const mfa_attention_kernel *kernel);
 /* The descriptor as the selected code object really executes it: the Swift struct lets callers
  * request any block dimensions / cache state (AttentionKernelDescriptor.swift:9-13); a
  * pre-compiled suite honours the nearest compiled variant and reports it here. */
@@ -193,6 +202,8 @@ typedef struct mfa_launch_params {
    * traversal-parallel: forward and backwardQuery cut the key range, backwardKeyValue the row range;
    * the pieces' partial results (forward: un-normalised O, m, l; backward: fp32 gradient slabs) go to
    * this scratch and a second small kernel merges them -- no atomics.  NULL (default) = never split.
+   * Second use: row-major copies of transposed operands for the matrix-core kernels (see
+   * mfa_attention_kernel_needs_workspace_for_fast_path; such launches are not split; 256-byte aligned).
    * Size it with mfa_attention_kernel_workspace_size.  Contents need no initialisation. */
   void *workspace;
   uint64_t workspaceBytes;

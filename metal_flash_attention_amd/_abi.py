@@ -184,6 +184,8 @@ SYMBOLS = [
     ("mfa_attention_kernel_threadgroup_size", ctypes.c_uint32, [_KERNEL]),
     ("mfa_attention_kernel_threadgroup_memory_allocation", ctypes.c_uint32, [_KERNEL]),
     ("mfa_attention_kernel_variant", ctypes.c_char_p, [_KERNEL]),
+    ("mfa_attention_kernel_fallback_variant", ctypes.c_char_p, [_KERNEL]),
+    ("mfa_attention_kernel_needs_workspace_for_fast_path", ctypes.c_int, [_KERNEL]),
     ("mfa_attention_kernel_effective_descriptor", ctypes.c_int, [_KERNEL, _P(mfa_attention_kernel_descriptor)]),
     ("mfa_launch_params_init", None, [_P(mfa_launch_params)]),
     ("mfa_attention_kernel_launch", ctypes.c_int, [_KERNEL, _P(_BUFS), _P(mfa_launch_params), ctypes.c_void_p]),

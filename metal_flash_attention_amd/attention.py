@@ -276,6 +276,17 @@ class AttentionKernel:
         return lib().mfa_attention_kernel_variant(self._handle).decode()
 
     @property
+    def fallbackVariant(self) -> str:
+        """the general code object behind launches the selected variant cannot take ("" if it is the general one)"""
+        return lib().mfa_attention_kernel_fallback_variant(self._handle).decode()
+
+    @property
+    def needsWorkspaceForFastPath(self) -> bool:
+        """transposed operands: the matrix-core kernel runs on row-major copies in the caller's workspace (workspaceSize);
+        without a workspace the launch runs `fallbackVariant`"""
+        return bool(lib().mfa_attention_kernel_needs_workspace_for_fast_path(self._handle))
+
+    @property
     def effectiveDescriptor(self) -> AttentionKernelDescriptor:
         out = _abi.mfa_attention_kernel_descriptor()
         check(lib().mfa_attention_kernel_effective_descriptor(self._handle, ctypes.byref(out)))

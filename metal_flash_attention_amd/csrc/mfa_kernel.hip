@@ -25,6 +25,7 @@ struct mfa_attention_kernel {
   VariantInfo variant;            // preferred code object
   VariantInfo fallback;           // general code object, used when a launch does not meet the
   bool hasFallback = false;       // preferred variant's alignment requirements
+  bool relayout = false;          // transposed operands: the preferred variant runs on row-major copies in the caller's workspace
   std::mutex attrMutex;
   uint64_t attrDeviceMask = 0;    // devices on which the LDS attribute has been raised (variant)
   uint64_t attrDeviceMaskFallback = 0;
@@ -114,11 +115,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
   auto add = [&](bool ok, const VariantInfo &v) { if (ok) candidates.push_back(v); };
   VariantInfo v;
+  bool relayout = false;
   if (type == MFA_FORWARD) {
-    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
-                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_O];
+    // transposed operands (transposeState): the matrix-core kernels read row-major tiles; with a workspace the launch
+    // re-lays the transposed operands out (an HBM-bound pass, attn_relayout below), without one it runs the general kernel
+    relayout = kdesc->transposeState[MFA_Q] || kdesc->transposeState[MFA_K] || kdesc->transposeState[MFA_V] || kdesc->transposeState[MFA_O];
     const int b16 = bucket16(D, B16_FORWARD);
-    if (same16 && rowMajor && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
+    if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
       VariantInfo v3;
       bool have3 = false;
       switch (b16) {
@@ -144,12 +147,12 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     }
   } else {
     const int pg = kdesc->memoryPrecisions[MFA_dO];
-    const bool rowMajor = !kdesc->transposeState[MFA_Q] && !kdesc->transposeState[MFA_K] &&
-                          !kdesc->transposeState[MFA_V] && !kdesc->transposeState[MFA_dO];
+    relayout = kdesc->transposeState[MFA_Q] || kdesc->transposeState[MFA_K] || kdesc->transposeState[MFA_V] || kdesc->transposeState[MFA_dO];
+    if (type == MFA_BACKWARD_QUERY) relayout = relayout || kdesc->transposeState[MFA_O] || kdesc->transposeState[MFA_dQ];
+    else relayout = relayout || kdesc->transposeState[MFA_dK] || kdesc->transposeState[MFA_dV];
     const int b16 = bucket16(D, type == MFA_BACKWARD_QUERY ? B16_DQ : B16_DKV);
-    if (same16 && pg != MFA_FP32 && rowMajor && (D % 8) == 0 && b16 > 0) {
-      if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ) &&
-          !kdesc->transposeState[MFA_O] && !kdesc->transposeState[MFA_dQ]) {
+    if (same16 && pg != MFA_FP32 && (D % 8) == 0 && b16 > 0) {
+      if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ)) {
         switch (b16) {
           case 160: add(dq16_variant_d160(pq, pg, &v), v); break;
           case 192: add(dq16_variant_d192(pq, pg, &v), v); break;
@@ -165,8 +168,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         }
       }
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
-          kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV] &&
-          !kdesc->transposeState[MFA_dK] && !kdesc->transposeState[MFA_dV]) {
+          kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV]) {
         switch (b16) {   // role-split wave pairs (attn_dkv16_rs.h)
           case 96: add(dkv16_rs_variant_d96(pq, pg, &v), v); break;
           case 160: add(dkv16_rs_variant_d160(pq, pg, &v), v); break;
@@ -269,6 +271,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   kernel->variant = variant;
   kernel->fallback = general;
   kernel->hasFallback = fast;
+  kernel->relayout = fast && relayout;
   kernel->effective = *kdesc;
   // register precisions the code object REALLY uses (AttentionDescriptor+Precisions.swift:149-215 describes Apple's choices):
   // the matrix-core kernels feed P (forward, dK/dV) and dS (backward) to the MFMA in the inputs' 16-bit type whatever
@@ -323,6 +326,12 @@ uint32_t mfa_attention_kernel_threadgroup_memory_allocation(const mfa_attention_
 const char *mfa_attention_kernel_variant(const mfa_attention_kernel *kernel) {
   return kernel ? kernel->variant.name : "";
 }
+const char *mfa_attention_kernel_fallback_variant(const mfa_attention_kernel *kernel) {
+  return kernel && kernel->hasFallback ? kernel->fallback.name : "";
+}
+int mfa_attention_kernel_needs_workspace_for_fast_path(const mfa_attention_kernel *kernel) {
+  return kernel && kernel->relayout ? 1 : 0;
+}
 mfa_status mfa_attention_kernel_effective_descriptor(const mfa_attention_kernel *kernel,
                                                      mfa_attention_kernel_descriptor *out) {
   if (!kernel || !out) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
@@ -357,7 +366,90 @@ struct LaunchPlan {
   uint32_t splits = 1;          // > 1: column-parallel forward through the caller's workspace
   float *wsO = nullptr, *wsML = nullptr;
   uint64_t workspaceNeeded = 0;
+  // transposed operands served through row-major copies in the caller's workspace
+  struct Relayout { int slot; OperandView user; void *copy; uint32_t seq; bool output; };
+  Relayout relayouts[MFA_BUFFER_SLOTS];
+  int nRelayouts = 0;
+  uint32_t heads = 1, batches = 1;
 };
+
+// ---- re-layout pass: element (r, d) of a [seq][D] matrix between a transposed view ([D][seq], leading dimension ld) and a
+// compact row-major copy ([seq][D]); 32 x 32 tiles through LDS, both sides coalesced.  HBM-bound: 2 x seq x D x size bytes.
+}  // extern "C"
+template <typename E>
+static __global__ __launch_bounds__(256) void attn_relayout(const char *tptr, char *cptr, uint32_t seq, uint32_t D, int64_t tld,
+                                                            int64_t theadStride, int64_t tbatchStride, uint32_t heads, int toTransposed) {
+  __shared__ E tile[32][33];
+  const uint32_t tilesD = (D + 31) / 32;
+  const uint32_t r0 = (blockIdx.x / tilesD) * 32, d0 = (blockIdx.x % tilesD) * 32;
+  const uint32_t head = blockIdx.y, batch = blockIdx.z;
+  const E *tsrc = reinterpret_cast<const E *>(tptr) + (int64_t)head * theadStride + (int64_t)batch * tbatchStride;
+  E *tdst = const_cast<E *>(tsrc);
+  E *copy = reinterpret_cast<E *>(cptr) + ((int64_t)batch * heads + head) * (int64_t)seq * D;
+  const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  if (!toTransposed) {   // transposed view -> row-major copy
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t d = d0 + ty + 8 * i, r = r0 + tx;
+      if (d < D && r < seq) tile[ty + 8 * i][tx] = tsrc[(int64_t)d * tld + r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t r = r0 + ty + 8 * i, d = d0 + tx;
+      if (d < D && r < seq) copy[(int64_t)r * D + d] = tile[tx][ty + 8 * i];
+    }
+  } else {               // row-major copy -> transposed view
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t r = r0 + ty + 8 * i, d = d0 + tx;
+      if (d < D && r < seq) tile[ty + 8 * i][tx] = copy[(int64_t)r * D + d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t d = d0 + ty + 8 * i, r = r0 + tx;
+      if (d < D && r < seq) tdst[(int64_t)d * tld + r] = tile[tx][ty + 8 * i];
+    }
+  }
+}
+
+extern "C" {
+
+static void launch_relayout(const LaunchPlan &plan, const LaunchPlan::Relayout &r, hipStream_t stream) {
+  const uint32_t D = plan.args.D;
+  const dim3 grid(((r.seq + 31) / 32) * ((D + 31) / 32), plan.heads, plan.batches);
+  const char *t = static_cast<const char *>(r.user.ptr);
+  char *c = static_cast<char *>(r.copy);
+  if (r.user.precision == PREC_FP32)
+    hipLaunchKernelGGL(attn_relayout<uint32_t>, grid, dim3(256), 0, stream, t, c, r.seq, D, r.user.ld, r.user.headStride, r.user.batchStride, plan.heads, r.output ? 1 : 0);
+  else
+    hipLaunchKernelGGL(attn_relayout<uint16_t>, grid, dim3(256), 0, stream, t, c, r.seq, D, r.user.ld, r.user.headStride, r.user.batchStride, plan.heads, r.output ? 1 : 0);
+}
+
+static bool is_output_slot(int type, int slot) {
+  switch (type) {
+    case MFA_FORWARD: return slot == SLOT_O;
+    case MFA_BACKWARD_QUERY: return slot == SLOT_dQ;
+    default: return slot == SLOT_dK || slot == SLOT_dV;
+  }
+}
+
+// bytes of workspace the row-major copies of this launch's transposed operands take (256-byte aligned each)
+static uint64_t relayout_workspace_bytes(const mfa_attention_kernel *kernel, uint32_t row, uint32_t column, uint32_t heads, uint32_t batches) {
+  const int type = kernel->desc.type;
+  uint64_t total = 0;
+  for (int slot = 0; slot < MFA_BUFFER_SLOTS; ++slot) {
+    if (!slot_used(type, slot) || slot == SLOT_L || slot == SLOT_D) continue;
+    const int op = slot_operand(slot);
+    if (!kernel->desc.transposeState[op]) continue;
+    const bool rowOperand = (op == MFA_Q || op == MFA_O || op == MFA_dO || op == MFA_dQ);
+    const uint64_t seq = rowOperand ? row : column;
+    const uint64_t esz = kernel->desc.memoryPrecisions[op] == MFA_FP32 ? 4 : 2;
+    total += ((uint64_t)heads * batches * seq * kernel->desc.headDimension * esz + 255) & ~255ull;
+  }
+  return total;
+}
 
 // Column-parallel heuristic: split only when the row-parallel grid cannot fill the 256 CUs and the
 // traversal is long enough to amortise the combine pass; aim at ~2 workgroups per CU, keep >= 4 key
@@ -428,11 +520,41 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
     return fail(MFA_ERR_INVALID_ARGUMENT, "causal masking requires column >= row");
   const uint32_t heads = p->heads ? p->heads : 1, batches = p->batches ? p->batches : 1;
   if (heads > 65535 || batches > 65535) return fail(MFA_ERR_INVALID_ARGUMENT, "heads and batches must be <= 65535");
-  plan->useFallback = kernel->hasFallback && (!meets_fast_requirements(kernel, *args) ||
+  plan->heads = heads;
+  plan->batches = batches;
+  plan->nRelayouts = 0;
+  bool relayoutMissing = false;
+  if (kernel->relayout) {
+    const uint64_t need = relayout_workspace_bytes(kernel, p->row, p->column, heads, batches);
+    plan->workspaceNeeded = need;
+    if (p->workspace && p->workspaceBytes >= need && (reinterpret_cast<uintptr_t>(p->workspace) & 255) == 0) {
+      char *cursor = static_cast<char *>(p->workspace);
+      for (int slot = 0; slot < MFA_BUFFER_SLOTS; ++slot) {
+        if (!slot_used(type, slot) || slot == SLOT_L || slot == SLOT_D || !args->op[slot].transposed) continue;
+        OperandView &v = args->op[slot];
+        const int op = slot_operand(slot);
+        const bool rowOperand = (op == MFA_Q || op == MFA_O || op == MFA_dO || op == MFA_dQ);
+        const uint32_t seq = rowOperand ? p->row : p->column;
+        LaunchPlan::Relayout &r = plan->relayouts[plan->nRelayouts++];
+        r.slot = slot; r.user = v; r.copy = cursor; r.seq = seq; r.output = is_output_slot(type, slot);
+        const uint64_t esz = v.precision == PREC_FP32 ? 4 : 2;
+        cursor += ((uint64_t)heads * batches * seq * D * esz + 255) & ~255ull;
+        v.ptr = r.copy; v.transposed = 0; v.ld = D;
+        v.headStride = (int64_t)seq * D; v.batchStride = (int64_t)heads * seq * D;
+      }
+    } else {
+      relayoutMissing = true;   // no (or too small a) workspace: the general kernel reads the transposed operands in place
+    }
+  }
+  plan->useFallback = kernel->hasFallback && (relayoutMissing || !meets_fast_requirements(kernel, *args) ||
                                               (args->causal && !kernel->variant.causal) ||
                                               (args->mask && !kernel->variant.launchSparse && !kernel->variant.sparse) ||
                                               // attn_dkv16_rs lists at most 4096 active 256-row blocks in LDS
                                               (args->mask && type == MFA_BACKWARD_KEY_VALUE && p->row > 4096u * 256u));
+  if (plan->useFallback && plan->nRelayouts) {   // (alignment, mask limits ...): the general kernel takes the user's views
+    for (int i = 0; i < plan->nRelayouts; ++i) args->op[plan->relayouts[i].slot] = plan->relayouts[i].user;
+    plan->nRelayouts = 0;
+  }
   plan->variant = plan->useFallback ? &kernel->fallback : &kernel->variant;
   // parallelization dimension: rows for forward / backwardQuery, columns for backwardKeyValue
   // (SquareAttentionTest.swift:355-367)
@@ -449,7 +571,7 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   // Traversal-parallel launches through the caller's workspace, for grids that cannot fill the GPU: forward cuts
   // the key range (partial (O, m, l), online-softmax merge), backwardQuery the key range and backwardKeyValue
   // the row range (partial dQ / dK, dV in fp32 slabs, summed by attn_bwd_combine).
-  const bool splittable = !plan->useFallback && plan->variant->launchSplit && !args->rowLen && !args->colLen && !args->mask &&
+  const bool splittable = !plan->useFallback && !kernel->relayout && plan->variant->launchSplit && !args->rowLen && !args->colLen && !args->mask &&
                           (type != MFA_FORWARD || !args->causal);
   if (splittable) {
     const uint32_t s = choose_splits((uint64_t)sibBlocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column);
@@ -499,10 +621,14 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   if (st != MFA_OK) return st;
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
+  for (int i = 0; i < plan.nRelayouts; ++i)
+    if (!plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], (hipStream_t)stream);
   if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, (hipStream_t)stream, plan.args);
   else if (plan.args.mask && plan.variant->launchSparse) plan.variant->launchSparse(plan.grid, (hipStream_t)stream, plan.args);
   else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, (hipStream_t)stream, plan.args);
   else plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
+  for (int i = 0; i < plan.nRelayouts; ++i)
+    if (plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], (hipStream_t)stream);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return hip_fail(err, plan.variant->name);
   return MFA_OK;
@@ -512,8 +638,12 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
                                                uint64_t *bytes) {
   if (!kernel || !params || !bytes) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
   *bytes = 0;
-  if (!kernel->variant.launchSplit) return MFA_OK;
   if (params->row == 0 || params->column == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "row and column must be non-zero");
+  if (kernel->relayout) {   // row-major copies of the transposed operands (without them the launch runs the general kernel)
+    *bytes = relayout_workspace_bytes(kernel, params->row, params->column, params->heads ? params->heads : 1, params->batches ? params->batches : 1);
+    return MFA_OK;
+  }
+  if (!kernel->variant.launchSplit) return MFA_OK;
   const int type = kernel->desc.type;
   if (params->rowLengths || params->columnLengths || params->blockMask || (type == MFA_FORWARD && params->causal)) return MFA_OK;
   const uint32_t heads = params->heads ? params->heads : 1, batches = params->batches ? params->batches : 1;
@@ -541,10 +671,14 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   err = hipEventCreate(&stop);
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
   auto go = [&]() {
+    for (int i = 0; i < plan.nRelayouts; ++i)
+      if (!plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], s);
     if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);
     else if (plan.args.mask && plan.variant->launchSparse) plan.variant->launchSparse(plan.grid, s, plan.args);
     else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, s, plan.args);
     else plan.variant->launch(plan.grid, s, plan.args);
+    for (int i = 0; i < plan.nRelayouts; ++i)
+      if (plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], s);
   };
   for (int i = 0; i < warmup; ++i) go();
   (void)hipEventRecord(start, s);

@@ -140,11 +140,19 @@ class DeviceRun:
         for t in types:
             self.kernels[t] = AttentionKernel(desc.kernelDescriptor(t))
 
-    def execute(self):
+    def execute(self, with_workspace: bool = False):
+        """with_workspace: give every launch the scratch it asks for (workspaceSize): split launches, and the row-major
+        copies that let the matrix-core kernels serve transposed operands"""
         torch = self.torch
         stream = torch.cuda.current_stream().cuda_stream
+        self.workspace_bytes = {}
         for t, kernel in self.kernels.items():  # forward -> backwardQuery -> backwardKeyValue
-            kernel.dispatch(self.buffers, row=self.R, column=self.C, stream=stream, causal=self.causal)
+            ws = None
+            if with_workspace:
+                need = kernel.workspaceSize(row=self.R, column=self.C)
+                self.workspace_bytes[t] = need
+                ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda") if need else None
+            kernel.dispatch(self.buffers, row=self.R, column=self.C, stream=stream, causal=self.causal, workspace=ws)
         torch.cuda.synchronize()
         return self.results()
 

@@ -427,7 +427,8 @@ def test_size_independent_properties_at_full_size():
 # ---- 16-bit matrix-core backward kernels (attn_dq16 / attn_dkv16) -----------------------------
 BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), (1, 100, 128), (100, 1, 64),
                 (129, 77, 40), (96, 640, 80), (1024, 1024, 128), (513, 1030, 64), (256, 256, 256), (300, 333, 200), (65, 700, 256),
-                (300, 333, 96), (257, 130, 88), (200, 449, 160), (129, 300, 152), (256, 320, 192), (100, 1000, 176)]
+                (300, 333, 96), (257, 130, 88), (200, 449, 160), (129, 300, 152), (256, 320, 192), (100, 1000, 176),
+                (200, 300, 104), (77, 530, 120)]
 
 
 @pytest.mark.parametrize("low_mid", [False, True])
@@ -467,6 +468,34 @@ def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
     assert all(run.tails_ok.values()), run.tails_ok
 
 
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("tr", [(True, True, True, True), (False, True, False, False), (False, False, True, True), (True, False, False, False)])
+@pytest.mark.parametrize("shape", [(300, 449, 128), (130, 200, 64), (200, 150, 256), (257, 129, 104)])
+def test_transposed_operands_reach_the_matrix_cores_through_a_workspace(shape, tr, low_mid):
+    """transposeState (AttentionKernelDescriptor.swift:30-41) with 16-bit inputs: given a workspace, every transposed operand
+    is re-laid out row-major (inputs before, outputs after the launch) and the 16-bit matrix-core code object runs; without
+    one the general kernel reads the transposed buffers in place.  Both agree with the oracle; the canary tails stay intact."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=R + 3 * C + D)
+    desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.BF16, tr=tr)
+    run = harness.DeviceRun(desc, net)
+    for k in run.kernels.values():
+        assert k.needsWorkspaceForFastPath and not k.variant.startswith("attn_generic") and k.fallbackVariant.startswith("attn_generic")
+    got = run.execute(with_workspace=True)
+    assert all(v > 0 for v in run.workspace_bytes.values()), run.workspace_bytes
+    round_inputs(net, desc)
+    ref = net.run()
+    failures, report = harness.compare(ref, got, TOL_MIXED)
+    assert not failures, (failures, [k.variant for k in run.kernels.values()])
+    assert all(run.tails_ok.values()), run.tails_ok
+    run2 = harness.DeviceRun(desc, net)
+    slow = run2.execute()                      # no workspace: general kernels
+    failures, report = harness.compare(ref, slow, TOL_MIXED)
+    assert not failures, failures
+    for name in ("O", "dQ", "dK", "dV"):       # the two paths differ by the 16-bit rounding of P and dS only
+        assert np.abs(got[name] - slow[name]).max() < 3e-2, name
+
+
 def test_backward_16bit_matches_general_kernels(monkeypatch):
     """Same inputs through the fp32-arithmetic general kernels (reached through a layout the matrix-core kernels do not take:
     V and dV stored transposed) and the 16-bit matrix-core kernels: gradients agree to the 16-bit rounding of P and dS."""
@@ -475,7 +504,7 @@ def test_backward_16bit_matches_general_kernels(monkeypatch):
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
     fast = harness.DeviceRun(desc, net).execute()
     run = harness.DeviceRun(make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=(False, False, True, False)), net)
-    assert all("generic" in k.variant for t, k in run.kernels.items() if t != AttentionKernelType.forward)
+    assert all("generic" in k.fallbackVariant and k.needsWorkspaceForFastPath for k in run.kernels.values())   # no workspace below
     slow = run.execute()
     for name in ("D", "dQ", "dK", "dV"):
         assert np.abs(fast[name] - slow[name]).max() < 2e-2, name

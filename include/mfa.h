@@ -25,9 +25,14 @@
  *     also when lowPrecisionIntermediates is 0 and the reference would keep them in FP32 registers
  *     (+Precisions.swift:201-205).  S, the accumulators, L and D arithmetic are fp32.
  *   - lowPrecisionIntermediates = 1 (the reference then holds P, and with FP16 also S, in 16-bit registers) lets the
- *     D <= 128 forward kernel multiply Q by log2(e)/sqrt(D) once, rounded to the inputs' type, instead of scaling every
- *     score in fp32: L moves by up to ~2e-3 (BF16) / 2e-4 (FP16) natural-log units.  With the flag clear the scale is
- *     applied in fp32 per score.
+ *     hand-placed kernels (forward D <= 128 and 192 < D <= 256, backward 96 < D <= 128) multiply one operand of S = Q K^T
+ *     by log2(e)/sqrt(D) once, rounded to the inputs' type (forward and backwardQuery: Q; backwardKeyValue: K), instead
+ *     of scaling every score in fp32: L moves by up to ~2e-3 (BF16) / 2e-4 (FP16) natural-log units, P by the same
+ *     relative amount.  With the flag clear the scale is applied in fp32 per score.
+ *   - backwardKeyValue, 96 < D <= 128: the per-row terms L and D enter S and dP through the matrix pipe as the sum of two
+ *     16-bit values (16 / 22 bits of mantissa for BF16 / FP16 inputs): an absolute error of ~2^-16 |L| in the exponent of P.
+ *   - Transposed operands (transposeState) run on the 16-bit matrix cores only when the launch is given a workspace
+ *     (mfa_attention_kernel_needs_workspace_for_fast_path); without one the fp32-arithmetic kernels serve them.
  *   - Head dimensions: D <= 384 (the reference's tables end there, +Parameters.swift:77-285).  16-bit matrix-core code
  *     objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic kernels whatever the storage type.
  *     Accumulators stay in registers at every D; larger D is MFA_ERR_UNSUPPORTED.

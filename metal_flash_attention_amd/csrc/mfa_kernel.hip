@@ -374,42 +374,68 @@ struct LaunchPlan {
 };
 
 // ---- re-layout pass: element (r, d) of a [seq][D] matrix between a transposed view ([D][seq], leading dimension ld) and a
-// compact row-major copy ([seq][D]); 32 x 32 tiles through LDS, both sides coalesced.  HBM-bound: 2 x seq x D x size bytes.
+// compact row-major copy ([seq][D]); 64 x 64 tiles through LDS, 16-byte accesses on both sides.  HBM-bound: 2 x seq x D x size bytes.
 }  // extern "C"
 template <typename E>
 static __global__ __launch_bounds__(256) void attn_relayout(const char *tptr, char *cptr, uint32_t seq, uint32_t D, int64_t tld,
                                                             int64_t theadStride, int64_t tbatchStride, uint32_t heads, int toTransposed) {
-  __shared__ E tile[32][33];
-  const uint32_t tilesD = (D + 31) / 32;
-  const uint32_t r0 = (blockIdx.x / tilesD) * 32, d0 = (blockIdx.x % tilesD) * 32;
+  // 64 x 64 tile, 16-byte global accesses on both sides (V elements each), element-wise through LDS in between
+  constexpr int V = 16 / sizeof(E), T = 64, CH = T / V;      // chunks of V elements per tile row
+  __shared__ E tile[T][T + 2];
+  const uint32_t tilesD = (D + T - 1) / T;
+  const uint32_t r0 = (blockIdx.x / tilesD) * T, d0 = (blockIdx.x % tilesD) * T;
   const uint32_t head = blockIdx.y, batch = blockIdx.z;
-  const E *tsrc = reinterpret_cast<const E *>(tptr) + (int64_t)head * theadStride + (int64_t)batch * tbatchStride;
-  E *tdst = const_cast<E *>(tsrc);
+  E *tview = const_cast<E *>(reinterpret_cast<const E *>(tptr)) + (int64_t)head * theadStride + (int64_t)batch * tbatchStride;
   E *copy = reinterpret_cast<E *>(cptr) + ((int64_t)batch * heads + head) * (int64_t)seq * D;
-  const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-  if (!toTransposed) {   // transposed view -> row-major copy
+  typedef E vec __attribute__((ext_vector_type(V)));
+  // the 16-byte path needs whole chunks inside the matrix and 16-byte aligned rows on both sides
+  const bool wide = (seq % V) == 0 && (D % V) == 0 && (tld % V) == 0 && ((reinterpret_cast<uintptr_t>(tview) | reinterpret_cast<uintptr_t>(copy)) & 15) == 0;
+  // transposed view: rows = d, contiguous along the sequence; copy: rows = sequence position, contiguous along d
+  for (int c = threadIdx.x; c < T * CH; c += 256) {          // load: tile[d][r] always
+    const uint32_t a = c / CH, b = (c % CH) * V;              // row a of the SOURCE tile, elements b .. b+V-1
+    if (!toTransposed) {                                      // source = transposed view: row a = d, elements = sequence
+      const uint32_t d = d0 + a, r = r0 + b;
+      if (d < D && wide && r + V <= seq) {
+        const vec x = *reinterpret_cast<const vec *>(tview + (int64_t)d * tld + r);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t d = d0 + ty + 8 * i, r = r0 + tx;
-      if (d < D && r < seq) tile[ty + 8 * i][tx] = tsrc[(int64_t)d * tld + r];
+        for (int k = 0; k < V; ++k) tile[a][b + k] = x[k];
+      } else if (d < D) {
+        for (int k = 0; k < V; ++k) if (r + k < seq) tile[a][b + k] = tview[(int64_t)d * tld + r + k];
+      }
+    } else {                                                  // source = row-major copy: row a = sequence, elements = d
+      const uint32_t r = r0 + a, d = d0 + b;
+      if (r < seq && wide && d + V <= D) {
+        const vec x = *reinterpret_cast<const vec *>(copy + (int64_t)r * D + d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) tile[b + k][a] = x[k];
+      } else if (r < seq) {
+        for (int k = 0; k < V; ++k) if (d + k < D) tile[b + k][a] = copy[(int64_t)r * D + d + k];
+      }
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < T * CH; c += 256) {          // store
+    const uint32_t a = c / CH, b = (c % CH) * V;
+    if (!toTransposed) {                                      // destination = copy: row a = sequence, elements = d
+      const uint32_t r = r0 + a, d = d0 + b;
+      if (r < seq && wide && d + V <= D) {
+        vec x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t r = r0 + ty + 8 * i, d = d0 + tx;
-      if (d < D && r < seq) copy[(int64_t)r * D + d] = tile[tx][ty + 8 * i];
-    }
-  } else {               // row-major copy -> transposed view
+        for (int k = 0; k < V; ++k) x[k] = tile[b + k][a];
+        *reinterpret_cast<vec *>(copy + (int64_t)r * D + d) = x;
+      } else if (r < seq) {
+        for (int k = 0; k < V; ++k) if (d + k < D) copy[(int64_t)r * D + d + k] = tile[b + k][a];
+      }
+    } else {                                                  // destination = transposed view: row a = d, elements = sequence
+      const uint32_t d = d0 + a, r = r0 + b;
+      if (d < D && wide && r + V <= seq) {
+        vec x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t r = r0 + ty + 8 * i, d = d0 + tx;
-      if (d < D && r < seq) tile[ty + 8 * i][tx] = copy[(int64_t)r * D + d];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t d = d0 + ty + 8 * i, r = r0 + tx;
-      if (d < D && r < seq) tdst[(int64_t)d * tld + r] = tile[tx][ty + 8 * i];
+        for (int k = 0; k < V; ++k) x[k] = tile[a][b + k];
+        *reinterpret_cast<vec *>(tview + (int64_t)d * tld + r) = x;
+      } else if (d < D) {
+        for (int k = 0; k < V; ++k) if (r + k < seq) tview[(int64_t)d * tld + r + k] = tile[a][b + k];
+      }
     }
   }
 }
@@ -418,7 +444,7 @@ extern "C" {
 
 static void launch_relayout(const LaunchPlan &plan, const LaunchPlan::Relayout &r, hipStream_t stream) {
   const uint32_t D = plan.args.D;
-  const dim3 grid(((r.seq + 31) / 32) * ((D + 31) / 32), plan.heads, plan.batches);
+  const dim3 grid(((r.seq + 63) / 64) * ((D + 63) / 64), plan.heads, plan.batches);
   const char *t = static_cast<const char *>(r.user.ptr);
   char *c = static_cast<char *>(r.copy);
   if (r.user.precision == PREC_FP32)

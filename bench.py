@@ -69,6 +69,7 @@ WORKLOADS = {
     "fwd_bf16_d64": dict(N=4096, D=64, dtype="bf16", batch=8, heads=32, types=("forward",)),     # config 2, batched
     "fwd_bf16_d64_1head": dict(N=4096, D=64, dtype="bf16", batch=1, heads=1, types=("forward",)),  # config 2 as written
     "fwd_bf16_d256": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",)),   # config 4, batched
+    "fwd_bf16_d256_mixed": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",), low_mid=True),
     "fwdbwd_f32_d128": dict(N=4096, D=128, dtype="f32", batch=2, heads=16,
                             types=("forward", "backwardQuery", "backwardKeyValue")),             # config 3, batched
     "fwdbwd_bf16_d128": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16,

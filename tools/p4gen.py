@@ -10,7 +10,8 @@ cannot index sub-registers of an asm operand, so the stream is emitted here with
     a[128:191] Q fragments      (rb, ks) -> 128 + 4 (8 rb + ks)
     a[192:255] K fragments      (kb, ks) -> 192 + 4 (8 kb + ks)          the 64-key tile being multiplied
     v[32:95]   score tile of even tiles,  v[96:159] of odd tiles  (rb, kb) -> 16 (2 rb + kb)
-    v[160:191] P^T fragments    (rb, u)  -> 160 + 4 (4 rb + u)
+    v[160:191] FOLD streams: -m of the lane's row, sixteen copies per rb -> 160 + 16 rb (the accumulator start of every score
+               block; exact-scale streams leave them unused).  P^T fragments (rb, u) are packed in place into their score block
     v[192:223] V^T fragment ring, eight slots: fragment f = 4 u + db lives in slot f % 8
     v[224:255] addresses and softmax temporaries
     v[0:31]    left to hipcc (operands of the statement, its own values)
@@ -33,7 +34,7 @@ import sys
 # ---------------------------------------------------------------- register map
 O_BASE, Q_BASE, K_BASE = 0, 128, 192
 S_BASE = (32, 96)
-P_BASE, VF_BASE = 160, 192
+CM_BASE, VF_BASE = 160, 192
 T_KADDR = 224          # 8: K fragment address per ks
 T_VADDR = 232          # V^T read base of the tile being read
 T_MX = 233             # 4: running block maxima (rb, kb) -> 2 rb + kb
@@ -45,8 +46,6 @@ T_MASKV = 245
 T_TL = 246             # 2: mask limits relative to the tile
 T_THR = 248            # 2: m + THR                      (exact-scale streams)
 T_RS = 248             # 8: rescale temporaries v248..v255 (exact-scale streams; FOLD streams borrow V^T ring slots 0, 1)
-T_ONES = 248           # 4: FOLD streams: A operand of the extra k-step (-1.0 in k-slots 0, 1)
-T_MF = (252, 28)       # 4 each: FOLD streams: B operand of the extra k-step per rb (m_hi, m_lo in k-slots 0, 1)
 FIRST_OWNED_VGPR = 28
 
 KSLOT, VBASE, VSLOT, VRING = 16384, 32768, 16384, 3
@@ -120,12 +119,19 @@ def s_blk(par, rb, kb):
     return V(S_BASE[par] + 16 * (2 * rb + kb), 16)
 
 
-def p_word(rb, u, w):
-    return V(P_BASE + 4 * (4 * rb + u) + w)
+# P^T fragment (rb, u) of a tile = 16 keys 16 u .. of the 64: packed IN PLACE into the first eight registers of its own score
+# block (kb = u >> 1): the block is not written again before the V^T P^T products that read the fragment have been issued
+def p_word(par, rb, u, w):
+    return V(S_BASE[par] + 16 * (2 * rb + (u >> 1)) + 4 * (u & 1) + w)
 
 
-def p_frag(rb, u):
-    return V(P_BASE + 4 * (4 * rb + u), 4)
+def p_frag(par, rb, u):
+    return V(S_BASE[par] + 16 * (2 * rb + (u >> 1)) + 4 * (u & 1), 4)
+
+
+def cm_blk(rb):
+    """FOLD streams: sixteen registers holding -m of the lane's row: the accumulator start of every score block of rb"""
+    return V(CM_BASE + 16 * rb, 16)
 
 
 def vf_frag(f):
@@ -224,12 +230,9 @@ class Stream:
                 c = I(0) if ks == 0 else s_blk(par, rb, kb)
                 out.append((s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), c))
             return out
-        for kb in range(2):   # FOLD: S' = (-1) * m + K Q'^T: the block starts from the extra k-step
-            for rb in range(2):
-                out.append((s_blk(par, rb, kb), V(T_ONES, 4), V(T_MF[rb], 4), I(0)))
-            for ks in range(8):
-                for rb in range(2):
-                    out.append((s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), s_blk(par, rb, kb)))
+        for kb, rb, ks in self.qk_order():   # FOLD: S' = -m + K Q'^T: the running maximum is the accumulator's start value
+            c = cm_blk(rb) if ks == 0 else s_blk(par, rb, kb)
+            out.append((s_blk(par, rb, kb), k_frag(kb, ks), q_frag(rb, ks), c))
         return out
 
     def phase_a(self, par, mfma, softmax, zero_o):
@@ -294,7 +297,7 @@ class Stream:
         if steady and "pack" in self.cfg.abl:
             return
         # MFMA step u (16 keys) of key block kb uses registers 8 (u & 1) .. + 7
-        self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, p_word(rb, 2 * kb + r // 8, (r % 8) // 2), [x0, x1])
+        self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, p_word(prev, rb, 2 * kb + r // 8, (r % 8) // 2), [x0, x1])
 
     def v_read(self, i):
         """V^T read i (0..31): fragment f = i // 2 = 4 u + db, half i % 2 (keys +0..3 / +8..11 of the 16-key group)"""
@@ -369,7 +372,7 @@ class Stream:
                 f = 4 * u + db
                 if rb == 0 and f % 2 == 0:
                     self.lds_need(vids[2 * f + 3])   # both halves of fragments f and f + 1 have returned
-                self.mfma(o_acc(rb, db), vf_frag(f), p_frag(rb, u), o_acc(rb, db))
+                self.mfma(o_acc(rb, db), vf_frag(f), p_frag(par ^ 1, rb, u), o_acc(rb, db))
             for fn in fill[g]:
                 fn()
         while self.xe_pending:
@@ -506,20 +509,14 @@ class Stream:
         for kind, lbl, back, par, first in self.outofline:
             self.label(lbl)
             if kind == "dec" and cfg.fold:
-                # m_up = m + max(mx', 0) (first tile: m + mx'); kept as the exact sum of a 16-bit pair (hi, lo) so that the
-                # extra k-step subtracts EXACTLY the m that L = m + log2 l reports; shift = m_new - m_old re-bases this
-                # tile's scores, corr = 2^-shift re-bases O and l at the end of phase B (+Softmax.swift:290-301)
+                # m_up = m + max(mx', 0) (first tile: m + mx'); shift = m_up - m re-bases this tile's scores, corr = 2^-shift
+                # re-bases O and l at the end of phase B (+Softmax.swift:290-301); the start block of the following tiles = -m_up
                 ta, tb = V(T_SW), V(T_SW + 1)
                 for rb in range(2):
                     mn, m = V(T_MN + rb), VN("m%d" % rb)
                     if not first:
                         self.emit("v_max_f32", mn, [I(0), mn])
                     self.emit("v_add_f32", ta, [m, mn])
-                    self.to16_f32(tb, ta)                     # hi = m_up cut to the 16-bit type's mantissa
-                    self.emit("v_sub_f32", ta, [ta, tb])
-                    self.to16_f32(ta, ta)                     # lo
-                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(T_MF[rb]), [tb, ta])   # (+hi, +lo): the A operand is -1.0
-                    self.emit("v_add_f32", ta, [tb, ta])      # m_new = hi + lo (exact in fp32)
                     self.emit("v_sub_f32", tb, [ta, m])       # shift
                     self.emit("v_mov_b32", m, [ta])
                     self.emit("v_exp_f32", V(T_CORR + rb), [tb], neg0=1)
@@ -527,6 +524,8 @@ class Stream:
                         for r in range(16):
                             x = s_elem(par, rb, kb, r)
                             self.emit("v_sub_f32", x, [x, tb])
+                    for r in range(16):
+                        self.emit("v_sub_f32", V(CM_BASE + 16 * rb + r), [I(0), ta])
                 self.emit("s_mov_b32", SN("pend"), [I(0 if first else 1)])   # first tile: O and l are still zero, nothing to re-base
                 self.emit("s_branch", None, [], target=back)
             elif kind == "dec":   # onlineCorrectO factors (+Softmax.swift:290-301): m_up = max(m, m_new), corr = 2^(m - m_up)
@@ -578,9 +577,8 @@ class Stream:
             self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
         if self.cfg.fold:
-            self.emit("v_mov_b32", V(T_ONES), [VN("onesw")])
-            for r in list(range(T_ONES + 1, T_ONES + 4)) + [T_MF[0] + i for i in range(4)] + [T_MF[1] + i for i in range(4)]:
-                self.emit("v_mov_b32", V(r), [I(0)])
+            for r in range(32):
+                self.emit("v_mov_b32", V(CM_BASE + r), [I(0)])
         self.emit("s_mov_b32", SN("pend"), [I(0)])
         self.emit("s_mov_b32", SN("j"), [I(0)])
         self.emit("s_mov_b32", SN("vrd"), [I(2 * VSLOT)])    # "image of V(-1)"

@@ -31,7 +31,12 @@ template <typename T, int STREAM> static void fill_p4_dev(VariantInfo *v, const 
   fill_p4<T, p4::S_BF16_THR8>(v, name);
   v->func = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false>);
   v->launch = &launch_p4<T, STREAM, false>;
-  v->launchCausal = nullptr; v->funcCausal = nullptr; v->causal = false;
+  if constexpr (p4::stream_profiles(STREAM)) {   // phase clocks of causal launches too (tools/p4_prof.py --causal)
+    v->launchCausal = &launch_p4<T, STREAM, true>;
+    v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, true>);
+  } else {
+    v->launchCausal = nullptr; v->funcCausal = nullptr; v->causal = false;
+  }
 }
 
 // Product streams: impl 0 = scale applied in fp32 (exact S; selected when the descriptor keeps the attention matrix in

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--heads", type=int, default=256)
     ap.add_argument("--impl", default="BF16_FOLD_PROF", help="p4:<n>, or the name of a PROF stream of tools/p4gen.py")
+    ap.add_argument("--causal", action="store_true")
     args = ap.parse_args()
     if not args.impl.startswith("p4:"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -43,9 +44,24 @@ def main():
     bufs[Op.O], bufs[Op.L] = o, torch.zeros((H, N), device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(3):
-        k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream)
+        k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, causal=args.causal)
     torch.cuda.synchronize()
-    ms = k.time(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, warmup=1, iterations=5) / 5
+    ms = k.time(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, warmup=3, iterations=10, causal=args.causal) / 10
+    if args.causal:
+        c = o[:, ::64, 0:4].contiguous().view(torch.int32).double()      # [H][N/64 waves][pa, pw, pb, nt]
+        nblk = N // 256
+        c = c.view(H, nblk, 4, 4).mean(0)                                 # [block][wave][4]
+        print(f"{k.variant} causal: {ms:.4f} ms/launch")
+        print("block  nt | per wave: steady tiles it computed (from the clock sums / mean tile), loop cycles (pa+pw+pb)")
+        tile = (c[-1, 3, :3].sum() / (c[-1, 3, 3] - 1)).item()
+        for b in (0, 1, nblk // 2, nblk - 2, nblk - 1):
+            row = "  ".join(f"w{w}: {c[b, w, :3].sum().item():9.0f} cyc ({c[b, w, :3].sum().item() / tile:5.1f} t)" for w in range(4))
+            print(f"{b:4d} {int(c[b, 3, 3].item()):4d} | {row}")
+        tot_pair = [(c[i, 3, :3].sum() + c[nblk - 1 - i, 3, :3].sum()).item() for i in range(nblk // 2)]
+        print("longest wave's loop cycles per pair of blocks:", " ".join(f"{x / tile:.1f}t" for x in tot_pair), f"  (tile = {tile:.0f} cycles)")
+        per_cu_pairs = (nblk // 2) * H / 256
+        print(f"launch time per pair on a CU: {ms * 1e-3 / per_cu_pairs * 1e6:.1f} us")
+        return
     c = o[:, ::64, 0:4].contiguous().view(torch.int32).double()      # [H][N/64 waves][pa, pw, pb, nt]
     steady = c[..., 3] - 1
     per = c[..., :3] / steady[..., None]

@@ -4,16 +4,16 @@
 
 namespace mfa {
 
-template <typename T, int STREAM, bool CAUSAL>
+template <typename T, int STREAM, bool CAUSAL, typename TG>
 static void launch_dq_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z};
-  hipLaunchKernelGGL((attn_dq16_p4<T, STREAM, CAUSAL>), dim3(grid.x * grid.y * grid.z), dim3(256), dq4::LDS_BYTES, stream, args, g);
+  hipLaunchKernelGGL((attn_dq16_p4<T, STREAM, CAUSAL, TG>), dim3(grid.x * grid.y * grid.z), dim3(256), dq4::LDS_BYTES, stream, args, g);
 }
 
 // `v` arrives filled by dq16_variant (eight waves x 32 rows, the same 256 rows per workgroup): split and block-sparse
 // launches keep that kernel's code objects
-template <typename T, int STREAM> static void fill_dq_p4(VariantInfo *v, const char *name) {
-  v->func = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, false>);
+template <typename T, int STREAM, typename TG = T> static void fill_dq_p4(VariantInfo *v, const char *name) {
+  v->func = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, false, TG>);
   v->name = name;
   v->parallelization = 256;
   v->traversal = 64;
@@ -22,16 +22,22 @@ template <typename T, int STREAM> static void fill_dq_p4(VariantInfo *v, const c
   v->ldsBytes = v->ldsBytes > (uint32_t)dq4::LDS_BYTES ? v->ldsBytes : (uint32_t)dq4::LDS_BYTES;
   v->cacheLeft = true;
   v->cacheSecond = true;
-  v->launch = &launch_dq_p4<T, STREAM, false>;
-  v->launchCausal = &launch_dq_p4<T, STREAM, true>;
-  v->funcCausal = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, true>);
+  v->launch = &launch_dq_p4<T, STREAM, false, TG>;
+  v->launchCausal = &launch_dq_p4<T, STREAM, true, TG>;
+  v->funcCausal = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, true, TG>);
   v->causal = true;
 }
 
 // impl 0: Q as stored, softmax scale in fp32 (descriptors that keep the attention matrix in FP32 registers); impl 10: Q
 // pre-multiplied by the scale in the 16-bit type (lowPrecisionIntermediates, like the forward FOLD stream)
-bool dq16_p4_variant(int precision, int D, int impl, VariantInfo *out) {
+bool dq16_p4_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
   if (D != 128) return false;
+  if (precision == PREC_FP16 && gprecision == PREC_BF16) {   // the reference's own mix: FP16 Q, K, V with BF16 dO
+    if (impl == 0) { fill_dq_p4<_Float16, dq4::S_F16_EXACT, __bf16>(out, "attn_dq16p4_f16_dObf16_d128_w4x64_exact"); return true; }
+    if (impl == 10) { fill_dq_p4<_Float16, dq4::S_F16_FOLD, __bf16>(out, "attn_dq16p4_f16_dObf16_d128_w4x64"); return true; }
+    return false;
+  }
+  if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
     if (impl == 0) { fill_dq_p4<__bf16, dq4::S_BF16_EXACT>(out, "attn_dq16p4_bf16_d128_w4x64_exact"); return true; }
     if (impl == 10) { fill_dq_p4<__bf16, dq4::S_BF16_FOLD>(out, "attn_dq16p4_bf16_d128_w4x64"); return true; }

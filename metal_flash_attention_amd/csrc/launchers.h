@@ -54,7 +54,7 @@ bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out);
 // split / block-sparse launchers it keeps.  lprec / dprec: storage types of L and D (fixed per instruction stream)
 bool dkv16_p4_variant(int precision, int lprec, int dprec, int D, int impl, VariantInfo *out);
 // backwardQuery counterpart: four waves x 64 rows (attn_dq16_p4.h); `out` arrives filled by dq16_variant
-bool dq16_p4_variant(int precision, int D, int impl, VariantInfo *out);
+bool dq16_p4_variant(int precision, int gprecision, int D, int impl, VariantInfo *out);
 // 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)
 bool fwd16_v4_variant(int precision, int D, int impl, VariantInfo *out);
 

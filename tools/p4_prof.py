@@ -62,6 +62,7 @@ def main():
         per_cu_pairs = (nblk // 2) * H / 256
         print(f"launch time per pair on a CU: {ms * 1e-3 / per_cu_pairs * 1e6:.1f} us")
         return
+    fixed = o[:, ::64, 4:7].contiguous().view(torch.int32).double()   # [H][waves][entry -> statement, statement, statement -> stores issued]
     c = o[:, ::64, 0:4].contiguous().view(torch.int32).double()      # [H][N/64 waves][pa, pw, pb, nt]
     steady = c[..., 3] - 1
     per = c[..., :3] / steady[..., None]
@@ -71,6 +72,12 @@ def main():
         print(f"  {name:20s} {per[..., i].mean():8.1f} {per[..., i].min():8.1f} {per[..., i].max():8.1f}")
     tot = per.sum(-1)
     print(f"  {'tile total':20s} {tot.mean():8.1f} {tot.min():8.1f} {tot.max():8.1f}   (64 MFMA = 2048 cycles of matrix pipe)")
+    loop = (c[..., :3].sum(-1))
+    print("per workgroup (mean over waves): kernel entry -> statement %.0f, statement %.0f (of which the steady tiles %.0f: prologue + first tile + "
+          "drain %.0f), statement -> stores complete %.0f shader-clock cycles" % (fixed[..., 0].mean(), fixed[..., 1].mean(), loop.mean(),
+          (fixed[..., 1] - loop).mean(), fixed[..., 2].mean()))
+    per_wg_us = ms * 1e3 / ((N // 256) * H / 256)
+    print("launch time per workgroup on a CU: %.1f us" % per_wg_us)
     tiles_per_cu = (N // 64) * (N // 256) * H / 256
     print(f"  implied clock if the loop were the whole launch: {tot.mean() * tiles_per_cu / (ms * 1e-3) / 1e9:.2f} GHz")
 

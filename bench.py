@@ -87,6 +87,9 @@ WORKLOADS = {
                                  types=("forward", "backwardQuery", "backwardKeyValue")),
     "dq_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, causal=True,
                                 timed=("backwardQuery",), types=("forward", "backwardQuery", "backwardKeyValue")),
+    # the reference's own low-precision mix (+Precisions.swift:13-17): FP16 Q, K, V with BF16 dO, FP16 L, BF16 D
+    "fwdbwd_f16_d128_refmix": dict(N=4096, D=128, dtype="f16", batch=4, heads=16, low_mid=True,
+                                   types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwdbwd_bf16_d128_mixed": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True,
                                    types=("forward", "backwardQuery", "backwardKeyValue")),
     # the headline shape with Q, K, V, O stored transposed ([D][N]): with a workspace the launch re-lays them out (an

@@ -31,6 +31,9 @@
  *     relative amount.  With the flag clear the scale is applied in fp32 per score.
  *   - backwardKeyValue, 96 < D <= 128: the per-row terms L and D enter S and dP through the matrix pipe as the sum of two
  *     16-bit values (16 / 22 bits of mantissa for BF16 / FP16 inputs): an absolute error of ~2^-16 |L| in the exponent of P.
+ *   - FP16 Q, K, V with BF16 dO (the reference's own low-precision mix), backwardKeyValue, 96 < D <= 128: the two products that
+ *     read dO run in BF16 -- V is rounded to BF16 once per workgroup and P is packed to BF16 for dV -- while S and dK stay
+ *     FP16; the other kernels convert dO to FP16 instead (exact in FP16's range).
  *   - Transposed operands (transposeState) run on the 16-bit matrix cores only when the launch is given a workspace
  *     (mfa_attention_kernel_needs_workspace_for_fast_path); without one the fp32-arithmetic kernels serve them.
  *   - Head dimensions: D <= 384 (the reference's tables end there, +Parameters.swift:77-285).  16-bit matrix-core code

@@ -31,9 +31,15 @@ template <typename T, int STREAM> static void fill_dkv_p4(VariantInfo *v, const 
 // precision: Q, K, V and dO (one 16-bit type); lprec / dprec: storage types of L and D.  The streams exist for the two
 // combinations the reference's descriptors produce (+Precisions.swift:13-96): FP16 L with BF16 D (mixed-precision mode)
 // and FP32 L, D.  impl >= 1000 (developer build): stream index.
-bool dkv16_p4_variant(int precision, int lprec, int dprec, int D, int impl, VariantInfo *out) {
+bool dkv16_p4_variant(int precision, int gprecision, int lprec, int dprec, int D, int impl, VariantInfo *out) {
   if (D != 128) return false;
   const bool mixed = lprec == PREC_FP16 && dprec == PREC_BF16, f32 = lprec == PREC_FP32 && dprec == PREC_FP32;
+  if (precision == PREC_FP16 && gprecision == PREC_BF16) {   // the reference's own mix: FP16 Q, K, V with BF16 dO
+    if (impl == 0 && mixed) { fill_dkv_p4<_Float16, dkv4::S_F16_DOBF16_MIXED>(out, "attn_dkv16p4_f16_dObf16_d128_w4x64"); return true; }
+    if (impl == 0 && f32) { fill_dkv_p4<_Float16, dkv4::S_F16_DOBF16_F32>(out, "attn_dkv16p4_f16_dObf16_d128_w4x64_exact"); return true; }
+    return false;
+  }
+  if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
     if (impl == 0 && mixed) { fill_dkv_p4<__bf16, dkv4::S_BF16_MIXED>(out, "attn_dkv16p4_bf16_d128_w4x64"); return true; }
     if (impl == 0 && f32) { fill_dkv_p4<__bf16, dkv4::S_BF16_F32>(out, "attn_dkv16p4_bf16_d128_w4x64_exact"); return true; }

@@ -175,9 +175,9 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           case 192: add(dkv16_rs_variant_d192(pq, pg, &v), v); break;
           default: {
             const bool rs = dkv16_rs_variant(pq, pg, b16, 0, &v);
-            if (rs && b16 == 128 && pq == pg) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
+            if (rs && b16 == 128) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
               VariantInfo v4 = v;
-              add(dkv16_p4_variant(pq, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], 128, 0, &v4), v4);
+              add(dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], 128, 0, &v4), v4);
             }
             add(rs, v);
             break;
@@ -208,7 +208,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       else if (std::strncmp(knob, "rs:", 3) == 0) have = dkv16_rs_variant(pq, pg, bk, std::atoi(knob + 3), &dev);
       else if (std::strncmp(knob, "p4:", 3) == 0)
         have = dkv16_rs_variant(pq, pg, bk, 0, &dev) &&
-               dkv16_p4_variant(pq, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], bk, std::atoi(knob + 3), &dev);
+               dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], bk, std::atoi(knob + 3), &dev);
     }
     knob = std::getenv("MFA_DQ16_IMPL");
     if (type == MFA_BACKWARD_QUERY && knob && !candidates.empty() && std::strncmp(knob, "p4:", 3) == 0) {

@@ -20,7 +20,7 @@ def _check(R, C, cblk=0, causal=False, cfg=None, seed=0, **kw):
     cfg = cfg or V["BF16_MIXED"]
     ev, ek, mv, mk, wg = dkv4sim.check(R=R, C=C, cblk=cblk, causal=causal, cfg=cfg, seed=seed, **kw)
     # P and dS enter the second products in the 16-bit type (8 / 11 bits of mantissa), as in attn_dkv16_rs
-    rel = 2.5e-3 if cfg.dtype == "f16" else 1.2e-2
+    rel = 2.5e-3 if (cfg.dtype == "f16" and not cfg.mix) else 1.2e-2    # mix streams: P and V enter the dO products as BF16
     assert ev < rel * max(1.0, mv) and ek < rel * max(1.0, mk), (ev, mv, ek, mk)
     return wg
 

@@ -64,11 +64,17 @@ IN_S = ["qres", "gres", "lres", "dres", "nsteps", "rscale", "qinc", "ginc", "ldi
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", prof=0, abl=(), exact=0):
+    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", prof=0, abl=(), exact=0, gdtype=None):
         """dtype: type of Q, K, V, dO and of the packed P / dS'; lprec / dprec: storage types of L and D.
         exact: K stays as stored and the softmax scale is applied in fp32, P = exp2(scale2 * (Q K^T - L / scale2)) (one packed
         multiply per two scores more); otherwise K arrives pre-multiplied by scale2, rounded to the 16-bit type."""
         self.dtype, self.lprec, self.dprec, self.prof, self.exact = dtype, lprec, dprec, prof, exact
+        # gdtype: storage type of dO when it differs from Q / K / V (the reference's own mix: FP16 Q, K, V with BF16 dO,
+        # +Precisions.swift:13-17).  The two products that read dO -- dP = dO V^T and dV^T += dO^T P -- then run in dO's type
+        # (V is converted once per workgroup, P is packed to that type), S and dK^T += Q^T dS' in the type of Q and K.  The
+        # extra k-steps share one B operand: -2.0, the same bit pattern 0xC000 in both types; the pairs carry half the term.
+        self.gdtype = gdtype or dtype
+        self.mix = self.gdtype != self.dtype
         self.abl = frozenset(abl)
 
 
@@ -170,21 +176,22 @@ class Stream(_P4Stream):
         """closures turning the loaded L / D into the 16-bit pairs the extra k-steps consume (exact sums: hi + lo)"""
         cfg = self.cfg
         ops = []
-        mask = 0xFFFF0000 if cfg.dtype == "bf16" else 0xFFFFE000
         for raw, prec, dst, isd in ((T_LRAW, cfg.lprec, LP, False), (T_DRAW, cfg.dprec, DPR, True)):
             x, t = V(raw), V(T_T0)
+            ptype = cfg.gdtype if isd else cfg.dtype          # the pair travels in the type of the product it joins
+            mask = 0xFFFF0000 if ptype == "bf16" else 0xFFFFE000
             if prec == "f16":
                 ops.append(lambda x=x: self.emit("v_cvt_f32_f16", x, [x]))
             elif prec == "bf16":
                 ops.append(lambda x=x: self.emit("v_lshlrev_b32", x, [I(16), x]))
             if isd:     # the buffer holds D * scale (+Softmax.swift:472-503); dP' needs D itself
                 ops.append(lambda x=x: self.emit("v_mul_f32", x, [SN("rscale"), x]))
-            elif cfg.exact:   # S'' = Q K^T - L / scale2
+            elif cfg.exact or cfg.mix:   # S'' = Q K^T - L / scale2 (mix: and / or the half that the -2.0 operand doubles)
                 ops.append(lambda x=x: self.emit("v_mul_f32", x, [SN("rscale2"), x]))
             ops.append(lambda x=x, t=t: self.emit("v_and_b32", t, [I(mask), x]))          # hi
             ops.append(lambda x=x, t=t: self.emit("v_sub_f32", x, [x, t]))                # remainder
             ops.append(lambda x=x: self.emit("v_and_b32", x, [I(mask), x]))               # lo
-            ops.append(lambda x=x, t=t, dst=dst: self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst), [t, x]))
+            ops.append(lambda x=x, t=t, dst=dst, ptype=ptype: self.emit("v_cvt_pk_%s_f32" % ptype, V(dst), [t, x]))
         return ops
 
     def addr_advance(self, names):
@@ -205,7 +212,7 @@ class Stream(_P4Stream):
 
     def packp_op(self, kb, u, w):
         r = 8 * u + 2 * w
-        self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, V(P16 + 4 * (2 * kb + u) + w), [V(SP + 16 * kb + r), V(SP + 16 * kb + r + 1)])
+        self.emit("v_cvt_pk_%s_f32" % self.cfg.gdtype, V(P16 + 4 * (2 * kb + u) + w), [V(SP + 16 * kb + r), V(SP + 16 * kb + r + 1)])
 
     def scale_op(self, kb, r):   # exact streams: two scores times scale2
         x = V(SP + 16 * kb + r, 2)
@@ -345,7 +352,8 @@ class Stream(_P4Stream):
                 self.stamp(stamps[g])
             if fr is not None:
                 self.lds_need(self.frag_rid[fr])
-            self.mfma(d, a_, b_, c_)
+            # products 18..51 (dP and dV^T) read dO: they run in its type
+            self.emit("v_mfma_f32_32x32x16_" + (cfg.gdtype if 18 <= g < 52 else cfg.dtype), d, [a_, b_, c_])
             for fn in fill[g]:
                 fn()
         self.stamp("pd")
@@ -420,10 +428,10 @@ def write_inc(path):
              "// header for the register map and the step table).", "#pragma once", ""]
     lines.append("#define MFA_DKV4_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256)))
     lines.append("")
-    lines.append("// X(name, stamps the shader clock, applies the softmax scale in fp32)")
+    lines.append("// X(name, stamps the shader clock, applies the softmax scale in fp32, dO is BF16 next to FP16 Q / K / V)")
     lines.append("#define MFA_DKV4_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d) \\" % (name, cfg.prof, cfg.exact))
+        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.mix))
     lines.append("")
     lines.append("")
     for name, cfg in VARIANTS.items():
@@ -446,9 +454,11 @@ VARIANTS = {
     "F16_MIXED": Cfg("f16", "f16", "bf16"),
     "BF16_F32": Cfg("bf16", "f32", "f32", exact=1),  # lowPrecisionInputs alone: FP32 L, D and the attention matrix in FP32 registers
     "F16_F32": Cfg("f16", "f32", "f32", exact=1),
+    "F16_DOBF16_MIXED": Cfg("f16", "f16", "bf16", gdtype="bf16"),          # the reference's default low-precision mix
+    "F16_DOBF16_F32": Cfg("f16", "f32", "f32", exact=1, gdtype="bf16"),
     "BF16_MIXED_PROF": Cfg("bf16", "f16", "bf16", prof=1),
 }
-PRODUCT_STREAMS = ("BF16_MIXED", "F16_MIXED", "BF16_F32", "F16_F32")
+PRODUCT_STREAMS = ("BF16_MIXED", "F16_MIXED", "BF16_F32", "F16_F32", "F16_DOBF16_MIXED", "F16_DOBF16_F32")
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

@@ -32,9 +32,10 @@ def load_prec(buf, prec):
     return h16_to_f32(buf.view(np.uint16).astype(np.uint32), prec == "f16").astype(np.float64)
 
 
-def reference(q, k, v, do, f16=False, causal=False, scale=None):
+def reference(q, k, v, do, f16=False, causal=False, scale=None, g16=None):
     """float64 backward pass on the 16-bit inputs: L (base-2 log-sum-exp of the scaled scores), D * scale, dV, dK"""
-    qf, kf, vf, gf = (to_f32(x, f16).astype(np.float64) for x in (q, k, v, do))
+    qf, kf, vf = (to_f32(x, f16).astype(np.float64) for x in (q, k, v))
+    gf = to_f32(do, f16 if g16 is None else g16).astype(np.float64)
     R, C = qf.shape[0], kf.shape[0]
     scale = scale if scale is not None else 1.0 / np.sqrt(qf.shape[1])
     s = qf @ kf.T * scale
@@ -79,6 +80,8 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
     kp = f32_to_h16((kfl * scale2).astype(np.float32).reshape(-1), f16).astype(np.uint16).reshape(k.shape)   # K' = K * scale2
     if cfg.exact:
         kp = k
+    if cfg.mix:     # V in dO's type (attn_dkv16_p4.h converts the fragments once)
+        vfl = f32_to_h16(to_f32(v, f16).reshape(-1), cfg.gdtype == "f16").astype(np.uint16).reshape(v.shape)
     lane = np.arange(64)
     kc, hi, n16 = lane & 31, lane >> 5, lane & 15
     for w in wg.waves:
@@ -111,7 +114,7 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
             "ra0": ra0.astype(np.uint32), "ra1": (ra0 ^ 32).astype(np.uint32),
             "ta0": (trow * 64 + ((tchunk ^ (hi & 3)) * 16) + thalf * 8).astype(np.uint32),
             "ta1": ((trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8).astype(np.uint32),
-            "onesw": np.where(lane < 32, 0xBC00BC00 if f16 else 0xBF80BF80, 0).astype(np.uint32),
+            "onesw": np.where(lane < 32, 0xC000C000 if cfg.mix else (0xBC00BC00 if f16 else 0xBF80BF80), 0).astype(np.uint32),
             "tk": ((c0 + 64 * wave + kc) - coff - 4 * hi - row_first).astype(np.int64).astype(np.uint32),
             "kvback": (back + 16 * lane).astype(np.uint32),
         })
@@ -119,9 +122,9 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
         if causal:   # steps whose rows do not all see this wave's last key
             maskuntil = max(0, -(-(c0 + 64 * wave + 63 - coff - row_first) // 32))
         w.sn.update({"qres": (qb, R * ld2), "gres": (gb, R * ld2), "lres": (lbuf, R * lesz), "dres": (dbuf, R * desz),
-                     "nsteps": nsteps, "rscale": float(np.float32(1.0) / scale), "qinc": 32 * ld2, "ginc": 32 * ld2,
+                     "nsteps": nsteps, "rscale": float(np.float32(0.5 if cfg.mix else 1.0) / scale), "qinc": 32 * ld2, "ginc": 32 * ld2,
                      "ldinc": 32 * lesz, "wr0": wave * 2048, "ringend": RING * STAGE, "maskuntil": maskuntil,
-                     "rscale2": float(np.float32(1.0) / scale2), "scale2x2": float(scale2)})
+                     "rscale2": float(np.float32(0.5 if cfg.mix else 1.0) / (scale2 if cfg.exact else np.float32(1.0))), "scale2x2": float(scale2)})
     wg.run(order)
     dV = np.zeros((256, D), np.float32)
     dK = np.zeros((256, D), np.float32)
@@ -147,8 +150,9 @@ def check(R=96, C=256, cfg=None, causal=False, seed=0, cblk=0, **kw):
     cfg = cfg or Cfg()
     f16 = cfg.dtype == "f16"
     rng = np.random.default_rng(seed)
-    q, k, v, do = (rand16((n, 128), rng, f16=f16) for n in (R, C, C, R))
-    L, Dt, dv, dk = reference(q, k, v, do, f16, causal)
+    q, k, v = (rand16((n, 128), rng, f16=f16) for n in (R, C, C))
+    do = rand16((R, 128), rng, f16=cfg.gdtype == "f16")
+    L, Dt, dv, dk = reference(q, k, v, do, f16, causal, g16=cfg.gdtype == "f16")
     # the kernel sees L and D as stored
     Ls = load_prec(store_prec(L, cfg.lprec)[0], cfg.lprec)
     Ds = load_prec(store_prec(Dt, cfg.dprec)[0], cfg.dprec)

@@ -62,6 +62,8 @@ def main():
         per_cu_pairs = (nblk // 2) * H / 256
         print(f"launch time per pair on a CU: {ms * 1e-3 / per_cu_pairs * 1e6:.1f} us")
         return
+    extra = o[:, ::64, 7:9].contiguous().view(torch.int32).double()
+    print("kernel entry -> Q loads issued %.0f, -> Q loads returned %.0f cycles" % (extra[..., 0].mean(), extra[..., 1].mean()))
     fixed = o[:, ::64, 4:7].contiguous().view(torch.int32).double()   # [H][waves][entry -> statement, statement, statement -> stores issued]
     c = o[:, ::64, 0:4].contiguous().view(torch.int32).double()      # [H][N/64 waves][pa, pw, pb, nt]
     steady = c[..., 3] - 1

@@ -18,7 +18,7 @@ template <typename T, int STREAM> static void fill_p5(VariantInfo *v, const char
   v->siblingParallelization = v->parallelization;
   v->parallelization = 256;
   v->traversal = 32;
-  v->headBlock = 256;
+  v->headBlock = p5::stream_bucket(STREAM);
   v->threads = 256;
   v->ldsBytes = v->ldsBytes > (uint32_t)p5::LDS_BYTES ? v->ldsBytes : (uint32_t)p5::LDS_BYTES;
   v->cacheLeft = true;
@@ -31,17 +31,24 @@ template <typename T, int STREAM> static void fill_p5(VariantInfo *v, const char
 
 // impl 0 = scale applied in fp32; impl 10 = FOLD (see attn_fwd16_p4.hip); 1000 + stream index: developer streams
 bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out) {
-  if (D != 256) return false;
   if (precision == PREC_BF16) {
-    if (impl == 0) { fill_p5<__bf16, p5::S_BF16_THR8>(out, "attn_fwd16p5_bf16_d256_w4x64_thr8"); return true; }
-    if (impl == 10) { fill_p5<__bf16, p5::S_BF16_FOLD>(out, "attn_fwd16p5_bf16_d256_w4x64_thr8_fold"); return true; }
+    if (D == 256 && impl == 0) { fill_p5<__bf16, p5::S_BF16_THR8>(out, "attn_fwd16p5_bf16_d256_w4x64_thr8"); return true; }
+    if (D == 256 && impl == 10) { fill_p5<__bf16, p5::S_BF16_FOLD>(out, "attn_fwd16p5_bf16_d256_w4x64_thr8_fold"); return true; }
+    if (D == 192 && impl == 0) { fill_p5<__bf16, p5::S_D192_BF16_THR8>(out, "attn_fwd16p5_bf16_d192_w4x64_thr8"); return true; }
+    if (D == 192 && impl == 10) { fill_p5<__bf16, p5::S_D192_BF16_FOLD>(out, "attn_fwd16p5_bf16_d192_w4x64_thr8_fold"); return true; }
+    if (D == 160 && impl == 0) { fill_p5<__bf16, p5::S_D160_BF16_THR8>(out, "attn_fwd16p5_bf16_d160_w4x64_thr8"); return true; }
+    if (D == 160 && impl == 10) { fill_p5<__bf16, p5::S_D160_BF16_FOLD>(out, "attn_fwd16p5_bf16_d160_w4x64_thr8_fold"); return true; }
 #ifdef MFA_DEV_VARIANTS
-    if (impl == 1000 + p5::S_BF16_FOLD_PROF) { fill_p5<__bf16, p5::S_BF16_FOLD_PROF>(out, "attn_fwd16p5_DEV_BF16_FOLD_PROF"); return true; }
+    if (D == 256 && impl == 1000 + p5::S_BF16_FOLD_PROF) { fill_p5<__bf16, p5::S_BF16_FOLD_PROF>(out, "attn_fwd16p5_DEV_BF16_FOLD_PROF"); return true; }
 #endif
   }
   if (precision == PREC_FP16) {
-    if (impl == 0) { fill_p5<_Float16, p5::S_F16_THR8>(out, "attn_fwd16p5_f16_d256_w4x64_thr8"); return true; }
-    if (impl == 10) { fill_p5<_Float16, p5::S_F16_FOLD>(out, "attn_fwd16p5_f16_d256_w4x64_thr8_fold"); return true; }
+    if (D == 256 && impl == 0) { fill_p5<_Float16, p5::S_F16_THR8>(out, "attn_fwd16p5_f16_d256_w4x64_thr8"); return true; }
+    if (D == 256 && impl == 10) { fill_p5<_Float16, p5::S_F16_FOLD>(out, "attn_fwd16p5_f16_d256_w4x64_thr8_fold"); return true; }
+    if (D == 192 && impl == 0) { fill_p5<_Float16, p5::S_D192_F16_THR8>(out, "attn_fwd16p5_f16_d192_w4x64_thr8"); return true; }
+    if (D == 192 && impl == 10) { fill_p5<_Float16, p5::S_D192_F16_FOLD>(out, "attn_fwd16p5_f16_d192_w4x64_thr8_fold"); return true; }
+    if (D == 160 && impl == 0) { fill_p5<_Float16, p5::S_D160_F16_THR8>(out, "attn_fwd16p5_f16_d160_w4x64_thr8"); return true; }
+    if (D == 160 && impl == 10) { fill_p5<_Float16, p5::S_D160_F16_FOLD>(out, "attn_fwd16p5_f16_d160_w4x64_thr8_fold"); return true; }
   }
   return false;
 }

@@ -52,12 +52,13 @@ static const char *kDefaultTables[3][2] = {
      "| 384 | 64  | 32 | 384 | Q, O |\n",
      // forward, mixed: D <= 128 -> 4 waves x 64 rows, 64-key steps (attn_fwd16_p4.h); | 128 | 256 | 32 | 128 | selects the
      // 8 waves x 32 rows kernel with 32-key pipeline steps (attn_fwd16_v3.h), which also serves the other buckets;
-     // D in (192, 256] -> 4 waves x 64 rows, 32-key steps (attn_fwd16_p5.h); | 256 | 128 | 32 | 256 | selects 4 waves x 32 rows
+     // D in (128, 256] -> 4 waves x 64 rows, 32-key steps (attn_fwd16_p5.h; buckets 160, 192, 256); | D | 128 | 32 | D | selects
+     // the 4 waves x 32 rows objects
      "| 32  | 128 | 32 | 32  | Q, O |\n"
      "| 64  | 256 | 32 | 64  | Q, O |\n"
      "| 128 | 256 | 64 | 128 | Q, O |\n"
-     "| 160 | 128 | 32 | 160 | Q, O |\n"
-     "| 192 | 128 | 32 | 192 | Q, O |\n"
+     "| 160 | 256 | 32 | 160 | Q, O |\n"
+     "| 192 | 256 | 32 | 192 | Q, O |\n"
      "| 256 | 256 | 32 | 256 | Q, O |\n"
      "| 384 | 64  | 32 | 384 | Q, O |\n"},
     {// backwardQuery, FP32

@@ -138,10 +138,10 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         v = v3;
         add(fwd16_p4_variant(pq, 128, lowS ? 10 : 0, &v), v);
       }
-      if (have3 && b16 == 256) {   // four waves x 64 rows, 32-key steps (attn_fwd16_p5.h)
+      if (have3 && (b16 == 160 || b16 == 192 || b16 == 256)) {   // four waves x 64 rows, 32-key steps (attn_fwd16_p5.h)
         const bool lowS = kdesc->registerPrecisions[MFA_P] > MFA_FP32;
         v = v3;
-        add(fwd16_p5_variant(pq, 256, lowS ? 10 : 0, &v), v);
+        add(fwd16_p5_variant(pq, b16, lowS ? 10 : 0, &v), v);
       }
       add(have3, v3);
     }

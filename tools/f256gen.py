@@ -45,7 +45,7 @@ T_MN, T_SW, T_CORR, T_LB = 248, 250, 252, 254
 T_TL = T_SW                      # mask limits: only inside the mask section, which runs before the maxima
 FIRST_OWNED_VGPR = 30
 MASK_VALUE = -(0.875 / 1.44269504089) * 3.402823466e+38   # +Softmax.swift:242-243
-NKS, NDB = 16, 8
+NKS = 16                         # k-steps the Q' fragment map is laid out for (D = 256)
 STAGE, VIMG, RING = 32768, 16384, 4
 
 INOUT_V = ["m0", "m1", "l0", "l1", "koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3", "ka0", "ka1", "ta0", "ta1"]
@@ -56,8 +56,13 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "wr0", "ringend",
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, prof=0, abl=()):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, prof=0, abl=(), D=256):
+        """D: head-dimension bucket of the code object (160, 192 or 256): D / 16 k-steps per score block, D / 32 blocks of O^T
+        per row block; the register map keeps its D = 256 positions (smaller buckets leave the tail of the Q' and O ranges unused)"""
         self.dtype, self.thr, self.fold, self.prof, self.abl = dtype, float(thr), fold, prof, frozenset(abl)
+        self.D, self.nks, self.ndb = D, D // 16, D // 32
+        self.pw = -(-D // 64)            # LDS-DMA pieces (1 KiB) per wave and operand tile: 32 keys x D x 2 bytes over four waves
+        assert D % 32 == 0 and (self.nks + 2 * self.ndb) % 4 == 0
 
 
 def q_frag(rb, ks):
@@ -85,7 +90,7 @@ def af_half(i, h):
 
 
 def o_acc(rb, db):
-    return A(16 * (8 * rb + db), 16)
+    return A(16 * (8 * rb + db), 16)    # (stride 8 blocks per rb whatever the bucket)
 
 
 class Stream(_P4Stream):
@@ -93,23 +98,27 @@ class Stream(_P4Stream):
         _P4Stream.__init__(self, cfg)
         self.frag_rid = {}
 
-    # ---- fragment i of a step: 0..15 K rows (k-step i) of the step's own tile, 16..31 V^T (u, db) of the PREVIOUS tile
+    # ---- fragment i of a step: 0..nks-1 K rows (k-step i) of the step's own tile, then 2 ndb V^T fragments (u, db) of the PREVIOUS tile
     def frag_read(self, i):
-        if i < 16:
+        nks, ndb = self.cfg.nks, self.cfg.ndb
+        if i < nks:
             self.frag_rid[i] = self.lds_read("ds_read_b128", af(i), VN("ka%d" % (i & 1)), (i >> 1) * 2048, note="K rows ks%d" % i)
         else:
-            u, db = divmod(i - 16, 8)
+            u, db = divmod(i - nks, ndb)
             off = VIMG + db * 2048 + u * 1024
             self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ta0"), off, note="V^T u%d db%d" % (u, db))
             self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ta1"), off)
 
     def dma_piece(self, i):
-        name, res, base = (("koff%d" % i, "kres", 0) if i < 4 else ("voff%d" % (i - 4), "vres", VIMG))
-        self.emit("s_add_u32", M0, [SN("wr"), I(base + (i & 3) * 1024)])
+        """piece i of this wave: 0..pw-1 of the K tile, pw..2pw-1 of the V tile"""
+        pw = self.cfg.pw
+        name, res, base = (("koff%d" % i, "kres", 0) if i < pw else ("voff%d" % (i - pw), "vres", VIMG))
+        self.emit("s_add_u32", M0, [SN("wr"), I(base + (i % pw) * 1024)])
         self.emit("buffer_load_dwordx4_lds", None, [VN(name), SN(res, 4)])
 
     def dma_advance(self, i):
-        name, inc = ("koff%d" % i, "kinc") if i < 4 else ("voff%d" % (i - 4), "vinc")
+        pw = self.cfg.pw
+        name, inc = ("koff%d" % i, "kinc") if i < pw else ("voff%d" % (i - pw), "vinc")
         self.emit("v_add_u32_e64", VN(name), [VN(name), SN(inc)], clamp=1)
 
     def wr_advance(self):
@@ -136,37 +145,38 @@ class Stream(_P4Stream):
         if cfg.fold:
             for rb in range(2):
                 mm.append((s_blk(par, rb), V(ONES, 4), V(MF[rb], 4), I(0), None))
-        for ks in range(NKS):
+        nks, ndb, npc = cfg.nks, cfg.ndb, 2 * cfg.pw
+        for ks in range(nks):
             for rb in range(2):
                 c = I(0) if (ks == 0 and not cfg.fold) else s_blk(par, rb)
                 mm.append((s_blk(par, rb), af(ks), q_frag(rb, ks), c, ks))
         ng = len(mm)
-        f0 = ng - 32                       # matrix instructions in front of the first fragment's
+        f0 = ng - 2 * nks                  # matrix instructions in front of the first fragment's
         fill = [[] for _ in range(ng)]
 
         def at(g, fn):
             fill[g].append(fn)
 
         if mfma:
-            for i in range(12):            # K fragments 4..15 (0..3 were requested behind the previous seam)
+            for i in range(nks - 4):       # K fragments 4.. (0..3 were requested behind the previous seam)
                 at(f0 + 2 * i + 1, lambda i=i: self.frag_read(i + 4))
-            if softmax:                    # V^T fragments 16..19 of the previous tile, for phase B
-                for i in range(12, 16):
+            if softmax:                    # the first four V^T fragments of the previous tile, for phase B
+                for i in range(nks - 4, nks):
                     at(f0 + 2 * i + 1, lambda i=i: self.frag_read(i + 4))
             if dma and "dma" not in cfg.abl:
-                for i in range(8):         # LDS-DMA of tile j+2
+                for i in range(npc):       # LDS-DMA of tile j+2
                     at(f0 + 2 * i, lambda i=i: self.dma_piece(i))
-                    at(f0 + 16 + 2 * (i // 2), lambda i=i: self.dma_advance(i))
-                at(f0 + 24, lambda: self.wr_advance())
+                    at(f0 + 2 * npc + 2 * (i // 2), lambda i=i: self.dma_advance(i))
+                at(f0 + 3 * npc, lambda: self.wr_advance())
             if zero_o:
-                for g in range(32):
-                    for t in range(8):
-                        at(f0 + g, lambda r=8 * g + t: self.emit("v_accvgpr_write_b32", A(r), [I(0)]))
+                regs = [16 * (8 * rb + db) + r for rb in range(2) for db in range(ndb) for r in range(16)]
+                for n, r in enumerate(regs):
+                    at(f0 + (n * 2 * nks) // len(regs), lambda r=r: self.emit("v_accvgpr_write_b32", A(r), [I(0)]))
         if softmax:
             # element pair (r, r + 1) of block rb: exp2 in one gap, row sums and pack in the next (in place: word 4 u + w)
             pairs = [(rb, r) for rb in range(2) for r in range(0, 16, 2)]
             for n, (rb, r) in enumerate(pairs):
-                g = f0 + 2 * n
+                g = f0 + (n * (2 * nks - 1)) // 16 if nks < 16 else f0 + 2 * n
                 at(g, lambda rb=rb, r=r: self.exp_pair(prev, rb, r))
                 at(g + 1, lambda rb=rb, r=r: self.sum_pack(prev, rb, r))
         for g in range(ng):
@@ -195,14 +205,17 @@ class Stream(_P4Stream):
         prev = par ^ 1
         if not mfma and softmax:
             self.emit("s_nop", None, [I(15)], note="S(0) is still leaving the matrix pipe")
-        fill = [[] for _ in range(32)]
+        nks, ndb = cfg.nks, cfg.ndb
+        nb = 4 * ndb                       # matrix instructions of the phase
+        seam_gap = nb - 8                  # behind the products of the fourth-last V^T fragment: the last four slots free up after it
+        fill = [[] for _ in range(nb)]
 
         def at(g, fn):
             fill[g].append(fn)
 
         if mfma:
-            for i in range(16, 28):        # V^T fragments 20..31 (16..19 were requested in phase A)
-                at(2 * (i - 16) + 1, lambda i=i: self.frag_read(i + 4))
+            for j in range(2 * ndb - 4):   # V^T fragments 4.. of the tile (the first four were requested in phase A)
+                at(2 * j + 1, lambda j=j: self.frag_read(nks + j + 4))
         if softmax:
             mask_lbl, mask_back = self.newlabel("MASK"), self.newlabel("MASKBACK")
 
@@ -224,24 +237,24 @@ class Stream(_P4Stream):
             else:
                 at(11, lambda: self.decide_3())
                 at(12, lambda: self.decide_4(dec_lbl))
-                for e in range(32):        # s * scale2 - m in gaps 13..23
-                    at(13 + e // 3, lambda e=e: self.fma_op(par, e // 16, e % 16))
+                for e in range(32):        # s * scale2 - m from gap 13 on (D = 256: three per gap up to gap 23)
+                    at(13 + (e // 3 if nb == 32 else (e * (nb - 13)) // 32), lambda e=e: self.fma_op(par, e // 16, e % 16))
         if seam:
             def do_seam():
-                self.emit("s_waitcnt", None, [], vmcnt=8 if "dma" not in cfg.abl else 0)
+                self.emit("s_waitcnt", None, [], vmcnt=2 * cfg.pw if "dma" not in cfg.abl else 0)
                 self.emit("s_barrier")
                 for n in ("ka0", "ka1"):
                     self.emit("v_add_u32", VN(n), [SN("delta"), VN(n)])
-            at(22, lambda: self.stage_delta())
-            at(24, do_seam)
+            at(seam_gap - 2, lambda: self.stage_delta())
+            at(seam_gap, do_seam)
             for i in range(4):
-                at(25 + 2 * i, lambda i=i: self.frag_read(i))
-            # the V^T addresses move once fragment 31 of this step is requested (gap 23)
-            at(26, lambda: [self.emit("v_add_u32", VN(n), [SN("deltav"), VN(n)]) for n in ("ta0", "ta1")])
-        for g in range(32):
+                at(seam_gap + 1 + 2 * i, lambda i=i: self.frag_read(i))
+            # the V^T addresses move once the last fragment of this step is requested (gap seam_gap - 1)
+            at(seam_gap + 2, lambda: [self.emit("v_add_u32", VN(n), [SN("deltav"), VN(n)]) for n in ("ta0", "ta1")])
+        for g in range(nb):
             if mfma:
-                u, db, rb = g // 16, (g % 16) // 2, g % 2
-                fr = 16 + 8 * u + db
+                u, db, rb = g // (2 * ndb), (g % (2 * ndb)) // 2, g % 2
+                fr = nks + ndb * u + db
                 self.lds_need(self.frag_rid[fr])
                 self.mfma(o_acc(rb, db), af(fr), p_frag(prev, rb, u), o_acc(rb, db))
             for fn in fill[g]:
@@ -357,7 +370,7 @@ class Stream(_P4Stream):
                 self.emit("s_nop", None, [I(15)])
                 self.emit("s_nop", None, [I(7)])
                 for rb in range(2):
-                    for i0 in range(0, 128, 2):
+                    for i0 in range(0, 16 * cfg.ndb, 2):
                         for t in range(2):
                             self.emit("v_accvgpr_read_b32", V(T_RS + t), [A(128 * rb + i0 + t)])
                         for t in range(2):
@@ -376,8 +389,9 @@ class Stream(_P4Stream):
         self.outofline = []
         # ---- Q' fragments: attn_fwd16_p5.h parks them in LDS, lane-linear, 32 x 1 KiB per wave at `qback`
         self.emit("s_waitcnt", None, [], lgkmcnt=0)
-        for i in range(32):
-            self.lds_read("ds_read_b128", V(QF + 4 * i, 4), VN("qback"), i * 1024)
+        for rb in range(2):
+            for ks in range(cfg.nks):
+                self.lds_read("ds_read_b128", q_frag(rb, ks), VN("qback"), (cfg.nks * rb + ks) * 1024)
         for rb in range(2):
             self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
@@ -388,13 +402,14 @@ class Stream(_P4Stream):
         self.lds_flush()
         self.emit("s_barrier")                                # every wave has its fragments: the ring may be written
         self.emit("s_mov_b32", SN("wr"), [SN("wr0")])
+        npc = 2 * cfg.pw
         for t in range(2):                                   # tiles 0 and 1
-            for i in range(8):
+            for i in range(npc):
                 self.dma_piece(i)
-            for i in range(8):
+            for i in range(npc):
                 self.dma_advance(i)
             self.wr_advance()
-        self.emit("s_waitcnt", None, [], vmcnt=8)
+        self.emit("s_waitcnt", None, [], vmcnt=npc)
         self.emit("s_barrier")
         self.emit("s_mov_b32", SN("pend"), [I(0)])
         self.emit("s_mov_b32", SN("j"), [I(0)])
@@ -433,7 +448,7 @@ class Stream(_P4Stream):
             self.lds_flush()                                  # the K fragments requested behind the last seam are not used
             self.emit("s_nop", None, [I(3)])
             self.phase_a(lastpar ^ 1, mfma=False, softmax=True)
-            for i in range(16, 20):
+            for i in range(cfg.nks, cfg.nks + 4):
                 self.frag_read(i)
             self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
             self.phase_b(lastpar ^ 1, mfma=True, softmax=False, seam=False)
@@ -445,12 +460,12 @@ class Stream(_P4Stream):
         self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
         self.emit("s_cbranch_scc1", None, [], target=done)
         if "dma" not in cfg.abl:
-            for i in range(8):
+            for i in range(npc):
                 self.dma_piece(i)
-            for i in range(8):
+            for i in range(npc):
                 self.dma_advance(i)
             self.wr_advance()
-        self.emit("s_waitcnt", None, [], vmcnt=8 if "dma" not in cfg.abl else 0)
+        self.emit("s_waitcnt", None, [], vmcnt=npc if "dma" not in cfg.abl else 0)
         self.emit("s_barrier")
         self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_branch", None, [], target=skip)
@@ -469,10 +484,10 @@ def write_inc(path):
              "// header for the register map and the phase tables).", "#pragma once", ""]
     lines.append("#define MFA_P5_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256)))
     lines.append("")
-    lines.append("// X(name, folds Q scale and running maximum into the matrix pipe, stamps the shader clock)")
+    lines.append("// X(name, folds Q scale and running maximum into the matrix pipe, stamps the shader clock, head-dimension bucket)")
     lines.append("#define MFA_P5_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.prof))
+        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.fold, cfg.prof, cfg.D))
     lines.append("")
     lines.append("")
     for name, cfg in VARIANTS.items():
@@ -495,6 +510,10 @@ VARIANTS = {
     "F16_FOLD": Cfg("f16", fold=1),
     "BF16_FOLD_PROF": Cfg("bf16", fold=1, prof=1),
 }
+for _d in (192, 160):       # the head-dimension buckets between 128 and 256
+    for _t in ("bf16", "f16"):
+        VARIANTS["D%d_%s_THR8" % (_d, _t.upper())] = Cfg(_t, D=_d)
+        VARIANTS["D%d_%s_FOLD" % (_d, _t.upper())] = Cfg(_t, fold=1, D=_d)
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

@@ -11,12 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from f256gen import Cfg, RING, STAGE, Stream  # noqa: E402
 from p4sim import FLT_MAX, ROWMAP, Workgroup, f32_to_h16, h16_to_f32, rand_bf16, reference  # noqa: E402
 
-D = 256
-
-
 def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 1, 2, 3), stream=None):
-    """q [R][256], k / v [C][256] as uint16 bit patterns.  Returns O [256][256] f32, L [256]."""
+    """q [R][D], k / v [C][D] as uint16 bit patterns (D = cfg.D).  Returns O [256][D] f32, L [256]."""
     cfg = cfg or Cfg()
+    D, nks, ndb, pw = cfg.D, cfg.nks, cfg.ndb, cfg.pw
     f16 = cfg.dtype == "f16"
     R, C = q.shape[0], k.shape[0]
     instrs = stream if stream is not None else Stream(cfg).build()
@@ -40,8 +38,8 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         wave = w.id
         r0 = rblk * 256 + wave * 64
         back = wave * 32768
-        for i in range(32):
-            rb, ks = divmod(i, 16)
+        for i in range(2 * nks):
+            rb, ks = divmod(i, nks)
             data = np.zeros((64, 16), np.uint8)
             for l in range(64):
                 row = r0 + 32 * rb + int(qq[l])
@@ -50,11 +48,13 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
                     data[l] = q[row, d0:d0 + 8].view(np.uint8)
             wg.lds_write16(back + i * 1024 + 16 * lane, data)
         koff = []
-        for i in range(4):
-            p = (wave * 4 + i) * 64 + lane
+        for i in range(pw):
+            p = (wave * pw + i) * 64 + lane
             db, key, slot = p >> 7, (p >> 2) & 31, p & 3
             chunk = db * 4 + (slot ^ ((key >> 2) & 3))
-            koff.append((key * ld2 + chunk * 16).astype(np.uint32))
+            koff.append(np.where(chunk * 8 < D, key * ld2 + chunk * 16, 0xFFFFFF00).astype(np.uint32))
+        while len(koff) < 4:
+            koff.append(np.full(64, 0xFFFFFF00, np.uint32))
         trow = (n16 >> 2) + 4 * hi
         tchunk = 2 * ((lane >> 4) & 1) + ((n16 & 3) >> 1)
         thalf = (n16 & 3) & 1
@@ -81,7 +81,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 32 + 1)) if wlast >= r0 else 1
         w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": 32 * ld2,
-                     "vinc": 32 * ld2, "wr0": wave * 4096, "ringend": RING * STAGE, "maskfrom": maskfrom})
+                     "vinc": 32 * ld2, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom})
     wg.run(order)
     O = np.zeros((256, D), np.float32)
     L = np.zeros(256, np.float32)
@@ -91,7 +91,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             l = w.vn["l%d" % b].view(np.float32)
             mm = w.vn["m%d" % b].view(np.float32)
             ltot = l[:32] + l[32:] + np.float32(1.401298464e-45)
-            for db in range(8):
+            for db in range(ndb):
                 for r in range(16):
                     reg = w.a[16 * (8 * b + db) + r].view(np.float32)
                     for h in range(2):
@@ -103,6 +103,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
 def check(R=256, C=96, rblk=0, cfg=None, causal=False, seed=0, spike=None, **kw):
     cfg = cfg or Cfg()
     f16 = cfg.dtype == "f16"
+    D = cfg.D
     rng = np.random.default_rng(seed)
     q, k, v = (rand_bf16(s, rng, f16=f16) for s in ((R, D), (C, D), (C, D)))
     if spike is not None:

@@ -39,6 +39,7 @@ bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 160 && impl == 0) { fill_p5<__bf16, p5::S_D160_BF16_THR8>(out, "attn_fwd16p5_bf16_d160_w4x64_thr8"); return true; }
     if (D == 160 && impl == 10) { fill_p5<__bf16, p5::S_D160_BF16_FOLD>(out, "attn_fwd16p5_bf16_d160_w4x64_thr8_fold"); return true; }
 #ifdef MFA_DEV_VARIANTS
+    if (D == 128 && impl == 10) { fill_p5<__bf16, p5::S_D128_BF16_FOLD>(out, "attn_fwd16p5_DEV_bf16_d128_w4x64_thr8_fold"); return true; }
     if (D == 256 && impl == 1000 + p5::S_BF16_FOLD_PROF) { fill_p5<__bf16, p5::S_BF16_FOLD_PROF>(out, "attn_fwd16p5_DEV_BF16_FOLD_PROF"); return true; }
 #endif
   }

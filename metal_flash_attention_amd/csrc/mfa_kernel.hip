@@ -200,6 +200,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       else if (std::strncmp(knob, "v3:", 3) == 0) have = fwd16_v3_variant(pq, bucket, std::atoi(knob + 3), &dev);
       else if (std::strncmp(knob, "v4:", 3) == 0) have = fwd16_v4_variant(pq, bucket, std::atoi(knob + 3), &dev);
       else if (std::strncmp(knob, "p4:", 3) == 0) have = fwd16_v3_variant(pq, bucket, 0, &dev) && fwd16_p4_variant(pq, bucket, std::atoi(knob + 3), &dev);
+      else if (std::strncmp(knob, "p5:", 3) == 0) have = fwd16_v3_variant(pq, bucket, 0, &dev) && fwd16_p5_variant(pq, bucket, std::atoi(knob + 3), &dev);
     }
     knob = std::getenv("MFA_DKV16_IMPL");
     if (type == MFA_BACKWARD_KEY_VALUE && knob && !candidates.empty()) {

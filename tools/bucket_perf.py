@@ -11,12 +11,15 @@ dims = [int(x) for x in sys.argv[1:]] or [128, 160, 192, 256]
 for D in dims:
     desc = AttentionDescriptor()
     desc.lowPrecisionInputs = True
+    desc.lowPrecisionIntermediates = os.environ.get("MIXED", "0") == "1"
     desc.lowPrecisionInputType = P.BF16
     desc.matrixDimensions = (N, N, D)
     desc.transposeState = (False,) * 4
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     bufs = {op: torch.randn((H, N, D), generator=g, device="cuda").to(torch.bfloat16) for op in (Op.Q, Op.K, Op.V, Op.dO)}
-    bufs[Op.O] = torch.zeros((H, N, D), device="cuda"); bufs[Op.L] = torch.zeros((H, N), device="cuda"); bufs[Op.D] = torch.zeros((H, N), device="cuda")
+    mem = desc.memoryPrecisions
+    tp = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
+    bufs[Op.O] = torch.zeros((H, N, D), device="cuda"); bufs[Op.L] = torch.zeros((H, N), device="cuda", dtype=tp[mem[Op.L]]); bufs[Op.D] = torch.zeros((H, N), device="cuda", dtype=tp[mem[Op.D]])
     for op in (Op.dQ, Op.dK, Op.dV):
         bufs[op] = torch.zeros((H, N, D), device="cuda")
     hs = {op: (N if op in (Op.L, Op.D) else N * D) for op in bufs}

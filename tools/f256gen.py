@@ -56,12 +56,17 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "wr0", "ringend",
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, prof=0, abl=(), D=256):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, prof=0, abl=(), D=256, xbp=0):
         """D: head-dimension bucket of the code object (160, 192 or 256): D / 16 k-steps per score block, D / 32 blocks of O^T
         per row block; the register map keeps its D = 256 positions (smaller buckets leave the tail of the Q' and O ranges unused)"""
         self.dtype, self.thr, self.fold, self.prof, self.abl = dtype, float(thr), fold, prof, frozenset(abl)
         self.D, self.nks, self.ndb = D, D // 16, D // 32
         self.pw = -(-D // 64)            # LDS-DMA pieces (1 KiB) per wave and operand tile: 32 keys x D x 2 bytes over four waves
+        # FOLD streams of the buckets up to 192: the Q' map leaves sixteen registers per row block unused -- they hold -m of the
+        # lane's row and START the accumulation of every score block (no extra k-step; m an exact fp32 value), as in
+        # tools/p4gen.py.  xbp: pairs of scores per row block pair whose exp2 already runs in phase B (behind the decision)
+        self.cinit = bool(fold) and self.nks <= 12
+        self.xbp = xbp
         assert D % 32 == 0 and (self.nks + 2 * self.ndb) % 4 == 0
 
 
@@ -87,6 +92,10 @@ def af(i):
 
 def af_half(i, h):
     return V(AF + 4 * (i % 4) + 2 * h, 2)
+
+
+def cm_blk(rb):
+    return V(QF + 64 * rb + 48, 16)     # the tail of row block rb's Q' range (free when D <= 192)
 
 
 def o_acc(rb, db):
@@ -142,13 +151,15 @@ class Stream(_P4Stream):
         cfg = self.cfg
         prev = par ^ 1
         mm = []
-        if cfg.fold:
+        if cfg.fold and not cfg.cinit:
             for rb in range(2):
                 mm.append((s_blk(par, rb), V(ONES, 4), V(MF[rb], 4), I(0), None))
         nks, ndb, npc = cfg.nks, cfg.ndb, 2 * cfg.pw
         for ks in range(nks):
             for rb in range(2):
-                c = I(0) if (ks == 0 and not cfg.fold) else s_blk(par, rb)
+                c = s_blk(par, rb)
+                if ks == 0 and (cfg.cinit or not cfg.fold):
+                    c = cm_blk(rb) if cfg.cinit else I(0)
                 mm.append((s_blk(par, rb), af(ks), q_frag(rb, ks), c, ks))
         ng = len(mm)
         f0 = ng - 2 * nks                  # matrix instructions in front of the first fragment's
@@ -177,7 +188,8 @@ class Stream(_P4Stream):
             pairs = [(rb, r) for rb in range(2) for r in range(0, 16, 2)]
             for n, (rb, r) in enumerate(pairs):
                 g = f0 + (n * (2 * nks - 1)) // 16 if nks < 16 else f0 + 2 * n
-                at(g, lambda rb=rb, r=r: self.exp_pair(prev, rb, r))
+                if n >= cfg.xbp:       # (the first xbp pairs were exponentiated in phase B of their own step)
+                    at(g, lambda rb=rb, r=r: self.exp_pair(prev, rb, r))
                 at(g + 1, lambda rb=rb, r=r: self.sum_pack(prev, rb, r))
         for g in range(ng):
             d, a_, b_, c_, fr = mm[g]
@@ -234,6 +246,9 @@ class Stream(_P4Stream):
             first = not mfma
             if cfg.fold:
                 at(11, lambda: self.decide_4_fold(dec_lbl, first))
+                pairs = [(rb, r) for rb in range(2) for r in range(0, 16, 2)]
+                for n in range(cfg.xbp):       # exp2 of the first pairs right here: S' needs no further arithmetic
+                    at(12 + (n * (nb - 12)) // cfg.xbp, lambda n=n: self.exp_pair(par, pairs[n][0], pairs[n][1]))
             else:
                 at(11, lambda: self.decide_3())
                 at(12, lambda: self.decide_4(dec_lbl))
@@ -335,6 +350,23 @@ class Stream(_P4Stream):
                         self.emit("v_cmp_gt_i32", VCC, [I((r & 3) + 8 * (r >> 2)), V(T_TL + rb)])
                         self.emit("v_cndmask_b32", x, [x, V(T_THR), VCC])
                 self.emit("s_branch", None, [], target=back)
+            elif kind == "dec" and cfg.cinit:
+                ta, tb = V(T_SW), V(T_SW + 1)
+                for rb in range(2):
+                    mn, m = V(T_MN + rb), VN("m%d" % rb)
+                    if not first:
+                        self.emit("v_max_f32", mn, [I(0), mn])
+                    self.emit("v_add_f32", ta, [m, mn])       # m_up
+                    self.emit("v_sub_f32", tb, [ta, m])       # shift
+                    self.emit("v_mov_b32", m, [ta])
+                    self.emit("v_exp_f32", V(T_CORR + rb), [tb], neg0=1)
+                    for r in range(16):
+                        x = s_elem(par, rb, r)
+                        self.emit("v_sub_f32", x, [x, tb])
+                    for r in range(16):
+                        self.emit("v_sub_f32", V(QF + 64 * rb + 48 + r), [I(0), ta])    # the start block of the following steps
+                self.emit("s_mov_b32", SN("pend"), [I(0 if first else 1)])
+                self.emit("s_branch", None, [], target=back)
             elif kind == "dec" and cfg.fold:
                 ta, tb = V(T_SW), V(T_SW + 1)
                 for rb in range(2):
@@ -395,7 +427,11 @@ class Stream(_P4Stream):
         for rb in range(2):
             self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
-        if cfg.fold:
+        if cfg.cinit:
+            for rb in range(2):
+                for r in range(16):
+                    self.emit("v_mov_b32", V(QF + 64 * rb + 48 + r), [I(0)])
+        elif cfg.fold:
             self.emit("v_mov_b32", V(ONES), [VN("onesw")])
             for r in (ONES + 1, ONES + 2, ONES + 3, MF[0], MF[0] + 1, MF[1], MF[1] + 1):
                 self.emit("v_mov_b32", V(r), [I(0)])
@@ -510,6 +546,7 @@ VARIANTS = {
     "F16_FOLD": Cfg("f16", fold=1),
     "BF16_FOLD_PROF": Cfg("bf16", fold=1, prof=1),
 }
+VARIANTS["D128_BF16_FOLD"] = Cfg("bf16", fold=1, D=128, xbp=8)     # developer stream: the 32-key-step structure at the headline's D
 for _d in (192, 160):       # the head-dimension buckets between 128 and 256
     for _t in ("bf16", "f16"):
         VARIANTS["D%d_%s_THR8" % (_d, _t.upper())] = Cfg(_t, D=_d)

@@ -122,7 +122,11 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
   }
   const uint32_t qinc = BR * ldq2, ginc = BR * ldg2;
   u32x4 qreg[SCH], greg[SCH];
-  float ldreg = 0.f;
+  // L / D value of the block being loaded, AS LOADED: no instruction touches it before it is written to LDS a step later
+  // (converting at the load made hipcc wait for it -- and for every tile load issued before it -- inside issue_loads)
+  // One code path for the three storage types: two 16-bit loads (FP32: the two halves; 16-bit types: the element twice) --
+  // a branch per type left hipcc copying in-flight registers at the merge, i.e. waiting again.
+  uint16_t ldlo = 0, ldhi = 0;
   // L (wave 0) and D (wave 1) slices of a row block, 32 lanes each: one uniform resource and precision per
   // wave, rows past R read as zero through the resource bounds   (+Softmax.swift:356-381, :472-503)
   const bool ldloader = wave < 2 && lane < 32;
@@ -158,12 +162,8 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
       goff[i] = __builtin_elementwise_add_sat(goff[i], ginc);
     }
     if (ldloader) {
-      if (ldprec == PREC_FP32) {
-        ldreg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ldres, ldoff, 0, 0));
-      } else {
-        const uint16_t h = __builtin_amdgcn_raw_buffer_load_b16(ldres, ldoff, 0, 0);
-        ldreg = ldprec == PREC_FP16 ? (float)__builtin_bit_cast(_Float16, h) : bf16_bits_to_f32(h);
-      }
+      ldlo = __builtin_amdgcn_raw_buffer_load_b16(ldres, ldoff, 0, 0);
+      ldhi = __builtin_amdgcn_raw_buffer_load_b16(ldres, ldoff + (ldesz - 2u), 0, 0);
       ldoff += BR * ldesz;
     }
   };
@@ -175,7 +175,11 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
         *reinterpret_cast<u32x4 *>(base + wlds[i]) = qreg[i];
         *reinterpret_cast<u32x4 *>(base + TILE + wlds[i]) = __builtin_bit_cast(u32x4, convert_chunk<T, TG>(greg[i]));
       }
-    if (ldloader) reinterpret_cast<float *>(base + 2 * TILE)[wave * 32 + lane] = ldreg;
+    if (ldloader) {
+      const float ldval = ldprec == PREC_FP32 ? __builtin_bit_cast(float, (uint32_t)ldlo | ((uint32_t)ldhi << 16))
+                        : ldprec == PREC_FP16 ? (float)__builtin_bit_cast(_Float16, ldlo) : bf16_bits_to_f32(ldlo);
+      reinterpret_cast<float *>(base + 2 * TILE)[wave * 32 + lane] = ldval;
+    }
   };
 
   // row fragment of k-step t (16 elements from d = 16t; this lane: row kc, elements 16t + 8hi .. +7):

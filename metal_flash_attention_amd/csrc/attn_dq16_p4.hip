@@ -42,7 +42,9 @@ bool dq16_p4_variant(int precision, int gprecision, int D, int impl, VariantInfo
     if (impl == 0) { fill_dq_p4<__bf16, dq4::S_BF16_EXACT>(out, "attn_dq16p4_bf16_d128_w4x64_exact"); return true; }
     if (impl == 10) { fill_dq_p4<__bf16, dq4::S_BF16_FOLD>(out, "attn_dq16p4_bf16_d128_w4x64"); return true; }
 #ifdef MFA_DEV_VARIANTS
-    if (impl == 1000 + dq4::S_BF16_FOLD_PROF) { fill_dq_p4<__bf16, dq4::S_BF16_FOLD_PROF>(out, "attn_dq16p4_DEV_BF16_FOLD_PROF"); return true; }
+#define MFA_DQ4_DEV(name) if (impl == 1000 + dq4::S_##name) { fill_dq_p4<__bf16, dq4::S_##name>(out, "attn_dq16p4_DEV_" #name); return true; }
+    MFA_DQ4_DEV_STREAM_LIST(MFA_DQ4_DEV)
+#undef MFA_DQ4_DEV
 #endif
   }
   if (precision == PREC_FP16) {

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--heads", type=int, default=64)
     ap.add_argument("--prof", type=int, default=1, help="0: time the product stream instead")
+    ap.add_argument("--stream", default="", help="name of a PROF / ablation stream of the kernel's generator")
     args = ap.parse_args()
     import torch
     from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType as T,
@@ -50,7 +51,7 @@ def main():
         if args.kernel == "dkv":
             os.environ["MFA_DKV16_IMPL"] = "p4:%d" % (1000 + list(dkv4gen.VARIANTS).index("BF16_MIXED_PROF"))
         else:
-            os.environ["MFA_DQ16_IMPL"] = "p4:%d" % (1000 + list(dq4gen.VARIANTS).index("BF16_FOLD_PROF"))
+            os.environ["MFA_DQ16_IMPL"] = "p4:%d" % (1000 + list(dq4gen.VARIANTS).index(args.stream or "BF16_FOLD_PROF"))
     kt = T.backwardKeyValue if args.kernel == "dkv" else T.backwardQuery
     k = AttentionKernel(desc.kernelDescriptor(kt))
     for _ in range(3):

@@ -187,6 +187,9 @@ class Stream(_P4Stream):
 
         # fragment i + 4 takes the slot of fragment i once both of its matrix instructions are issued
         for i in range(44):
+            if "reads" in cfg.abl and i + 4 >= 4:      # timing-only: fragments 4.. are never refreshed (WRONG RESULTS)
+                self.frag_rid[i + 4] = 0
+                continue
             at(2 * i + 1, lambda i=i: self.frag_read(i + 4))
         # LDS-DMA of tile j+2: one piece per even gap of S(0); offsets advance in P(0)
         if "dma" not in cfg.abl:
@@ -216,7 +219,8 @@ class Stream(_P4Stream):
                     seq += [lambda rb=rb, kb=kb, r=r: self.exp_op(rb, kb, r) for r in range(8 * u, 8 * u + 8)]
             per = -(-len(seq) // 13)
             for n, fn in enumerate(seq):
-                at(g0 + 3 + n // per, fn)
+                if "exp" not in cfg.abl:
+                    at(g0 + 3 + n // per, fn)
             g1 = g0 + 16           # S(1) after P(0), Q(0) after P(1)
             seq = []
             for rb in range(2):
@@ -232,7 +236,8 @@ class Stream(_P4Stream):
                     g, used = g + 1, 0
                     quota = (5 if len(seq) > 32 else 3) if g % 2 == 0 else 2
                 assert g < g1 + 16
-                at(g, fn)
+                if "mulpack" not in cfg.abl:
+                    at(g, fn)
                 used += 1
 
         # ---- seam (gap 88): own DMA pieces of tile j+1 have landed; barrier; first fragments of tile j+1
@@ -345,6 +350,11 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d) \\" % (name, cfg.prof, cfg.exact))
     lines.append("")
+    lines.append("#define MFA_DQ4_DEV_STREAM_LIST(X) \\")
+    for name, cfg in VARIANTS.items():
+        if cfg.prof:
+            lines.append("  X(%s) \\" % name)
+    lines.append("")
     lines.append("")
     for name, cfg in VARIANTS.items():
         ins = Stream(cfg).build()
@@ -365,6 +375,12 @@ VARIANTS = {
     "BF16_EXACT": Cfg("bf16", exact=1),
     "F16_EXACT": Cfg("f16", exact=1),
     "BF16_FOLD_PROF": Cfg("bf16", prof=1),
+    # timing-only ablations (WRONG RESULTS; developer build): fillers left out of the tile
+    "ABL_DMA": Cfg("bf16", prof=1, abl=("dma",)),
+    "ABL_EXP": Cfg("bf16", prof=1, abl=("exp",)),
+    "ABL_MULPACK": Cfg("bf16", prof=1, abl=("mulpack",)),
+    "ABL_READS": Cfg("bf16", prof=1, abl=("reads",)),
+    "ABL_ALL": Cfg("bf16", prof=1, abl=("dma", "exp", "mulpack", "reads")),
 }
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ template <typename T, int STREAM> static void fill_dkv_p4(VariantInfo *v, const 
   v->siblingParallelization = v->parallelization;   // split / block-sparse launches: the role-split kernel's workgroups
   v->parallelization = 256;   // key columns per workgroup: four waves x 64
   v->traversal = 32;
-  v->headBlock = 128;
+  v->headBlock = dkv4::stream_bucket(STREAM);
   v->threads = 256;
   v->ldsBytes = v->ldsBytes > (uint32_t)dkv4::LDS_BYTES ? v->ldsBytes : (uint32_t)dkv4::LDS_BYTES;
   v->cacheLeft = true;
@@ -32,24 +32,31 @@ template <typename T, int STREAM> static void fill_dkv_p4(VariantInfo *v, const 
 // combinations the reference's descriptors produce (+Precisions.swift:13-96): FP16 L with BF16 D (mixed-precision mode)
 // and FP32 L, D.  impl >= 1000 (developer build): stream index.
 bool dkv16_p4_variant(int precision, int gprecision, int lprec, int dprec, int D, int impl, VariantInfo *out) {
-  if (D != 128) return false;
+  if (D != 128 && D != 64) return false;
   const bool mixed = lprec == PREC_FP16 && dprec == PREC_BF16, f32 = lprec == PREC_FP32 && dprec == PREC_FP32;
+  const bool d64 = D == 64;
   if (precision == PREC_FP16 && gprecision == PREC_BF16) {   // the reference's own mix: FP16 Q, K, V with BF16 dO
-    if (impl == 0 && mixed) { fill_dkv_p4<_Float16, dkv4::S_F16_DOBF16_MIXED>(out, "attn_dkv16p4_f16_dObf16_d128_w4x64"); return true; }
-    if (impl == 0 && f32) { fill_dkv_p4<_Float16, dkv4::S_F16_DOBF16_F32>(out, "attn_dkv16p4_f16_dObf16_d128_w4x64_exact"); return true; }
+    if (impl == 0 && mixed && !d64) { fill_dkv_p4<_Float16, dkv4::S_F16_DOBF16_MIXED>(out, "attn_dkv16p4_f16_dObf16_d128_w4x64"); return true; }
+    if (impl == 0 && f32 && !d64) { fill_dkv_p4<_Float16, dkv4::S_F16_DOBF16_F32>(out, "attn_dkv16p4_f16_dObf16_d128_w4x64_exact"); return true; }
+    if (impl == 0 && mixed && d64) { fill_dkv_p4<_Float16, dkv4::S_D64_F16_DOBF16_MIXED>(out, "attn_dkv16p4_f16_dObf16_d64_w4x64"); return true; }
+    if (impl == 0 && f32 && d64) { fill_dkv_p4<_Float16, dkv4::S_D64_F16_DOBF16_F32>(out, "attn_dkv16p4_f16_dObf16_d64_w4x64_exact"); return true; }
     return false;
   }
   if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
-    if (impl == 0 && mixed) { fill_dkv_p4<__bf16, dkv4::S_BF16_MIXED>(out, "attn_dkv16p4_bf16_d128_w4x64"); return true; }
-    if (impl == 0 && f32) { fill_dkv_p4<__bf16, dkv4::S_BF16_F32>(out, "attn_dkv16p4_bf16_d128_w4x64_exact"); return true; }
+    if (impl == 0 && mixed && !d64) { fill_dkv_p4<__bf16, dkv4::S_BF16_MIXED>(out, "attn_dkv16p4_bf16_d128_w4x64"); return true; }
+    if (impl == 0 && f32 && !d64) { fill_dkv_p4<__bf16, dkv4::S_BF16_F32>(out, "attn_dkv16p4_bf16_d128_w4x64_exact"); return true; }
+    if (impl == 0 && mixed && d64) { fill_dkv_p4<__bf16, dkv4::S_D64_BF16_MIXED>(out, "attn_dkv16p4_bf16_d64_w4x64"); return true; }
+    if (impl == 0 && f32 && d64) { fill_dkv_p4<__bf16, dkv4::S_D64_BF16_F32>(out, "attn_dkv16p4_bf16_d64_w4x64_exact"); return true; }
 #ifdef MFA_DEV_VARIANTS
-    if (impl == 1000 + dkv4::S_BF16_MIXED_PROF && mixed) { fill_dkv_p4<__bf16, dkv4::S_BF16_MIXED_PROF>(out, "attn_dkv16p4_DEV_BF16_MIXED_PROF"); return true; }
+    if (impl == 1000 + dkv4::S_BF16_MIXED_PROF && mixed && !d64) { fill_dkv_p4<__bf16, dkv4::S_BF16_MIXED_PROF>(out, "attn_dkv16p4_DEV_BF16_MIXED_PROF"); return true; }
 #endif
   }
   if (precision == PREC_FP16 && impl == 0) {
-    if (mixed) { fill_dkv_p4<_Float16, dkv4::S_F16_MIXED>(out, "attn_dkv16p4_f16_d128_w4x64"); return true; }
-    if (f32) { fill_dkv_p4<_Float16, dkv4::S_F16_F32>(out, "attn_dkv16p4_f16_d128_w4x64_exact"); return true; }
+    if (mixed && !d64) { fill_dkv_p4<_Float16, dkv4::S_F16_MIXED>(out, "attn_dkv16p4_f16_d128_w4x64"); return true; }
+    if (f32 && !d64) { fill_dkv_p4<_Float16, dkv4::S_F16_F32>(out, "attn_dkv16p4_f16_d128_w4x64_exact"); return true; }
+    if (mixed && d64) { fill_dkv_p4<_Float16, dkv4::S_D64_F16_MIXED>(out, "attn_dkv16p4_f16_d64_w4x64"); return true; }
+    if (f32 && d64) { fill_dkv_p4<_Float16, dkv4::S_D64_F16_F32>(out, "attn_dkv16p4_f16_d64_w4x64_exact"); return true; }
   }
   return false;
 }

@@ -175,9 +175,9 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           case 192: add(dkv16_rs_variant_d192(pq, pg, &v), v); break;
           default: {
             const bool rs = dkv16_rs_variant(pq, pg, b16, 0, &v);
-            if (rs && b16 == 128) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
+            if (rs && (b16 == 128 || b16 == 64)) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
               VariantInfo v4 = v;
-              add(dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], 128, 0, &v4), v4);
+              add(dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], b16, 0, &v4), v4);
             }
             add(rs, v);
             break;

@@ -64,7 +64,7 @@ IN_S = ["qres", "gres", "lres", "dres", "nsteps", "rscale", "qinc", "ginc", "ldi
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", prof=0, abl=(), exact=0, gdtype=None):
+    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", prof=0, abl=(), exact=0, gdtype=None, D=128):
         """dtype: type of Q, K, V, dO and of the packed P / dS'; lprec / dprec: storage types of L and D.
         exact: K stays as stored and the softmax scale is applied in fp32, P = exp2(scale2 * (Q K^T - L / scale2)) (one packed
         multiply per two scores more); otherwise K arrives pre-multiplied by scale2, rounded to the 16-bit type."""
@@ -75,6 +75,10 @@ class Cfg:
         # extra k-steps share one B operand: -2.0, the same bit pattern 0xC000 in both types; the pairs carry half the term.
         self.gdtype = gdtype or dtype
         self.mix = self.gdtype != self.dtype
+        # D: head-dimension bucket (128, or 64: four k-steps and two head-dimension blocks -- 36 matrix instructions per step,
+        # one LDS-DMA piece per wave and operand tile; the register map keeps its D = 128 positions)
+        self.D, self.nks, self.ndb = D, D // 16, D // 32
+        assert D in (64, 128)
         self.abl = frozenset(abl)
 
 
@@ -135,6 +139,8 @@ class Stream(_P4Stream):
     # ---------------------------------------------------------------- LDS fragment reads
     def frag_read(self, i):
         """issue the LDS read(s) of ring fragment i of the current step (addresses: ra* row reads, ta* transposing reads)"""
+        if self.cfg.D == 64:
+            return self.frag_read64(i)
         if i < 16:          # row fragment ks of Q (i < 8) or dO: 16 bytes at chunk (2 ks + hi) ^ swizzle of row (lane & 31)
             ks = i % 8
             img = 0 if i < 8 else GIMG
@@ -147,15 +153,46 @@ class Stream(_P4Stream):
             self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ta0"), off, note="%s^T u%d db%d" % ("dO" if i < 24 else "Q", u, db))
             self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ta1"), off)
 
+    def frag_read64(self, i):
+        """D = 64: fragments 0..3 Q rows (ks), 4..7 dO rows, 8..11 dO^T (u, db), 12..15 Q^T (u, db)"""
+        if i < 8:
+            ks = i % 4
+            img = 0 if i < 4 else GIMG
+            self.frag_rid[i] = self.lds_read("ds_read_b128", af(i), VN("ra%d" % (ks & 1)), img + (ks >> 1) * 2048,
+                                             note="%s rows ks%d" % ("Q" if i < 4 else "dO", ks))
+        else:
+            u, db = divmod(i % 4, 2)
+            img = GIMG if i < 12 else 0
+            off = img + db * 2048 + u * 1024
+            self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ta0"), off, note="%s^T u%d db%d" % ("dO" if i < 12 else "Q", u, db))
+            self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ta1"), off)
+
     # ---------------------------------------------------------------- global -> LDS / registers
-    def dma_stage(self, pieces=range(4)):
+    def dma_stage(self, pieces=None):
+        if self.cfg.D == 64:      # one 1 KiB piece per wave and operand tile
+            for name, res, base in (("qoff0", "qres", 0), ("goff0", "gres", GIMG)):
+                if pieces is None or name in pieces:
+                    self.emit("s_add_u32", M0, [SN("wr"), I(base)])
+                    self.emit("buffer_load_dwordx4_lds", None, [VN(name), SN(res, 4)])
+            return
+        self._dma_stage128(range(4) if pieces is None else pieces)
+
+    def dma_advance(self, pieces=None):
+        if self.cfg.D == 64:
+            for name, inc in (("qoff0", "qinc"), ("goff0", "ginc")):
+                if pieces is None or name in pieces:
+                    self.emit("v_add_u32_e64", VN(name), [VN(name), SN(inc)], clamp=1)
+            return
+        self._dma_advance128(range(4) if pieces is None else pieces)
+
+    def _dma_stage128(self, pieces=range(4)):
         """this wave's four 1 KiB pieces of the stage `wr` points at: Q pieces 2w, 2w+1, dO pieces 2w, 2w+1"""
         for i in pieces:
             name, res, base = (("qoff%d" % i, "qres", 0) if i < 2 else ("goff%d" % (i - 2), "gres", GIMG))
             self.emit("s_add_u32", M0, [SN("wr"), I(base + (i & 1) * 1024)])
             self.emit("buffer_load_dwordx4_lds", None, [VN(name), SN(res, 4)])
 
-    def dma_advance(self, pieces=range(4)):
+    def _dma_advance128(self, pieces=range(4)):
         for i in pieces:
             name, inc = ("qoff%d" % i, "qinc") if i < 2 else ("goff%d" % (i - 2), "ginc")
             self.emit("v_add_u32_e64", VN(name), [VN(name), SN(inc)], clamp=1)
@@ -247,6 +284,8 @@ class Stream(_P4Stream):
 
     # ---------------------------------------------------------------- one step
     def step(self, first=False):
+        if self.cfg.D == 64:
+            return self.step64()
         cfg = self.cfg
         fill = [[] for _ in range(N_MFMA)]
 
@@ -265,8 +304,8 @@ class Stream(_P4Stream):
         # the offsets advance in the following even gaps
         if "dma" not in cfg.abl:
             for i in range(4):
-                at(2 + 2 * i, lambda i=i: self.dma_stage([i]))
-                at(10 + 2 * i, lambda i=i: self.dma_advance([i]))
+                at(2 + 2 * i, lambda i=i: self._dma_stage128([i]))
+                at(10 + 2 * i, lambda i=i: self._dma_advance128([i]))
             at(18, lambda: self.wr_advance())
         # ---- row-read addresses move to the next stage once the last row fragment (15) is requested (gap 27)
         at(0, lambda: self.stage_delta())
@@ -358,6 +397,109 @@ class Stream(_P4Stream):
                 fn()
         self.stamp("pd")
 
+    def step64(self):
+        """D = 64: 36 matrix instructions -- S 0..9 (two extra k-steps + 4 k-steps x 2 key blocks), dP 10..19, dV^T 20..27
+        (u, db, kb), dK^T 28..35.  The same pipeline as D = 128, compressed: the VALU work of a product's result still runs
+        beside the next product's matrix instructions."""
+        cfg = self.cfg
+        NM = 36
+        fill = [[] for _ in range(NM)]
+
+        def at(g, fn):
+            fill[g].append(fn)
+
+        def first(i):
+            return (2 + 2 * i) if i < 4 else (12 + 2 * (i - 4)) if i < 8 else (20 + 2 * (i - 8)) if i < 12 else (28 + 2 * (i - 12))
+        for i in range(12):
+            at(first(i) + 1, lambda i=i: self.frag_read(i + 4))
+        if "dma" not in cfg.abl:
+            at(2, lambda: self.dma_stage(["qoff0"]))
+            at(4, lambda: self.dma_stage(["goff0"]))
+            at(6, lambda: self.dma_advance(["qoff0"]))
+            at(8, lambda: self.dma_advance(["goff0"]))
+            at(12, lambda: self.wr_advance())
+        at(0, lambda: self.stage_delta())
+        at(10, lambda: self.addr_advance(["ra0", "ra1"]))          # the last row fragment (7) is requested in gap 9
+        mask_lbl, mask_back = self.newlabel("MASK"), self.newlabel("MASKBACK")
+
+        def mask_branch():
+            self.emit("s_cmp_lt_i32", None, [SN("j"), SN("maskuntil")])
+            self.emit("s_cbranch_scc1", None, [], target=mask_lbl)
+            self.label(mask_back)
+        at(11, mask_branch)
+        self.outofline.append((mask_lbl, mask_back))
+        # P = exp2(S') from gap 12, five per gap; the 16-bit packs of u = 0 are done by gap 18 (dV^T starts at 20), of u = 1 by 21
+        order = [(kb, u) for u in range(2) for kb in range(2)]
+        seq = []
+        for n, (kb, u) in enumerate(order):
+            if cfg.exact:
+                seq += [lambda kb=kb, r=r: self.scale_op(kb, r) for r in range(8 * u, 8 * u + 8, 2)]
+            seq += [lambda kb=kb, r=r: self.exp_op(kb, r) for r in range(8 * u, 8 * u + 8)]
+            if n >= 1:
+                pkb, pu = order[n - 1]
+                seq += [lambda kb=pkb, u=pu, w=w: self.packp_op(kb, u, w) for w in range(4)]
+        seq += [lambda kb=order[3][0], u=order[3][1], w=w: self.packp_op(kb, u, w) for w in range(4)]
+        per = 7 if cfg.exact else 5
+        for n, fn in enumerate(seq):
+            assert 12 + n // per <= 21
+            at(12 + n // per, fn)
+        # dS' = P * dP' and its packs: u = 0 in gaps 22..27 (the dK^T products start at 28), u = 1 in 28..31 (needed from 32)
+        seq0, seq1 = [], []
+        for kb in range(2):
+            seq0 += [lambda kb=kb, r=r: self.mul_op(kb, r) for r in range(0, 8, 2)]
+        for kb in range(2):
+            seq0 += [lambda kb=kb, w=w: self.packds_op(kb, 0, w) for w in range(4)]
+        for kb in range(2):
+            seq1 += [lambda kb=kb, r=r: self.mul_op(kb, r) for r in range(8, 16, 2)]
+        for kb in range(2):
+            seq1 += [lambda kb=kb, w=w: self.packds_op(kb, 1, w) for w in range(4)]
+        for n, fn in enumerate(seq0):
+            at(22 + (n * 6) // len(seq0), fn)
+        for n, fn in enumerate(seq1):
+            at(28 + (n * 4) // len(seq1), fn)
+
+        def seam():
+            self.emit("s_waitcnt", None, [], vmcnt=2 if "dma" not in cfg.abl else 0)
+            self.emit("s_barrier")
+            self.addr_advance(["ta0", "ta1"])
+        at(28, seam)
+        conv = self.ld_convert_ops()
+        for n, fn in enumerate(conv):
+            at(29 + (n * 6) // len(conv), fn)
+        at(35, lambda: self.ld_load())
+        for i in range(4):
+            at(29 + 2 * i, lambda i=i: self.frag_read(i))
+        mm = []
+        for kb in range(2):
+            mm.append((sp_blk(kb), V(LP, 4), V(ONES, 4), I(0), None))
+        for ks in range(4):
+            for kb in range(2):
+                mm.append((sp_blk(kb), af(ks), kf(kb, ks), sp_blk(kb), ks))
+        for kb in range(2):
+            mm.append((dp_blk(kb), V(DPR, 4), V(ONES, 4), I(0), None))
+        for ks in range(4):
+            for kb in range(2):
+                mm.append((dp_blk(kb), af(4 + ks), vf(kb, ks), dp_blk(kb), 4 + ks))
+        for u in range(2):
+            for db in range(2):
+                for kb in range(2):
+                    mm.append((dv_acc(db, kb), af(8 + 2 * u + db), p16(kb, u), dv_acc(db, kb), 8 + 2 * u + db))
+        for u in range(2):
+            for db in range(2):
+                for kb in range(2):
+                    mm.append((dk_acc(db, kb), af(12 + 2 * u + db), ds16(kb, u), dk_acc(db, kb), 12 + 2 * u + db))
+        assert len(mm) == NM
+        stamps = {10: "pa", 20: "pb", 28: "pc"}
+        for g, (d, a_, b_, c_, fr) in enumerate(mm):
+            if g in stamps:
+                self.stamp(stamps[g])
+            if fr is not None:
+                self.lds_need(self.frag_rid[fr])
+            self.emit("v_mfma_f32_32x32x16_" + (cfg.gdtype if 10 <= g < 28 else cfg.dtype), d, [a_, b_, c_])
+            for fn in fill[g]:
+                fn()
+        self.stamp("pd")
+
     # ---------------------------------------------------------------- whole traversal
     def build(self):
         cfg = self.cfg
@@ -366,6 +508,8 @@ class Stream(_P4Stream):
         # 32 x 1 KiB per wave at `kvback`; they move to their fixed registers here
         self.emit("s_waitcnt", None, [], lgkmcnt=0)
         for i in range(32):
+            if cfg.D == 64 and (i % 8) >= 4:
+                continue           # (kb, ks) with ks >= 4 does not exist; the hand-over slots keep their D = 128 positions
             self.lds_read("ds_read_b128", V((KF if i < 16 else VF) + 4 * (i % 16), 4), VN("kvback"), i * 1024)
         for r in range(256):
             self.emit("v_accvgpr_write_b32", A(r), [I(0)])
@@ -384,7 +528,7 @@ class Stream(_P4Stream):
         self.dma_stage()
         self.dma_advance()
         self.wr_advance()
-        self.emit("s_waitcnt", None, [], vmcnt=4)
+        self.emit("s_waitcnt", None, [], vmcnt=4 if cfg.D == 128 else 2)
         for fn in self.ld_convert_ops():
             fn()
         self.emit("s_barrier")
@@ -428,10 +572,10 @@ def write_inc(path):
              "// header for the register map and the step table).", "#pragma once", ""]
     lines.append("#define MFA_DKV4_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256)))
     lines.append("")
-    lines.append("// X(name, stamps the shader clock, applies the softmax scale in fp32, dO is BF16 next to FP16 Q / K / V)")
+    lines.append("// X(name, stamps the shader clock, applies the softmax scale in fp32, dO is BF16 next to FP16 Q / K / V, head-dimension bucket)")
     lines.append("#define MFA_DKV4_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.mix))
+        lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.mix, cfg.D))
     lines.append("")
     lines.append("")
     for name, cfg in VARIANTS.items():
@@ -457,6 +601,12 @@ VARIANTS = {
     "F16_DOBF16_MIXED": Cfg("f16", "f16", "bf16", gdtype="bf16"),          # the reference's default low-precision mix
     "F16_DOBF16_F32": Cfg("f16", "f32", "f32", exact=1, gdtype="bf16"),
     "BF16_MIXED_PROF": Cfg("bf16", "f16", "bf16", prof=1),
+    "D64_BF16_MIXED": Cfg("bf16", "f16", "bf16", D=64),
+    "D64_F16_MIXED": Cfg("f16", "f16", "bf16", D=64),
+    "D64_BF16_F32": Cfg("bf16", "f32", "f32", exact=1, D=64),
+    "D64_F16_F32": Cfg("f16", "f32", "f32", exact=1, D=64),
+    "D64_F16_DOBF16_MIXED": Cfg("f16", "f16", "bf16", gdtype="bf16", D=64),
+    "D64_F16_DOBF16_F32": Cfg("f16", "f32", "f32", exact=1, gdtype="bf16", D=64),
 }
 PRODUCT_STREAMS = ("BF16_MIXED", "F16_MIXED", "BF16_F32", "F16_F32", "F16_DOBF16_MIXED", "F16_DOBF16_F32")
 

@@ -60,7 +60,8 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
     Returns dV, dK [256][128] float32 of key block `cblk`."""
     cfg = cfg or Cfg()
     f16 = cfg.dtype == "f16"
-    R, C, D = q.shape[0], k.shape[0], 128
+    R, C, D = q.shape[0], k.shape[0], cfg.D
+    nks, ndb, pw = cfg.nks, cfg.ndb, (2 if cfg.D == 128 else 1)
     instrs = stream if stream is not None else Stream(cfg).build()
     wg = Workgroup(instrs, dma_mode)
     ld2 = D * 2
@@ -90,6 +91,8 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
         for i in range(32):
             src = kp if i < 16 else vfl
             kb_, ks = divmod(i % 16, 8)
+            if ks >= nks:
+                continue
             data = np.zeros((64, 16), np.uint8)
             for l in range(64):
                 col = c0 + 64 * wave + 32 * kb_ + int(kc[l])
@@ -100,10 +103,10 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
         # DMA source offsets: piece i of wave w fills 16-byte positions (2 w + i) * 64 + lane of a tile
         offs = []
         for i in range(2):
-            p = (2 * wave + i) * 64 + lane
+            p = (pw * wave + i) * 64 + lane
             db, row, slot = p >> 7, (p >> 2) & 31, p & 3
             chunk = db * 4 + (slot ^ ((row >> 2) & 3))
-            offs.append(((row_first + row) * ld2 + chunk * 16).astype(np.uint32))
+            offs.append(np.where((i < pw) & (chunk * 8 < D), (row_first + row) * ld2 + chunk * 16, 0xFFFFFF00).astype(np.uint32))
         trow = (n16 >> 2) + 4 * hi
         tchunk = 2 * ((lane >> 4) & 1) + ((n16 & 3) >> 1)
         thalf = (n16 & 3) & 1
@@ -123,7 +126,7 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
             maskuntil = max(0, -(-(c0 + 64 * wave + 63 - coff - row_first) // 32))
         w.sn.update({"qres": (qb, R * ld2), "gres": (gb, R * ld2), "lres": (lbuf, R * lesz), "dres": (dbuf, R * desz),
                      "nsteps": nsteps, "rscale": float(np.float32(0.5 if cfg.mix else 1.0) / scale), "qinc": 32 * ld2, "ginc": 32 * ld2,
-                     "ldinc": 32 * lesz, "wr0": wave * 2048, "ringend": RING * STAGE, "maskuntil": maskuntil,
+                     "ldinc": 32 * lesz, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskuntil": maskuntil,
                      "rscale2": float(np.float32(0.5 if cfg.mix else 1.0) / (scale2 if cfg.exact else np.float32(1.0))), "scale2x2": float(scale2)})
     wg.run(order)
     dV = np.zeros((256, D), np.float32)
@@ -132,7 +135,7 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
         assert not w.lds_q and not w.vm_q, "memory operations left in flight"
         for kb_ in range(2):
             keys = 64 * w.id + 32 * kb_ + np.arange(32)
-            for db in range(4):
+            for db in range(ndb):
                 for r in range(16):
                     for h in range(2):
                         dcol = 32 * db + ROWMAP[r][h]
@@ -150,8 +153,8 @@ def check(R=96, C=256, cfg=None, causal=False, seed=0, cblk=0, **kw):
     cfg = cfg or Cfg()
     f16 = cfg.dtype == "f16"
     rng = np.random.default_rng(seed)
-    q, k, v = (rand16((n, 128), rng, f16=f16) for n in (R, C, C))
-    do = rand16((R, 128), rng, f16=cfg.gdtype == "f16")
+    q, k, v = (rand16((n, cfg.D), rng, f16=f16) for n in (R, C, C))
+    do = rand16((R, cfg.D), rng, f16=cfg.gdtype == "f16")
     L, Dt, dv, dk = reference(q, k, v, do, f16, causal, g16=cfg.gdtype == "f16")
     # the kernel sees L and D as stored
     Ls = load_prec(store_prec(L, cfg.lprec)[0], cfg.lprec)

@@ -17,7 +17,7 @@ template <typename T, int STREAM, typename TG = T> static void fill_dq_p4(Varian
   v->name = name;
   v->parallelization = 256;
   v->traversal = 64;
-  v->headBlock = 128;
+  v->headBlock = dq4::stream_bucket(STREAM);
   v->threads = 256;
   v->ldsBytes = v->ldsBytes > (uint32_t)dq4::LDS_BYTES ? v->ldsBytes : (uint32_t)dq4::LDS_BYTES;
   v->cacheLeft = true;
@@ -31,25 +31,32 @@ template <typename T, int STREAM, typename TG = T> static void fill_dq_p4(Varian
 // impl 0: Q as stored, softmax scale in fp32 (descriptors that keep the attention matrix in FP32 registers); impl 10: Q
 // pre-multiplied by the scale in the 16-bit type (lowPrecisionIntermediates, like the forward FOLD stream)
 bool dq16_p4_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
-  if (D != 128) return false;
+  if (D != 128 && D != 64) return false;
+  const bool d64 = D == 64;
   if (precision == PREC_FP16 && gprecision == PREC_BF16) {   // the reference's own mix: FP16 Q, K, V with BF16 dO
-    if (impl == 0) { fill_dq_p4<_Float16, dq4::S_F16_EXACT, __bf16>(out, "attn_dq16p4_f16_dObf16_d128_w4x64_exact"); return true; }
-    if (impl == 10) { fill_dq_p4<_Float16, dq4::S_F16_FOLD, __bf16>(out, "attn_dq16p4_f16_dObf16_d128_w4x64"); return true; }
+    if (impl == 0 && !d64) { fill_dq_p4<_Float16, dq4::S_F16_EXACT, __bf16>(out, "attn_dq16p4_f16_dObf16_d128_w4x64_exact"); return true; }
+    if (impl == 10 && !d64) { fill_dq_p4<_Float16, dq4::S_F16_FOLD, __bf16>(out, "attn_dq16p4_f16_dObf16_d128_w4x64"); return true; }
+    if (impl == 0 && d64) { fill_dq_p4<_Float16, dq4::S_D64_F16_EXACT, __bf16>(out, "attn_dq16p4_f16_dObf16_d64_w4x64_exact"); return true; }
+    if (impl == 10 && d64) { fill_dq_p4<_Float16, dq4::S_D64_F16_FOLD, __bf16>(out, "attn_dq16p4_f16_dObf16_d64_w4x64"); return true; }
     return false;
   }
   if (precision != gprecision) return false;
   if (precision == PREC_BF16) {
-    if (impl == 0) { fill_dq_p4<__bf16, dq4::S_BF16_EXACT>(out, "attn_dq16p4_bf16_d128_w4x64_exact"); return true; }
-    if (impl == 10) { fill_dq_p4<__bf16, dq4::S_BF16_FOLD>(out, "attn_dq16p4_bf16_d128_w4x64"); return true; }
+    if (impl == 0 && !d64) { fill_dq_p4<__bf16, dq4::S_BF16_EXACT>(out, "attn_dq16p4_bf16_d128_w4x64_exact"); return true; }
+    if (impl == 10 && !d64) { fill_dq_p4<__bf16, dq4::S_BF16_FOLD>(out, "attn_dq16p4_bf16_d128_w4x64"); return true; }
+    if (impl == 0 && d64) { fill_dq_p4<__bf16, dq4::S_D64_BF16_EXACT>(out, "attn_dq16p4_bf16_d64_w4x64_exact"); return true; }
+    if (impl == 10 && d64) { fill_dq_p4<__bf16, dq4::S_D64_BF16_FOLD>(out, "attn_dq16p4_bf16_d64_w4x64"); return true; }
 #ifdef MFA_DEV_VARIANTS
-#define MFA_DQ4_DEV(name) if (impl == 1000 + dq4::S_##name) { fill_dq_p4<__bf16, dq4::S_##name>(out, "attn_dq16p4_DEV_" #name); return true; }
+#define MFA_DQ4_DEV(name) if (impl == 1000 + dq4::S_##name && D == dq4::stream_bucket(dq4::S_##name)) { fill_dq_p4<__bf16, dq4::S_##name>(out, "attn_dq16p4_DEV_" #name); return true; }
     MFA_DQ4_DEV_STREAM_LIST(MFA_DQ4_DEV)
 #undef MFA_DQ4_DEV
 #endif
   }
   if (precision == PREC_FP16) {
-    if (impl == 0) { fill_dq_p4<_Float16, dq4::S_F16_EXACT>(out, "attn_dq16p4_f16_d128_w4x64_exact"); return true; }
-    if (impl == 10) { fill_dq_p4<_Float16, dq4::S_F16_FOLD>(out, "attn_dq16p4_f16_d128_w4x64"); return true; }
+    if (impl == 0 && !d64) { fill_dq_p4<_Float16, dq4::S_F16_EXACT>(out, "attn_dq16p4_f16_d128_w4x64_exact"); return true; }
+    if (impl == 10 && !d64) { fill_dq_p4<_Float16, dq4::S_F16_FOLD>(out, "attn_dq16p4_f16_d128_w4x64"); return true; }
+    if (impl == 0 && d64) { fill_dq_p4<_Float16, dq4::S_D64_F16_EXACT>(out, "attn_dq16p4_f16_d64_w4x64_exact"); return true; }
+    if (impl == 10 && d64) { fill_dq_p4<_Float16, dq4::S_D64_F16_FOLD>(out, "attn_dq16p4_f16_d64_w4x64"); return true; }
   }
   return false;
 }

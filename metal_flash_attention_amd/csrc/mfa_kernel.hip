@@ -158,9 +158,9 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           case 192: add(dq16_variant_d192(pq, pg, &v), v); break;
           default: {
             const bool w8 = dq16_variant(pq, pg, b16, &v);
-            if (w8 && b16 == 128) {   // four waves x 64 rows, hand-placed stream (attn_dq16_p4.h): the same block dimensions
-              VariantInfo v4 = v;     // as the 8 x 32 kernel, which keeps the launches this one lacks
-              add(dq16_p4_variant(pq, pg, 128, kdesc->registerPrecisions[MFA_P] > MFA_FP32 ? 10 : 0, &v4), v4);
+            if (w8 && (b16 == 128 || b16 == 64)) {   // four waves x 64 rows, hand-placed stream (attn_dq16_p4.h): the same block
+              VariantInfo v4 = v;                    // dimensions as the 8 x 32 kernel, which keeps the launches this one lacks
+              add(dq16_p4_variant(pq, pg, b16, kdesc->registerPrecisions[MFA_P] > MFA_FP32 ? 10 : 0, &v4), v4);
             }
             add(w8, v);
             break;

@@ -457,6 +457,7 @@ def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
     assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
     assert ("attn_dkv16rs" in variants["backwardKeyValue"]) == (dkv_impl == "rs"), variants
     assert ("attn_dkv16p4" in variants["backwardKeyValue"]) == (dkv_impl == "p4"), variants
+    assert ("attn_dq16p4" in variants["backwardQuery"]) == (D <= 128), variants   # attn_dq16_p4.h: buckets 64 and 128 (D in (64, 128])
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run()

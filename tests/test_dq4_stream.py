@@ -52,6 +52,22 @@ def test_every_compiled_variant(name):
     _check(200, 260, cfg=V[name], causal=True, seed=5)
 
 
+@pytest.mark.parametrize("name", ["D64_BF16_FOLD", "D64_F16_EXACT"])
+@pytest.mark.parametrize("R,C,rblk,causal", [(256, 64, 0, False), (256, 128, 0, False), (256, 576, 0, False), (200, 130, 0, False),
+                                             (70, 1, 0, False), (512, 512, 1, True), (300, 400, 1, True), (128, 128, 0, True)])
+def test_d64_deferred_second_key_block(name, R, C, rblk, causal):
+    """the 64 bucket's stream updates dQ with a tile's second key block beside the NEXT tile (and after the loop for the
+    last one): one tile, many tiles (the ring wraps), ragged edges, waves that leave the loop early (causal)"""
+    _check(R, C, rblk=rblk, causal=causal, cfg=V[name], seed=6)
+
+
+@pytest.mark.parametrize("dma_mode", ["early", "late"])
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 2, 1, 0)])
+def test_d64_ring_discipline(dma_mode, order):
+    _check(256, 448, cfg=V["D64_BF16_FOLD"], dma_mode=dma_mode, order=order, seed=3)
+    _check(256, 448, cfg=V["D64_BF16_FOLD"], causal=True, dma_mode=dma_mode, order=order, seed=3)
+
+
 def test_stream_file_is_current():
     """csrc/attn_dq16_p4_stream.inc is what tools/dq4gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_dq16_p4_stream.inc")

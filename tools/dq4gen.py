@@ -43,6 +43,7 @@ from p4gen import A, F, I, M0, SN, V, VCC, VN, Stream as _P4Stream, render  # no
 DQ_BASE, Q_BASE, G_BASE = 0, 128, 192
 CL, CD, ST, DP, AF = 24, 56, 88, 152, 216
 T_TL, T_MASKV = 232, 234
+T_TB = 236           # D = 64: transposing-read addresses of the previous tile (v236, v237)
 FIRST_OWNED_VGPR = 24
 
 STAGE, VIMG, RING = 32768, 16384, 4
@@ -57,10 +58,10 @@ IN_S = ["kres", "vres", "nt", "wnt", "kinc", "vinc", "wr0", "ringend", "maskfrom
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", prof=0, exact=0, abl=()):
+    def __init__(self, dtype="bf16", prof=0, exact=0, abl=(), D=128):
         """exact: Q stays as stored, -L arrives divided by log2(e)/sqrt(D) and the scale is applied in fp32 before the exp2
         (one packed multiply per two scores more); otherwise Q arrives pre-multiplied, rounded to the 16-bit type"""
-        self.dtype, self.prof, self.exact, self.abl = dtype, prof, exact, frozenset(abl)
+        self.dtype, self.prof, self.exact, self.abl, self.D = dtype, prof, exact, frozenset(abl), D
 
 
 def st_blk(rb, kb):
@@ -114,13 +115,16 @@ class Stream(_P4Stream):
             self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ta0"), off, note="K^T kb%d u%d db%d" % (kb, u, db))
             self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ta1"), off)
 
+    # D = 128: pieces 0..3 K, 4..7 V (four 1 KiB pieces per wave and operand tile); D = 64: 0, 1 K, 2, 3 V
     def dma_piece(self, i):
-        name, res, base = (("koff%d" % i, "kres", 0) if i < 4 else ("voff%d" % (i - 4), "vres", VIMG))
-        self.emit("s_add_u32", M0, [SN("wr"), I(base + (i & 3) * 1024)])
+        pw = self.cfg.D // 32
+        name, res, base = (("koff%d" % i, "kres", 0) if i < pw else ("voff%d" % (i - pw), "vres", VIMG))
+        self.emit("s_add_u32", M0, [SN("wr"), I(base + (i % pw) * 1024)])
         self.emit("buffer_load_dwordx4_lds", None, [VN(name), SN(res, 4)])
 
     def dma_advance(self, i):
-        name, inc = ("koff%d" % i, "kinc") if i < 4 else ("voff%d" % (i - 4), "vinc")
+        pw = self.cfg.D // 32
+        name, inc = ("koff%d" % i, "kinc") if i < pw else ("voff%d" % (i - pw), "vinc")
         self.emit("v_add_u32_e64", VN(name), [VN(name), SN(inc)], clamp=1)
 
     def wr_advance(self):
@@ -275,12 +279,164 @@ class Stream(_P4Stream):
                 fn()
         self.stamp("pc")
 
+    # ---------------------------------------------------------------- one tile, D = 64
+    # 48 matrix instructions in six groups of 8: S(0) P(0) S(1) Q'(1) P(1) Q(0), where Q'(1) is the dQ update of key block 1
+    # of the PREVIOUS tile: the exp2 / multiply / pack work of a tile (1400 VALU cycles beside 1536 of the matrix pipe) then
+    # has no point where the matrix instructions wait for it -- block 1's runs from the middle of one tile to the middle of
+    # the next.  In place as before: S(1) of the next tile overwrites P(1) after the multiplies have read it, P(1) of the
+    # next tile overwrites dS'(1) after Q'(1) has read it.
+    def frag_read64(self, i):
+        grp, r = divmod(i, 4)
+        if grp in (0, 1, 2, 4):        # row fragments: K kb0 | V kb0 | K kb1 | V kb1
+            kb, isv, ks = (0, 0, r) if grp == 0 else (0, 1, r) if grp == 1 else (1, 0, r) if grp == 2 else (1, 1, r)
+            off = (VIMG if isv else 0) + (ks >> 1) * 4096 + kb * 2048
+            self.frag_rid[i] = self.lds_read("ds_read_b128", af(i), VN("ka%d" % (ks & 1)), off,
+                                             note="%s rows kb%d ks%d" % ("V" if isv else "K", kb, ks))
+        else:                          # K^T: kb1 of the previous tile (group 3, addresses v236, v237) | kb0 of this tile (group 5)
+            kb = 1 if grp == 3 else 0
+            u, db = divmod(r, 2)
+            off = db * 4096 + kb * 2048 + u * 1024
+            a0, a1 = (V(T_TB), V(T_TB + 1)) if grp == 3 else (VN("ta0"), VN("ta1"))
+            self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), a0, off, note="K^T kb%d u%d db%d%s" % (kb, u, db, " (previous tile)" if grp == 3 else ""))
+            self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), a1, off)
+
+    def valu_schedule64(self):
+        """(gap, prev, fn) of the exp2 / multiply / pack work of ONE tile, gap counted from the tile's first matrix
+        instruction (48.. = beside the next tile's: prev = True there); greedy, earliest gap whose VALU cycles are free"""
+        cfg = self.cfg
+        load, out = [0] * 48, []
+        total = (64 * 16 + 64 * 4 + 32 * 4 + (32 * 8 if cfg.exact else 0))
+        cap = 40 if cfg.exact else -(-total // 48) + 3     # two exp2 per gap (+ one packed scale multiply)
+        state = {"g": 0}
+
+        def place(release, cost, fn, last):
+            g = max(release, state["g"])
+            while load[g % 48] + cost > cap:
+                g += 1
+            assert g <= last, (g, last)
+            load[g % 48] += cost
+            state["g"] = g
+            out.append((g, fn))
+        s_end, p_end, q_start, s_next = (7, 23), (15, 39), (40, 48 + 24), (48 + 0, 48 + 16)
+        for kb in range(2):
+            state["g"] = 0
+            for rb in range(2):
+                for u in range(2):
+                    if cfg.exact:
+                        for r in range(8 * u, 8 * u + 8, 2):
+                            place(s_end[kb] + 4, 8, lambda rb=rb, kb=kb, r=r: self.scale_op(rb, kb, r), s_next[kb] - 1)
+                    for r in range(8 * u, 8 * u + 8):
+                        place(s_end[kb] + 4, 16, lambda rb=rb, kb=kb, r=r: self.exp_op(rb, kb, r), s_next[kb] - 1)
+            state["g"] = max(state["g"], p_end[kb] + 3)
+            for rb in range(2):
+                for r in range(0, 16, 2):
+                    place(p_end[kb] + 3, 8, lambda rb=rb, kb=kb, r=r: self.mul_op(rb, kb, r), s_next[kb] - 1)
+            for u in range(2):
+                for rb in range(2):
+                    for w in range(4):
+                        place(p_end[kb] + 3, 4, lambda rb=rb, kb=kb, u=u, w=w: self.pack_op(rb, kb, u, w), q_start[kb] - 2)
+        return out
+
+    def tile64(self, tail=False):
+        """tail: what is left of the last tile after the loop -- its block-1 VALU work and Q'(1)"""
+        cfg = self.cfg
+        NM = 48
+        fill = [[] for _ in range(NM)]
+
+        def at(g, fn):
+            fill[g].append(fn)
+        sched = self.valu_schedule64()
+        if tail:
+            for g, fn in sched:
+                if g >= NM:
+                    fn()
+            self.emit("s_nop", None, [I(4)])
+            for i in range(12, 16):
+                self.frag_read64(i)
+            for i in range(12, 16):
+                u, db = divmod(i - 12, 2)
+                for rb in range(2):
+                    self.lds_need(self.frag_rid[i])
+                    self.mfma(dq_acc(rb, db), af(i), ds16(rb, 1, u), dq_acc(rb, db))
+            return
+        # previous tile's work first in a gap: its multiplies must be out of the way of S(1)
+        for g, fn in sched:
+            if g >= NM:
+                at(g - NM, fn)
+        for i in range(20):
+            at(2 * i + 1, lambda i=i: self.frag_read64(i + 4))
+        for i in range(4):
+            at(2 * i, lambda i=i: self.dma_piece(i))
+            at(8 + 2 * i, lambda i=i: self.dma_advance(i))
+        at(26, lambda: self.wr_advance())
+        at(24, lambda: self.stage_delta())
+        at(32, lambda: self.addr_advance(["ka0", "ka1"]))     # the last row fragment (19) is requested in gap 31
+
+        def mask_branch(kb):
+            lbl, back = self.newlabel("MASK"), self.newlabel("MASKBACK")
+            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("maskfrom")])
+            self.emit("s_cbranch_scc1", None, [], target=lbl)
+            self.label(back)
+            self.outofline.append((lbl, back, kb))
+        at(10, lambda: mask_branch(0))
+        at(26, lambda: mask_branch(1))
+        for g, fn in sched:
+            if g < NM:
+                at(g, fn)
+
+        def seam():
+            self.emit("s_waitcnt", None, [], vmcnt=4)
+            self.emit("s_barrier")
+            self.emit("v_mov_b32", V(T_TB), [VN("ta0")])
+            self.emit("v_mov_b32", V(T_TB + 1), [VN("ta1")])
+            self.addr_advance(["ta0", "ta1"])
+        at(40, seam)
+        for i in range(4):
+            at(41 + 2 * i, lambda i=i: self.frag_read64(i))
+
+        mm = []
+        for i in range(24):
+            grp, r = divmod(i, 4)
+            for rb in range(2):
+                if grp in (0, 2):
+                    kb = grp // 2
+                    mm.append((st_blk(rb, kb), af(i), q_frag(rb, r), V(CL + 16 * rb, 16) if r == 0 else st_blk(rb, kb), i))
+                elif grp in (1, 4):
+                    kb = grp // 4
+                    mm.append((dp_blk(rb, kb), af(i), g_frag(rb, r), V(CD + 16 * rb, 16) if r == 0 else dp_blk(rb, kb), i))
+                else:
+                    kb = 1 if grp == 3 else 0
+                    u, db = divmod(r, 2)
+                    mm.append((dq_acc(rb, db), af(i), ds16(rb, kb, u), dq_acc(rb, db), i))
+        assert len(mm) == NM
+        stamps = {16: "pa", 32: "pb"}
+        for g, (d, a_, b_, c_, fr) in enumerate(mm):
+            if g in stamps:
+                self.stamp(stamps[g])
+            self.lds_need(self.frag_rid[fr])
+            self.mfma(d, a_, b_, c_)
+            for fn in fill[g]:
+                fn()
+        self.stamp("pc")
+
     # ---------------------------------------------------------------- whole traversal
     def build(self):
         cfg = self.cfg
+        d64 = cfg.D == 64
+        npieces, frag_read, tile = (4, self.frag_read64, self.tile64) if d64 else (8, self.frag_read, self.tile)
         self.outofline = []
         for r in range(128):
+            if d64 and (r // 16) % 4 >= 2:
+                continue                                     # (rb, db) -> 16 (4 rb + db) with db < 2
             self.emit("v_accvgpr_write_b32", A(r), [I(0)])
+        if d64:
+            # block 1 of "the tile before the first": P = exp2(0), dP' = 0 -> dS' = 0; its K^T is read from tile 0
+            for rb in range(2):
+                for r in range(16):
+                    self.emit("v_mov_b32", V(ST + 16 * (2 + rb) + r), [I(0)])
+                    self.emit("v_mov_b32", V(DP + 16 * (2 + rb) + r), [I(0)])
+            self.emit("v_mov_b32", V(T_TB), [VN("ta0")])
+            self.emit("v_mov_b32", V(T_TB + 1), [VN("ta1")])
         for rb in range(2):
             for r in range(16):
                 self.emit("v_mov_b32", V(CL + 16 * rb + r), [VN("negl%d" % rb)])
@@ -288,19 +444,19 @@ class Stream(_P4Stream):
         self.emit("v_mov_b32", V(T_MASKV), [F(-(0.875 / 1.44269504089) * 3.402823466e+38)])   # +Softmax.swift:242-243
         self.emit("s_mov_b32", SN("wr"), [SN("wr0")])
         for t in range(2):                                   # tiles 0 and 1
-            for i in range(8):
+            for i in range(npieces):
                 self.dma_piece(i)
-            for i in range(8):
+            for i in range(npieces):
                 self.dma_advance(i)
             self.wr_advance()
-        self.emit("s_waitcnt", None, [], vmcnt=8)
+        self.emit("s_waitcnt", None, [], vmcnt=npieces)
         self.emit("s_barrier")
         self.emit("s_mov_b32", SN("j"), [I(0)])
         self.emit("s_mov_b32", SN("stg"), [I(0)])
         for acc in ("pa", "pb", "pc", "pd"):
             self.emit("s_mov_b32", SN(acc), [I(0)])
         for i in range(4):
-            self.frag_read(i)
+            frag_read(i)
         if cfg.prof:
             self.emit("s_memtime", SN("ptime", 2))
             self.emit("s_waitcnt", None, [], lgkmcnt=0)
@@ -310,24 +466,27 @@ class Stream(_P4Stream):
         loop, skip, done, fin = (self.newlabel(x) for x in ("LOOP", "SKIP", "DONE", "FIN"))
         self.label(loop)
         head_out = self.lds_issued - self.lds_done
-        self.tile()
+        tile()
         assert self.lds_issued - self.frag_rid[0] == 3 and self.lds_issued - self.lds_done <= head_out, "loop-carried LDS queue state"
         self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_cmp_lt_i32", None, [SN("j"), SN("wnt")])
         self.emit("s_cbranch_scc1", None, [], target=loop)
         self.emit("s_waitcnt", None, [], lgkmcnt=0)
+        self.lds_done = self.lds_issued
+        if d64:
+            self.tile64(tail=True)
         # a wave whose rows are done before the workgroup's last tile (causal) still owes the others its barriers and its
         # share of the LDS-DMA pieces: tiles j = wnt .. nt-1 without arithmetic (tile j: DMA of tile j+2, barrier of j+1)
         self.label(skip)
         self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
         self.emit("s_cbranch_scc1", None, [], target=done)
         if "dma" not in cfg.abl:
-            for i in range(8):
+            for i in range(npieces):
                 self.dma_piece(i)
-            for i in range(8):
+            for i in range(npieces):
                 self.dma_advance(i)
             self.wr_advance()
-        self.emit("s_waitcnt", None, [], vmcnt=8 if "dma" not in cfg.abl else 0)
+        self.emit("s_waitcnt", None, [], vmcnt=npieces if "dma" not in cfg.abl else 0)
         self.emit("s_barrier")
         self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_branch", None, [], target=skip)
@@ -345,10 +504,10 @@ def write_inc(path):
              "// header for the register map and the tile table).", "#pragma once", ""]
     lines.append("#define MFA_DQ4_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256)))
     lines.append("")
-    lines.append("// X(name, stamps the shader clock, applies the softmax scale in fp32)")
+    lines.append("// X(name, stamps the shader clock, applies the softmax scale in fp32, head-dimension bucket)")
     lines.append("#define MFA_DQ4_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d) \\" % (name, cfg.prof, cfg.exact))
+        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.D))
     lines.append("")
     lines.append("#define MFA_DQ4_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
@@ -359,7 +518,7 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         ins = Stream(cfg).build()
         txt = render(ins)
-        lines.append("// %s: dtype=%s prof=%d exact=%d -- %d instructions" % (name, cfg.dtype, cfg.prof, cfg.exact, len(txt)))
+        lines.append("// %s: dtype=%s prof=%d exact=%d D=%d -- %d instructions" % (name, cfg.dtype, cfg.prof, cfg.exact, cfg.D, len(txt)))
         lines.append("#define MFA_DQ4_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)
@@ -375,6 +534,11 @@ VARIANTS = {
     "BF16_EXACT": Cfg("bf16", exact=1),
     "F16_EXACT": Cfg("f16", exact=1),
     "BF16_FOLD_PROF": Cfg("bf16", prof=1),
+    "D64_BF16_FOLD": Cfg("bf16", D=64),
+    "D64_F16_FOLD": Cfg("f16", D=64),
+    "D64_BF16_EXACT": Cfg("bf16", exact=1, D=64),
+    "D64_F16_EXACT": Cfg("f16", exact=1, D=64),
+    "D64_BF16_FOLD_PROF": Cfg("bf16", prof=1, D=64),
     # timing-only ablations (WRONG RESULTS; developer build): fillers left out of the tile
     "ABL_DMA": Cfg("bf16", prof=1, abl=("dma",)),
     "ABL_EXP": Cfg("bf16", prof=1, abl=("exp",)),

@@ -36,7 +36,9 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
     Returns dQ [256][128] float32 of row block `rblk`."""
     cfg = cfg or Cfg()
     f16 = cfg.dtype == "f16"
-    R, C, D = q.shape[0], k.shape[0], 128
+    R, C, D = q.shape[0], k.shape[0], cfg.D
+    assert q.shape[1] == D
+    nks, ndb, pw = D // 16, D // 32, D // 32
     instrs = stream if stream is not None else Stream(cfg).build()
     wg = Workgroup(instrs, dma_mode)
     ld2 = D * 2
@@ -60,7 +62,7 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
         r0 = rblk * 256 + wave * 64
         for base, src in ((128, qs), (192, do)):
             for b in range(2):
-                for s_ in range(8):
+                for s_ in range(nks):
                     for l in range(64):
                         row = r0 + b * 32 + int(qq[l])
                         d0 = 16 * s_ + 8 * int(hi[l])
@@ -68,8 +70,8 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
                         for t in range(4):
                             w.a[base + 4 * (b * 8 + s_) + t][l] = chunk[t]
         koff, voff = [], []
-        for i in range(4):
-            p = (wave * 4 + i) * 64 + lane
+        for i in range(pw):
+            p = (wave * pw + i) * 64 + lane
             db, key, slot = p >> 8, (p >> 2) & 63, p & 3
             chunk = db * 4 + (slot ^ ((key >> 2) & 3))
             koff.append((key * ld2 + chunk * 16).astype(np.uint32))
@@ -93,7 +95,8 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
             "ta1": ((trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8).astype(np.uint32),
         })
         for i in range(4):
-            w.vn["koff%d" % i], w.vn["voff%d" % i] = koff[i], voff[i]
+            oob = np.full(64, 0xFFFFFF00, np.uint32)
+            w.vn["koff%d" % i], w.vn["voff%d" % i] = (koff[i], voff[i]) if i < pw else (oob, oob)
         minlim = min(C - 1, r0 + coff) if causal else C - 1
         maskfrom = (minlim + 1) // 64 if (causal or ragged) else nt
         wnt = nt
@@ -101,13 +104,13 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 64 + 1)) if wlast >= r0 else 1
         w.sn.update({"kres": (kb_, C * ld2), "vres": (vb_, C * ld2), "nt": nt, "wnt": wnt, "kinc": 64 * ld2, "vinc": 64 * ld2,
-                     "wr0": wave * 4096, "ringend": RING * STAGE, "maskfrom": maskfrom, "scale2x2": float(scale2)})
+                     "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom, "scale2x2": float(scale2)})
     wg.run(order)
     dQ = np.zeros((256, D), np.float32)
     for w in wg.waves:
         assert not w.lds_q and not w.vm_q, "memory operations left in flight"
         for b in range(2):
-            for db in range(4):
+            for db in range(ndb):
                 for r in range(16):
                     reg = w.a[16 * (4 * b + db) + r].view(np.float32)
                     for h in range(2):
@@ -119,7 +122,7 @@ def check(R=256, C=192, cfg=None, causal=False, seed=0, rblk=0, **kw):
     cfg = cfg or Cfg()
     f16 = cfg.dtype == "f16"
     rng = np.random.default_rng(seed)
-    q, k, v, do = (rand16((n, 128), rng, f16=f16) for n in (R, C, C, R))
+    q, k, v, do = (rand16((n, cfg.D), rng, f16=f16) for n in (R, C, C, R))
     L, Dt, dq = reference(q, k, v, do, f16, causal)
     dQ, wg = run_block(q, k, v, do, L, Dt, rblk, cfg, causal, **kw)
     n = min(256, R - rblk * 256)

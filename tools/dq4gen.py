@@ -58,10 +58,11 @@ IN_S = ["kres", "vres", "nt", "wnt", "kinc", "vinc", "wr0", "ringend", "maskfrom
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", prof=0, exact=0, abl=(), D=128):
+    def __init__(self, dtype="bf16", prof=0, exact=0, abl=(), D=128, defer=None):
         """exact: Q stays as stored, -L arrives divided by log2(e)/sqrt(D) and the scale is applied in fp32 before the exp2
         (one packed multiply per two scores more); otherwise Q arrives pre-multiplied, rounded to the 16-bit type"""
         self.dtype, self.prof, self.exact, self.abl, self.D = dtype, prof, exact, frozenset(abl), D
+        self.defer = (D == 64) if defer is None else defer     # dQ update of a tile's second key block beside the next tile
 
 
 def st_blk(rb, kb):
@@ -279,14 +280,15 @@ class Stream(_P4Stream):
                 fn()
         self.stamp("pc")
 
-    # ---------------------------------------------------------------- one tile, D = 64
-    # 48 matrix instructions in six groups of 8: S(0) P(0) S(1) Q'(1) P(1) Q(0), where Q'(1) is the dQ update of key block 1
-    # of the PREVIOUS tile: the exp2 / multiply / pack work of a tile (1400 VALU cycles beside 1536 of the matrix pipe) then
-    # has no point where the matrix instructions wait for it -- block 1's runs from the middle of one tile to the middle of
-    # the next.  In place as before: S(1) of the next tile overwrites P(1) after the multiplies have read it, P(1) of the
-    # next tile overwrites dS'(1) after Q'(1) has read it.
+    # ---------------------------------------------------------------- one tile, second key block's update deferred
+    # Six groups of G = D/8 matrix instructions: S(0) P(0) S(1) Q'(1) P(1) Q(0), where Q'(1) is the dQ update of key block 1
+    # of the PREVIOUS tile: the exp2 / multiply / pack work of a tile (1400 VALU cycles beside 1536 of the matrix pipe at
+    # D = 64) then has no point where the matrix instructions wait for it -- block 1's runs from the middle of one tile to
+    # the middle of the next.  In place as before: S(1) of the next tile overwrites P(1) after the multiplies have read it,
+    # P(1) of the next tile overwrites dS'(1) after Q'(1) has read it.
     def frag_read64(self, i):
-        grp, r = divmod(i, 4)
+        nks, ndb = self.cfg.D // 16, self.cfg.D // 32
+        grp, r = divmod(i, nks)
         if grp in (0, 1, 2, 4):        # row fragments: K kb0 | V kb0 | K kb1 | V kb1
             kb, isv, ks = (0, 0, r) if grp == 0 else (0, 1, r) if grp == 1 else (1, 0, r) if grp == 2 else (1, 1, r)
             off = (VIMG if isv else 0) + (ks >> 1) * 4096 + kb * 2048
@@ -294,30 +296,33 @@ class Stream(_P4Stream):
                                              note="%s rows kb%d ks%d" % ("V" if isv else "K", kb, ks))
         else:                          # K^T: kb1 of the previous tile (group 3, addresses v236, v237) | kb0 of this tile (group 5)
             kb = 1 if grp == 3 else 0
-            u, db = divmod(r, 2)
+            u, db = divmod(r, ndb)
             off = db * 4096 + kb * 2048 + u * 1024
             a0, a1 = (V(T_TB), V(T_TB + 1)) if grp == 3 else (VN("ta0"), VN("ta1"))
             self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), a0, off, note="K^T kb%d u%d db%d%s" % (kb, u, db, " (previous tile)" if grp == 3 else ""))
             self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), a1, off)
 
     def valu_schedule64(self):
-        """(gap, prev, fn) of the exp2 / multiply / pack work of ONE tile, gap counted from the tile's first matrix
-        instruction (48.. = beside the next tile's: prev = True there); greedy, earliest gap whose VALU cycles are free"""
+        """(gap, fn) of the exp2 / multiply / pack work of ONE tile, gap counted from the tile's first matrix instruction
+        (NM.. = beside the next tile's); greedy, earliest gap whose VALU cycles are free"""
         cfg = self.cfg
-        load, out = [0] * 48, []
+        G = cfg.D // 8
+        NM = 6 * G
+        load, out = [0] * NM, []
         total = (64 * 16 + 64 * 4 + 32 * 4 + (32 * 8 if cfg.exact else 0))
-        cap = 40 if cfg.exact else -(-total // 48) + 3     # two exp2 per gap (+ one packed scale multiply)
+        cap = 40 if cfg.exact else -(-total // NM) + 3     # D = 64: two exp2 per gap (+ one packed scale multiply)
+        cap = max(cap, 24 if cfg.exact else 20)
         state = {"g": 0}
 
         def place(release, cost, fn, last):
             g = max(release, state["g"])
-            while load[g % 48] + cost > cap:
+            while load[g % NM] + cost > cap:
                 g += 1
             assert g <= last, (g, last)
-            load[g % 48] += cost
+            load[g % NM] += cost
             state["g"] = g
             out.append((g, fn))
-        s_end, p_end, q_start, s_next = (7, 23), (15, 39), (40, 48 + 24), (48 + 0, 48 + 16)
+        s_end, p_end, q_start, s_next = (G - 1, 3 * G - 1), (2 * G - 1, 5 * G - 1), (5 * G, NM + 3 * G), (NM, NM + 2 * G)
         for kb in range(2):
             state["g"] = 0
             for rb in range(2):
@@ -340,7 +345,10 @@ class Stream(_P4Stream):
     def tile64(self, tail=False):
         """tail: what is left of the last tile after the loop -- its block-1 VALU work and Q'(1)"""
         cfg = self.cfg
-        NM = 48
+        nks, ndb = cfg.D // 16, cfg.D // 32
+        G = 2 * nks
+        NM = 6 * G
+        npieces = 2 * (cfg.D // 32)
         fill = [[] for _ in range(NM)]
 
         def at(g, fn):
@@ -351,26 +359,29 @@ class Stream(_P4Stream):
                 if g >= NM:
                     fn()
             self.emit("s_nop", None, [I(4)])
-            for i in range(12, 16):
+            for i in range(3 * nks, 3 * nks + 4):
                 self.frag_read64(i)
-            for i in range(12, 16):
-                u, db = divmod(i - 12, 2)
+            for i in range(3 * nks, 4 * nks):
+                u, db = divmod(i - 3 * nks, ndb)
                 for rb in range(2):
                     self.lds_need(self.frag_rid[i])
                     self.mfma(dq_acc(rb, db), af(i), ds16(rb, 1, u), dq_acc(rb, db))
+                    if rb == 1 and i + 4 < 4 * nks:
+                        self.frag_read64(i + 4)
             return
         # previous tile's work first in a gap: its multiplies must be out of the way of S(1)
         for g, fn in sched:
             if g >= NM:
                 at(g - NM, fn)
-        for i in range(20):
+        nfr = 6 * nks
+        for i in range(nfr - 4):
             at(2 * i + 1, lambda i=i: self.frag_read64(i + 4))
-        for i in range(4):
+        for i in range(npieces):
             at(2 * i, lambda i=i: self.dma_piece(i))
-            at(8 + 2 * i, lambda i=i: self.dma_advance(i))
-        at(26, lambda: self.wr_advance())
-        at(24, lambda: self.stage_delta())
-        at(32, lambda: self.addr_advance(["ka0", "ka1"]))     # the last row fragment (19) is requested in gap 31
+            at(2 * npieces + 2 * i, lambda i=i: self.dma_advance(i))
+        at(3 * G + 2, lambda: self.wr_advance())
+        at(3 * G, lambda: self.stage_delta())
+        at(10 * nks - 8, lambda: self.addr_advance(["ka0", "ka1"]))     # the last row fragment (5 nks - 1) is requested one gap earlier
 
         def mask_branch(kb):
             lbl, back = self.newlabel("MASK"), self.newlabel("MASKBACK")
@@ -378,25 +389,25 @@ class Stream(_P4Stream):
             self.emit("s_cbranch_scc1", None, [], target=lbl)
             self.label(back)
             self.outofline.append((lbl, back, kb))
-        at(10, lambda: mask_branch(0))
-        at(26, lambda: mask_branch(1))
+        at(G + 2, lambda: mask_branch(0))
+        at(3 * G + 2, lambda: mask_branch(1))
         for g, fn in sched:
             if g < NM:
                 at(g, fn)
 
         def seam():
-            self.emit("s_waitcnt", None, [], vmcnt=4)
+            self.emit("s_waitcnt", None, [], vmcnt=npieces)
             self.emit("s_barrier")
             self.emit("v_mov_b32", V(T_TB), [VN("ta0")])
             self.emit("v_mov_b32", V(T_TB + 1), [VN("ta1")])
             self.addr_advance(["ta0", "ta1"])
-        at(40, seam)
+        at(NM - 8, seam)
         for i in range(4):
-            at(41 + 2 * i, lambda i=i: self.frag_read64(i))
+            at(NM - 7 + 2 * i, lambda i=i: self.frag_read64(i))
 
         mm = []
-        for i in range(24):
-            grp, r = divmod(i, 4)
+        for i in range(nfr):
+            grp, r = divmod(i, nks)
             for rb in range(2):
                 if grp in (0, 2):
                     kb = grp // 2
@@ -406,10 +417,10 @@ class Stream(_P4Stream):
                     mm.append((dp_blk(rb, kb), af(i), g_frag(rb, r), V(CD + 16 * rb, 16) if r == 0 else dp_blk(rb, kb), i))
                 else:
                     kb = 1 if grp == 3 else 0
-                    u, db = divmod(r, 2)
+                    u, db = divmod(r, ndb)
                     mm.append((dq_acc(rb, db), af(i), ds16(rb, kb, u), dq_acc(rb, db), i))
         assert len(mm) == NM
-        stamps = {16: "pa", 32: "pb"}
+        stamps = {2 * G: "pa", 4 * G: "pb"}
         for g, (d, a_, b_, c_, fr) in enumerate(mm):
             if g in stamps:
                 self.stamp(stamps[g])
@@ -422,11 +433,12 @@ class Stream(_P4Stream):
     # ---------------------------------------------------------------- whole traversal
     def build(self):
         cfg = self.cfg
-        d64 = cfg.D == 64
-        npieces, frag_read, tile = (4, self.frag_read64, self.tile64) if d64 else (8, self.frag_read, self.tile)
+        d64 = cfg.defer
+        npieces = 2 * (cfg.D // 32)
+        frag_read, tile = (self.frag_read64, self.tile64) if d64 else (self.frag_read, self.tile)
         self.outofline = []
         for r in range(128):
-            if d64 and (r // 16) % 4 >= 2:
+            if (r // 16) % 4 >= cfg.D // 32:
                 continue                                     # (rb, db) -> 16 (4 rb + db) with db < 2
             self.emit("v_accvgpr_write_b32", A(r), [I(0)])
         if d64:
@@ -539,6 +551,7 @@ VARIANTS = {
     "D64_BF16_EXACT": Cfg("bf16", exact=1, D=64),
     "D64_F16_EXACT": Cfg("f16", exact=1, D=64),
     "D64_BF16_FOLD_PROF": Cfg("bf16", prof=1, D=64),
+    "BF16_FOLD_DEFER_PROF": Cfg("bf16", prof=1, defer=True),     # developer: the 64 bucket's group order at D = 128
     # timing-only ablations (WRONG RESULTS; developer build): fillers left out of the tile
     "ABL_DMA": Cfg("bf16", prof=1, abl=("dma",)),
     "ABL_EXP": Cfg("bf16", prof=1, abl=("exp",)),

@@ -64,6 +64,14 @@ def main():
         return
     extra = o[:, ::64, 7:9].contiguous().view(torch.int32).double()
     print("kernel entry -> Q loads issued %.0f, -> Q loads returned %.0f cycles" % (extra[..., 0].mean(), extra[..., 1].mean()))
+    more = o[:, ::64, 9:12].contiguous().view(torch.int32).double()
+    import numpy as _np
+    for nm, x in (("Q issue - descriptors", (extra[..., 0] - more[..., 2])), ("Q back - Q issue", extra[..., 1] - extra[..., 0]),
+                  ("stores complete", o[:, ::64, 6].contiguous().view(torch.int32).double())):
+        q = _np.percentile(x.cpu().numpy().ravel(), [0, 10, 25, 50, 75, 90, 100])
+        print("  %-24s percentiles 0/10/25/50/75/90/100: %s" % (nm, " ".join("%.0f" % v for v in q)))
+    print("kernel entry -> block decoded %.0f, -> lengths known %.0f, -> descriptors built %.0f cycles (min over waves %.0f / %.0f / %.0f)" % (
+        more[..., 0].mean(), more[..., 1].mean(), more[..., 2].mean(), more[..., 0].min(), more[..., 1].min(), more[..., 2].min()))
     fixed = o[:, ::64, 4:7].contiguous().view(torch.int32).double()   # [H][waves][entry -> statement, statement, statement -> stores issued]
     c = o[:, ::64, 0:4].contiguous().view(torch.int32).double()      # [H][N/64 waves][pa, pw, pb, nt]
     steady = c[..., 3] - 1

@@ -80,10 +80,10 @@ static const char *kDefaultTables[3][2] = {
      "| 128 | 128 | 32 | 128 | K, V, dV, dK |\n"
      "| 256 | 128 | 32 | 256 | K, V, dV, dK |\n"
      "| 384 | 32  | 32 | 384 | dV, dK       |\n",
-     // backwardKeyValue, mixed: D <= 64 and D in (96, 128] -> 4 waves x 64 keys (attn_dkv16_p4.h); | 128 | 128 | 32 | 128 | selects the role-split wave pairs
-     // (attn_dkv16_rs.h), which also serve the other buckets; | 128 | 128 | 64 | 128 | the one-wave-per-key-block kernel (attn_bwd16.h)
+     // backwardKeyValue, mixed: D <= 128 -> 4 waves x 64 keys (attn_dkv16_p4.h); | 128 | 128 | 32 | 128 | selects the role-split wave pairs
+     // (attn_dkv16_rs.h), which also serve the other buckets (a 96-wide object too: | 96 | 128 | 32 | 96 |); | 128 | 128 | 64 | 128 | the
+     // one-wave-per-key-block kernel (attn_bwd16.h)
      "| 64  | 256 | 32 | 64  | K, V, dV, dK |\n"
-     "| 96  | 128 | 32 | 96  | K, V, dV, dK |\n"
      "| 128 | 256 | 32 | 128 | K, V, dV, dK |\n"
      "| 160 | 64  | 32 | 160 | K, V, dV, dK |\n"
      "| 192 | 64  | 32 | 192 | K, V, dV, dK |\n"

@@ -169,21 +169,23 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       }
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
           kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV]) {
+        auto add_bucket = [&](int b) {   // buckets 64, 128, 256
+          const bool rs = dkv16_rs_variant(pq, pg, b, 0, &v);
+          if (rs && (b == 128 || b == 64)) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
+            VariantInfo v4 = v;
+            add(dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], b, 0, &v4), v4);
+          }
+          add(rs, v);
+        };
         switch (b16) {   // role-split wave pairs (attn_dkv16_rs.h)
-          case 96: add(dkv16_rs_variant_d96(pq, pg, &v), v); break;
+          // 64 < D <= 96: the 128 bucket's stream is 1.4 x faster than the 96-wide role-split pairs
+          // (profiles/r02_bucket96_dkv.txt) and is what the default table row asks for; a | 96 | 128 | 32 | 96 | row selects these
+          case 96: add(dkv16_rs_variant_d96(pq, pg, &v), v); add_bucket(128); break;
           case 160: add(dkv16_rs_variant_d160(pq, pg, &v), v); break;
           case 192: add(dkv16_rs_variant_d192(pq, pg, &v), v); break;
-          default: {
-            const bool rs = dkv16_rs_variant(pq, pg, b16, 0, &v);
-            if (rs && (b16 == 128 || b16 == 64)) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
-              VariantInfo v4 = v;
-              add(dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], b16, 0, &v4), v4);
-            }
-            add(rs, v);
-            break;
-          }
+          default: add_bucket(b16); break;
         }
-        add(dkv16_variant(pq, pg, b16, &v), v);          // one wave per key block (attn_bwd16.h; D = 64, 128 only)
+        add(dkv16_variant(pq, pg, b16 == 96 ? 128 : b16, &v), v);   // one wave per key block (attn_bwd16.h; D = 64, 128 only)
       }
     }
   }
@@ -230,9 +232,6 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   // and a table edit must not silently move a 16-bit problem onto fp32 arithmetic; it serves the launches they cannot)
   const bool fast = !candidates.empty();
   if (!fast) candidates.push_back(general);
-  uint16_t wantHead = 0;   // the smallest compiled head block that holds the requested one
-  for (const VariantInfo &c : candidates)
-    if (c.headBlock >= kdesc->headBlock && (wantHead == 0 || c.headBlock < wantHead)) wantHead = c.headBlock;
   // left-hand operands of the kernel type: (first, second) = (Q, -) / (Q, dO) / (K, V)
   const int firstLeft = type == MFA_BACKWARD_KEY_VALUE ? MFA_K : MFA_Q;
   const int secondLeft = type == MFA_FORWARD ? MFA_Q : type == MFA_BACKWARD_QUERY ? MFA_dO : MFA_V;
@@ -245,7 +244,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   };
   auto distance = [&](const VariantInfo &c) {
     int d = 0;
-    if (c.headBlock != wantHead) d += 8;
+    if (c.headBlock < kdesc->headBlock) d += 8;   // (every candidate's head block holds D; among equals the smaller one wins below)
     if (c.parallelization != kdesc->parallelization) d += 4;
     if (c.traversal != kdesc->traversal) d += 2;
     if (c.cacheLeft != (kdesc->cacheState[firstLeft] != 0)) d += 1;
@@ -254,8 +253,10 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     return d;
   };
   size_t best = 0;
-  for (size_t i = 1; i < candidates.size(); ++i)
-    if (distance(candidates[i]) < distance(candidates[best])) best = i;
+  for (size_t i = 1; i < candidates.size(); ++i) {
+    const int di = distance(candidates[i]), db = distance(candidates[best]);
+    if (di < db || (di == db && candidates[i].headBlock < candidates[best].headBlock)) best = i;
+  }
   if (kdesc->strictBlockDimensions && distance(candidates[best]) != 0) {
     std::string have;
     for (const VariantInfo &c : candidates)

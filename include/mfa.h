@@ -25,13 +25,13 @@
  *     also when lowPrecisionIntermediates is 0 and the reference would keep them in FP32 registers
  *     (+Precisions.swift:201-205).  S, the accumulators, L and D arithmetic are fp32.
  *   - lowPrecisionIntermediates = 1 (the reference then holds P, and with FP16 also S, in 16-bit registers) lets the
- *     hand-placed kernels (forward D <= 128 and 192 < D <= 256, backward 96 < D <= 128) multiply one operand of S = Q K^T
+ *     hand-placed kernels (forward 64 < D <= 256, backward D <= 128) multiply one operand of S = Q K^T
  *     by log2(e)/sqrt(D) once, rounded to the inputs' type (forward and backwardQuery: Q; backwardKeyValue: K), instead
  *     of scaling every score in fp32: L moves by up to ~2e-3 (BF16) / 2e-4 (FP16) natural-log units, P by the same
  *     relative amount.  With the flag clear the scale is applied in fp32 per score.
- *   - backwardKeyValue, 96 < D <= 128: the per-row terms L and D enter S and dP through the matrix pipe as the sum of two
+ *   - backwardKeyValue, D <= 128: the per-row terms L and D enter S and dP through the matrix pipe as the sum of two
  *     16-bit values (16 / 22 bits of mantissa for BF16 / FP16 inputs): an absolute error of ~2^-16 |L| in the exponent of P.
- *   - FP16 Q, K, V with BF16 dO (the reference's own low-precision mix), backwardKeyValue, 96 < D <= 128: the two products that
+ *   - FP16 Q, K, V with BF16 dO (the reference's own low-precision mix), backwardKeyValue, D <= 128: the two products that
  *     read dO run in BF16 -- V is rounded to BF16 once per workgroup and P is packed to BF16 for dV -- while S and dK stay
  *     FP16; the other kernels convert dO to FP16 instead (exact in FP16's range).
  *   - Transposed operands (transposeState) run on the 16-bit matrix cores only when the launch is given a workspace

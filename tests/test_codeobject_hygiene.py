@@ -1,0 +1,57 @@
+"""What hipcc made of the C++ around the hand-placed statements (attn_fwd16_p4 / p5, attn_dq16_p4, attn_dkv16_p4), read back
+from the gfx950 code objects of the last build.  The statements own all but ~28 registers per lane, so any per-lane value
+hipcc keeps live across them goes to scratch; in the causal forward kernels that once turned every prologue LDS-DMA piece
+into `scratch_load; s_waitcnt vmcnt(0); buffer_load ... lds` -- one piece in flight at a time
+(profiles/r02_fwd16_causal_pass_loop_scratch.txt).  No GPU needed: llvm-objdump on csrc/build/*.o."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+OBJECTS = ["attn_fwd16_p4", "attn_fwd16_p5", "attn_dq16_p4", "attn_dkv16_p4"]
+
+
+def _kernels(obj):
+    path = os.path.join(CSRC, "build", obj + ".o")
+    tools = [os.path.join(LLVM, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.exists(path) or not all(os.path.exists(t) for t in tools):
+        pytest.skip("needs the object files of the last build and the ROCm llvm tools")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, dev = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.o")
+        subprocess.check_call([tools[0], "-O", "binary", "--only-section=.hip_fatbin", path, fat])
+        subprocess.check_call([tools[1], "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + dev])
+        text = subprocess.check_output([tools[2], "-d", "--no-show-raw-insn", dev], text=True)
+    kernels, name = {}, None
+    for line in text.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(_ZN3mfa[^>]+)>:", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = []
+        elif name and line.startswith("\t"):
+            kernels[name].append(line.split("//")[0].strip())
+    return kernels
+
+
+@pytest.mark.parametrize("obj", OBJECTS)
+def test_lds_dma_pieces_are_issued_back_to_back(obj):
+    kernels = _kernels(obj)
+    assert kernels
+    for name, ins in kernels.items():
+        for i, t in enumerate(ins):
+            if t.startswith("buffer_load") and t.endswith("lds"):
+                window = ins[max(0, i - 4):i]
+                assert not any(w.startswith("s_waitcnt vmcnt(0)") for w in window), (name, i, window)
+                assert not any(w.startswith("scratch_load") for w in window), (name, i, window)
+
+
+@pytest.mark.parametrize("obj", OBJECTS)
+def test_scratch_stays_out_of_the_way(obj):
+    """a handful of spills around the statement are fine (values the epilogue needs); dozens mean loop invariants again"""
+    for name, ins in _kernels(obj).items():
+        n = sum(1 for t in ins if t.startswith("scratch_"))
+        assert n <= 40, (name, n)

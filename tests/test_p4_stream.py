@@ -139,3 +139,26 @@ def test_filler_budget():
     inner = first[:31] + first[32:63]      # the two phase seams carry waits, barrier, loop control (and the skipped mask code)
     assert max(inner) <= 7, max(inner)
     assert sum(inner) / len(inner) < 5.8, sum(inner) / len(inner)
+
+
+def test_model_executes_buffer_stores():
+    """buffer_store_dwordx4 in the lane-exact model (for streams that write their results themselves):
+    16 bytes per lane at its own offset, out-of-range lanes dropped by the resource bounds, counted in vmcnt"""
+    from p4gen import A, I, SN, V, VN, Stream, render
+    st = Stream(p4gen.VARIANTS["BF16_FOLD"])
+    for r in range(4):
+        st.emit("v_mov_b32", V(40 + r), [I(r + 1)])
+    st.emit("v_accvgpr_write_b32", A(7), [I(9)])
+    st.emit("buffer_store_dwordx4", None, [V(40, 4), VN("off"), SN("ores", 4)])
+    st.emit("s_waitcnt", None, [], vmcnt=0)
+    assert any(t.startswith("buffer_store_dwordx4 v[40:43], %[off], %[ores], 0 offen") for t in render(st.ins))
+    wg = p4sim.Workgroup(st.ins)
+    mem = np.zeros(64 * 16, np.uint8)          # offsets start at byte 8: the last lane of wave 3 falls outside
+    for w in wg.waves:
+        w.vn["off"] = ((np.arange(64) + 64 * (w.id & 0)) * 16 + (8 if w.id == 3 else 0)).astype(np.uint32)
+        w.sn["ores"] = (mem, mem.size if w.id == 3 else 0)   # only wave 3 has a live resource
+    wg.run((0, 1, 2, 3))
+    words = mem[8:8 + 63 * 16].view(np.uint32).reshape(63, 4)
+    assert (words == np.array([1, 2, 3, 4], np.uint32)).all()
+    assert not mem[:8].any() and not mem[8 + 63 * 16:].any()
+    assert all(not w.vm_q for w in wg.waves)

@@ -699,6 +699,8 @@ def render_one(ins, suffix="%="):
         return "buffer_load_dwordx4 %s, %s, 0 offen lds" % (fmt(ins.s[0]), fmt(ins.s[1]))
     if op in ("buffer_load_dword", "buffer_load_ushort"):
         return "%s %s, %s, %s, 0 offen" % (op, fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
+    if op == "buffer_store_dwordx4":     # s = (four data registers, per-lane byte offset, buffer resource)
+        return "buffer_store_dwordx4 %s, %s, %s, 0 offen" % (fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
     if op in ("ds_read_b128", "ds_read_b64_tr_b16"):
         return "%s %s, %s offset:%d" % (op, fmt(ins.d), fmt(ins.s[0]), m["offset"])
     if op == "v_fma_f32":

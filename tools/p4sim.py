@@ -278,6 +278,17 @@ class Workgroup:
             dest = (d[0], d[1])
             w.poison.add(dest)
             w.vm_q.append((dest, data))
+        elif op == "buffer_store_dwordx4":
+            # data registers are read at issue; the write counts in vmcnt like a load (gfx950 has no separate store counter)
+            regs = w.regs(s[0])
+            off = w.rd(s[1]).astype(np.int64)
+            buf, nrec = w.sn[s[2][1]]
+            words = np.stack([(w.v if kind == "v" else w.a)[idx] for kind, idx in regs], axis=1).astype(np.uint32)   # [64][4]
+            for l in range(64):
+                o = int(off[l])
+                if 0 <= o and o + 16 <= nrec:
+                    buf[o:o + 16] = words[l].view(np.uint8)
+            w.vm_q.append((None, None))
         elif op == "v_exp_f32":
             x = w.rdf(s[0]).astype(np.float64)
             if m.get("neg0"):

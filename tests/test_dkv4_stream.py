@@ -87,3 +87,16 @@ def test_step_shape_and_filler_budget():
         inner = gaps[:60] + gaps[61:]
         assert max(inner) <= 7, (name, max(inner), inner.index(max(inner)))
         assert sum(gaps) / len(gaps) < 4.0, sum(gaps) / len(gaps)
+
+
+def test_d64_step_shape():
+    """the 64 bucket: 36 matrix instructions per step (S 10, dP 10 with the per-row k-step, dV^T 8, dK^T 8)"""
+    for name in ("D64_BF16_MIXED", "D64_BF16_F32"):
+        ins = dkv4gen.Stream(V[name]).build()
+        loop = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("LOOP"))
+        end = next(i for i, x in enumerate(ins) if x.op == "s_cbranch_scc1" and x.mod.get("target", "").startswith("LOOP"))
+        body = [x for x in ins[loop:end] if x.op != "label"]
+        n_mfma = sum(1 for x in body if x.op.startswith("v_mfma"))
+        assert n_mfma == 36, (name, n_mfma)
+        assert sum(1 for x in body if x.op == "s_barrier") == 1
+        assert (len(body) - n_mfma) / n_mfma < 5.5, (name, len(body))   # the same exp2 / multiply / pack work as at D = 128 beside half the matrix instructions

@@ -95,3 +95,27 @@ def test_tile_shape_and_filler_budget():
         inner = gaps[:88] + gaps[89:]
         assert max(inner) <= 7, (name, max(inner), inner.index(max(inner)))
         assert sum(gaps) / len(gaps) < 3.8, sum(gaps) / len(gaps)
+
+
+def test_d64_tile_shape():
+    """the 64 bucket: 48 matrix instructions per tile in the loop plus 8 after it (the last tile's second key block), one
+    barrier per tile, the exp2 / multiply / pack work spread so that no gap holds more than 40 VALU cycles of it"""
+    ins = dq4gen.Stream(V["D64_BF16_FOLD"]).build()
+    loop = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("LOOP"))
+    end = next(i for i, x in enumerate(ins) if x.op == "s_cbranch_scc1" and x.mod.get("target", "").startswith("LOOP"))
+    body = [x for x in ins[loop:end] if x.op != "label"]
+    assert sum(1 for x in body if x.op.startswith("v_mfma")) == 48
+    assert sum(1 for x in body if x.op == "s_barrier") == 1
+    skip = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("SKIP"))
+    assert sum(1 for x in ins[end:skip] if x.op.startswith("v_mfma")) == 8
+    cost = {"v_exp_f32": 16, "v_mul_f32": 4, "v_cvt_pk_bf16_f32": 4, "v_pk_mul_f32": 8}
+    gaps, cur = [], None
+    for x in body:
+        if x.op.startswith("v_mfma"):
+            if cur is not None:
+                gaps.append(cur)
+            cur = 0
+        elif cur is not None:
+            cur += cost.get(x.op, 0)
+    assert max(gaps) <= 40, max(gaps)
+    assert sum(gaps) == 64 * 16 + 64 * 4 + 32 * 4 - (cur or 0) or sum(gaps) + (cur or 0) == 64 * 16 + 64 * 4 + 32 * 4

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 4
+#define MFA_ABI_VERSION 5
 
 /* ---- status codes (replace fatalError, e.g. AttentionKernel.swift:33,
  *      AttentionDescriptor.swift:45/72/90/97, AttentionParameterRow.swift:50/57/100) -------- */
@@ -144,7 +144,11 @@ mfa_status mfa_attention_descriptor_kernel_descriptor(const mfa_attention_descri
 /* ---- parameter tables (AttentionDescriptor+Parameters.swift:13-66, :77-285;
  *      text format of AttentionParameterRow.parseTable, AttentionParameterRow.swift:22-74):
  *      "| max D | parallelization | traversal | head | cached operands |" one row per line.
- *      `mixed` selects the table used when BOTH low-precision flags are set (+Parameters.swift:16). */
+ *      `mixed` = 1 selects the table consulted whenever `lowPrecisionInputs` is set -- Q, K, V in a 16-bit type, i.e. the
+ *      16-bit matrix-core code objects -- whatever `lowPrecisionIntermediates` says; `mixed` = 0 the table of FP32 inputs.
+ *      DEPARTURE from the reference, which takes its mixed tables only when BOTH flags are set (+Parameters.swift:16):
+ *      there the tables follow the register footprint that FP16 intermediates halve; on gfx950 S, P and the accumulators are
+ *      fp32 registers in every kernel and what changes the code object is the storage type of the inputs. */
 mfa_status mfa_parameter_table_get(int type, int mixed, char *out, size_t capacity);
 mfa_status mfa_parameter_table_set(int type, int mixed, const char *text); /* validates, then installs */
 mfa_status mfa_parameter_table_reset(void);                                /* back to built-in gfx950 tables */

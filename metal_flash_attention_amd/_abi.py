@@ -199,7 +199,7 @@ SYMBOLS = [
 ]
 
 _lib = None
-EXPECTED_ABI = 4   # MFA_ABI_VERSION of include/mfa.h this file mirrors
+EXPECTED_ABI = 5   # MFA_ABI_VERSION of include/mfa.h this file mirrors
 
 
 class MFAError(RuntimeError):
@@ -226,14 +226,18 @@ def lib() -> ctypes.CDLL:
     except ImportError:
         pass
     handle = ctypes.CDLL(LIB_PATH)
-    for name, restype, argtypes in SYMBOLS + GEMM_SYMBOLS:
-        fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
-        fn.restype = restype
-        fn.argtypes = argtypes
+    # version first: a stale library (the .so is git-ignored and travels separately from the sources) must fail with this
+    # message, not with a bare AttributeError on the first symbol it lacks
+    handle.mfa_abi_version.restype = ctypes.c_int
+    handle.mfa_abi_version.argtypes = []
     got = int(handle.mfa_abi_version())
     if got != EXPECTED_ABI:   # the struct mirrors above describe exactly one layout of mfa_launch_params & co.
         raise ImportError(f"{LIB_PATH} reports ABI version {got}, these bindings were written for {EXPECTED_ABI}: "
                           f"rebuild the library (make -C metal_flash_attention_amd/csrc)")
+    for name, restype, argtypes in SYMBOLS + GEMM_SYMBOLS:
+        fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
     _lib = handle
     return handle
 

@@ -206,6 +206,10 @@ def parameterFile(type: AttentionKernelType, mixed: bool) -> str:  # noqa: A002
 
 
 def setParameterFile(type: AttentionKernelType, mixed: bool, text: str) -> None:  # noqa: A002
+    """Install a parameter table (text format of AttentionParameterRow.parseTable).  `mixed=True` is the table consulted for
+    every descriptor with lowPrecisionInputs (16-bit Q, K, V -> the 16-bit matrix-core code objects), with or without
+    lowPrecisionIntermediates; `mixed=False` the table of FP32 inputs.  The reference consults its mixed tables only when
+    BOTH flags are set (+Parameters.swift:16) -- include/mfa.h and DESIGN.md 5 give the reason for the departure."""
     check(lib().mfa_parameter_table_set(int(type), int(bool(mixed)), text.encode()))
 
 

@@ -555,7 +555,11 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   if (kernel->relayout) {
     const uint64_t need = relayout_workspace_bytes(kernel, p->row, p->column, heads, batches);
     plan->workspaceNeeded = need;
-    if (p->workspace && p->workspaceBytes >= need && (reinterpret_cast<uintptr_t>(p->workspace) & 255) == 0) {
+    // per-batch lengths: the matrix-core kernels never write the padding rows of an output, so the write-back of a row-major
+    // output copy (uninitialised workspace) would overwrite the caller's padding region -- such launches take the general
+    // kernel, which reads and writes the transposed views in place
+    const bool lengths = args->rowLen || args->colLen;
+    if (!lengths && p->workspace && p->workspaceBytes >= need && (reinterpret_cast<uintptr_t>(p->workspace) & 255) == 0) {
       char *cursor = static_cast<char *>(p->workspace);
       for (int slot = 0; slot < MFA_BUFFER_SLOTS; ++slot) {
         if (!slot_used(type, slot) || slot == SLOT_L || slot == SLOT_D || !args->op[slot].transposed) continue;

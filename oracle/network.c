@@ -9,13 +9,19 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this file.  Nothing under metal_flash_attention_amd/ links or imports it.
  *
- * PARITY STATUS: "parity unpinned".  The reference ships no golden vectors for
- * this path (its inputs are unseeded random) and no Swift
- * toolchain exists in this image, so this restatement cannot be checked against
- * reference outputs.  It is instead cross-checked against (i) an independent
- * numpy fp64 twin (oracle/network_np.py), (ii) central finite differences of
- * the loss (idea: Documentation/Archive/FiniteDifferencingTest.swift:86-131)
- * and (iii) torch fp64 autograd, see tests/test_oracle.py.
+ * PARITY STATUS: "parity unpinned" against reference OUTPUTS.  The reference
+ * ships no golden vectors for this path (its inputs are unseeded random,
+ * SURVEY.md 8c) and no Swift toolchain exists in this image, so this
+ * restatement cannot be checked against vectors or outputs of the reference.
+ * What anchors it instead follows from the reference's FORMULAS alone
+ * (Network.swift:134-402), not from any code of this repository:
+ * (i) closed forms (tests/golden/closed_form.py: uniform and one-hot P, C = 1,
+ * the C = 2 logistic form with its analytic dS), (ii) metamorphic relations on
+ * RANDOM inputs (key shift K + 1 u^T, value shift V + 1 w^T, (aQ, K/a)
+ * rescaling, key permutation; tests/test_closed_form.py), (iii) an independent
+ * numpy fp64 twin (oracle/network_np.py), central finite differences of the
+ * loss (idea: Documentation/Archive/FiniteDifferencingTest.swift:86-131) and
+ * torch fp64 autograd (tests/test_oracle.py).  DESIGN.md 8 says the same.
  *
  * Arithmetic contract: every scalar sum below is accumulated in fp32 in the
  * same ORDER as the Swift loops (sequential over d for dot products,

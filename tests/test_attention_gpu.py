@@ -390,6 +390,92 @@ def test_config5_shard_forward_n16384_d128_bf16_two_heads():
         assert np.abs(got["O"] - ref["O"]).max() < 5e-3 and np.abs(got["L"] - ref["L"]).max() < 1e-3
 
 
+# ---- the code objects bench.py times, at FULL size, in the reference's mixed-precision mode ------------------------------
+# (lowPrecisionInputs + lowPrecisionIntermediates: FOLD / pre-scaled streams, FP16 L, BF16 D).  Oracle on the rounded inputs,
+# the reference's own mixed tolerances (SquareAttentionTest.swift:539-554: O 5e-2, L 7e-3, D 1e-1, gradients 5e-2) plus a
+# tighter bound that states what these streams really deliver; the variant names are the ones bench.py prints.
+def _full_size_mixed(R, D, in_type, backward, seed=0):
+    net = Network(NetworkDescriptor(R, R, D), seed=seed)
+    desc = make_desc(R, R, D, low_in=True, low_mid=True, in_type=in_type)
+    run = harness.DeviceRun(desc, net, run_backward=backward)
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(backward=backward)
+    variants = {t.name: k.variant for t, k in run.kernels.items()}
+    tol = {k: v for k, v in TOL_MIXED.items() if backward or k in ("O", "L")}
+    failures, report = harness.compare(ref, got, tol)
+    assert not failures, (failures, variants)
+    assert all(run.tails_ok.values()), run.tails_ok
+    return report, variants
+
+
+def test_headline_code_object_forward_n4096_d128_bf16_mixed():
+    """The kernel of bench.py's default line (fwd_bf16_d128): O AND L at N = 4096 against the oracle."""
+    report, variants = _full_size_mixed(4096, 128, P.BF16, backward=False)
+    assert variants["forward"].startswith("attn_fwd16p4") and variants["forward"].endswith("_fold"), variants
+    # Q' = Q log2e / sqrt(D) rounded to bf16 once (8-bit mantissa: relative 2^-9 per product term, random signs) and L kept
+    # in FP16 (ulp 2^-7 log2 units = 5.4e-3 nats at |L| in [8, 16), half of it the rounding bound)
+    print("full-size mixed", variants, report)
+    assert report["O"] < 5e-3 and report["L"] < 7e-3, report
+
+
+def test_headline_code_objects_forward_backward_n4096_d128_bf16_mixed():
+    """bench.py's fwdbwd_bf16_d128_mixed / dq_bf16_d128 / dkv_bf16_d128: all six outputs at N = 4096."""
+    report, variants = _full_size_mixed(4096, 128, P.BF16, backward=True, seed=1)
+    assert variants["forward"].endswith("_fold") and "attn_dq16p4" in variants["backwardQuery"] and \
+        "attn_dkv16p4" in variants["backwardKeyValue"], variants
+    print("full-size mixed", variants, report)
+    assert max(report[k] for k in ("dQ", "dK", "dV")) < 2e-2 and report["D"] < 5e-2, report
+
+
+def test_reference_mix_forward_backward_n4096_d128_f16_bf16_dO():
+    """The reference's own low-precision mix (+Precisions.swift:13-17: FP16 Q, K, V, BF16 dO, FP16 L, BF16 D) at N = 4096
+    (bench.py's fwdbwd_f16_d128_refmix)."""
+    report, variants = _full_size_mixed(4096, 128, P.FP16, backward=True, seed=2)
+    assert variants["forward"].startswith("attn_fwd16p4_f16") and variants["forward"].endswith("_fold"), variants
+    print("full-size refmix", variants, report)
+    assert report["O"] < 2e-3 and report["L"] < 7e-3, report
+
+
+def test_config4_code_object_forward_n8192_d256_bf16_mixed():
+    """bench.py's fwd_bf16_d256_mixed: the FOLD stream of the 64-rows-per-wave D <= 256 kernel at N = 8192."""
+    report, variants = _full_size_mixed(8192, 256, P.BF16, backward=False)
+    assert variants["forward"].startswith("attn_fwd16p5") and variants["forward"].endswith("_fold"), variants
+    print("full-size mixed", variants, report)
+    assert report["O"] < 5e-3 and report["L"] < 7e-3, report
+
+
+def _fuzz_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        D = int(rng.choice([8, 40, 64, 72, 96, 104, 112, 120, 128, 136, 152, 160, 176, 192, 200, 232, 256]))
+        causal = bool(rng.integers(2))
+        R = int(rng.integers(1, 700))
+        C = int(rng.integers(R if causal else 1, 900))
+        out.append((i, R, C, D, causal, bool(rng.integers(2)), "BF16" if rng.integers(2) else "FP16"))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(50, seed=0), ids=lambda c: "%d-%dx%dx%d-%s-%s-%s" % (
+    c[0], c[1], c[2], c[3], "causal" if c[4] else "dense", "mixed" if c[5] else "fp32mid", c[6]))
+def test_fuzz_random_problems(case):
+    """A seeded slice of tools/fuzz_shapes.py: random (R, C, D, causal, precision mode, 16-bit type) problems through all
+    three kernels against the oracle, the reference's mixed tolerances, canary tails, no NaN."""
+    i, R, C, D, causal, low_mid, in_type = case
+    net = Network(NetworkDescriptor(R, C, D), seed=1000 + i)
+    desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P[in_type])
+    run = harness.DeviceRun(desc, net, causal=causal)
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(causal=causal)
+    failures, report = harness.compare(ref, got, TOL_MIXED_SHORT if C <= 20 else TOL_MIXED)
+    variants = [k.variant for k in run.kernels.values()]
+    assert not failures, (failures, variants)
+    assert all(run.tails_ok.values()), (run.tails_ok, variants)
+    assert all(np.isfinite(got[n]).all() for n in ("O", "dQ", "dK", "dV")), variants
+
+
 def test_size_independent_properties_at_full_size():
     """Properties that need no oracle: (i) V = 1 gives O = 1 exactly up to rounding (rows of P sum to
     one); (ii) permuting the keys (rows of K and V together) leaves O and L unchanged up to
@@ -495,6 +581,42 @@ def test_transposed_operands_reach_the_matrix_cores_through_a_workspace(shape, t
     assert not failures, failures
     for name in ("O", "dQ", "dK", "dV"):       # the two paths differ by the 16-bit rounding of P and dS only
         assert np.abs(got[name] - slow[name]).max() < 3e-2, name
+
+
+def test_transposed_outputs_with_lengths_leave_the_padding_alone():
+    """Transposed O ([D][Rmax] per head) + per-batch lengths + a workspace: the write-back of a row-major output copy would
+    overwrite the caller's padding columns with uninitialised workspace bytes (the matrix-core kernels never write padding
+    rows), so such launches run on the general kernel in place.  Padding must keep its poison, the rest equals the oracle."""
+    import torch
+    B, H, Rmax, Cmax, D = 2, 2, 200, 333, 128
+    rlen, clen = [200, 77], [333, 100]
+    desc = make_desc(Rmax, Cmax, D, low_in=True, in_type=P.BF16, tr=(False, False, False, True))
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    assert kernel.needsWorkspaceForFastPath
+    rng = np.random.default_rng(5)
+    host = {n: round_trip(rng.standard_normal((B, H, Rmax if n == "Q" else Cmax, D)).astype(np.float32), int(P.BF16)) for n in ("Q", "K", "V")}
+    dev = lambda x: torch.from_numpy((np.ascontiguousarray(x).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+    bufs = {Op.Q: dev(host["Q"]), Op.K: dev(host["K"]), Op.V: dev(host["V"]),
+            Op.O: torch.full((B, H, D, Rmax), float("nan"), device="cuda"), Op.L: torch.full((B, H, Rmax), float("nan"), device="cuda")}
+    hs = {Op.Q: Rmax * D, Op.K: Cmax * D, Op.V: Cmax * D, Op.O: Rmax * D, Op.L: Rmax}
+    bs = {op: v * H for op, v in hs.items()}
+    need = kernel.workspaceSize(row=Rmax, column=Cmax, heads=H, batches=B)
+    ws = torch.full((need + 256,), 0x7F, dtype=torch.uint8, device="cuda")     # garbage a write-back would expose
+    kernel.dispatch(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs, workspace=ws,
+                    stream=torch.cuda.current_stream().cuda_stream,
+                    rowLengths=torch.tensor(rlen, dtype=torch.int32, device="cuda"),
+                    columnLengths=torch.tensor(clen, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    o = bufs[Op.O].cpu().numpy()
+    for b in range(B):
+        for h in range(H):
+            R, C = rlen[b], clen[b]
+            net = Network(NetworkDescriptor(R, C, D), seed=0)
+            net.Q, net.K, net.V = (np.ascontiguousarray(host[n][b, h, :(R if n == "Q" else C)]) for n in ("Q", "K", "V"))
+            net.invalidate()
+            ref = net.run(backward=False)
+            assert np.abs(o[b, h][:, :R].T - ref["O"]).max() < 1.5e-2
+            assert np.isnan(o[b, h][:, R:]).all(), "padding columns of the transposed O were written"
 
 
 def test_backward_16bit_matches_general_kernels(monkeypatch):

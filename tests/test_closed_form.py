@@ -70,6 +70,41 @@ def test_oracle_key_permutation_property():
         assert np.abs(a[name][perm] - b[name]).max() < 1e-5, name
 
 
+def _random_inputs(R, C, D, seed):
+    rng = np.random.default_rng(seed)
+    return {n: rng.standard_normal(sh).astype(np.float32) for n, sh in (("Q", (R, D)), ("K", (C, D)), ("V", (C, D)), ("dO", (R, D)))}
+
+
+def _assert_relation(base_out, new_out, expect, tol, what, scale_by=None, relative=False):
+    for name in ("O", "L", "D", "dV", "dK", "dQ"):
+        want = expect(name, np.asarray(base_out[name], np.float64))
+        err = float(np.abs(np.asarray(new_out[name], np.float64) - want).max())
+        bound = tol[name] if isinstance(tol, dict) else tol
+        if scale_by is not None:
+            bound *= scale_by.get(name, 1.0)
+        if relative:      # 16-bit storage of an output (FP16 L, BF16 D): the rounding step grows with the magnitude
+            bound *= max(1.0, float(np.abs(want).max()))
+        assert err <= bound, f"{what}: {name} violates the relation by {err:.3e} (bound {bound:.3g})"
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 64), (37, 53, 20), (256, 300, 128), (4096, 4096, 64)])
+@pytest.mark.parametrize("relation", closed_form.RELATIONS)
+def test_oracle_metamorphic_relations_on_random_inputs(relation, shape):
+    """Non-degenerate anchors: RANDOM Q, K, V, dO (P neither uniform nor one-hot); what Network.swift:134-402 implies for the
+    transformed problem must hold between two runs of the C oracle.  (4096, 4096, 64) is BASELINE config 2's shape."""
+    R, C, D = shape
+    base, new, expect = closed_form.transform(relation, _random_inputs(R, C, D, seed=31), seed=R + D)
+    a, b = _oracle(base), _oracle(new)
+    if relation == "qk_rescale":     # exact powers of two: bit-identical
+        for name in ("O", "L", "D", "dV", "dK", "dQ"):
+            assert np.array_equal(np.asarray(b[name]), expect(name, np.asarray(a[name])).astype(np.float32)), name
+        return
+    # fp32 rounding floor of sums of N cancelling terms (as in _assert_close)
+    grow = max(1.0, np.sqrt(max(R, C)) / 10.0)
+    _assert_relation(a, b, expect, FP32_TOL, f"oracle {relation} {shape}",
+                     scale_by=dict(dQ=4 * grow, dK=4 * grow, dV=grow, D=4.0, O=2.0, L=2.0))
+
+
 def test_c1_fixture_single_thread_and_all_cores():
     """BASELINE config 1 (forward, one head, N=128, D=64, fp32, CPU only): the committed fixture is reproduced bit for
     bit by one thread (the unparallelised reference's analogue) and by all host threads."""
@@ -131,3 +166,51 @@ def test_hip_bf16_reproduces_closed_forms(case, shape):
         scale = max(1.0, float(np.abs(e).max()))
         err = float(np.abs(np.asarray(got[name], np.float64) - e).max())
         assert err <= TOL_MIXED[name] * scale, f"HIP bf16 {case} {shape} {variants}: {name} err {err:.3e} (scale {scale:.3g})"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(128, 128, 64), (300, 520, 128), (4096, 4096, 128)])
+@pytest.mark.parametrize("relation", closed_form.RELATIONS)
+def test_hip_fp32_metamorphic_relations_on_random_inputs(relation, shape):
+    """The same relations between two launches of the HIP kernels on RANDOM fp32 inputs ((4096, 4096, 128) = BASELINE config 3)."""
+    R, C, D = shape
+    base, new, expect = closed_form.transform(relation, _random_inputs(R, C, D, seed=41), seed=R + D)
+    a, va = _device(base, R, C, D)
+    b, vb = _device(new, R, C, D)
+    grow = max(1.0, np.sqrt(max(R, C)) / 10.0)
+    tol = 0.0 if relation == "qk_rescale" else FP32_TOL
+    _assert_relation(a, b, expect, tol, f"HIP fp32 {relation} {shape} {va}",
+                     scale_by=dict(dQ=4 * grow, dK=4 * grow, dV=grow, D=4.0, O=2.0, L=2.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("shape", [(4096, 4096, 64), (4096, 4096, 128), (1000, 777, 256)])
+@pytest.mark.parametrize("relation", closed_form.RELATIONS)
+def test_hip_bf16_metamorphic_relations_on_random_inputs(relation, shape, low_mid):
+    """The 16-bit matrix-core kernels (BASELINE config 2's shape, the headline head dimension, the D = 256 kernels; both precision
+    modes): inputs and shift vectors on a 1/8 grid so that every transformed operand is exact in bf16.  qk_rescale must be
+    bit-identical (every product is scaled by an exact power of two, the folded scale included); the shifts move O / L / D by
+    the predicted amounts within the 16-bit kernels' own error (P rounded to bf16, tile order)."""
+    import harness
+    from test_attention_gpu import make_desc
+    from metal_flash_attention_amd import GEMMOperandPrecision as P
+    R, C, D = shape
+    base, new, expect = closed_form.transform(relation, _random_inputs(R, C, D, seed=51), seed=R + D, grid=0.125)
+    for x in list(base.values()) + list(new.values()):
+        assert np.array_equal(round_trip(x, int(P.BF16)), x), "operands must be exact in bf16"
+
+    def run(inputs):
+        desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.BF16)
+        r = harness.DeviceRun(desc, closed_form.FixedNetwork(inputs), seed=78)
+        out = r.execute()
+        assert all(r.tails_ok.values())
+        return out, [k.variant for k in r.kernels.values()]
+
+    a, va = run(base)
+    b, vb = run(new)
+    if relation == "qk_rescale":
+        _assert_relation(a, b, expect, 0.0, f"HIP bf16 {relation} {shape} {va}")
+    else:
+        _assert_relation(a, b, expect, dict(O=1.5e-2, L=2e-3 if low_mid else 1e-3, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2),
+                         f"HIP bf16 {relation} {shape} {va}", relative=True)

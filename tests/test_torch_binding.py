@@ -127,3 +127,25 @@ def test_strided_views_are_passed_without_a_copy(dtype, monkeypatch):
     orf.sum().backward()
     got = q2.grad[:, :, 0].permute(0, 2, 1, 3).float()
     assert (got - qr.grad).abs().max().item() < (6e-2 if dtype != torch.float32 else 5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fast_scale_selects_the_mixed_precision_streams(dtype):
+    """fast_scale=True = the reference's mixed-precision mode (lowPrecisionIntermediates): FOLD / pre-scaled streams, FP16 L and
+    BF16 D between forward and backward; same function, same tolerances.  The upstream gradient arrives as a strided view."""
+    from metal_flash_attention_amd import torch_binding as tb
+    from metal_flash_attention_amd import AttentionKernelType
+    B, H, R, C, D = 2, 3, 300, 449, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q, k, v = (torch.randn(B, H, n, D, generator=g, device="cuda").to(dtype).requires_grad_(True) for n in (R, C, C))
+    w = torch.randn(B, R, H, D, generator=g, device="cuda").to(torch.bfloat16).permute(0, 2, 1, 3)   # [B, H, R, D] view
+    o = tb.flash_attention(q, k, v, fast_scale=True)
+    assert tb._kernel(dtype, R, C, D, AttentionKernelType.forward, True).variant.endswith("_fold")
+    assert not tb._kernel(dtype, R, C, D, AttentionKernelType.forward, False).variant.endswith("_fold")
+    o.backward(w)
+    qr, kr, vr, orf = reference(q, k, v, False)
+    orf.backward(w.float())
+    assert (o.float() - orf).abs().max().item() < 3e-2
+    for got, ref, name in ((q.grad, qr.grad, "dQ"), (k.grad, kr.grad, "dK"), (v.grad, vr.grad, "dV")):
+        assert (got.float() - ref).abs().max().item() < 5e-2, name

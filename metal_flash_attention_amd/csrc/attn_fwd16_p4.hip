@@ -4,8 +4,14 @@
 
 namespace mfa {
 
+// persistent form (attn_fwd16_p4p.hip): dense launches without per-batch lengths; false = not served, launch this kernel
+template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args);
+
 template <typename T, int STREAM, bool CAUSAL>
 static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if constexpr (!CAUSAL && (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD)) {
+    if (launch_p4p<T, p4::stream_folds(STREAM)>(grid, stream, args)) return;
+  }
   Fwd16Grid g{grid.x, grid.y, grid.z};
   const uint32_t groups = CAUSAL ? (grid.x + 1) / 2 : grid.x;   // causal: one workgroup per pair of row blocks (last - i, i)
   hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, CAUSAL>), dim3(groups * grid.y * grid.z), dim3(256), p4::LDS_BYTES, stream, args, g);

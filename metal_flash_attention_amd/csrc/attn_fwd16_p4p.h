@@ -1,0 +1,134 @@
+// attn_fwd16_p4p.h -- PERSISTENT form of attn_fwd16_p4 (forward attention, D <= 128, 16-bit Q/K/V, four waves x 64 rows): one
+// workgroup per compute unit walks the 256-row blocks blockIdx, blockIdx + gridDim, ... and the block loop is INSIDE the
+// generated asm statement (tools/p4pgen.py -> attn_fwd16_p4p_stream.inc; the design and what it removes from the per-block
+// cost are in the generator's header and DESIGN.md 4.2.0).
+//
+//   reference: loopForward + createSetup / createCleanup, Sources/FlashAttention/Attention/AttentionKernel/
+//   AttentionKernel+Source.swift:158-200, +Caching.swift:286-425 -- same math as attn_fwd16_p4.h: the stream's tile
+//   traversal IS p4gen's; new are the block switch (next block's Q / K / V requested by LDS-DMA under the last two tiles), O / l
+//   and L = m + log2 l stored straight from the registers, and the block table.
+//
+// What is left to hipcc: the block table (64-byte entries in LDS: operand bases of the block's head, first row), the lane
+// constants of the LDS-DMA and store addressing, the scalar inputs.  Nothing is live after the statement.
+// Dense launches only (no causal mask, no per-batch lengths, no block mask): those keep attn_fwd16_p4.
+#pragma once
+#include "attn_fwd16_p4.h"
+#include "attn_fwd16_p4p_stream.inc"
+
+namespace mfa {
+namespace p4p {
+
+constexpr int QIMG = MFA_P4P_QIMG, TABLE = MFA_P4P_TABLE, TABLE_ENTRIES = MFA_P4P_TABLE_ENTRIES, LDS_BYTES = MFA_P4P_LDS_BYTES;
+
+#define MFA_P4P_ENUM(name, f16, fold, o16, l16) S_##name,
+enum : int { MFA_P4P_STREAM_LIST(MFA_P4P_ENUM) S_COUNT };
+#undef MFA_P4P_ENUM
+
+struct StreamTraits { bool f16, fold, o16, l16; };
+constexpr StreamTraits traits(int s) {
+#define MFA_P4P_TRAITS(name, f16, fold, o16, l16) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0};
+  MFA_P4P_STREAM_LIST(MFA_P4P_TRAITS)
+#undef MFA_P4P_TRAITS
+  return StreamTraits{false, false, false, false};
+}
+
+}  // namespace p4p
+
+#define MFA_P4P_RUN_STREAM(STREAM)                                                                                       \
+  asm volatile(STREAM                                                                                                    \
+               :                                                                                                         \
+               : [kbase] "v"(kbase), [vbase] "v"(vbase), [lim0] "v"(lim), [lim1] "v"(lim), [kv0] "v"(kv[0]), [kv1] "v"(kv[1]), \
+                 [kv2] "v"(kv[2]), [kv3] "v"(kv[3]), [vv] "v"(vv), [qv0] "v"(qv[0]), [qv1] "v"(qv[1]), [qv2] "v"(qv[2]),  \
+                 [qv3] "v"(qv[3]), [ov0] "v"(ov[0]), [ov1] "v"(ov[1]), [ov2] "v"(ov[2]), [ov3] "v"(ov[3]), [lv] "v"(lv),  \
+                 [ewa] "v"(ewa), [era] "v"(era),                                                                          \
+                 [nt] "s"(nt), [maskfrom] "s"(maskfrom), [scale2] "s"(a.scale2), [kinc] "s"(kinc), [vinc] "s"(vinc),      \
+                 [ldsk] "s"(ldsk), [ldsv] "s"(ldsv), [ldsq] "s"(ldsq), [qrel] "s"(qrel), [nblk] "s"(nblk), [tbl] "s"(tbl), \
+                 [wave64] "s"(wave64), [ldq2] "s"(ldq2), [ldo] "s"(ldob), [nrecq] "s"(nrecq), [nreck] "s"(nreck),         \
+                 [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl), [dr] "s"(dr)                                 \
+               : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_P4P_OWNED_VGPRS, MFA_P4P_OWNED_SGPRS)
+
+// T: __bf16 or _Float16 (must match the stream); STREAM: p4p::S_*.  `total` = row blocks x heads x batches; workgroup w of G
+// takes the blocks w, w + G, ... in fwd16_decode_block's order (G a multiple of 8: a workgroup stays with the heads of its XCD)
+template <typename T, int STREAM>
+__global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const Fwd16Grid grid, const uint32_t total, const uint32_t stagger) {
+  using namespace p4p;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr StreamTraits TR = traits(STREAM);
+  static_assert(TR.f16 == __is_same(T, _Float16), "stream and element type disagree");
+  constexpr int BC = 64, GROWS = 256;
+  constexpr uint32_t OOB = 0xFFFFFF00u;
+  const int tid = threadIdx.x;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
+  const uint32_t G = gridDim.x, first = blockIdx.x;
+  if (first >= total) return;
+  const uint32_t nblk = (total - first + G - 1) / G;   // <= TABLE_ENTRIES (the launcher sizes the grid)
+
+  // ---- block table: what attn_fwd16_p4 decodes per workgroup, once per block of this workgroup
+  uint32_t *table = reinterpret_cast<uint32_t *>(smem + TABLE);
+  for (uint32_t n = tid; n < nblk; n += 256) {
+    uint32_t rblk, head, batch;
+    fwd16_decode_block(grid, first + n * G, &rblk, &head, &batch);
+    const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
+                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
+                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
+    uint32_t *e = table + 16 * n;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
+    e[10] = rblk * GROWS;
+  }
+  __syncthreads();
+  // desynchronise the compute units: blocks that end in lockstep store 32 MB at once and the next block's loads queue
+  // behind them (profiles/r02_fwd16p4_block_overhead_persistent_experiment.txt)
+  for (uint32_t i = 0; i < (stagger & 0xFFFFu) * ((first >> 3) & 31u); ++i) __builtin_amdgcn_s_sleep(8);   // 512 clocks per step
+
+  const uint32_t R = a.R, C = a.C, dr = a.D;
+  const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2, ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
+  constexpr uint32_t OSZ = TR.o16 ? 2 : 4, LSZ = TR.l16 ? 2 : 4;
+  const uint32_t ldob = (uint32_t)a.op[SLOT_O].ld * OSZ;
+  const uint32_t nrecq = R * ldq2, nreck = C * ldk2, nrecv = C * ldv2, nreco = R * ldob, nrecl = R * LSZ;
+  const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
+  // a block walks an EVEN number of key tiles (an odd count gets one fully masked tile): the two K images and the score-tile
+  // parity then line up from block to block.  Tiles from `maskfrom` on hold keys >= C (maskAttentionMatrixEdge, +Softmax.swift:228-260)
+  uint32_t nt = (C + BC - 1) / BC;
+  nt += nt & 1u;
+  const uint32_t maskfrom = C / BC;
+  const int lim = (int)C - 1 - 4 * hi;   // register r of a lane covers key (r & 3) + 8 (r >> 2) + 4 hi of its 32-key block
+
+  // ---- lane parts of the LDS-DMA source offsets (the stream adds the scalar parts: first row of the piece x leading dimension).
+  // Piece i of a K-shaped image (K tiles, the wave's Q image): 16-byte position p = i * 64 + lane holds row p >> 4, chunk
+  // (p & 15) ^ (row & 15); a V image holds [D/32][64 keys][32 d] sub-tiles (attn_fwd16_p4.h)
+  uint32_t kv[4], qv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t kc = (lane & 15) ^ ((4 * i + (lane >> 4)) & 15);
+    kv[i] = kc * 8 < dr ? (uint32_t)(lane >> 4) * ldk2 + kc * 16 : OOB;
+    qv[i] = kc * 8 < dr ? (uint32_t)(lane >> 4) * ldq2 + kc * 16 : OOB;
+  }
+  const uint32_t vc = wave * 4 + (lane & 3);
+  const uint32_t vv = vc * 8 < dr ? (uint32_t)(lane >> 2) * ldv2 + vc * 16 : OOB;
+  // stores: a 32 x 32 block of O^T goes through a 4 KiB slice of LDS (in: lane = row q, 16-byte chunk (2 g + hi) ^ (q & 7) of
+  // its 128-byte row; out: lane = (row & 7, chunk)), so that eight lanes cover one 128-byte line of a row; columns >= D are out of range
+  const uint32_t row8 = lane >> 3, chunk = lane & 7;
+  const uint32_t ewa = (uint32_t)q * 128 + ((hi ^ (q & 7)) << 4), era = row8 * 128 + ((chunk ^ row8) << 4);
+  uint32_t ov[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const uint32_t col = 32 * db + 4 * chunk;
+    ov[db] = col < dr ? row8 * ldob + col * OSZ : OOB;
+  }
+  const uint32_t lv = hi == 0 ? (uint32_t)q * LSZ : OOB;   // L: one lane per row
+
+  const uint32_t lds0 = lds_addr(smem);
+  const uint32_t kbase = lds0 + q * 256 + ((hi ^ (q & 15)) << 4);
+  const int n16 = lane & 15;
+  const uint32_t vbase = lds0 + p4::VBASE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
+  const uint32_t ldsk = lds0 + wave * 4096, ldsv = lds0 + p4::VBASE + wave * 4096;
+  const uint32_t qrel = QIMG + wave * 16384, ldsq = lds0 + qrel, tbl = lds0 + TABLE, wave64 = wave * 64;
+
+#define MFA_P4P_RUN(name, f16, fold, o16, l16) if constexpr (STREAM == S_##name) MFA_P4P_RUN_STREAM(MFA_P4P_STREAM_##name);
+  MFA_P4P_STREAM_LIST(MFA_P4P_RUN)
+#undef MFA_P4P_RUN
+}
+
+} // namespace mfa

@@ -1,0 +1,94 @@
+// attn_fwd16_p4p.hip -- instantiations and launcher of the persistent four-wave forward kernel (attn_fwd16_p4p.h).
+#include "attn_fwd16_p4p.h"
+#include "launchers.h"
+
+#include <cstdlib>
+#include <mutex>
+
+namespace mfa {
+
+// sleep steps (x 512 clocks) per unit of (workgroup >> 3) & 31 in front of a workgroup's first block
+#ifndef P4P_STAGGER
+#define P4P_STAGGER 0
+#endif
+
+namespace {
+
+struct DeviceInfo { int cus = 0; uint64_t attrMask[p4p::S_COUNT * 2] = {}; };
+std::mutex g_mutex;
+DeviceInfo g_devices[64];
+
+template <typename T, int STREAM>
+bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return false;
+  int cus;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    DeviceInfo &d = g_devices[device];
+    if (d.cus == 0) {
+      int n = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n <= 0) return false;
+      d.cus = n;
+    }
+    cus = d.cus;
+    constexpr int slot = STREAM * 2 + (__is_same(T, _Float16) ? 1 : 0);
+    if (!d.attrMask[slot]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_fwd16_p4p<T, STREAM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              p4p::LDS_BYTES) != hipSuccess)
+        return false;
+      d.attrMask[slot] = 1;
+    }
+  }
+  const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
+  // one workgroup per compute unit; more only when a workgroup's share would not fit the block table.  A multiple of 8 keeps
+  // fwd16_decode_block's head -> XCD affinity for every block of a workgroup
+  uint64_t groups = total < (uint64_t)cus ? total : (uint64_t)cus;
+  if ((total + groups - 1) / groups > (uint64_t)p4p::TABLE_ENTRIES) groups = (total + p4p::TABLE_ENTRIES - 1) / p4p::TABLE_ENTRIES;
+  if (groups >= 8) groups = (groups + 7) / 8 * 8;
+  if (groups > total) groups = total;
+  if ((total + groups - 1) / groups > (uint64_t)p4p::TABLE_ENTRIES) return false;
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  uint32_t stagger = P4P_STAGGER;
+#ifdef MFA_DEV_VARIANTS
+  if (const char *e = std::getenv("MFA_P4P_STAGGER")) stagger = (uint32_t)std::atoi(e);
+#endif
+  hipLaunchKernelGGL((attn_fwd16_p4p<T, STREAM>), dim3((uint32_t)groups), dim3(256), p4p::LDS_BYTES, stream, args, g, (uint32_t)total, stagger);
+  return true;
+}
+
+}  // namespace
+
+// Dense launch of a D <= 128 forward problem on the persistent kernel.  Returns false when the launch is not one it serves
+// (the caller then launches attn_fwd16_p4): per-batch lengths, a storage type of O / L no stream was generated for.
+template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if (args.causal || args.rowLen || args.colLen || args.mask) return false;
+#ifdef MFA_DEV_VARIANTS   // developer builds: A/B against the one-block-per-workgroup kernel, phase clocks (tools/p4p_prof.py)
+  if (std::getenv("MFA_P4_NO_PERSISTENT")) return false;
+  if constexpr (!FOLD && __is_same(T, __bf16)) {
+    if (std::getenv("MFA_P4P_PROF") && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == PREC_FP32)
+      return launch_stream<T, p4p::S_BF16_EXACT_PROF>(grid, stream, args);
+  }
+#endif
+  const int po = args.op[SLOT_O].precision, pl = args.op[SLOT_L].precision;
+  constexpr int PT = __is_same(T, _Float16) ? PREC_FP16 : PREC_BF16;
+  const bool o16 = po == PT, l16 = pl == PREC_FP16;
+  if (!o16 && po != PREC_FP32) return false;
+  if (!l16 && pl != PREC_FP32) return false;
+  if constexpr (FOLD) {
+    if (!l16) return false;   // (FOLD streams exist with FP16 L: the mixed-precision mode's storage type)
+    if constexpr (__is_same(T, _Float16)) return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16>(grid, stream, args);
+    else return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16>(grid, stream, args);
+  } else {
+    if (l16) return false;
+    if constexpr (__is_same(T, _Float16)) return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT>(grid, stream, args);
+    else return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT>(grid, stream, args);
+  }
+}
+
+template bool launch_p4p<__bf16, true>(dim3, hipStream_t, const KernelArgs &);
+template bool launch_p4p<__bf16, false>(dim3, hipStream_t, const KernelArgs &);
+template bool launch_p4p<_Float16, true>(dim3, hipStream_t, const KernelArgs &);
+template bool launch_p4p<_Float16, false>(dim3, hipStream_t, const KernelArgs &);
+
+} // namespace mfa

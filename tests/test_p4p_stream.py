@@ -1,0 +1,117 @@
+"""CPU checks of the PERSISTENT forward stream (tools/p4pgen.py -> csrc/attn_fwd16_p4p_stream.inc) on the lane-exact model
+(tools/p4psim.py): one workgroup walks several 256-row blocks inside ONE instruction stream -- block table in LDS, the next
+block's Q / K / V requested by LDS-DMA under the last two tiles, O / l and L = m + log2 l stored from the registers behind a
+`vmcnt(34)` -- and every row of every block must equal a float64 attention (Network.swift:134-200 in matrix form).  No GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import p4pgen  # noqa: E402
+import p4psim  # noqa: E402
+
+FOLD = p4pgen.VARIANTS["BF16_FOLD_L16"]
+EXACT = p4pgen.VARIANTS["BF16_EXACT"]
+
+
+def _check(H, R, C, cfg=FOLD, blocks=None, seed=0, D=128, spike=None, tol_o=None, **kw):
+    rng = np.random.default_rng(seed)
+    f16 = cfg.dtype == "f16"
+    q, k, v = (p4psim.rand_bf16(s, rng, f16=f16) for s in ((H, R, D), (H, C, D), (H, C, D)))
+    if spike is not None:   # one key aligned with one query of head 0: forces the deferred rescale at a chosen tile
+        qrow, krow, gain = spike
+        qf = p4psim.h16_to_f32(q[0, qrow].astype(np.uint32), f16)
+        k[0, krow] = p4psim.f32_to_h16((qf * gain).astype(np.float32), f16).astype(np.uint16)
+    nrb = (R + 255) // 256
+    if blocks is None:
+        blocks = [(h, rb) for h in range(H) for rb in range(nrb)]
+    O, L, wg, raw = p4psim.run_workgroup(q, k, v, blocks, cfg, D=D, **kw)
+    tol_o = tol_o or ((3e-2 if not f16 else 4e-3) if cfg.o16 else 4e-3)
+    tol_l = (2e-2 if cfg.l16 else 2e-5) + (6e-4 if f16 else 5e-3) * bool(cfg.fold)
+    pad = lambda x: np.concatenate([x, np.zeros(x.shape[:-1] + (128 - D,), x.dtype)], axis=-1) if D < 128 else x
+    for h, rb in blocks:
+        Oref, Lref = p4psim.reference(q[h], k[h], v[h], f16=f16)
+        rows = slice(rb * 256, min(R, rb * 256 + 256))
+        dO, dL = np.abs(O[h, rows] - Oref[rows]).max(), np.abs(L[h, rows] - Lref[rows]).max()
+        assert dO < tol_o and dL < tol_l * max(1.0, np.abs(Lref[rows]).max() / 8), (h, rb, dO, dL)
+    return wg, raw, (q, k, v)
+
+
+@pytest.mark.parametrize("C", [1, 64, 128, 192, 449])
+def test_tile_counts_even_and_odd(C):
+    """an odd tile count walks one extra, fully masked tile; C <= 64 walks two"""
+    _check(2, 256, C)
+
+
+@pytest.mark.parametrize("H,R,C", [(1, 700, 130), (3, 200, 100), (2, 300, 320)])
+def test_ragged_rows_and_keys(H, R, C):
+    _check(H, R, C, seed=1)
+
+
+@pytest.mark.parametrize("dma_mode", ["early", "late"])
+@pytest.mark.parametrize("stores", ["early", "late"])
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 2, 1, 0)])
+def test_ring_and_store_discipline(dma_mode, stores, order):
+    """LDS-DMA data landing as early / as late as the waits allow, stores reaching memory at issue / only when a wait retires
+    them, waves running ahead of / behind each other -- three blocks, so two block switches"""
+    _check(3, 256, 256, dma_mode=dma_mode, stores=stores, order=order, seed=2)
+
+
+def test_blocks_out_of_order_and_single_block():
+    """the table decides which block comes next (fwd16_decode_block's order is not ascending rows)"""
+    _check(2, 512, 192, blocks=[(1, 1), (0, 0), (1, 0), (0, 1)], seed=3)
+    _check(1, 256, 320, blocks=[(0, 0)], seed=3)
+
+
+def test_untouched_blocks_keep_their_bytes():
+    """a workgroup writes the rows of ITS blocks only; rows beyond R and L of other blocks stay as they were"""
+    wg, (om, lm), _ = _check(2, 300, 128, blocks=[(1, 0)], seed=4)
+    o = om.view(np.float32).reshape(2, 300, 128)
+    assert (om.reshape(2, 300, 512)[0] == 0xCD).all() and (om.reshape(2, 300, 512)[1, 256:] == 0xCD).all()
+    assert np.isfinite(o[1, :256]).all()
+    l = lm.view(np.uint16).reshape(2, 300)
+    assert (l[0] == 0xCDCD).all() and (l[1, 256:] == 0xCDCD).all() and (l[1, :256] != 0xCDCD).any()
+
+
+@pytest.mark.parametrize("cfg", [FOLD, EXACT], ids=["fold", "exact"])
+def test_deferred_rescale_in_a_later_block(cfg):
+    """cdna_hip_programming.md T13 across a block switch: the spike sits in the SECOND block of head 0"""
+    wg, _, _ = _check(1, 512, 320, cfg=cfg, spike=(300, 200, 3.0), seed=5, tol_o=1.2e-2)
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 2 * 128 + 128   # two epilogues + at least one rescale
+
+
+@pytest.mark.parametrize("name", sorted(p4pgen.PRODUCT_STREAMS))   # (the PROF stream adds clock stamps only)
+def test_every_compiled_stream(name):
+    _check(2, 256, 200, cfg=p4pgen.VARIANTS[name], seed=6)
+
+
+@pytest.mark.parametrize("D", [72, 96, 120])
+@pytest.mark.parametrize("name", ["BF16_FOLD_L16", "BF16_EXACT_O16"])
+def test_head_dimensions_below_the_bucket(D, name):
+    """D < 128: chunks beyond D are fetched out of range (zeros) and the stores of columns >= D are issued out of range --
+    the count of stores per block (what vmcnt(34) relies on) does not change; bytes beyond column D stay untouched"""
+    cfg = p4pgen.VARIANTS[name]
+    wg, (om, lm), _ = _check(2, 256, 192, cfg=cfg, D=D, seed=7, ld=128)
+    osz = 2 if cfg.o16 else 4
+    assert (om.reshape(2, 256, 128 * osz)[:, :, D * osz:] == 0xCD).all()
+    assert wg.waves[0].count["buffer_store_dwordx2" if cfg.o16 else "buffer_store_dwordx4"] == 2 * 32
+
+
+def test_stream_file_is_current():
+    """csrc/attn_fwd16_p4p_stream.inc is what tools/p4pgen.py generates"""
+    path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4p_stream.inc")
+    import tempfile
+    with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:
+        p4pgen.write_inc(tmp.name)
+        assert open(path).read() == open(tmp.name).read(), "run python tools/p4pgen.py"
+
+
+def test_stores_per_block_match_the_wait():
+    """every block issues exactly NST vector-memory stores per wave: the vmcnt(NST) waits of the next block's first tiles then
+    cover every LDS-DMA piece requested before them"""
+    wg, _, _ = _check(3, 256, 128, seed=8)
+    w = wg.waves[0]
+    stores = sum(w.count.get(op, 0) for op in ("buffer_store_dwordx4", "buffer_store_dwordx2", "buffer_store_dword", "buffer_store_short"))
+    assert stores == 3 * p4pgen.NST

@@ -366,6 +366,8 @@ class Stream:
             if cfg.dma == "b":
                 at(0, lambda: self.vwr_update())
             at(1, lambda: self.vrd_advance())
+            if getattr(self, "persistent", False):   # tools/p4pgen.py: the last tiles' LDS-DMA pieces belong to the next block
+                self.b_hook(at, par, mfma)
         for g in range(32):
             if mfma:
                 u, db, rb = g // 8, (g % 8) // 2, g % 2
@@ -662,6 +664,8 @@ def fmt(o):
         return "%%[%s]" % o[1]
     if k == "S":
         return "%%[%s]" % o[1]
+    if k == "sr":       # a fixed scalar register (persistent streams, tools/p4pgen.py)
+        return "s%d" % o[1] if o[2] == 1 else "s[%d:%d]" % (o[1], o[1] + o[2] - 1)
     if k == "vcc_lo":
         return "vcc_lo"
     if k == "i":

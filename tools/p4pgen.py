@@ -1,0 +1,585 @@
+#!/usr/bin/env python3
+"""Generator of the PERSISTENT instruction stream of the D <= 128 forward kernel (csrc/attn_fwd16_p4p.h).
+
+attn_fwd16_p4 (tools/p4gen.py) keeps the traversal of ONE 256-row block in an asm statement and pays the block's fixed
+cost in the open: argument decoding, the Q loads, the first three LDS-DMA tiles, the epilogue through LDS and the drain of
+its stores -- 28.5 k of a 64-tile block's 211 k shader clocks, because a kernel that owns all 512 registers
+runs one workgroup per compute unit.  Here the BLOCK LOOP is inside the statement: one workgroup per compute unit walks the
+blocks `blockIdx, blockIdx + gridDim, ...` and
+
+  * the first three K / V tiles of block n + 1 are simply the ring's next tiles: the LDS-DMA fillers of block n's last two
+    tiles switch to the next block's descriptors (K in phase B(nt - 2), V in B(nt - 1));
+  * Q of block n + 1 arrives by LDS-DMA in images of its own (4 x 16 KiB behind the ring), requested in B(nt - 1);
+  * O of block n leaves the accumulator registers directly: 1 / l, 32 buffer stores per wave (lane = row, four consecutive
+    d per register group), L = m + log2 l; nothing passes through LDS and nothing waits for the stores -- gfx950 counts
+    loads and stores in one in-order vmcnt, so the first waits of block n + 1 are `vmcnt(34)`: every LDS-DMA piece older
+    than the 34 stores has landed;
+  * what hipcc did per workgroup (block decode, descriptors) is a table of 64-byte entries in LDS that the C++ prologue
+    fills once per workgroup; the stream reads entry n + 1 while block n starts.
+
+The tile traversal itself is p4gen's (phase tables, register map, ring discipline, deferred rescale); a block always walks
+an EVEN number of tiles (an odd count gets one fully masked tile), so the two K images and the score-tile parity line up
+from block to block.  Dense launches only (no causal mask, no per-batch lengths, no block mask): those keep attn_fwd16_p4.
+
+Registers the statement owns beyond p4gen's map:
+    v28..v31    m0, m1, l0, l1
+    v248..v255  LDS-DMA offsets koff0..3, voff0..3 (exact-scale streams: v160..v167, their -m blocks are unused)
+    s40..s99    descriptors, block state, loop counters (PSGPR below); hipcc passes inputs only, nothing is live after it
+
+The same instruction list runs on the lane-exact model (tools/p4psim.py, tests/test_p4p_stream.py): several blocks per
+workgroup, LDS-DMA landing early / late, stores retiring late.
+
+Usage: python tools/p4pgen.py   (rewrites metal_flash_attention_amd/csrc/attn_fwd16_p4p_stream.inc)
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import p4gen  # noqa: E402
+from p4gen import (A, F, I, M0, SN, V, VCC, VN, Cfg, Ins, Stream, KSLOT, VBASE, VSLOT, VRING, O_BASE, Q_BASE, CM_BASE,  # noqa: E402
+                   T_KADDR, T_LB, T_CORR, T_MX, T_MN, T_SW, T_TL, T_MASKV, S_BASE)
+
+QIMG = VBASE + VRING * VSLOT          # 80 KiB: the four waves' Q images (16 KiB each)
+TABLE = QIMG + 4 * 16384              # 144 KiB: block table, 64 bytes per entry
+TABLE_ENTRIES = 256
+LDS_BYTES = TABLE + TABLE_ENTRIES * 64
+assert LDS_BYTES == 160 * 1024
+NST = 34                               # buffer stores per wave and block: 32 x O, 2 x L
+DESC_FLAGS = 0x00020000                # raw buffer, 32-bit data format (the words hipcc's make_buffer_rsrc uses)
+OOB = 0xFFFFFF00
+
+
+def SR(n, cnt=1):
+    return ("sr", n, cnt)
+
+
+# ---------------------------------------------------------------- fixed scalar registers (clobbered by the statement)
+PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
+             qbn=(56, 2), kbn=(58, 2), vbn=(60, 2), obn=(62, 2), lbn=(64, 2), row0n=(66, 1),
+             ob=(68, 2), lb=(70, 2), row0=(72, 1), blk=(73, 1), hasnext=(74, 1), ntm1=(75, 1), ntm2=(76, 1),
+             j=(77, 1), vrd=(78, 1), vwr=(79, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
+             kc0=(86, 1), kc1=(87, 1), kc2=(88, 1), kc3=(89, 1), vc0=(90, 1), vc1=(91, 1), vc2=(92, 1), vc3=(93, 1),
+             q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1))
+FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 100
+
+# inputs of the statement (hipcc allocates them below s40 / v28)
+IN_V = ["kbase", "vbase", "lim0", "lim1", "kv0", "kv1", "kv2", "kv3", "vv", "qv0", "qv1", "qv2", "qv3", "ov0", "ov1", "ov2", "ov3",
+        "lv", "ewa", "era"]
+IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qrel", "nblk", "tbl", "wave64", "ldq2", "ldo",
+        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "dr"]
+
+
+class PCfg(Cfg):
+    """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
+
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0):
+        Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb)
+        self.o16, self.l16 = o16, l16
+        # pprof (developer builds, exact-scale streams only: their -m blocks v168.. are free): shader-clock sums per segment of
+        # the block loop in v168..v183, written to O[first row of the wave's last block][0:16] when the workgroup ends
+        self.pprof = pprof
+        assert not (pprof and fold)
+
+
+PROF_ACC = 168
+PROF_MAGIC = 0x50524F46
+PROF_NAMES = ["table", "wait_q", "qfrag", "tile0_a", "tile0_b", "loop_a", "loop_wait", "loop_b", "tile1_wait", "tail", "epilogue", "blocks"]
+
+
+def s(name, cnt=None, off=0):
+    base, n = PSGPR[name]
+    return SR(base + off, n if cnt is None else cnt)
+
+
+class PStream(Stream):
+    persistent = True
+
+    def __init__(self, cfg):
+        Stream.__init__(self, cfg)
+        dma_base = 248 if cfg.fold else 160
+        self.vfixed = {"m0": 28, "m1": 29, "l0": 30, "l1": 31}
+        for i in range(4):
+            self.vfixed["koff%d" % i] = dma_base + i
+            self.vfixed["voff%d" % i] = dma_base + 4 + i
+
+    # ---- operand mapping: p4gen's named temporaries become fixed registers
+    def finish(self):
+        def m(o):
+            if o is None:
+                return None
+            if o[0] == "V" and o[1] in self.vfixed:
+                return V(self.vfixed[o[1]])
+            if o[0] == "S" and o[1] in PSGPR:
+                base, n = PSGPR[o[1]]
+                return SR(base, o[2] if len(o) > 2 else n)
+            return o
+        for ins in self.ins:
+            ins.d = m(ins.d)
+            ins.s = tuple(m(x) for x in ins.s)
+        return self.ins
+
+    # ---- hooks called by p4gen.Stream.phase_b
+    def b_hook(self, at, par, mfma):
+        """phase B(j) of the persistent stream: the LDS-DMA pieces of the block's last two tiles belong to the NEXT block"""
+        ksw, vsw = self.newlabel("KSW"), self.newlabel("VSW")
+
+        def check(reg, lbl):
+            self.emit("s_cmp_eq_u32", None, [SN("j"), s(reg)])
+            self.emit("s_cbranch_scc1", None, [], target=lbl)
+            self.label(lbl + "_BACK")
+        at(16, lambda: check("ntm2", ksw))
+        at(17, lambda: check("ntm1", vsw))
+        self.outofline.append(("ksw", ksw, ksw + "_BACK", par, False))
+        self.outofline.append(("vsw", vsw, vsw + "_BACK", par, False))
+
+    def pstamp(self, name, first=False):
+        """developer streams: add the shader-clock time since the previous stamp to accumulator `name` (s_memtime returns
+        through lgkmcnt: a stamp sits only where no LDS read is in flight)"""
+        if not self.cfg.pprof:
+            return
+        self.emit("s_memtime", SR(98, 2))
+        self.emit("s_waitcnt", None, [], lgkmcnt=0)
+        self.lds_done = self.lds_issued
+        if not first:
+            self.emit("s_sub_u32", s("t3"), [SR(98), s("plast")])
+            acc = V(PROF_ACC + PROF_NAMES.index(name))
+            self.emit("v_add_u32", acc, [s("t3"), acc])
+        self.emit("s_mov_b32", s("plast"), [SR(98)])
+
+    def lds_write(self, op, addr, data, offset):
+        """LDS writes share the in-order LDS queue (and lgkmcnt) with the reads"""
+        self.emit(op, None, [addr, data], offset=offset)
+        self.lds_issued += 1
+
+    # ---- pieces
+    def desc(self, name, base, nrec):
+        """128-bit buffer resource `name` = (64-bit base in SGPR pair `base`, byte count `nrec`)"""
+        self.emit("s_mov_b32", s(name, 1, 0), [s(base, 1, 0)])
+        self.emit("s_and_b32", s(name, 1, 1), [s(base, 1, 1), I(0xFFFF)])
+        self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
+        self.emit("s_mov_b32", s(name, 1, 3), [I(DESC_FLAGS)])
+
+    def load_next(self):
+        """entry `blk` of the block table -> the *n registers (Q, K, V, O, L bases and the first row of the block)"""
+        tv, tb = 96, 100                       # address register, twelve data registers v100..v111 (score tile, free here)
+        self.emit("s_lshl_b32", s("t0"), [s("blk"), I(6)])
+        self.emit("s_add_u32", s("t0"), [s("t0"), SN("tbl")])
+        self.emit("v_mov_b32", V(tv), [s("t0")])
+        ids = [self.lds_read("ds_read_b128", V(tb + 4 * i, 4), V(tv), 16 * i, note="block table") for i in range(3)]
+        self.lds_need(ids[-1])
+        self.lds_flush()
+        for i, (name, off) in enumerate((("qbn", 0), ("qbn", 1), ("kbn", 0), ("kbn", 1), ("vbn", 0), ("vbn", 1), ("obn", 0),
+                                         ("obn", 1), ("lbn", 0), ("lbn", 1), ("row0n", 0))):
+            self.emit("v_readfirstlane_b32", s(name, 1, off), [V(tb + i)])
+        self.emit("s_nop", None, [I(4)], note="v_readfirstlane -> SALU / VMEM use of the scalar")
+
+    def switch_k(self):
+        self.emit("s_mov_b32", s("kres", 1, 0), [s("kbn", 1, 0)])
+        self.emit("s_and_b32", s("kres", 1, 1), [s("kbn", 1, 1), I(0xFFFF)])
+        for i in range(4):
+            self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("kv%d" % i), s("kc%d" % i)], clamp=1)
+
+    def switch_v(self):
+        self.emit("s_mov_b32", s("vres", 1, 0), [s("vbn", 1, 0)])
+        self.emit("s_and_b32", s("vres", 1, 1), [s("vbn", 1, 1), I(0xFFFF)])
+        for i in range(4):
+            self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("vv"), s("vc%d" % i)], clamp=1)
+
+    def issue_q(self, temps):
+        """the wave's 64 rows of the next block's Q by LDS-DMA into its own image: piece i = rows 4 i .. 4 i + 3"""
+        self.desc("tres", "qbn", "nrecq")
+        self.emit("s_add_u32", s("t0"), [s("row0n"), SN("wave64")])
+        self.emit("s_mul_i32", s("qrow"), [s("t0"), SN("ldq2")])
+        for i in range(16):
+            t = V(temps[i % len(temps)])
+            self.emit("v_add_u32_e64", t, [VN("qv%d" % (i & 3)), s("qrow")], clamp=1)
+            self.emit("s_add_u32", M0, [SN("ldsq"), I(i * 1024)])
+            self.emit("buffer_load_dwordx4_lds", None, [t, s("tres", 4)])
+            if i != 15:
+                self.emit("s_add_u32", s("qrow"), [s("qrow"), s("q4")])
+
+    def issue_tile(self, which, image, advance=True):
+        for i in range(4):
+            if which == "k":
+                self.emit("s_add_u32", M0, [SN("ldsk"), I(image * KSLOT + i * 1024)])
+                self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), s("kres", 4)])
+            else:
+                self.emit("s_add_u32", M0, [SN("vwr"), I(i * 1024)])
+                self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), s("vres", 4)])
+        for i in range(4):
+            if which == "k":
+                self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1)
+            else:
+                self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1)
+
+    def q_fragments(self):
+        """Q image -> B-operand fragments a[128:191] (FOLD: times log2(e)/sqrt(D), rounded to the 16-bit type)"""
+        cfg = self.cfg
+        qa, qd = 96, 32                         # eight addresses v96..v103, 64 data registers v32..v95
+        for ks in range(8):
+            self.emit("v_add_u32", V(qa + ks), [SN("qrel"), V(T_KADDR + ks)])
+        ids = []
+        for b in range(2):
+            for ks in range(8):
+                ids.append(self.lds_read("ds_read_b128", V(qd + 4 * (8 * b + ks), 4), V(qa + ks), b * 8192, note="Q(%d,%d)" % (b, ks)))
+        t0, t1 = V(104), V(105)
+        for n in range(16):
+            self.lds_need(ids[n])
+            for w in range(4):
+                x = V(qd + 4 * n + w)
+                if cfg.fold:
+                    if cfg.dtype == "bf16":
+                        self.emit("v_lshlrev_b32", t0, [I(16), x])
+                        self.emit("v_and_b32", t1, [I(0xFFFF0000), x])
+                    else:
+                        self.emit("v_cvt_f32_f16", t0, [x])
+                        self.emit("v_lshrrev_b32", t1, [I(16), x])
+                        self.emit("v_cvt_f32_f16", t1, [t1])
+                    self.emit("v_mul_f32", t0, [SN("scale2"), t0])
+                    self.emit("v_mul_f32", t1, [SN("scale2"), t1])
+                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, x, [t0, t1])
+                self.emit("v_accvgpr_write_b32", A(Q_BASE + 4 * n + w), [x])
+        self.lds_flush()
+
+    def epilogue(self):
+        """O /= l (+Source.swift:165-171) and L = m + log2 l (+Caching.swift:373-377), straight from the registers"""
+        cfg = self.cfg
+        self.emit("s_nop", None, [I(15)], note="the last accumulating MFMAs leave the matrix pipe")
+        self.emit("s_nop", None, [I(7)])
+        self.desc("tres", "ob", "nreco")
+        self.desc("lres", "lb", "nrecl")
+        ltot, inv, ta, tb = (T_MX, T_MX + 1), (T_MN, T_MN + 1), V(T_SW), V(T_SW + 1)
+        for rb in range(2):
+            lt, iv = V(ltot[rb]), V(inv[rb])
+            self.emit("v_mov_b32", ta, [VN("l%d" % rb)])
+            self.emit("v_mov_b32", tb, [VN("l%d" % rb)])
+            self.emit("s_nop", None, [I(1)], note="VALU write -> permlane read")
+            self.emit("v_permlane32_swap_b32", ta, [tb], swap=1)
+            self.emit("v_add_f32", lt, [ta, tb])
+            self.emit("v_add_f32", lt, [I(1), lt], note="+ denorm_min (+Caching.swift:311)")
+            self.emit("v_rcp_f32", iv, [lt])
+            self.emit("s_nop", None, [I(0)], note="trans -> VALU")
+            self.emit("v_fma_f32", ta, [lt, iv, F(1.0)], neg0=1)      # e = 1 - l r
+            self.emit("v_fma_f32", iv, [ta, iv, iv])                   # r += e r
+            self.emit("v_cmp_lt_f32", VCC, [F(1e-30), lt])
+            self.emit("v_cndmask_b32", iv, [I(0), iv, VCC])            # a row without keys: O = 0
+        # O leaves through a 4 KiB slice of LDS per wave (its share of the V image the ring is not using: the one after V'(0)'s),
+        # one 32 x 32 block at a time: lane = row with four consecutive columns per register group goes in (16-byte chunks,
+        # chunk index XOR row & 7), lane = (row & 7, chunk) comes out -- eight lanes then cover one 128-byte line of a row and a
+        # store instruction touches 8 lines instead of 32 (measured: 3.4 k instead of 9.0 k clocks per block for the 32 stores)
+        vo = V(T_TL)
+        wa, ra = [T_CORR, T_CORR + 1, T_LB, T_LB + 1], T_MASKV     # (re-initialised by the next block / dead after the loop)
+        self.emit("s_add_u32", s("t2"), [SN("vwr"), I(VSLOT)])
+        self.emit("s_cmp_ge_u32", None, [s("t2"), SN("t1")])
+        self.emit("s_cselect_b32", s("t2"), [SN("ldsv"), s("t2")])
+        for g in range(4):
+            if g:
+                self.emit("v_xor_b32", V(wa[g]), [I(g << 5), VN("ewa")])
+                self.emit("v_add_u32", V(wa[g]), [s("t2"), V(wa[g])])
+            else:
+                self.emit("v_add_u32", V(wa[g]), [s("t2"), VN("ewa")])
+        self.emit("v_add_u32", V(ra), [s("t2"), VN("era")])
+        self.emit("s_lshl_b32", s("t4"), [SN("ldo"), I(3)])          # eight rows
+        pending = None
+
+        def stores(blk):
+            rb, db, dst, ids = blk
+            self.lds_need(ids[-1])
+            for k in range(4):
+                if k == 0:
+                    self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
+                    if rb:
+                        self.emit("s_add_u32", s("t0"), [s("t0"), I(32)])
+                    self.emit("s_mul_i32", s("t0"), [s("t0"), SN("ldo")])
+                else:
+                    self.emit("s_add_u32", s("t0"), [s("t0"), s("t4")])
+                self.emit("v_add_u32_e64", vo, [VN("ov%d" % db), s("t0")], clamp=1)
+                if cfg.o16:
+                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k), [V(dst + 4 * k), V(dst + 4 * k + 1)])
+                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k + 1), [V(dst + 4 * k + 2), V(dst + 4 * k + 3)])
+                    self.emit("buffer_store_dwordx2", None, [V(dst + 4 * k, 2), vo, s("tres", 4)], offset=0)
+                else:
+                    self.emit("buffer_store_dwordx4", None, [V(dst + 4 * k, 4), vo, s("tres", 4)], offset=0)
+
+        for b in range(8):
+            rb, db = divmod(b, 4)
+            src, dst = S_BASE[0] + 16 * (b & 3), S_BASE[1] + 16 * (b & 3)
+            for r in range(16):
+                self.emit("v_accvgpr_read_b32", V(src + r), [A(O_BASE + 16 * b + r)])
+            for r in range(16):
+                self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])
+            for g in range(4):
+                self.lds_write("ds_write_b128", V(wa[g]), V(src + 4 * g, 4), 0)
+            ids = [self.lds_read("ds_read_b128", V(dst + 4 * k, 4), V(ra), 1024 * k, note="O(%d,%d) rows %d.." % (rb, db, 8 * k)) for k in range(4)]
+            if pending is not None:
+                stores(pending)
+            pending = (rb, db, dst, ids)
+        stores(pending)
+        self.lds_flush()
+        for rb in range(2):
+            x = V(T_SW + rb)
+            self.emit("v_log_f32", x, [V(ltot[rb])])
+            self.emit("s_nop", None, [I(0)], note="trans -> VALU")
+            self.emit("v_add_f32", x, [VN("m%d" % rb), x])
+            self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
+            if rb:
+                self.emit("s_add_u32", s("t0"), [s("t0"), I(32)])
+            self.emit("s_lshl_b32", s("t0"), [s("t0"), I(1 if cfg.l16 else 2)])
+            self.emit("v_add_u32_e64", vo, [VN("lv"), s("t0")], clamp=1)
+            if cfg.l16:
+                self.emit("v_cvt_f16_f32", x, [x])
+                self.emit("buffer_store_short", None, [x, vo, s("lres", 4)], offset=0)
+            else:
+                self.emit("buffer_store_dword", None, [x, vo, s("lres", 4)], offset=0)
+
+    def emit_outofline(self):
+        mine = [x for x in self.outofline if x[0] in ("ksw", "vsw")]
+        self.outofline = [x for x in self.outofline if x[0] not in ("ksw", "vsw")]
+        Stream.emit_outofline(self)
+        for kind, lbl, back, par, _ in mine:
+            self.label(lbl)
+            self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(0)])
+            self.emit("s_cbranch_scc1", None, [], target=back)      # last block: the ring runs ahead into zeros (out of range)
+            if kind == "ksw":
+                self.switch_k()
+            else:
+                self.switch_v()
+                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
+            self.emit("s_branch", None, [], target=back)
+
+    # ------------------------------------------------------------ whole stream
+    def build(self):
+        cfg = self.cfg
+        self.outofline = []
+        self.xe_pending = []
+        self.first_tiles = False
+        blk_lbl, loop, end_even, end_odd, done, fin, nonext, epi = (
+            self.newlabel(x) for x in ("BLOCK", "LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN", "NONEXT", "EPI"))
+        # ---- once per workgroup
+        for ks in range(8):
+            self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
+        self.emit("s_sub_u32", s("ntm1"), [SN("nt"), I(1)])
+        self.emit("s_sub_u32", s("ntm2"), [SN("nt"), I(2)])
+        self.emit("s_mov_b32", s("vrd"), [I(2 * VSLOT)])     # "image of V(-1)"
+        self.emit("s_mov_b32", s("vwr"), [SN("ldsv")])       # V(0) goes to image 0
+        self.emit("s_add_u32", s("t1"), [SN("ldsv"), I(VRING * VSLOT)])
+        # scalar parts of the LDS-DMA start offsets: K piece i begins at row 16 wave + 4 i, V piece i at key 16 i
+        self.emit("s_lshr_b32", s("t0"), [SN("kinc"), I(6)])                 # 2 ld(K)
+        self.emit("s_lshr_b32", s("t2"), [SN("wave64"), I(2)])
+        self.emit("s_mul_i32", s("kc0"), [s("t0"), s("t2")])
+        self.emit("s_lshl_b32", s("t0"), [s("t0"), I(2)])
+        for i in range(1, 4):
+            self.emit("s_add_u32", s("kc%d" % i), [s("kc%d" % (i - 1)), s("t0")])
+        self.emit("s_lshr_b32", s("t0"), [SN("vinc"), I(2)])                 # 16 x 2 ld(V)
+        self.emit("s_mov_b32", s("vc0"), [I(0)])
+        for i in range(1, 4):
+            self.emit("s_add_u32", s("vc%d" % i), [s("vc%d" % (i - 1)), s("t0")])
+        self.emit("s_lshl_b32", s("q4"), [SN("ldq2"), I(2)])
+        for name, nrec in (("kres", "nreck"), ("vres", "nrecv")):
+            self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
+            self.emit("s_mov_b32", s(name, 1, 3), [I(DESC_FLAGS)])
+        # ---- first block: its Q, K(0), V(0), K(1) are requested here; later blocks find theirs requested by their predecessor
+        self.emit("s_mov_b32", s("blk"), [I(0)])
+        self.load_next()
+        self.issue_q((S_BASE[0] + 0, S_BASE[0] + 1, S_BASE[0] + 2, S_BASE[0] + 3))
+        self.switch_k()
+        self.issue_tile("k", 0)
+        self.switch_v()
+        self.issue_tile("v", 0)
+        self.issue_tile("k", 1)
+        self.emit("s_waitcnt", None, [], vmcnt=0)
+        # ================= block loop =================
+        if cfg.pprof:
+            for i in range(16):
+                self.emit("v_mov_b32", V(PROF_ACC + i), [I(0)])
+        self.label(blk_lbl)
+        self.pstamp("table", first=True)
+        for name in ("ob", "lb"):
+            self.emit("s_mov_b32", s(name, 1, 0), [s(name + "n", 1, 0)])
+            self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
+        self.emit("s_mov_b32", s("row0"), [s("row0n")])
+        self.emit("s_add_u32", s("blk"), [s("blk"), I(1)])
+        self.emit("s_mov_b32", s("hasnext"), [I(0)])
+        self.emit("s_cmp_ge_u32", None, [s("blk"), SN("nblk")])
+        self.emit("s_cbranch_scc1", None, [], target=nonext)
+        self.emit("s_mov_b32", s("hasnext"), [I(1)])
+        self.load_next()
+        self.label(nonext)
+        self.pstamp("table")
+        # this wave's Q image, and its pieces of K(0), V(0), K(1): everything older than the previous block's stores
+        self.emit("s_waitcnt", None, [], vmcnt=NST)
+        self.pstamp("wait_q")
+        self.q_fragments()
+        self.emit("s_barrier")
+        self.pstamp("qfrag")
+        for rb in range(2):
+            self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
+            self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
+            self.emit("v_mov_b32", VN("l%d" % rb), [I(0)])
+            self.emit("v_mov_b32", VN("m%d" % rb), [F(0.0) if cfg.fold else F(-3.402823466e+38)])
+        if cfg.fold:
+            for r in range(32):
+                self.emit("v_mov_b32", V(CM_BASE + r), [I(0)])
+        self.emit("s_mov_b32", SN("pend"), [I(0)])
+        self.emit("s_mov_b32", SN("j"), [I(0)])
+        for i in range(16):
+            self.k_read(0, i)
+        self.lds_flush()
+        self.first_tiles = True
+        self.phase_a(0, mfma=True, softmax=False, zero_o=True)
+        self.emit("s_waitcnt", None, [], vmcnt=NST)          # K(1) (older than the stores)
+        self.emit("s_barrier")
+        self.pstamp("tile0_a")
+        self.phase_b(0, mfma=False, softmax=True, vids={})
+        self.first_tiles = False
+        self.emit("s_mov_b32", SN("j"), [I(1)])
+        self.pstamp("tile0_b")
+        self.label(loop)
+        for par, endl in ((1, end_even), (0, end_odd)):
+            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
+            self.emit("s_cbranch_scc1", None, [], target=endl)
+            vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
+            self.lds_flush()
+            self.pstamp("loop_a")
+            self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j) (and, in tile 1, the stores)
+            self.emit("s_barrier")
+            self.pstamp("loop_wait")
+            if cfg.pprof and par == 1:                      # the wait of tile 1 separately (it includes the previous block's stores)
+                self.emit("s_cmp_eq_u32", None, [SN("j"), I(1)])
+                self.emit("s_cselect_b32", s("t3"), [s("t3"), I(0)])
+                acc = V(PROF_ACC + PROF_NAMES.index("tile1_wait"))
+                self.emit("v_add_u32", acc, [s("t3"), acc])
+            self.phase_b(par, mfma=True, softmax=True, vids=vids)
+            self.pstamp("loop_b")
+            self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
+        self.emit("s_branch", None, [], target=loop)
+        for lastpar, lbl in ((0, end_even), (1, end_odd)):
+            self.label(lbl)
+            vids = self.phase_a(lastpar ^ 1, mfma=False, softmax=True, zero_o=False)
+            self.lds_flush()
+            self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
+            self.phase_b(lastpar ^ 1, mfma=True, softmax=False, vids=vids)
+            self.emit("s_branch", None, [], target=done)
+        self.label(done)
+        self.emit("s_barrier")       # every wave is done with the V image the epilogue stages O in (last read in phase B(nt-1))
+        self.pstamp("tail")
+        for rb in range(2):
+            self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
+        self.epilogue()
+        self.pstamp("epilogue")
+        if cfg.pprof:
+            acc = V(PROF_ACC + PROF_NAMES.index("blocks"))
+            self.emit("v_add_u32", acc, [I(1), acc])
+        self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(1)])
+        self.emit("s_cbranch_scc1", None, [], target=blk_lbl)
+        self.emit("s_waitcnt", None, [], vmcnt=0)
+        if cfg.pprof:   # lane 0 leaves the sums in O[first row of the wave's last block][0:16] (fp32 O)
+            self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
+            self.emit("s_mul_i32", s("t0"), [s("t0"), SN("ldo")])
+            self.emit("v_mov_b32", V(T_TL), [s("t0")])
+            self.emit("v_mov_b32", V(PROF_ACC + 15), [I(PROF_MAGIC)])
+            self.emit("s_mov_b64", ("exec",), [I(1)])
+            for i in range(4):
+                self.emit("buffer_store_dwordx4", None, [V(PROF_ACC + 4 * i, 4), V(T_TL), s("tres", 4)], offset=16 * i)
+            self.emit("s_mov_b64", ("exec",), [I(-1)])
+            self.emit("s_waitcnt", None, [], vmcnt=0)
+        self.emit("s_branch", None, [], target=fin)
+        self.emit_outofline()
+        self.label(fin)
+        return self.finish()
+
+
+# ---------------------------------------------------------------- rendering
+def render_one(ins):
+    op, m = ins.op, ins.mod
+    f = p4gen.fmt
+    if op in ("buffer_store_dwordx4", "buffer_store_dwordx2", "buffer_store_dword", "buffer_store_short"):
+        off = " offset:%d" % m["offset"] if m.get("offset") else ""
+        return "%s %s, %s, %s, 0 offen%s" % (op, f(ins.s[0]), f(ins.s[1]), f(ins.s[2]), off)
+    if op == "v_fma_f32" and not m.get("neg2"):
+        return "v_fma_f32 %s, %s%s, %s, %s" % (f(ins.d), "-" if m.get("neg0") else "", f(ins.s[0]), f(ins.s[1]), f(ins.s[2]))
+    if op == "s_cmp_lt_u32":
+        return "s_cmp_lt_u32 %s, %s" % (f(ins.s[0]), f(ins.s[1]))
+    if op == "s_memtime":
+        return "s_memtime %s" % f(ins.d)
+    if op == "s_mov_b64" and ins.d == ("exec",):
+        return "s_mov_b64 exec, %s" % f(ins.s[0])
+    if op == "ds_write_b128":
+        return "ds_write_b128 %s, %s offset:%d" % (f(ins.s[0]), f(ins.s[1]), m["offset"])
+    if op in ("v_cvt_f32_f16", "v_cvt_f16_f32", "v_rcp_f32", "v_log_f32"):
+        return "%s_e32 %s, %s" % (op, f(ins.d), f(ins.s[0]))
+    return p4gen.render_one(ins)
+
+
+def render(instrs):
+    return [render_one(i) for i in instrs]
+
+
+VARIANTS = {
+    # name: cfg            (X-macro columns: folds the scale, 16-bit O, FP16 L)
+    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1),          # headline: mixed-precision mode, fp32 O, FP16 L
+    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1),
+    "BF16_EXACT": PCfg("bf16", 8, fold=0),                    # lowPrecisionInputs only: scale in fp32, fp32 O and L
+    "BF16_EXACT_O16": PCfg("bf16", 8, fold=0, o16=1),
+    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1),
+    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1),
+    "F16_EXACT": PCfg("f16", 8, fold=0),
+    "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1),
+    "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
+}
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof)
+
+
+def write_inc(path):
+    lines = ["// GENERATED by tools/p4pgen.py -- do not edit.  Persistent instruction streams of attn_fwd16_p4p (see the generator's",
+             "// header for the block loop, the register map and the block table).", "#pragma once", ""]
+    lines.append("#define MFA_P4P_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(p4gen.FIRST_OWNED_VGPR, 256)))
+    lines.append("#define MFA_P4P_OWNED_SGPRS " + ", ".join('"s%d"' % i for i in range(FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR + 1)))
+    lines.append("#define MFA_P4P_QIMG %d" % QIMG)
+    lines.append("#define MFA_P4P_TABLE %d" % TABLE)
+    lines.append("#define MFA_P4P_TABLE_ENTRIES %d" % TABLE_ENTRIES)
+    lines.append("#define MFA_P4P_LDS_BYTES %d" % LDS_BYTES)
+    lines.append("")
+    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16)")
+    lines.append("#define MFA_P4P_PRODUCT_STREAM_LIST(X) \\")
+    for name, cfg in VARIANTS.items():
+        if name in PRODUCT_STREAMS:
+            lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16))
+    lines.append("")
+    lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates")
+    lines.append("#define MFA_P4P_DEV_STREAM_LIST(X) \\")
+    for name, cfg in VARIANTS.items():
+        if name not in PRODUCT_STREAMS:
+            lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16))
+    lines.append("")
+    lines.append("#ifdef MFA_DEV_VARIANTS")
+    lines.append("#define MFA_P4P_STREAM_LIST(X) MFA_P4P_PRODUCT_STREAM_LIST(X) MFA_P4P_DEV_STREAM_LIST(X)")
+    lines.append("#else")
+    lines.append("#define MFA_P4P_STREAM_LIST(X) MFA_P4P_PRODUCT_STREAM_LIST(X)")
+    lines.append("#endif")
+    lines.append("")
+    lines.append("")
+    for name, cfg in VARIANTS.items():
+        ins = PStream(cfg).build()
+        txt = render(ins)
+        if name not in PRODUCT_STREAMS:
+            lines.append("#ifdef MFA_DEV_VARIANTS")
+        n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
+        lines.append("// %s: dtype=%s thr=%g fold=%d xb=%d o16=%d l16=%d -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.fold, cfg.xb, cfg.o16, cfg.l16, len(txt), n_mfma))
+        lines.append("#define MFA_P4P_STREAM_%s \\" % name)
+        for t in txt:
+            lines.append('  "%s\\n\\t" \\' % t)
+        lines.append('  ""')
+        if name not in PRODUCT_STREAMS:
+            lines.append("#endif")
+        lines.append("")
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4p_stream.inc")
+    write_inc(out)
+    print("wrote", os.path.normpath(out), "-", len(PStream(VARIANTS["BF16_FOLD_L16"]).build()), "instructions in the headline stream")

@@ -25,7 +25,7 @@ PY
 )
 export MFA_PROFILED_VARIANT=$(python bench.py $ARGS 2>/dev/null | tail -n 1 | python -c "import json,sys; print(json.load(sys.stdin)['config']['kernel_variants'][0])")
 python tools/summarize_prof.py "$OUT" "bench.py $ARGS" "$WORKLOAD" > "$OUT/summary.txt" 2>&1
-cp "$OUT/summary.txt" "profiles/r02_${WORKLOAD}_summary.txt"
+cp "$OUT/summary.txt" "profiles/${ROUND:-r03}_${WORKLOAD}_summary.txt"
 cp profiles/traffic.json "$OUT/traffic.json"   # gpurun merges only gpurun_out/ back: copy it into profiles/ after the call
 # the raw rocprofv3 databases are large (gpurun copies at most 64 MiB back): keep the summary, the logs and traffic.json
 [ -n "${KEEP_RAW:-}" ] || rm -rf "$OUT/stats" "$OUT/pmc1" "$OUT/pmc2" "$OUT/pmc3" "$OUT/pmc4"

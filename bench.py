@@ -288,9 +288,16 @@ def main():
         def step2():
             k2.dispatch(bufs2, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs, stream=stream, workspace=workspace)
 
+        t_spin2 = time.perf_counter()          # the same untimed spin-up as the headline mode got (clocks settle under load)
+        n2 = 0
+        while time.perf_counter() - t_spin2 < args.spinup_seconds:
+            step2()
+            n2 += 1
+            if n2 % 8 == 0:
+                torch.cuda.synchronize()
         for _ in range(max(args.warmup, 3)):
             step2()
-        sync_all()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.steps):

@@ -9,8 +9,8 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
 
 template <typename T, int STREAM, bool CAUSAL>
 static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
-  if constexpr (!CAUSAL && (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD)) {
-    if (launch_p4p<T, p4::stream_folds(STREAM)>(grid, stream, args)) return;
+  if constexpr (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD) {
+    if (launch_p4p<T, p4::stream_folds(STREAM)>(grid, stream, args)) return;   // (dense and causal)
   }
   Fwd16Grid g{grid.x, grid.y, grid.z};
   const uint32_t groups = CAUSAL ? (grid.x + 1) / 2 : grid.x;   // causal: one workgroup per pair of row blocks (last - i, i)

@@ -20,35 +20,38 @@ namespace p4p {
 
 constexpr int QIMG = MFA_P4P_QIMG, TABLE = MFA_P4P_TABLE, TABLE_ENTRIES = MFA_P4P_TABLE_ENTRIES, LDS_BYTES = MFA_P4P_LDS_BYTES;
 
-#define MFA_P4P_ENUM(name, f16, fold, o16, l16) S_##name,
+#define MFA_P4P_ENUM(name, f16, fold, o16, l16, causal) S_##name,
 enum : int { MFA_P4P_STREAM_LIST(MFA_P4P_ENUM) S_COUNT };
 #undef MFA_P4P_ENUM
 
-struct StreamTraits { bool f16, fold, o16, l16; };
+struct StreamTraits { bool f16, fold, o16, l16, causal; };
 constexpr StreamTraits traits(int s) {
-#define MFA_P4P_TRAITS(name, f16, fold, o16, l16) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0};
+#define MFA_P4P_TRAITS(name, f16, fold, o16, l16, causal) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, causal != 0};
   MFA_P4P_STREAM_LIST(MFA_P4P_TRAITS)
 #undef MFA_P4P_TRAITS
-  return StreamTraits{false, false, false, false};
+  return StreamTraits{false, false, false, false, false};
 }
 
 }  // namespace p4p
 
 #define MFA_P4P_RUN_STREAM(STREAM)                                                                                       \
   asm volatile(STREAM                                                                                                    \
-               :                                                                                                         \
-               : [kbase] "v"(kbase), [vbase] "v"(vbase), [lim0] "v"(lim), [lim1] "v"(lim), [kv0] "v"(kv[0]), [kv1] "v"(kv[1]), \
+               : [lim0] "+v"(lim0), [lim1] "+v"(lim1)                                                                     \
+               : [kbase] "v"(kbase), [vbase] "v"(vbase), [kv0] "v"(kv[0]), [kv1] "v"(kv[1]),                              \
                  [kv2] "v"(kv[2]), [kv3] "v"(kv[3]), [vv] "v"(vv), [qv0] "v"(qv[0]), [qv1] "v"(qv[1]), [qv2] "v"(qv[2]),  \
                  [qv3] "v"(qv[3]), [ov0] "v"(ov[0]), [ov1] "v"(ov[1]), [ov2] "v"(ov[2]), [ov3] "v"(ov[3]), [lv] "v"(lv),  \
-                 [ewa] "v"(ewa), [era] "v"(era),                                                                          \
+                 [ewa] "v"(ewa), [era] "v"(era), [qlane] "v"(qlane), [hi4] "v"(hi4),                                      \
                  [nt] "s"(nt), [maskfrom] "s"(maskfrom), [scale2] "s"(a.scale2), [kinc] "s"(kinc), [vinc] "s"(vinc),      \
                  [ldsk] "s"(ldsk), [ldsv] "s"(ldsv), [ldsq] "s"(ldsq), [qrel] "s"(qrel), [nblk] "s"(nblk), [tbl] "s"(tbl), \
                  [wave64] "s"(wave64), [ldq2] "s"(ldq2), [ldo] "s"(ldob), [nrecq] "s"(nrecq), [nreck] "s"(nreck),         \
-                 [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl), [dr] "s"(dr)                                 \
+                 [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl), [dr] "s"(dr), [coff] "s"(coff),              \
+                 [cm1] "s"(cm1), [rr] "s"(R), [ttot] "s"(ttot)                                                            \
                : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_P4P_OWNED_VGPRS, MFA_P4P_OWNED_SGPRS)
 
-// T: __bf16 or _Float16 (must match the stream); STREAM: p4p::S_*.  `total` = row blocks x heads x batches; workgroup w of G
-// takes the blocks w, w + G, ... in fwd16_decode_block's order (G a multiple of 8: a workgroup stays with the heads of its XCD)
+// T: __bf16 or _Float16 (must match the stream); STREAM: p4p::S_*.  `total` = units x heads x batches; workgroup w of G takes the
+// units w, w + G, ... in fwd16_decode_block's order (G a multiple of 8: a workgroup stays with the heads of its XCD).  A unit is
+// one row block (dense streams) or the PAIR of row blocks (last - i, i) (causal streams: row block i walks ~4 (i + 1) key tiles,
+// every pair the same number), the long one first
 template <typename T, int STREAM>
 __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const Fwd16Grid grid, const uint32_t total, const uint32_t stagger) {
   using namespace p4p;
@@ -62,22 +65,44 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   const uint32_t G = gridDim.x, first = blockIdx.x;
   if (first >= total) return;
-  const uint32_t nblk = (total - first + G - 1) / G;   // <= TABLE_ENTRIES (the launcher sizes the grid)
+  const uint32_t nunits = (total - first + G - 1) / G;   // blocks per unit x nunits <= TABLE_ENTRIES (the launcher sizes the grid)
 
   // ---- block table: what attn_fwd16_p4 decodes per workgroup, once per block of this workgroup
   uint32_t *table = reinterpret_cast<uint32_t *>(smem + TABLE);
-  for (uint32_t n = tid; n < nblk; n += 256) {
-    uint32_t rblk, head, batch;
-    fwd16_decode_block(grid, first + n * G, &rblk, &head, &batch);
+  Fwd16Grid dgrid = grid;
+  const uint32_t RB = grid.rowBlocks;
+  if constexpr (TR.causal) dgrid.rowBlocks = (RB + 1) / 2;
+  for (uint32_t n = tid; n < nunits; n += 256) {
+    uint32_t r, head, batch;
+    fwd16_decode_block(dgrid, first + n * G, &r, &head, &batch);
     const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
                               (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
                               (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
-    uint32_t *e = table + 16 * n;
+    // entry of the unit's block(s).  Causal, odd block count: the middle block is its own pair -- the units before it in this
+    // workgroup's list hold two entries each unless they are middle blocks themselves (same r for every unit whose index
+    // differs by a multiple of the decode period; counted, not assumed)
+    uint32_t pos = TR.causal ? 2 * n : n;
+    if constexpr (TR.causal) {
+      if (RB & 1u) {
+        for (uint32_t i = 0; i < n; ++i) {
+          uint32_t ri, hi_, bi;
+          fwd16_decode_block(dgrid, first + i * G, &ri, &hi_, &bi);
+          if (ri == RB - 1 - ri) --pos;
+        }
+      }
+    }
+    const uint32_t rows[2] = {TR.causal ? RB - 1 - r : r, r};
+    const int count = (TR.causal && rows[0] != rows[1]) ? 2 : 1;
+    for (int w = 0; w < count; ++w) {
+      uint32_t *e = table + 16 * (pos + w);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
-    e[10] = rblk * GROWS;
+      for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
+      e[10] = rows[w] * GROWS;
+    }
+    if (n == nunits - 1) table[16 * TABLE_ENTRIES - 1] = pos + count;   // blocks of this workgroup (the last table word is never an entry's)
   }
   __syncthreads();
+  const uint32_t nblk = __builtin_amdgcn_readfirstlane(table[16 * TABLE_ENTRIES - 1]);
   // desynchronise the compute units: blocks that end in lockstep store 32 MB at once and the next block's loads queue
   // behind them (profiles/r02_fwd16p4_block_overhead_persistent_experiment.txt)
   for (uint32_t i = 0; i < (stagger & 0xFFFFu) * ((first >> 3) & 31u); ++i) __builtin_amdgcn_s_sleep(8);   // 512 clocks per step
@@ -93,7 +118,10 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   uint32_t nt = (C + BC - 1) / BC;
   nt += nt & 1u;
   const uint32_t maskfrom = C / BC;
-  const int lim = (int)C - 1 - 4 * hi;   // register r of a lane covers key (r & 3) + 8 (r >> 2) + 4 hi of its 32-key block
+  // register r of a lane covers key (r & 3) + 8 (r >> 2) + 4 hi of its 32-key block; dense: every row sees all C keys (causal
+  // streams recompute both limits per block: min(C - 1, row + C - R) - 4 hi)
+  int lim0 = (int)C - 1 - 4 * hi, lim1 = lim0;
+  const uint32_t qlane = q, hi4 = 4 * hi, coff = C - R, cm1 = C - 1, ttot = (C + BC - 1) / BC;
 
   // ---- lane parts of the LDS-DMA source offsets (the stream adds the scalar parts: first row of the piece x leading dimension).
   // Piece i of a K-shaped image (K tiles, the wave's Q image): 16-byte position p = i * 64 + lane holds row p >> 4, chunk
@@ -126,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   const uint32_t ldsk = lds0 + wave * 4096, ldsv = lds0 + p4::VBASE + wave * 4096;
   const uint32_t qrel = QIMG + wave * 16384, ldsq = lds0 + qrel, tbl = lds0 + TABLE, wave64 = wave * 64;
 
-#define MFA_P4P_RUN(name, f16, fold, o16, l16) if constexpr (STREAM == S_##name) MFA_P4P_RUN_STREAM(MFA_P4P_STREAM_##name);
+#define MFA_P4P_RUN(name, f16, fold, o16, l16, causal) if constexpr (STREAM == S_##name) MFA_P4P_RUN_STREAM(MFA_P4P_STREAM_##name);
   MFA_P4P_STREAM_LIST(MFA_P4P_RUN)
 #undef MFA_P4P_RUN
 }

@@ -14,7 +14,7 @@ namespace mfa {
 
 namespace {
 
-struct DeviceInfo { int cus = 0; uint64_t attrMask[p4p::S_COUNT * 2] = {}; };
+struct DeviceInfo { int cus = 0; uint64_t attrMask[p4p::S_COUNT * 2 + 2] = {}; };
 std::mutex g_mutex;
 DeviceInfo g_devices[64];
 
@@ -40,14 +40,18 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
       d.attrMask[slot] = 1;
     }
   }
-  const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
+  // units: row blocks, or (causal) pairs of row blocks -- two table entries each
+  constexpr bool CAUSAL = p4p::traits(STREAM).causal;
+  constexpr uint64_t PER_UNIT = CAUSAL ? 2 : 1;
+  const uint64_t total = (uint64_t)(CAUSAL ? (grid.x + 1) / 2 : grid.x) * grid.y * grid.z;
   // one workgroup per compute unit; more only when a workgroup's share would not fit the block table.  A multiple of 8 keeps
   // fwd16_decode_block's head -> XCD affinity for every block of a workgroup
   uint64_t groups = total < (uint64_t)cus ? total : (uint64_t)cus;
-  if ((total + groups - 1) / groups > (uint64_t)p4p::TABLE_ENTRIES) groups = (total + p4p::TABLE_ENTRIES - 1) / p4p::TABLE_ENTRIES;
+  constexpr uint64_t MAX_UNITS = (p4p::TABLE_ENTRIES - 1) / PER_UNIT;   // (the table's last word holds the block count)
+  if ((total + groups - 1) / groups > MAX_UNITS) groups = (total + MAX_UNITS - 1) / MAX_UNITS;
   if (groups >= 8) groups = (groups + 7) / 8 * 8;
   if (groups > total) groups = total;
-  if ((total + groups - 1) / groups > (uint64_t)p4p::TABLE_ENTRIES) return false;
+  if ((total + groups - 1) / groups > MAX_UNITS) return false;
   Fwd16Grid g{grid.x, grid.y, grid.z};
   uint32_t stagger = P4P_STAGGER;
 #ifdef MFA_DEV_VARIANTS
@@ -62,7 +66,8 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
 // Dense launch of a D <= 128 forward problem on the persistent kernel.  Returns false when the launch is not one it serves
 // (the caller then launches attn_fwd16_p4): per-batch lengths, a storage type of O / L no stream was generated for.
 template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args) {
-  if (args.causal || args.rowLen || args.colLen || args.mask) return false;
+  if (args.rowLen || args.colLen || args.mask) return false;
+  if (args.causal && args.C < args.R) return false;
 #ifdef MFA_DEV_VARIANTS   // developer builds: A/B against the one-block-per-workgroup kernel, phase clocks (tools/p4p_prof.py)
   if (std::getenv("MFA_P4_NO_PERSISTENT")) return false;
   if constexpr (!FOLD && __is_same(T, __bf16)) {
@@ -77,12 +82,22 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   if (!l16 && pl != PREC_FP32) return false;
   if constexpr (FOLD) {
     if (!l16) return false;   // (FOLD streams exist with FP16 L: the mixed-precision mode's storage type)
-    if constexpr (__is_same(T, _Float16)) return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16>(grid, stream, args);
-    else return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16>(grid, stream, args);
+    if constexpr (__is_same(T, _Float16)) {
+      if (args.causal) return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16_CAUSAL>(grid, stream, args);
+      return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16>(grid, stream, args);
+    } else {
+      if (args.causal) return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16_CAUSAL>(grid, stream, args);
+      return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16>(grid, stream, args);
+    }
   } else {
     if (l16) return false;
-    if constexpr (__is_same(T, _Float16)) return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT>(grid, stream, args);
-    else return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT>(grid, stream, args);
+    if constexpr (__is_same(T, _Float16)) {
+      if (args.causal) return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT_CAUSAL>(grid, stream, args);
+      return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT>(grid, stream, args);
+    } else {
+      if (args.causal) return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT_CAUSAL>(grid, stream, args);
+      return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT>(grid, stream, args);
+    }
   }
 }
 

@@ -16,6 +16,18 @@ FOLD = p4pgen.VARIANTS["BF16_FOLD_L16"]
 EXACT = p4pgen.VARIANTS["BF16_EXACT"]
 
 
+def _pairs(H, R):
+    """the causal launch's table order: per head the pairs (last - i, i) of row blocks, the long one first"""
+    nrb = (R + 255) // 256
+    out = []
+    for h in range(H):
+        for p in range((nrb + 1) // 2):
+            out.append((h, nrb - 1 - p))
+            if p != nrb - 1 - p:
+                out.append((h, p))
+    return out
+
+
 def _check(H, R, C, cfg=FOLD, blocks=None, seed=0, D=128, spike=None, tol_o=None, **kw):
     rng = np.random.default_rng(seed)
     f16 = cfg.dtype == "f16"
@@ -26,13 +38,13 @@ def _check(H, R, C, cfg=FOLD, blocks=None, seed=0, D=128, spike=None, tol_o=None
         k[0, krow] = p4psim.f32_to_h16((qf * gain).astype(np.float32), f16).astype(np.uint16)
     nrb = (R + 255) // 256
     if blocks is None:
-        blocks = [(h, rb) for h in range(H) for rb in range(nrb)]
+        blocks = _pairs(H, R) if cfg.causal else [(h, rb) for h in range(H) for rb in range(nrb)]
     O, L, wg, raw = p4psim.run_workgroup(q, k, v, blocks, cfg, D=D, **kw)
     tol_o = tol_o or ((3e-2 if not f16 else 4e-3) if cfg.o16 else 4e-3)
     tol_l = (2e-2 if cfg.l16 else 2e-5) + (6e-4 if f16 else 5e-3) * bool(cfg.fold)
     pad = lambda x: np.concatenate([x, np.zeros(x.shape[:-1] + (128 - D,), x.dtype)], axis=-1) if D < 128 else x
     for h, rb in blocks:
-        Oref, Lref = p4psim.reference(q[h], k[h], v[h], f16=f16)
+        Oref, Lref = p4psim.reference(q[h], k[h], v[h], causal=bool(cfg.causal), f16=f16)
         rows = slice(rb * 256, min(R, rb * 256 + 256))
         dO, dL = np.abs(O[h, rows] - Oref[rows]).max(), np.abs(L[h, rows] - Lref[rows]).max()
         assert dO < tol_o and dL < tol_l * max(1.0, np.abs(Lref[rows]).max() / 8), (h, rb, dO, dL)
@@ -84,7 +96,8 @@ def test_deferred_rescale_in_a_later_block(cfg):
 
 @pytest.mark.parametrize("name", sorted(p4pgen.PRODUCT_STREAMS))   # (the PROF stream adds clock stamps only)
 def test_every_compiled_stream(name):
-    _check(2, 256, 200, cfg=p4pgen.VARIANTS[name], seed=6)
+    cfg = p4pgen.VARIANTS[name]
+    _check(2, 256, 320 if cfg.causal else 200, cfg=cfg, seed=6)     # (causal needs C >= R)
 
 
 @pytest.mark.parametrize("D", [72, 96, 120])
@@ -97,6 +110,32 @@ def test_head_dimensions_below_the_bucket(D, name):
     osz = 2 if cfg.o16 else 4
     assert (om.reshape(2, 256, 128 * osz)[:, :, D * osz:] == 0xCD).all()
     assert wg.waves[0].count["buffer_store_dwordx2" if cfg.o16 else "buffer_store_dwordx4"] == 2 * 32
+
+
+CAUSAL_FOLD = p4pgen.VARIANTS["BF16_FOLD_L16_CAUSAL"]
+CAUSAL_EXACT = p4pgen.VARIANTS["BF16_EXACT_CAUSAL"]
+
+
+@pytest.mark.parametrize("H,R,C", [(1, 512, 512), (2, 768, 768), (1, 300, 400), (1, 700, 1000), (1, 256, 256), (1, 1280, 1280)])
+def test_causal_pairs(H, R, C):
+    """causal streams: tile count, per-wave traversal bound, first masked tile and the lanes' limits are computed per block INSIDE
+    the stream; blocks arrive in pairs (long, short); odd block counts (768, 1280 rows) have a middle block that is its own pair"""
+    wg, _, _ = _check(H, R, C, cfg=CAUSAL_EXACT, seed=10)
+    counts = [w.count.get("v_mfma_f32_32x32x16_bf16", 0) for w in wg.waves]
+    assert len(set(w.count["s_barrier"] for w in wg.waves)) == 1, "waves disagree on the barriers"
+    if R == C and R % 256 == 0:
+        assert counts[0] < counts[3], counts      # a wave stops multiplying at the diagonal of ITS rows
+
+
+@pytest.mark.parametrize("dma_mode,stores,order", [("early", "late", (3, 2, 1, 0)), ("late", "early", (0, 1, 2, 3)), ("late", "late", (2, 0, 3, 1))])
+def test_causal_skip_loop_keeps_the_ring_and_the_block_switch_going(dma_mode, stores, order):
+    """waves whose rows end early only keep the barriers and their LDS-DMA share -- including the switch to the NEXT block's K / V
+    and their part of its Q image -- going; DMA landing early / late, stores retiring early / late, waves in any order"""
+    _check(2, 512, 512, cfg=CAUSAL_FOLD, dma_mode=dma_mode, stores=stores, order=order, seed=11)
+
+
+def test_causal_spike_below_the_diagonal():
+    wg, _, _ = _check(1, 512, 512, cfg=CAUSAL_FOLD, spike=(300, 200, 3.0), seed=12, tol_o=1.2e-2)
 
 
 def test_stream_file_is_current():

@@ -58,23 +58,28 @@ PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
              qbn=(56, 2), kbn=(58, 2), vbn=(60, 2), obn=(62, 2), lbn=(64, 2), row0n=(66, 1),
              ob=(68, 2), lb=(70, 2), row0=(72, 1), blk=(73, 1), hasnext=(74, 1), ntm1=(75, 1), ntm2=(76, 1),
              j=(77, 1), vrd=(78, 1), vwr=(79, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
-             kc0=(86, 1), kc1=(87, 1), kc2=(88, 1), kc3=(89, 1), vc0=(90, 1), vc1=(91, 1), vc2=(92, 1), vc3=(93, 1),
+             kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), wntb=(90, 1), maskb=(91, 1), ntu=(92, 1), t5=(93, 1),
              q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1))
 FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 100
 
 # inputs of the statement (hipcc allocates them below s40 / v28)
-IN_V = ["kbase", "vbase", "lim0", "lim1", "kv0", "kv1", "kv2", "kv3", "vv", "qv0", "qv1", "qv2", "qv3", "ov0", "ov1", "ov2", "ov3",
-        "lv", "ewa", "era"]
+INOUT_V = ["lim0", "lim1"]          # mask limits per row block: constant in dense streams, rewritten per block by causal ones
+IN_V = ["kbase", "vbase", "kv0", "kv1", "kv2", "kv3", "vv", "qv0", "qv1", "qv2", "qv3", "ov0", "ov1", "ov2", "ov3",
+        "lv", "ewa", "era", "qlane", "hi4"]
 IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qrel", "nblk", "tbl", "wave64", "ldq2", "ldo",
-        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "dr"]
+        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "dr", "coff", "cm1", "rr", "ttot"]
 
 
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb)
         self.o16, self.l16 = o16, l16
+        # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
+        # computed per block inside the stream; the block table lists the blocks in pairs (long, short) like attn_fwd16_p4's
+        # causal launch, so that every workgroup walks the same number of tiles
+        self.causal = causal
         # pprof (developer builds, exact-scale streams only: their -m blocks v168.. are free): shader-clock sums per segment of
         # the block loop in v168..v183, written to O[first row of the wave's last block][0:16] when the workgroup ends
         self.pprof = pprof
@@ -109,6 +114,10 @@ class PStream(Stream):
                 return None
             if o[0] == "V" and o[1] in self.vfixed:
                 return V(self.vfixed[o[1]])
+            if o[0] == "S" and self.cfg.causal and o[1] in ("nt", "wnt", "maskfrom"):
+                return SR(PSGPR[{"nt": "ntb", "wnt": "wntb", "maskfrom": "maskb"}[o[1]]][0], 1)
+            if o[0] == "S" and o[1] == "wnt":
+                return ("S", "nt", 1)            # dense: every wave walks the whole block
             if o[0] == "S" and o[1] in PSGPR:
                 base, n = PSGPR[o[1]]
                 return SR(base, o[2] if len(o) > 2 else n)
@@ -176,14 +185,84 @@ class PStream(Stream):
     def switch_k(self):
         self.emit("s_mov_b32", s("kres", 1, 0), [s("kbn", 1, 0)])
         self.emit("s_and_b32", s("kres", 1, 1), [s("kbn", 1, 1), I(0xFFFF)])
+        self.emit("s_mov_b32", s("t3"), [s("kc0")])
         for i in range(4):
-            self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("kv%d" % i), s("kc%d" % i)], clamp=1)
+            self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("kv%d" % i), s("t3")], clamp=1)
+            if i != 3:
+                self.emit("s_add_u32", s("t3"), [s("t3"), s("kstep")])
 
     def switch_v(self):
         self.emit("s_mov_b32", s("vres", 1, 0), [s("vbn", 1, 0)])
         self.emit("s_and_b32", s("vres", 1, 1), [s("vbn", 1, 1), I(0xFFFF)])
+        self.emit("s_mov_b32", s("t3"), [I(0)])
         for i in range(4):
-            self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("vv"), s("vc%d" % i)], clamp=1)
+            self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("vv"), s("t3")], clamp=1)
+            if i != 3:
+                self.emit("s_add_u32", s("t3"), [s("t3"), s("vstep")])
+
+    def block_geometry(self):
+        """causal streams, per block: tile count (made even), this wave's traversal bound, first tile that needs masking, the
+        lanes' mask limits -- what attn_fwd16_p4's C++ prologue computes per workgroup (attn_fwd16_p4.h, 'traversal range')"""
+        t0, t2, t3 = s("t0"), s("t2"), s("t3")
+        self.emit("s_add_u32", t0, [s("row0"), I(256)])
+        self.emit("s_min_u32", t0, [t0, SN("rr")])
+        self.emit("s_sub_u32", t0, [t0, I(1)])                       # last row of the block
+        self.emit("s_add_u32", t0, [t0, SN("coff")])
+        self.emit("s_lshr_b32", t0, [t0, I(6)])
+        self.emit("s_add_u32", t0, [t0, I(1)])
+        self.emit("s_min_u32", s("ntu"), [t0, SN("ttot")])           # tiles the block's last row can see
+        self.emit("s_add_u32", t2, [s("row0"), SN("wave64")])        # first row of the wave
+        self.emit("s_add_u32", t3, [t2, I(64)])
+        self.emit("s_min_u32", t3, [t3, SN("rr")])
+        self.emit("s_sub_u32", t3, [t3, I(1)])                       # its last row
+        self.emit("s_add_u32", t3, [t3, SN("coff")])
+        self.emit("s_lshr_b32", t3, [t3, I(6)])
+        self.emit("s_add_u32", t3, [t3, I(1)])
+        self.emit("s_min_u32", t3, [t3, s("ntu")])
+        self.emit("s_max_u32", t3, [t3, I(1)])
+        self.emit("s_cmp_ge_u32", None, [t2, SN("rr")])              # a wave beyond the last row: one tile, nothing stored
+        self.emit("s_cselect_b32", s("wntb"), [I(1), t3])
+        self.emit("s_add_u32", t3, [t2, SN("coff")])
+        self.emit("s_min_u32", t0, [t3, SN("cm1")])
+        self.emit("s_add_u32", t0, [t0, I(1)])
+        self.emit("s_lshr_b32", s("maskb"), [t0, I(6)])
+        self.emit("s_and_b32", t0, [s("ntu"), I(1)])
+        self.emit("s_add_u32", s("ntb"), [s("ntu"), t0])             # an odd count walks one fully masked tile more
+        self.emit("s_sub_u32", s("ntm1"), [s("ntb"), I(1)])
+        self.emit("s_sub_u32", s("ntm2"), [s("ntb"), I(2)])
+        for rb in range(2):
+            if rb:
+                self.emit("s_add_u32", t3, [t3, I(32)])
+            lim = VN("lim%d" % rb)
+            self.emit("v_add_u32", lim, [t3, VN("qlane")])
+            self.emit("v_min_u32", lim, [SN("cm1"), lim])
+            self.emit("v_sub_u32", lim, [lim, VN("hi4")])
+
+    def skip_tile(self, par):
+        """one tile of a wave whose own rows are done (causal): the workgroup's barrier and this wave's share of the LDS-DMA"""
+        self.emit("s_waitcnt", None, [], vmcnt=0)
+        self.emit("s_barrier")
+        self.vwr_update()
+        for kind, reg in (("k", "ntm2"), ("v", "ntm1")):
+            over = self.newlabel("NOSW")
+            self.emit("s_cmp_eq_u32", None, [SN("j"), s(reg)])
+            self.emit("s_cbranch_scc0", None, [], target=over)
+            self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(0)])
+            self.emit("s_cbranch_scc1", None, [], target=over)
+            if kind == "k":
+                self.switch_k()
+            else:
+                self.switch_v()
+                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
+            self.label(over)
+        for i in range(4):
+            self.dma_piece("k", par, i)
+        for i in range(4):
+            self.dma_piece("v", par, i)
+        for i in range(4):
+            self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1)
+            self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1)
+        self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
 
     def issue_q(self, temps):
         """the wave's 64 rows of the next block's Q by LDS-DMA into its own image: piece i = rows 4 i .. 4 i + 3"""
@@ -358,8 +437,9 @@ class PStream(Stream):
         # ---- once per workgroup
         for ks in range(8):
             self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
-        self.emit("s_sub_u32", s("ntm1"), [SN("nt"), I(1)])
-        self.emit("s_sub_u32", s("ntm2"), [SN("nt"), I(2)])
+        if not cfg.causal:
+            self.emit("s_sub_u32", s("ntm1"), [SN("nt"), I(1)])
+            self.emit("s_sub_u32", s("ntm2"), [SN("nt"), I(2)])
         self.emit("s_mov_b32", s("vrd"), [I(2 * VSLOT)])     # "image of V(-1)"
         self.emit("s_mov_b32", s("vwr"), [SN("ldsv")])       # V(0) goes to image 0
         self.emit("s_add_u32", s("t1"), [SN("ldsv"), I(VRING * VSLOT)])
@@ -367,13 +447,8 @@ class PStream(Stream):
         self.emit("s_lshr_b32", s("t0"), [SN("kinc"), I(6)])                 # 2 ld(K)
         self.emit("s_lshr_b32", s("t2"), [SN("wave64"), I(2)])
         self.emit("s_mul_i32", s("kc0"), [s("t0"), s("t2")])
-        self.emit("s_lshl_b32", s("t0"), [s("t0"), I(2)])
-        for i in range(1, 4):
-            self.emit("s_add_u32", s("kc%d" % i), [s("kc%d" % (i - 1)), s("t0")])
-        self.emit("s_lshr_b32", s("t0"), [SN("vinc"), I(2)])                 # 16 x 2 ld(V)
-        self.emit("s_mov_b32", s("vc0"), [I(0)])
-        for i in range(1, 4):
-            self.emit("s_add_u32", s("vc%d" % i), [s("vc%d" % (i - 1)), s("t0")])
+        self.emit("s_lshl_b32", s("kstep"), [s("t0"), I(2)])                 # four rows of K
+        self.emit("s_lshr_b32", s("vstep"), [SN("vinc"), I(2)])              # sixteen keys of V
         self.emit("s_lshl_b32", s("q4"), [SN("ldq2"), I(2)])
         for name, nrec in (("kres", "nreck"), ("vres", "nrecv")):
             self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
@@ -398,6 +473,14 @@ class PStream(Stream):
             self.emit("s_mov_b32", s(name, 1, 0), [s(name + "n", 1, 0)])
             self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
         self.emit("s_mov_b32", s("row0"), [s("row0n")])
+        if cfg.causal:
+            self.block_geometry()
+            # waves that skipped tiles did not walk the V read pointer: V(-1)'s image is the one before V(0)'s
+            self.emit("s_sub_u32", s("t0"), [s("vwr"), SN("ldsv")])
+            self.emit("s_sub_u32", s("t0"), [s("t0"), I(VSLOT)])
+            self.emit("s_add_u32", s("t2"), [s("t0"), I(VRING * VSLOT)])
+            self.emit("s_cmp_lt_i32", None, [s("t0"), I(0)])
+            self.emit("s_cselect_b32", s("vrd"), [s("t2"), s("t0")])
         self.emit("s_add_u32", s("blk"), [s("blk"), I(1)])
         self.emit("s_mov_b32", s("hasnext"), [I(0)])
         self.emit("s_cmp_ge_u32", None, [s("blk"), SN("nblk")])
@@ -436,7 +519,7 @@ class PStream(Stream):
         self.pstamp("tile0_b")
         self.label(loop)
         for par, endl in ((1, end_even), (0, end_odd)):
-            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
+            self.emit("s_cmp_ge_i32", None, [SN("j"), SN("wnt")])     # (dense streams: wnt = nt)
             self.emit("s_cbranch_scc1", None, [], target=endl)
             vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
             self.lds_flush()
@@ -453,13 +536,23 @@ class PStream(Stream):
             self.pstamp("loop_b")
             self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_branch", None, [], target=loop)
-        for lastpar, lbl in ((0, end_even), (1, end_odd)):
+        skip_odd, skip_even = self.newlabel("SKIPODD"), self.newlabel("SKIPEVEN")
+        for lastpar, lbl, nxt in ((0, end_even, skip_odd), (1, end_odd, skip_even)):
             self.label(lbl)
             vids = self.phase_a(lastpar ^ 1, mfma=False, softmax=True, zero_o=False)
             self.lds_flush()
             self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
             self.phase_b(lastpar ^ 1, mfma=True, softmax=False, vids=vids)
-            self.emit("s_branch", None, [], target=done)
+            self.emit("s_branch", None, [], target=nxt if cfg.causal else done)
+        if cfg.causal:
+            # a wave whose rows end before the block's last tile still owes the others its barriers and its LDS-DMA pieces
+            for par, lbl in ((1, skip_odd), (0, skip_even)):
+                self.label(lbl)
+                self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
+                self.emit("s_cbranch_scc1", None, [], target=done)
+                self.skip_tile(par)
+                if par == 0:
+                    self.emit("s_branch", None, [], target=skip_odd)
         self.label(done)
         self.emit("s_barrier")       # every wave is done with the V image the epilogue stages O in (last read in phase B(nt-1))
         self.pstamp("tail")
@@ -525,6 +618,14 @@ VARIANTS = {
     "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1),
     "F16_EXACT": PCfg("f16", 8, fold=0),
     "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1),
+    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1),
+    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1),
+    "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1),
+    "BF16_EXACT_O16_CAUSAL": PCfg("bf16", 8, fold=0, o16=1, causal=1),
+    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1),
+    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1),
+    "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1),
+    "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1),
     "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
 }
 PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof)
@@ -540,17 +641,17 @@ def write_inc(path):
     lines.append("#define MFA_P4P_TABLE_ENTRIES %d" % TABLE_ENTRIES)
     lines.append("#define MFA_P4P_LDS_BYTES %d" % LDS_BYTES)
     lines.append("")
-    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16)")
+    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16, causal)")
     lines.append("#define MFA_P4P_PRODUCT_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates")
     lines.append("#define MFA_P4P_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name not in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
     lines.append("")
     lines.append("#ifdef MFA_DEV_VARIANTS")
     lines.append("#define MFA_P4P_STREAM_LIST(X) MFA_P4P_PRODUCT_STREAM_LIST(X) MFA_P4P_DEV_STREAM_LIST(X)")
@@ -565,8 +666,8 @@ def write_inc(path):
         if name not in PRODUCT_STREAMS:
             lines.append("#ifdef MFA_DEV_VARIANTS")
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
-        lines.append("// %s: dtype=%s thr=%g fold=%d xb=%d o16=%d l16=%d -- %d instructions, %d matrix instructions"
-                     % (name, cfg.dtype, cfg.thr, cfg.fold, cfg.xb, cfg.o16, cfg.l16, len(txt), n_mfma))
+        lines.append("// %s: dtype=%s thr=%g fold=%d xb=%d o16=%d l16=%d causal=%d -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.fold, cfg.xb, cfg.o16, cfg.l16, cfg.causal, len(txt), n_mfma))
         lines.append("#define MFA_P4P_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)

@@ -88,7 +88,7 @@ class PWorkgroup(Workgroup):
     def execute(self, w, ins):
         op, d, s, m = ins.op, ins.d, ins.s, ins.mod
         scalar_kinds = ("sr",)
-        if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32"):
+        if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_min_u32", "s_max_u32"):
             vals = [self.sval(w, x) for x in s]
             if op == "s_mov_b32":
                 r = vals[0]
@@ -97,7 +97,7 @@ class PWorkgroup(Workgroup):
             else:
                 a, b = int(vals[0]) & 0xFFFFFFFF, int(vals[1]) & 0xFFFFFFFF
                 r = {"s_add_u32": a + b, "s_sub_u32": a - b, "s_and_b32": a & b, "s_lshl_b32": a << (b & 31),
-                     "s_lshr_b32": a >> (b & 31), "s_mul_i32": a * b}[op]
+                     "s_lshr_b32": a >> (b & 31), "s_mul_i32": a * b, "s_min_u32": min(a, b), "s_max_u32": max(a, b)}[op]
                 if op == "s_add_u32":
                     w.scc = int(a + b > 0xFFFFFFFF)
             if d[0] in ("sr", "m0"):
@@ -180,6 +180,9 @@ class PWorkgroup(Workgroup):
             self.lds_write16(addr, np.ascontiguousarray(words.T).view(np.uint8).reshape(64, 16))
             w.lds_q.append(([], np.zeros((0, 64), np.uint32)))   # counts in lgkmcnt like a read
             return None
+        if op == "v_sub_u32":
+            w.wr(d, (self.vsrc(w, s[0]).astype(np.int64) - self.vsrc(w, s[1]).astype(np.int64)) & 0xFFFFFFFF)
+            return None
         if op == "v_min_u32":
             w.wr(d, np.minimum(self.vsrc(w, s[0]), self.vsrc(w, s[1])))
             return None
@@ -223,7 +226,7 @@ class PWorkgroup(Workgroup):
                 self.lds_write16(addrs, data)
 
 
-def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None):
+def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None, causal=None):
     """One persistent workgroup over `blocks` = [(head, row block), ...].  q [H][R][D], k / v [H][C][D] uint16 bit patterns.
     Restates the C++ prologue of attn_fwd16_p4p (block table, lane constants, scalar inputs).  Returns O [H][R][D] float32
     (or the 16-bit patterns as float32 when cfg.o16), L [H][R] float32 (log2 units), the workgroup."""
@@ -275,6 +278,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
             "lim0": (C - 1 - 4 * hi).astype(np.int64).astype(np.uint32), "lim1": (C - 1 - 4 * hi).astype(np.int64).astype(np.uint32),
             "vv": vv, "lv": np.where(hi == 0, qq * lsz, p4pgen.OOB).astype(np.uint32),
             # epilogue: in as lane = row (16-byte chunks, chunk index XOR row & 7), out as lane = (row & 7, chunk)
+            "qlane": qq.astype(np.uint32), "hi4": (4 * hi).astype(np.uint32),
             "ewa": (qq * 128 + ((hi ^ (qq & 7)) << 4)).astype(np.uint32),
             "era": ((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4)).astype(np.uint32),
         })
@@ -287,7 +291,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
                      "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "ldsq": p4pgen.QIMG + wave * 16384,
                      "qrel": p4pgen.QIMG + wave * 16384, "nblk": len(blocks), "tbl": p4pgen.TABLE, "wave64": wave * 64,
                      "ldq2": ldq2, "ldo": ldo * osz, "nrecq": R * ldq2, "nreck": C * ldk2, "nrecv": C * ldv2,
-                     "nreco": R * ldo * osz, "nrecl": R * lsz, "dr": D})
+                     "nreco": R * ldo * osz, "nrecl": R * lsz, "dr": D, "coff": C - R, "cm1": C - 1, "rr": R, "ttot": (C + 63) // 64})
     wg.run(order)
     for w in wg.waves:
         assert not w.lds_q, "LDS reads left in flight"

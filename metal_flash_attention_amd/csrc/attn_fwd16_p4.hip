@@ -17,6 +17,15 @@ static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, CAUSAL>), dim3(groups * grid.y * grid.z), dim3(256), p4::LDS_BYTES, stream, args, g);
 }
 
+// column-parallel launch (few-workgroup problems: one head, long sequences): pieces of the key range, then the combine pass
+template <typename T, int STREAM>
+static void launch_p4_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
+  hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, false, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), p4::LDS_BYTES, stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
+  hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
+}
+
 template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false>);
   v->name = name;
@@ -31,6 +40,9 @@ template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char
   v->launchCausal = &launch_p4<T, STREAM, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, true>);
   v->causal = true;
+  v->launchSplit = &launch_p4_split<T, STREAM>;   // (block-sparse launches keep the sibling of the 8 x 32 kernel)
+  v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false, true>);
+  v->splitTarget = 256;   // one workgroup per compute unit
 }
 
 template <typename T, int STREAM> static void fill_p4_dev(VariantInfo *v, const char *name) {   // dense launches only

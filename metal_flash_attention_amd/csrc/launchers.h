@@ -9,6 +9,7 @@ struct VariantInfo {
   const char *name = "";
   uint16_t parallelization = 0; // rows (fwd, dQ) or columns (dK/dV) per workgroup
   uint16_t siblingParallelization = 0;   // the same for launchSparse / launchSplit when they belong to another kernel (0: equal)
+  uint16_t splitTarget = 0;     // workgroups a traversal-parallel launch aims at (0: 512 = two per compute unit)
   uint16_t traversal = 0;       // columns (fwd, dQ) or rows (dK/dV) per main-loop step
   uint16_t headBlock = 0;       // padded head dimension the code object is unrolled for
   uint32_t threads = 0;         // work-items per workgroup

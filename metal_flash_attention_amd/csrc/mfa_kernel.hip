@@ -482,10 +482,12 @@ static uint64_t relayout_workspace_bytes(const mfa_attention_kernel *kernel, uin
 // Column-parallel heuristic: split only when the row-parallel grid cannot fill the 256 CUs and the
 // traversal is long enough to amortise the combine pass; aim at ~2 workgroups per CU, keep >= 4 key
 // tiles (256 keys) per piece.
-static uint32_t choose_splits(uint64_t blocks, uint32_t column) {
+// `target`: workgroups the variant wants in flight (512 = two per compute unit; 256 for the kernels that own a compute unit's whole
+// register file and run one workgroup per compute unit -- a second round of half-length pieces would pay the per-block cost twice)
+static uint32_t choose_splits(uint64_t blocks, uint32_t column, uint32_t target = 512) {
   const uint32_t tiles = (column + 63) / 64;
   if (blocks >= 192 || tiles < 8) return 1;
-  uint64_t s = (512 + blocks - 1) / blocks;
+  uint64_t s = (target + blocks - 1) / blocks;
   if (s > tiles / 4) s = tiles / 4;
   if (s > 64) s = 64;
   return s < 2 ? 1 : (uint32_t)s;
@@ -606,7 +608,8 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   const bool splittable = !plan->useFallback && !kernel->relayout && plan->variant->launchSplit && !args->rowLen && !args->colLen && !args->mask &&
                           (type != MFA_FORWARD || !args->causal);
   if (splittable) {
-    const uint32_t s = choose_splits((uint64_t)sibBlocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column);
+    const uint32_t s = choose_splits((uint64_t)sibBlocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column,
+                                     plan->variant->splitTarget ? plan->variant->splitTarget : 512);
     if (s > 1) {
       plan->workspaceNeeded = split_workspace_bytes(type, s, heads, batches, p->row, p->column, D);
       if (p->workspace && p->workspaceBytes >= plan->workspaceNeeded &&
@@ -682,7 +685,8 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
   const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? params->column : params->row;
   const uint32_t wgPar = kernel->variant.siblingParallelization ? kernel->variant.siblingParallelization : kernel->variant.parallelization;
   const uint32_t blocks = (par + wgPar - 1) / wgPar;
-  const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? params->row : params->column);
+  const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? params->row : params->column,
+                                   kernel->variant.splitTarget ? kernel->variant.splitTarget : 512);
   if (s > 1) *bytes = split_workspace_bytes(type, s, heads, batches, params->row, params->column, kernel->desc.headDimension);
   return MFA_OK;
 }

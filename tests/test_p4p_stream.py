@@ -138,6 +138,15 @@ def test_causal_spike_below_the_diagonal():
     wg, _, _ = _check(1, 512, 512, cfg=CAUSAL_FOLD, spike=(300, 200, 3.0), seed=12, tol_o=1.2e-2)
 
 
+@pytest.mark.parametrize("C", [64, 128, 256, 449])
+def test_merged_block_switch_experiment(C):
+    """developer stream (slower on the GPU, kept as a record): the last tile's softmax finish beside the next block's first K Q^T.
+    The model found the hazard its first form had -- no barrier between a wave's wait for its own pieces of K'(1) and the other
+    waves' reads of them -- before any GPU run."""
+    _check(3, 256, C, cfg=p4pgen.VARIANTS["BF16_FOLD_L16_MERGE"], seed=13, dma_mode="late", order=(0, 1, 2, 3))
+    _check(2, 512, C, cfg=p4pgen.VARIANTS["BF16_FOLD_L16_MERGE"], seed=14, dma_mode="early", order=(3, 2, 1, 0))
+
+
 def test_stream_file_is_current():
     """csrc/attn_fwd16_p4p_stream.inc is what tools/p4pgen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4p_stream.inc")

@@ -59,8 +59,8 @@ PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
              ob=(68, 2), lb=(70, 2), row0=(72, 1), blk=(73, 1), hasnext=(74, 1), ntm1=(75, 1), ntm2=(76, 1),
              j=(77, 1), vrd=(78, 1), vwr=(79, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
              kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), wntb=(90, 1), maskb=(91, 1), ntu=(92, 1), t5=(93, 1),
-             q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1))
-FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 100
+             q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1), qswj=(101, 1))
+FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 101
 
 # inputs of the statement (hipcc allocates them below s40 / v28)
 INOUT_V = ["lim0", "lim1"]          # mask limits per row block: constant in dense streams, rewritten per block by causal ones
@@ -73,13 +73,19 @@ IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qre
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb)
         self.o16, self.l16 = o16, l16
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
         # computed per block inside the stream; the block table lists the blocks in pairs (long, short) like attn_fwd16_p4's
         # causal launch, so that every workgroup walks the same number of tiles
         self.causal = causal
+        # merge (dense streams; developer experiment that LOST, profiles/r03_p4p_merged_block_switch.txt): the softmax finish of a
+        # block's last tile runs beside the next block's first K Q^T products instead of beside nothing -- the pipeline's drain and
+        # fill share one phase at every block switch (-1.4 k clocks), but O must then be zeroed in the epilogue and its staging
+        # registers halve (+2.6 k)
+        self.merge = merge
+        assert not (merge and causal)
         # pprof (developer builds, exact-scale streams only: their -m blocks v168.. are free): shader-clock sums per segment of
         # the block loop in v168..v183, written to O[first row of the wave's last block][0:16] when the workgroup ends
         self.pprof = pprof
@@ -140,6 +146,10 @@ class PStream(Stream):
         at(17, lambda: check("ntm1", vsw))
         self.outofline.append(("ksw", ksw, ksw + "_BACK", par, False))
         self.outofline.append(("vsw", vsw, vsw + "_BACK", par, False))
+        if self.cfg.merge:      # the next block's Q is needed right behind this block's last tile: requested three tiles earlier
+            qsw = self.newlabel("QSW")
+            at(15, lambda: check("qswj", qsw))
+            self.outofline.append(("qsw", qsw, qsw + "_BACK", par, False))
 
     def pstamp(self, name, first=False):
         """developer streams: add the shader-clock time since the previous stamp to accumulator `name` (s_memtime returns
@@ -291,17 +301,18 @@ class PStream(Stream):
             else:
                 self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1)
 
-    def q_fragments(self):
-        """Q image -> B-operand fragments a[128:191] (FOLD: times log2(e)/sqrt(D), rounded to the 16-bit type)"""
+    def q_fragments(self, qa=96, tmp=(104, 105)):
+        """Q image -> B-operand fragments a[128:191] (FOLD: times log2(e)/sqrt(D), rounded to the 16-bit type); eight address
+        registers from `qa`, two temporaries, 64 data registers v32..v95 (the even tiles' score registers)"""
         cfg = self.cfg
-        qa, qd = 96, 32                         # eight addresses v96..v103, 64 data registers v32..v95
+        qd = 32
         for ks in range(8):
             self.emit("v_add_u32", V(qa + ks), [SN("qrel"), V(T_KADDR + ks)])
         ids = []
         for b in range(2):
             for ks in range(8):
                 ids.append(self.lds_read("ds_read_b128", V(qd + 4 * (8 * b + ks), 4), V(qa + ks), b * 8192, note="Q(%d,%d)" % (b, ks)))
-        t0, t1 = V(104), V(105)
+        t0, t1 = V(tmp[0]), V(tmp[1])
         for n in range(16):
             self.lds_need(ids[n])
             for w in range(4):
@@ -382,9 +393,17 @@ class PStream(Stream):
 
         for b in range(8):
             rb, db = divmod(b, 4)
-            src, dst = S_BASE[0] + 16 * (b & 3), S_BASE[1] + 16 * (b & 3)
+            # staging registers: four 16-register sets each way (an instruction reads its registers when it issues); the merged
+            # block switch has the odd tiles' score registers only (the even ones hold the next block's tile 0): two sets
+            if cfg.merge:
+                src, dst = S_BASE[1] + 16 * (b & 1), S_BASE[1] + 32 + 16 * (b & 1)
+            else:
+                src, dst = S_BASE[0] + 16 * (b & 3), S_BASE[1] + 16 * (b & 3)
             for r in range(16):
                 self.emit("v_accvgpr_read_b32", V(src + r), [A(O_BASE + 16 * b + r)])
+            if cfg.merge:       # the next block's first phase multiplied K Q^T beside this block's softmax: O is zeroed here
+                for r in range(16):
+                    self.emit("v_accvgpr_write_b32", A(O_BASE + 16 * b + r), [I(0)])
             for r in range(16):
                 self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])
             for g in range(4):
@@ -412,8 +431,8 @@ class PStream(Stream):
                 self.emit("buffer_store_dword", None, [x, vo, s("lres", 4)], offset=0)
 
     def emit_outofline(self):
-        mine = [x for x in self.outofline if x[0] in ("ksw", "vsw")]
-        self.outofline = [x for x in self.outofline if x[0] not in ("ksw", "vsw")]
+        mine = [x for x in self.outofline if x[0] in ("ksw", "vsw", "qsw")]
+        self.outofline = [x for x in self.outofline if x[0] not in ("ksw", "vsw", "qsw")]
         Stream.emit_outofline(self)
         for kind, lbl, back, par, _ in mine:
             self.label(lbl)
@@ -421,10 +440,49 @@ class PStream(Stream):
             self.emit("s_cbranch_scc1", None, [], target=back)      # last block: the ring runs ahead into zeros (out of range)
             if kind == "ksw":
                 self.switch_k()
-            else:
+            elif kind == "vsw":
                 self.switch_v()
+                if not self.cfg.merge:
+                    self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
+            else:
                 self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
             self.emit("s_branch", None, [], target=back)
+
+    def block_head(self, nonext):
+        """the block whose operands were requested under the previous one becomes the current one; read the table entry after it"""
+        cfg = self.cfg
+        for name in ("ob", "lb"):
+            self.emit("s_mov_b32", s(name, 1, 0), [s(name + "n", 1, 0)])
+            self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
+        self.emit("s_mov_b32", s("row0"), [s("row0n")])
+        if cfg.causal:
+            self.block_geometry()
+            # waves that skipped tiles did not walk the V read pointer: V(-1)'s image is the one before V(0)'s
+            self.emit("s_sub_u32", s("t0"), [s("vwr"), SN("ldsv")])
+            self.emit("s_sub_u32", s("t0"), [s("t0"), I(VSLOT)])
+            self.emit("s_add_u32", s("t2"), [s("t0"), I(VRING * VSLOT)])
+            self.emit("s_cmp_lt_i32", None, [s("t0"), I(0)])
+            self.emit("s_cselect_b32", s("vrd"), [s("t2"), s("t0")])
+        self.emit("s_add_u32", s("blk"), [s("blk"), I(1)])
+        self.emit("s_mov_b32", s("hasnext"), [I(0)])
+        self.emit("s_cmp_ge_u32", None, [s("blk"), SN("nblk")])
+        self.emit("s_cbranch_scc1", None, [], target=nonext)
+        self.emit("s_mov_b32", s("hasnext"), [I(1)])
+        self.load_next()
+        self.label(nonext)
+
+    def block_init(self):
+        cfg = self.cfg
+        for rb in range(2):
+            self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
+            self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
+            self.emit("v_mov_b32", VN("l%d" % rb), [I(0)])
+            self.emit("v_mov_b32", VN("m%d" % rb), [F(0.0) if cfg.fold else F(-3.402823466e+38)])
+        if cfg.fold:
+            for r in range(32):
+                self.emit("v_mov_b32", V(CM_BASE + r), [I(0)])
+        self.emit("s_mov_b32", SN("pend"), [I(0)])
+        self.emit("s_mov_b32", SN("j"), [I(0)])
 
     # ------------------------------------------------------------ whole stream
     def build(self):
@@ -440,6 +498,9 @@ class PStream(Stream):
         if not cfg.causal:
             self.emit("s_sub_u32", s("ntm1"), [SN("nt"), I(1)])
             self.emit("s_sub_u32", s("ntm2"), [SN("nt"), I(2)])
+        if cfg.merge:
+            self.emit("s_sub_u32", s("t0"), [SN("nt"), I(3)])
+            self.emit("s_max_i32", s("qswj"), [s("t0"), I(0)])   # tile whose phase B requests the next block's Q
         self.emit("s_mov_b32", s("vrd"), [I(2 * VSLOT)])     # "image of V(-1)"
         self.emit("s_mov_b32", s("vwr"), [SN("ldsv")])       # V(0) goes to image 0
         self.emit("s_add_u32", s("t1"), [SN("ldsv"), I(VRING * VSLOT)])
@@ -469,25 +530,7 @@ class PStream(Stream):
                 self.emit("v_mov_b32", V(PROF_ACC + i), [I(0)])
         self.label(blk_lbl)
         self.pstamp("table", first=True)
-        for name in ("ob", "lb"):
-            self.emit("s_mov_b32", s(name, 1, 0), [s(name + "n", 1, 0)])
-            self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
-        self.emit("s_mov_b32", s("row0"), [s("row0n")])
-        if cfg.causal:
-            self.block_geometry()
-            # waves that skipped tiles did not walk the V read pointer: V(-1)'s image is the one before V(0)'s
-            self.emit("s_sub_u32", s("t0"), [s("vwr"), SN("ldsv")])
-            self.emit("s_sub_u32", s("t0"), [s("t0"), I(VSLOT)])
-            self.emit("s_add_u32", s("t2"), [s("t0"), I(VRING * VSLOT)])
-            self.emit("s_cmp_lt_i32", None, [s("t0"), I(0)])
-            self.emit("s_cselect_b32", s("vrd"), [s("t2"), s("t0")])
-        self.emit("s_add_u32", s("blk"), [s("blk"), I(1)])
-        self.emit("s_mov_b32", s("hasnext"), [I(0)])
-        self.emit("s_cmp_ge_u32", None, [s("blk"), SN("nblk")])
-        self.emit("s_cbranch_scc1", None, [], target=nonext)
-        self.emit("s_mov_b32", s("hasnext"), [I(1)])
-        self.load_next()
-        self.label(nonext)
+        self.block_head(nonext)
         self.pstamp("table")
         # this wave's Q image, and its pieces of K(0), V(0), K(1): everything older than the previous block's stores
         self.emit("s_waitcnt", None, [], vmcnt=NST)
@@ -495,16 +538,7 @@ class PStream(Stream):
         self.q_fragments()
         self.emit("s_barrier")
         self.pstamp("qfrag")
-        for rb in range(2):
-            self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
-            self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
-            self.emit("v_mov_b32", VN("l%d" % rb), [I(0)])
-            self.emit("v_mov_b32", VN("m%d" % rb), [F(0.0) if cfg.fold else F(-3.402823466e+38)])
-        if cfg.fold:
-            for r in range(32):
-                self.emit("v_mov_b32", V(CM_BASE + r), [I(0)])
-        self.emit("s_mov_b32", SN("pend"), [I(0)])
-        self.emit("s_mov_b32", SN("j"), [I(0)])
+        self.block_init()
         for i in range(16):
             self.k_read(0, i)
         self.lds_flush()
@@ -539,6 +573,23 @@ class PStream(Stream):
         skip_odd, skip_even = self.newlabel("SKIPODD"), self.newlabel("SKIPEVEN")
         for lastpar, lbl, nxt in ((0, end_even, skip_odd), (1, end_odd, skip_even)):
             self.label(lbl)
+            if cfg.merge and lastpar == 1:
+                # A block ends behind an odd tile (even count).  With a block to follow, the softmax finish of that tile runs
+                # beside the NEXT block's first K Q^T products (its Q arrived three tiles ago, K'(0)'s fragments were fetched by
+                # phase B(nt-1) like any K(j+1)'s): the drain of this block's pipeline and the fill of the next share a phase
+                plain = self.newlabel("PLAINTAIL")
+                self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(0)])
+                self.emit("s_cbranch_scc1", None, [], target=plain)
+                if cfg.fold:
+                    for r in range(32):
+                        self.emit("v_mov_b32", V(CM_BASE + r), [I(0)])
+                self.q_fragments(qa=T_MX, tmp=(T_TL, T_TL + 1))
+                vids = self.phase_a(0, mfma=True, softmax=True, zero_o=False)
+                self.lds_flush()
+                self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
+                self.phase_b(0, mfma=True, softmax=False, vids=vids)
+                self.emit("s_branch", None, [], target=done)
+                self.label(plain)
             vids = self.phase_a(lastpar ^ 1, mfma=False, softmax=True, zero_o=False)
             self.lds_flush()
             self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
@@ -554,6 +605,10 @@ class PStream(Stream):
                 if par == 0:
                     self.emit("s_branch", None, [], target=skip_odd)
         self.label(done)
+        if cfg.merge:
+            # a merged switch has no barrier between this block's end and the next block's phase B(0), which reads K'(1): every
+            # wave's pieces of the next block's first tiles (requested two phases ago) land before the barrier below
+            self.emit("s_waitcnt", None, [], vmcnt=0)
         self.emit("s_barrier")       # every wave is done with the V image the epilogue stages O in (last read in phase B(nt-1))
         self.pstamp("tail")
         for rb in range(2):
@@ -563,8 +618,9 @@ class PStream(Stream):
         if cfg.pprof:
             acc = V(PROF_ACC + PROF_NAMES.index("blocks"))
             self.emit("v_add_u32", acc, [I(1), acc])
+        post = self.newlabel("POST")
         self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(1)])
-        self.emit("s_cbranch_scc1", None, [], target=blk_lbl)
+        self.emit("s_cbranch_scc1", None, [], target=post if cfg.merge else blk_lbl)
         self.emit("s_waitcnt", None, [], vmcnt=0)
         if cfg.pprof:   # lane 0 leaves the sums in O[first row of the wave's last block][0:16] (fp32 O)
             self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
@@ -577,6 +633,18 @@ class PStream(Stream):
             self.emit("s_mov_b64", ("exec",), [I(-1)])
             self.emit("s_waitcnt", None, [], vmcnt=0)
         self.emit("s_branch", None, [], target=fin)
+        if cfg.merge:
+            # behind a merged block switch: tile 0 of the new block has its scores; its softmax start follows the old block's epilogue
+            self.label(post)
+            nonext2 = self.newlabel("NONEXT")
+            self.pstamp("table", first=True)
+            self.block_head(nonext2)
+            self.pstamp("table")
+            self.block_init()
+            self.phase_b(0, mfma=False, softmax=True, vids={})   # (K(1) landed before the barrier in front of the epilogue)
+            self.emit("s_mov_b32", SN("j"), [I(1)])
+            self.pstamp("tile0_b")
+            self.emit("s_branch", None, [], target=loop)
         self.emit_outofline()
         self.label(fin)
         return self.finish()
@@ -627,8 +695,9 @@ VARIANTS = {
     "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1),
     "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1),
     "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
+    "BF16_FOLD_L16_MERGE": PCfg("bf16", 8, fold=1, l16=1, merge=1),   # developer builds only: merged block switch (lost)
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof)
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof and not c.merge)
 
 
 def write_inc(path):

@@ -88,7 +88,7 @@ class PWorkgroup(Workgroup):
     def execute(self, w, ins):
         op, d, s, m = ins.op, ins.d, ins.s, ins.mod
         scalar_kinds = ("sr",)
-        if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_min_u32", "s_max_u32"):
+        if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_min_u32", "s_max_u32", "s_max_i32"):
             vals = [self.sval(w, x) for x in s]
             if op == "s_mov_b32":
                 r = vals[0]
@@ -97,7 +97,8 @@ class PWorkgroup(Workgroup):
             else:
                 a, b = int(vals[0]) & 0xFFFFFFFF, int(vals[1]) & 0xFFFFFFFF
                 r = {"s_add_u32": a + b, "s_sub_u32": a - b, "s_and_b32": a & b, "s_lshl_b32": a << (b & 31),
-                     "s_lshr_b32": a >> (b & 31), "s_mul_i32": a * b, "s_min_u32": min(a, b), "s_max_u32": max(a, b)}[op]
+                     "s_lshr_b32": a >> (b & 31), "s_mul_i32": a * b, "s_min_u32": min(a, b), "s_max_u32": max(a, b),
+                     "s_max_i32": max(int(np.int32(np.uint32(a))), int(np.int32(np.uint32(b))))}[op]
                 if op == "s_add_u32":
                     w.scc = int(a + b > 0xFFFFFFFF)
             if d[0] in ("sr", "m0"):

@@ -344,7 +344,12 @@ def main():
                                            if w["dtype"] in SUSTAINED_TFLOPS_RANDOM else None),
                      "traffic": traffic_bytes, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_source,
                      "algorithmic_bytes": (3 * N * D * (2 if low else 4) + N * D * 4 + N * 4) * B * H if not backward else None,
-                     "kernel": "+".join(kernels[t].variant for t in types), "launch_ms": round(launch_ms, 4)},
+                     "kernel": "+".join(kernels[t].variant for t in types), "launch_ms": round(launch_ms, 4),
+                     # what the timed launches ran (mfa_attention_kernel_launch_form): e.g. the persistent form attn_fwd16_p4p of the
+                     # D <= 128 forward object -- the kernel name rocprofv3 reports for this command
+                     "launch_form": [kernels[t].launchForm(bufs, row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                                                           workspace=workspace if (t.name == "forward" or relayout) else None,
+                                                           causal=bool(w.get("causal", False))) for t in types]},
     }
 
     if other_mode is not None:

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 5
+#define MFA_ABI_VERSION 6
 
 /* ---- status codes (replace fatalError, e.g. AttentionKernel.swift:33,
  *      AttentionDescriptor.swift:45/72/90/97, AttentionParameterRow.swift:50/57/100) -------- */
@@ -257,6 +257,13 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel,
 /* Bytes of mfa_launch_params.workspace this launch would use (0 if it would not be split). */
 mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kernel,
                                                const mfa_launch_params *params, uint64_t *bytes);
+/* What a launch with these buffers and parameters would run, as text -- nothing is launched.  The code object is a property of
+ * the kernel object (mfa_attention_kernel_variant); the FORM is a property of the launch: the general kernel when the launch
+ * does not meet the matrix-core kernels' requirements, a re-layout pass in front, column-parallel pieces + combine through
+ * the workspace, or (dense and causal forward launches at D <= 128 without per-batch lengths) the persistent form
+ * `attn_fwd16_p4p`, which is the name rocprofv3 shows for such launches.  `buffers` as for mfa_attention_kernel_launch. */
+mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
+                                            const mfa_launch_params *params, char *out, size_t capacity);
 
 /* Timing helper: `warmup` untimed launches, then `iterations` back-to-back launches bracketed by
  * HIP events recorded on `stream` (the harness of SquareAttentionTest.swift:733-761 uses

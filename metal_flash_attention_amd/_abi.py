@@ -186,6 +186,7 @@ SYMBOLS = [
     ("mfa_attention_kernel_variant", ctypes.c_char_p, [_KERNEL]),
     ("mfa_attention_kernel_fallback_variant", ctypes.c_char_p, [_KERNEL]),
     ("mfa_attention_kernel_needs_workspace_for_fast_path", ctypes.c_int, [_KERNEL]),
+    ("mfa_attention_kernel_launch_form", ctypes.c_int, [_KERNEL, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]),
     ("mfa_attention_kernel_effective_descriptor", ctypes.c_int, [_KERNEL, _P(mfa_attention_kernel_descriptor)]),
     ("mfa_launch_params_init", None, [_P(mfa_launch_params)]),
     ("mfa_attention_kernel_launch", ctypes.c_int, [_KERNEL, _P(_BUFS), _P(mfa_launch_params), ctypes.c_void_p]),
@@ -199,7 +200,7 @@ SYMBOLS = [
 ]
 
 _lib = None
-EXPECTED_ABI = 5   # MFA_ABI_VERSION of include/mfa.h this file mirrors
+EXPECTED_ABI = 6   # MFA_ABI_VERSION of include/mfa.h this file mirrors
 
 
 class MFAError(RuntimeError):

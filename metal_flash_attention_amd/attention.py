@@ -357,6 +357,19 @@ class AttentionKernel:
         check(lib().mfa_attention_kernel_launch(self._handle, ctypes.byref(arr), ctypes.byref(params),
                                                 ctypes.c_void_p(stream or 0)))
 
+    def launchForm(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
+                   leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
+                   batchStrides: Optional[Mapping] = None, workspace=None, causal: bool = False, rowLengths=None,
+                   columnLengths=None, blockMask=None, blockMaskWords: int = 0, blockMaskStrides=(0, 0)) -> str:
+        """What `dispatch` with the same arguments would run (nothing is launched): the variant's own kernel, the general
+        kernel, column-parallel pieces + combine, a re-layout pass in front, or the persistent form `attn_fwd16_p4p` --
+        the name rocprofv3 shows for dense / causal forward launches at D <= 128 (mfa_attention_kernel_launch_form)."""
+        arr, params, _keep = self._marshal(buffers, row, column, heads, batches, leadingDimensions, headStrides, batchStrides,
+                                           workspace, causal, rowLengths, columnLengths, blockMask, blockMaskWords, blockMaskStrides)
+        out = ctypes.create_string_buffer(512)
+        check(lib().mfa_attention_kernel_launch_form(self._handle, ctypes.byref(arr), ctypes.byref(params), out, len(out)))
+        return out.value.decode()
+
     def time(self, buffers, *, row: int, column: int, heads: int = 1, batches: int = 1,
              leadingDimensions: Optional[Mapping] = None, headStrides: Optional[Mapping] = None,
              batchStrides: Optional[Mapping] = None, stream: Optional[int] = None,

@@ -6,6 +6,7 @@ namespace mfa {
 
 // persistent form (attn_fwd16_p4p.hip): dense launches without per-batch lengths; false = not served, launch this kernel
 template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args);
+template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args);
 
 template <typename T, int STREAM, bool CAUSAL>
 static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
@@ -43,6 +44,8 @@ template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char
   v->launchSplit = &launch_p4_split<T, STREAM>;   // (block-sparse launches keep the sibling of the 8 x 32 kernel)
   v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false, true>);
   v->splitTarget = 256;   // one workgroup per compute unit
+  if constexpr (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD)
+    v->launchForm = &p4p_form<T, p4::stream_folds(STREAM)>;
 }
 
 template <typename T, int STREAM> static void fill_p4_dev(VariantInfo *v, const char *name) {   // dense launches only

@@ -101,6 +101,25 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   }
 }
 
+// the launches launch_p4p serves (the same conditions, nothing launched)
+template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args) {
+  if (args.rowLen || args.colLen || args.mask) return nullptr;
+  if (args.causal && args.C < args.R) return nullptr;
+#ifdef MFA_DEV_VARIANTS
+  if (std::getenv("MFA_P4_NO_PERSISTENT")) return nullptr;
+#endif
+  const int po = args.op[SLOT_O].precision, pl = args.op[SLOT_L].precision;
+  constexpr int PT = __is_same(T, _Float16) ? PREC_FP16 : PREC_BF16;
+  if (po != PT && po != PREC_FP32) return nullptr;
+  if (FOLD ? pl != PREC_FP16 : pl != PREC_FP32) return nullptr;
+  return args.causal ? "attn_fwd16_p4p (persistent: one workgroup per compute unit walks the row-block pairs)"
+                     : "attn_fwd16_p4p (persistent: one workgroup per compute unit walks the row blocks)";
+}
+template const char *p4p_form<__bf16, true>(const KernelArgs &);
+template const char *p4p_form<__bf16, false>(const KernelArgs &);
+template const char *p4p_form<_Float16, true>(const KernelArgs &);
+template const char *p4p_form<_Float16, false>(const KernelArgs &);
+
 template bool launch_p4p<__bf16, true>(dim3, hipStream_t, const KernelArgs &);
 template bool launch_p4p<__bf16, false>(dim3, hipStream_t, const KernelArgs &);
 template bool launch_p4p<_Float16, true>(dim3, hipStream_t, const KernelArgs &);

@@ -18,6 +18,9 @@ struct VariantInfo {
   bool cacheSecond = false;     // the second of them alone (dO / V); fill code sets it = cacheLeft unless a variant splits the pair
   bool causal = false;          // the code object implements the causal mask itself (general kernels: always)
   void (*launch)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
+  // dense / causal launches that `launch` / `launchCausal` hand to another code object (the persistent form of the D <= 128
+  // forward kernel): its name for such a launch, nullptr when the variant's own kernel runs (mfa_attention_kernel_launch_form)
+  const char *(*launchForm)(const KernelArgs &args) = nullptr;
   // forward only: column-parallel launch (key range cut into `splits` pieces, partial results in the
   // caller's workspace, then the combine kernel); nullptr if the variant has none
   void (*launchSplit)(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream,

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -666,6 +667,28 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
     if (plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], (hipStream_t)stream);
   hipError_t err = hipGetLastError();
   if (err != hipSuccess) return hip_fail(err, plan.variant->name);
+  return MFA_OK;
+}
+
+mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
+                                            const mfa_launch_params *params, char *out, size_t capacity) {
+  if (!out || capacity == 0) return fail(MFA_ERR_INVALID_ARGUMENT, "null argument");
+  LaunchPlan plan;
+  mfa_status st = prepare_launch(kernel, buffers, params, &plan);
+  if (st != MFA_OK) return st;
+  std::string text;
+  if (plan.nRelayouts) text += "attn_relayout x" + std::to_string(plan.nRelayouts) + " + ";
+  if (plan.useFallback) {
+    text += std::string(plan.variant->name) + " (general kernel: the launch does not meet the requirements of " + kernel->variant.name + ")";
+  } else if (plan.splits > 1) {
+    text += std::string(plan.variant->name) + " column-parallel x" + std::to_string(plan.splits) + " + combine";
+  } else {
+    const bool sparse = plan.args.mask && plan.variant->launchSparse;
+    const char *form = (!sparse && plan.variant->launchForm) ? plan.variant->launchForm(plan.args) : nullptr;
+    text += form ? form : plan.variant->name;
+    if (sparse) text += " (block-sparse sibling)";
+  }
+  std::snprintf(out, capacity, "%s", text.c_str());
   return MFA_OK;
 }
 

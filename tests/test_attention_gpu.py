@@ -445,6 +445,27 @@ def test_config4_code_object_forward_n8192_d256_bf16_mixed():
     assert report["O"] < 5e-3 and report["L"] < 7e-3, report
 
 
+def test_launch_form_names_what_runs():
+    """mfa_attention_kernel_launch_form: the headline launch runs the persistent form (the kernel name rocprofv3 shows), per-batch
+    lengths keep the one-block kernel, one long head is cut into pieces, a misaligned leading dimension falls to the general kernel"""
+    import torch
+    N, D, H = 1024, 128, 64
+    desc = make_desc(N, N, D, low_in=True, low_mid=True, in_type=P.BF16)
+    k = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    z = lambda *s_, dt=torch.bfloat16: torch.zeros(s_, device="cuda", dtype=dt)
+    bufs = {Op.Q: z(H, N, D), Op.K: z(H, N, D), Op.V: z(H, N, D), Op.O: z(H, N, D, dt=torch.float32), Op.L: z(H, N, dt=torch.float16)}
+    hs = {Op.Q: N * D, Op.K: N * D, Op.V: N * D, Op.O: N * D, Op.L: N}
+    assert k.variant == "attn_fwd16p4_bf16_d128_w4x64_thr8_fold"
+    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs).startswith("attn_fwd16_p4p (persistent")
+    assert "row-block pairs" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, causal=True)
+    lens = torch.full((1,), N, dtype=torch.int32, device="cuda")
+    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens) == k.variant
+    one = {op: t[0] for op, t in bufs.items()}
+    ws = torch.empty(k.workspaceSize(row=N, column=N) + 256, dtype=torch.uint8, device="cuda")
+    assert "column-parallel x" in k.launchForm(one, row=N, column=N, workspace=ws)
+    assert "general kernel" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, leadingDimensions={Op.K: D + 1})
+
+
 def _fuzz_cases(count, seed):
     rng = np.random.default_rng(seed)
     out = []

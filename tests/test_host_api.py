@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in include/mfa.h but not exported"
     assert declared == {s[0] for s in _abi.SYMBOLS}, "ctypes table out of sync with the header"
-    assert _abi.lib().mfa_abi_version() == _abi.EXPECTED_ABI == 5
+    assert _abi.lib().mfa_abi_version() == _abi.EXPECTED_ABI == 6
 
 
 def test_struct_layouts_match_header():

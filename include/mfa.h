@@ -36,9 +36,11 @@
  *     FP16; the other kernels convert dO to FP16 instead (exact in FP16's range).
  *   - Transposed operands (transposeState) run on the 16-bit matrix cores only when the launch is given a workspace
  *     (mfa_attention_kernel_needs_workspace_for_fast_path); without one the fp32-arithmetic kernels serve them.
- *   - Head dimensions: D <= 384 (the reference's tables end there, +Parameters.swift:77-285).  16-bit matrix-core code
- *     objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic kernels whatever the storage type.
- *     Accumulators stay in registers at every D; larger D is MFA_ERR_UNSUPPORTED.
+ *   - Head dimensions: any.  16-bit matrix-core code objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic
+ *     kernels whatever the storage type, accumulators in registers; D > 384 (beyond the reference's tables, which fall through
+ *     to their last row, +Parameters.swift:60-65) runs D-blocked kernels that page the accumulators through the output
+ *     buffers like the reference does (+Accumulate.swift:403-469) -- O, dQ, dK, dV must then be FP32 (the fused 16-bit
+ *     output cast is MFA_ERR_UNSUPPORTED there).
  */
 #ifndef MFA_H
 #define MFA_H

@@ -16,6 +16,7 @@ struct VariantInfo {
   uint32_t ldsBytes = 0;        // dynamic LDS
   bool cacheLeft = false;       // left-hand operands cached in VGPRs (Q / Q,dO / K,V)
   bool cacheSecond = false;     // the second of them alone (dO / V); fill code sets it = cacheLeft unless a variant splits the pair
+  bool pagedAccumulators = false;   // accumulators paged through the output buffers (any-D kernels, attn_paged.h); else in registers
   bool causal = false;          // the code object implements the causal mask itself (general kernels: always)
   void (*launch)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
   // dense / causal launches that `launch` / `launchCausal` hand to another code object (the persistent form of the D <= 128
@@ -38,6 +39,9 @@ struct VariantInfo {
   // is registered by its launcher's first use of the same attribute path)
   const void *funcSplit = nullptr, *funcSplitCausal = nullptr;
 };
+
+// any head dimension (D > 384): D-blocked products, accumulators paged through the FP32 output buffers (attn_paged.h); type = kernel type
+bool paged_variant(int type, VariantInfo *out);
 
 // generic (fp32-MFMA) family: returns false if (DP) is not compiled
 bool generic_fwd_variant(int DP, VariantInfo *out);

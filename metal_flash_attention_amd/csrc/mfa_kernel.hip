@@ -108,9 +108,18 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       default: found = generic_dkv_variant(bucket, &general); break;
     }
   }
-  if (!found)
-    return fail(MFA_ERR_UNSUPPORTED, "no gfx950 code object for head dimension " + std::to_string(D) +
-                                         " (this build supports D <= 384)");
+  if (!found) {
+    // D > 384: the reference falls through to its tables' last row and pages the accumulators through the output buffers
+    // (+Parameters.swift:60-65, +Accumulate.swift:403-469); so do the any-D kernels -- which therefore need those buffers in FP32,
+    // as the reference always has them (+Precisions.swift:140-143)
+    static const int outs[3][2] = {{MFA_O, MFA_O}, {MFA_dQ, MFA_dQ}, {MFA_dK, MFA_dV}};
+    for (int i = 0; i < 2; ++i)
+      if (kdesc->memoryPrecisions[outs[type][i]] != MFA_FP32)
+        return fail(MFA_ERR_UNSUPPORTED, "head dimension " + std::to_string(D) + " > 384 pages the accumulators through the output buffer: " +
+                                             mfa_operand_name(outs[type][i]) + " must be FP32 (lowPrecisionOutputs is not available there)");
+    found = paged_variant(type, &general);
+  }
+  if (!found) return fail(MFA_ERR_UNSUPPORTED, "no gfx950 code object for head dimension " + std::to_string(D));
   const int pq = kdesc->memoryPrecisions[MFA_Q];
   const bool same16 = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
   auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
@@ -289,20 +298,21 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   kernel->effective.traversal = variant.traversal;
   kernel->effective.headBlock = variant.headBlock;
   // accumulators always live in registers on gfx950; left-hand operands per variant
+  const int8_t accCached = variant.pagedAccumulators ? 0 : 1;
   switch (type) {
     case MFA_FORWARD:
       kernel->effective.cacheState[MFA_Q] = variant.cacheLeft;
-      kernel->effective.cacheState[MFA_O] = 1;
+      kernel->effective.cacheState[MFA_O] = accCached;
       break;
     case MFA_BACKWARD_QUERY:
       kernel->effective.cacheState[MFA_Q] = variant.cacheLeft;
       kernel->effective.cacheState[MFA_dO] = variant.cacheSecond;
-      kernel->effective.cacheState[MFA_dQ] = 1;
+      kernel->effective.cacheState[MFA_dQ] = accCached;
       break;
     default:
       kernel->effective.cacheState[MFA_K] = variant.cacheLeft;
       kernel->effective.cacheState[MFA_V] = variant.cacheSecond;
-      kernel->effective.cacheState[MFA_dK] = kernel->effective.cacheState[MFA_dV] = 1;
+      kernel->effective.cacheState[MFA_dK] = kernel->effective.cacheState[MFA_dV] = accCached;
       break;
   }
   *out = kernel;

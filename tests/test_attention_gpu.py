@@ -1063,8 +1063,42 @@ def test_large_head_dimension_16bit_inputs(shape, in_type):
     assert all(run.tails_ok.values())
 
 
-def test_head_dimension_limit_is_reported():
+@pytest.mark.parametrize("tr", [(False,) * 4, (True, False, True, False), (True, True, True, True)])
+@pytest.mark.parametrize("shape", [(100, 130, 392), (64, 200, 512), (33, 77, 777), (257, 65, 1000)])
+def test_any_head_dimension_fp32(shape, tr):
+    """D > 384: the reference falls through to its tables' last row and pages the accumulators through the output buffers
+    (+Parameters.swift:60-65, +Accumulate.swift:403-469).  So do attn_paged_*: every head dimension, fp32 arithmetic, the
+    reference's fp32 tolerance scaled by sqrt(D / 384) for the longer dot products."""
+    R, C, D = shape
+    tol = 5e-5 * max(1.0, (D / 384.0) ** 0.5)
+    report, run = run_case(R, C, D, seed=sum(shape), tolerances={k: tol for k in TOL_FP32}, tr=tr)
+    assert all(k.variant.startswith("attn_paged_") and k.variant.endswith("_any_d") for k in run.kernels.values()), [k.variant for k in run.kernels.values()]
+    for t, k in run.kernels.items():     # nothing cached, accumulators paged: what the effective descriptor reports
+        assert k.blockDimensions == (32, 32, 64)
+
+
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_any_head_dimension_16bit_inputs_and_causal(in_type, causal):
+    R, C, D = 150, 170, 448
+    net = Network(NetworkDescriptor(R, C, D), seed=9 + D)
+    desc = make_desc(R, C, D, low_in=True, in_type=in_type)
+    run = harness.DeviceRun(desc, net, causal=causal)
+    assert all(k.variant.startswith("attn_paged_") for k in run.kernels.values())
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(causal=causal)
+    failures, report = harness.compare(ref, got, dict(O=1e-4, L=1e-4, D=2e-2, dV=2e-2, dK=2e-2, dQ=2e-2))
+    assert not failures, failures
+    assert all(run.tails_ok.values())
+
+
+def test_any_head_dimension_needs_fp32_outputs():
+    """the accumulators are paged through the OUTPUT buffers, which are always FP32 in the reference (+Precisions.swift:140-143):
+    the fused 16-bit output cast (this library's extension) is not available beyond D = 384, and says so"""
     from metal_flash_attention_amd import MFAError
+    desc = make_desc(64, 64, 392, low_in=True, in_type=P.BF16)
+    desc.lowPrecisionOutputs = True
     with pytest.raises(MFAError) as e:
-        AttentionKernel(make_desc(64, 64, 392).kernelDescriptor(AttentionKernelType.forward))
-    assert e.value.status == 3 and "D <= 384" in str(e.value)
+        AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    assert e.value.status == 3 and "must be FP32" in str(e.value)

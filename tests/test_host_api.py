@@ -146,9 +146,16 @@ def test_kernel_object_reports_geometry_without_a_gpu():
             assert k.variant
             eff = k.effectiveDescriptor
             assert eff.blockDimensions == (par, trav, head)
+    # any head dimension: beyond 384 the D-blocked kernels that page the accumulators through the FP32 output buffers
+    # (+Accumulate.swift:403-469); nothing cached, and no fused 16-bit output cast there
+    k = AttentionKernel(_desc(dims=(16, 16, 1000)).kernelDescriptor(T.forward))
+    assert k.variant == "attn_paged_fwd_f32_any_d" and k.blockDimensions == (32, 32, 64)
+    assert not any(k.effectiveDescriptor.cacheState.values())
+    low = _desc(dims=(16, 16, 1000), low_in=True, in_type=P.BF16)
+    low.lowPrecisionOutputs = True
     with pytest.raises(MFAError) as e:
-        AttentionKernel(_desc(dims=(16, 16, 1000)).kernelDescriptor(T.forward))
-    assert e.value.status == 3
+        AttentionKernel(low.kernelDescriptor(T.forward))
+    assert e.value.status == 3 and "must be FP32" in str(e.value)
 
 
 def test_launch_argument_validation_happens_before_any_gpu_call():

@@ -5,6 +5,9 @@ reference does not have -- only its tests call the kernels, Tests/FlashAttention
     o = flash_attention(q, k, v, causal=False)      # q [B, H, R, D], k / v [B, H, C, D]; bf16, fp16 or fp32
     o.sum().backward()                              # dQ, dK, dV through backwardQuery / backwardKeyValue
 
+    from metal_flash_attention_amd.torch_binding import flash_attention_op   # the same through torch.library ops
+    f = torch.compile(lambda q, k, v: flash_attention_op(q, k, v, causal=True), fullgraph=True)
+
 forward  = AttentionKernelType.forward           -> O (the inputs' dtype, fused cast), L (fp32), both saved
 backward = AttentionKernelType.backwardQuery     -> D, dQ      (needs O, dO, L)
            AttentionKernelType.backwardKeyValue  -> dK, dV     (needs L, D)
@@ -92,71 +95,135 @@ def _apply_layouts(hs, bs, lds, **operands):
     return out
 
 
+def _run_forward(q, k, v, causal, q_lengths, k_lengths, block_mask, fast_scale):
+    """forward dispatch -> (o, l, the (possibly strided) views handed to the kernel, lengths, mask arguments, fast_scale)"""
+    _check(q, k, v)
+    B, H, R, D = q.shape
+    C = k.shape[2]
+    hs, bs = _strides(B, H, R, C, D)
+    lds = {}
+    views = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v)
+    q, k, v = views["Q"], views["K"], views["V"]
+    o = torch.empty((B, H, R, D), dtype=q.dtype, device=q.device)      # fused output cast: no fp32 copy of O
+    fast_scale = bool(fast_scale) and q.dtype != torch.float32
+    l = torch.empty((B, H, R), dtype=torch.float16 if fast_scale else torch.float32, device=q.device)
+    kernel = _kernel(q.dtype, R, C, D, AttentionKernelType.forward, fast_scale)
+    need = kernel.workspaceSize(row=R, column=C, heads=H, batches=B)
+    lengths = q_lengths is not None or k_lengths is not None
+    mask_kw = {}
+    if block_mask is not None:   # int32 [ceil(R / 256)][words]: bit b of word w = column block 32 w + b (128 keys each)
+        _check_block_mask(block_mask, R, C)
+        block_mask = block_mask.to(device=q.device, dtype=torch.int32).contiguous()
+        mask_kw = dict(blockMask=block_mask, blockMaskWords=int(block_mask.shape[-1]))
+    if lengths:   # padding rows of the outputs are not written by the kernels: define them as zero
+        o.zero_()
+        l.zero_()
+        q_lengths = None if q_lengths is None else q_lengths.to(device=q.device, dtype=torch.int32).contiguous()
+        k_lengths = None if k_lengths is None else k_lengths.to(device=q.device, dtype=torch.int32).contiguous()
+    ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal and not lengths and not mask_kw else None
+    # the C side launches on the CURRENT device (hipGetDevice) and this stream: make both the tensors' device
+    with torch.cuda.device(q.device):
+        kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
+                        headStrides=hs, batchStrides=bs, leadingDimensions=lds,
+                        stream=torch.cuda.current_stream(q.device).cuda_stream, workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
+    return o, l, (q, k, v), (q_lengths, k_lengths), mask_kw, fast_scale
+
+
+def _run_backward(q, k, v, o, l, grad_out, causal, lengths, mask_kw, fast_scale):
+    """backwardQuery (writes D, dQ) then backwardKeyValue (dK, dV), the dispatch order of SquareAttentionTest.swift:355-368"""
+    B, H, R, D = q.shape
+    C = k.shape[2]
+    # dO in the kernels' gradient storage type (AttentionDescriptor+Precisions.swift:13-17): BF16 whenever
+    # the inputs are 16-bit (also next to FP16 Q/K/V, the reference's mix), FP32 with FP32 inputs
+    do = grad_out.to(torch.float32 if q.dtype == torch.float32 else torch.bfloat16)   # no copy when it already is
+    alloc = torch.zeros if lengths != (None, None) else torch.empty   # padding gets zero gradients
+    dq = alloc((B, H, R, D), dtype=q.dtype, device=q.device)
+    dk = alloc((B, H, C, D), dtype=q.dtype, device=q.device)
+    dv = alloc((B, H, C, D), dtype=q.dtype, device=q.device)
+    dterm = alloc((B, H, R), dtype=torch.bfloat16 if fast_scale else torch.float32, device=q.device)
+    bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
+    hs, bs = _strides(B, H, R, C, D)
+    lds = {}
+    # saved as the (possibly strided) views the forward used; a strided grad_out (e.g. the gradient of a permuted view)
+    # is passed with its own leading dimension / head / batch strides instead of being copied
+    bufs[Op.dO] = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v, dO=do)["dO"]
+    with torch.cuda.device(q.device):
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
+            _kernel(q.dtype, R, C, D, kind, fast_scale).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
+                                                                  batchStrides=bs, leadingDimensions=lds, stream=stream, causal=causal,
+                                                                  rowLengths=lengths[0], columnLengths=lengths[1], **mask_kw)
+    return dq, dk, dv
+
+
 class _FlashAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, causal: bool, q_lengths=None, k_lengths=None, block_mask=None, fast_scale=False):
-        _check(q, k, v)
-        B, H, R, D = q.shape
-        C = k.shape[2]
-        hs, bs = _strides(B, H, R, C, D)
-        lds = {}
-        views = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v)
-        q, k, v = views["Q"], views["K"], views["V"]
-        o = torch.empty((B, H, R, D), dtype=q.dtype, device=q.device)      # fused output cast: no fp32 copy of O
-        fast_scale = bool(fast_scale) and q.dtype != torch.float32
-        l = torch.empty((B, H, R), dtype=torch.float16 if fast_scale else torch.float32, device=q.device)
-        kernel = _kernel(q.dtype, R, C, D, AttentionKernelType.forward, fast_scale)
-        need = kernel.workspaceSize(row=R, column=C, heads=H, batches=B)
-        lengths = q_lengths is not None or k_lengths is not None
-        mask_kw = {}
-        if block_mask is not None:   # int32 [ceil(R / 256)][words]: bit b of word w = column block 32 w + b (128 keys each)
-            _check_block_mask(block_mask, R, C)
-            block_mask = block_mask.to(device=q.device, dtype=torch.int32).contiguous()
-            mask_kw = dict(blockMask=block_mask, blockMaskWords=int(block_mask.shape[-1]))
-        if lengths:   # padding rows of the outputs are not written by the kernels: define them as zero
-            o.zero_()
-            l.zero_()
-            q_lengths = None if q_lengths is None else q_lengths.to(device=q.device, dtype=torch.int32).contiguous()
-            k_lengths = None if k_lengths is None else k_lengths.to(device=q.device, dtype=torch.int32).contiguous()
-        ws = torch.empty(need, dtype=torch.uint8, device=q.device) if need and not causal and not lengths and not mask_kw else None
-        # the C side launches on the CURRENT device (hipGetDevice) and this stream: make both the tensors' device
-        with torch.cuda.device(q.device):
-            kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=H, batches=B,
-                            headStrides=hs, batchStrides=bs, leadingDimensions=lds,
-                            stream=torch.cuda.current_stream(q.device).cuda_stream, workspace=ws, causal=causal, rowLengths=q_lengths, columnLengths=k_lengths, **mask_kw)
+        o, l, (q, k, v), lengths, mask_kw, fast_scale = _run_forward(q, k, v, causal, q_lengths, k_lengths, block_mask, fast_scale)
         ctx.save_for_backward(q, k, v, o, l)
         ctx.causal = causal
         ctx.fast_scale = fast_scale
-        ctx.lengths = (q_lengths, k_lengths)
+        ctx.lengths = lengths
         ctx.mask_kw = mask_kw
         return o
 
     @staticmethod
     def backward(ctx, grad_out):
         q, k, v, o, l = ctx.saved_tensors
-        B, H, R, D = q.shape
-        C = k.shape[2]
-        # dO in the kernels' gradient storage type (AttentionDescriptor+Precisions.swift:13-17): BF16 whenever
-        # the inputs are 16-bit (also next to FP16 Q/K/V, the reference's mix), FP32 with FP32 inputs
-        do = grad_out.to(torch.float32 if q.dtype == torch.float32 else torch.bfloat16)   # no copy when it already is
-        alloc = torch.zeros if ctx.lengths != (None, None) else torch.empty   # padding gets zero gradients
-        dq = alloc((B, H, R, D), dtype=q.dtype, device=q.device)
-        dk = alloc((B, H, C, D), dtype=q.dtype, device=q.device)
-        dv = alloc((B, H, C, D), dtype=q.dtype, device=q.device)
-        dterm = alloc((B, H, R), dtype=torch.bfloat16 if ctx.fast_scale else torch.float32, device=q.device)
-        bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l, Op.D: dterm, Op.dO: do, Op.dQ: dq, Op.dK: dk, Op.dV: dv}
-        hs, bs = _strides(B, H, R, C, D)
-        lds = {}
-        # saved as the (possibly strided) views the forward used; a strided grad_out (e.g. the gradient of a permuted view)
-        # is passed with its own leading dimension / head / batch strides instead of being copied
-        bufs[Op.dO] = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v, dO=do)["dO"]
-        with torch.cuda.device(q.device):
-            stream = torch.cuda.current_stream(q.device).cuda_stream
-            for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
-                _kernel(q.dtype, R, C, D, kind, ctx.fast_scale).dispatch(bufs, row=R, column=C, heads=H, batches=B, headStrides=hs,
-                                                         batchStrides=bs, leadingDimensions=lds, stream=stream, causal=ctx.causal,
-                                                         rowLengths=ctx.lengths[0], columnLengths=ctx.lengths[1], **ctx.mask_kw)
+        dq, dk, dv = _run_backward(q, k, v, o, l, grad_out, ctx.causal, ctx.lengths, ctx.mask_kw, ctx.fast_scale)
         return dq, dk, dv, None, None, None, None, None
+
+
+# ---- the same two steps as torch.library custom ops: opaque to the tracer but with shape functions and an autograd formula, so a
+# function that calls flash_attention_op compiles with torch.compile(fullgraph=True) (the autograd.Function above is a graph break).
+# Dense / causal only; per-batch lengths and block masks stay on flash_attention().
+@torch.library.custom_op("mfa::attention_forward", mutates_args=(), device_types="cuda")
+def _op_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, fast_scale: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    o, l, _views, _lengths, _mask, _fast = _run_forward(q, k, v, causal, None, None, None, fast_scale)
+    return o, l
+
+
+@_op_forward.register_fake
+def _op_forward_fake(q, k, v, causal, fast_scale):
+    B, H, R, D = q.shape
+    fast = bool(fast_scale) and q.dtype != torch.float32
+    return q.new_empty((B, H, R, D)), q.new_empty((B, H, R), dtype=torch.float16 if fast else torch.float32)
+
+
+@torch.library.custom_op("mfa::attention_backward", mutates_args=(), device_types="cuda")
+def _op_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, l: torch.Tensor, grad_out: torch.Tensor,
+                 causal: bool, fast_scale: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    _check(q, k, v)
+    fast = bool(fast_scale) and q.dtype != torch.float32
+    return _run_backward(q, k, v, o, l, grad_out, causal, (None, None), {}, fast)
+
+
+@_op_backward.register_fake
+def _op_backward_fake(q, k, v, o, l, grad_out, causal, fast_scale):
+    return torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty_like(k, memory_format=torch.contiguous_format), \
+        torch.empty_like(v, memory_format=torch.contiguous_format)
+
+
+def _op_setup_context(ctx, inputs, output):
+    q, k, v, causal, fast_scale = inputs
+    o, l = output
+    ctx.save_for_backward(q, k, v, o, l)
+    ctx.causal, ctx.fast_scale = causal, fast_scale
+
+
+def _op_autograd(ctx, grad_o, grad_l):
+    q, k, v, o, l = ctx.saved_tensors
+    dq, dk, dv = torch.ops.mfa.attention_backward(q, k, v, o, l, grad_o, ctx.causal, ctx.fast_scale)
+    return dq, dk, dv, None, None
+
+
+_op_forward.register_autograd(_op_autograd, setup_context=_op_setup_context)
+
+
+def flash_attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, fast_scale: bool = False) -> torch.Tensor:
+    """flash_attention(q, k, v, causal, fast_scale=...) through the torch.library ops `mfa::attention_forward` /
+    `mfa::attention_backward`: traceable by torch.compile (fullgraph) and torch.export; dense or causal."""
+    return torch.ops.mfa.attention_forward(q, k, v, causal, fast_scale)[0]
 
 
 def pack_block_mask(bits: torch.Tensor) -> torch.Tensor:

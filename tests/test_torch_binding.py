@@ -25,6 +25,46 @@ def test_cpu_tensors_are_refused():
         flash_attention(q, q, q)
 
 
+def test_library_ops_have_shape_functions_without_a_gpu():
+    """mfa::attention_forward / mfa::attention_backward (torch.library): meta tensors flow through the registered shape functions
+    -- what torch.compile / torch.export need to trace a graph that calls the kernels"""
+    from metal_flash_attention_amd import torch_binding as tb  # noqa: F401  (registers the ops)
+    q = torch.empty(2, 3, 64, 32, device="meta", dtype=torch.bfloat16)
+    k = torch.empty(2, 3, 80, 32, device="meta", dtype=torch.bfloat16)
+    o, l = torch.ops.mfa.attention_forward(q, k, k, False, True)
+    assert o.shape == q.shape and o.dtype == torch.bfloat16 and l.shape == (2, 3, 64) and l.dtype == torch.float16
+    o, l = torch.ops.mfa.attention_forward(q.float(), k.float(), k.float(), True, True)      # fast_scale is a 16-bit notion
+    assert o.dtype == torch.float32 and l.dtype == torch.float32
+    dq, dk, dv = torch.ops.mfa.attention_backward(q, k, k, q, l, q, False, False)
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == k.shape
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_library_op_compiles_fullgraph_and_matches(dtype):
+    """flash_attention_op inside torch.compile(fullgraph=True): no graph break (the autograd.Function form is one), same forward and
+    gradients as the plain fp32 torch reference; torch.library.opcheck validates schema, fake implementation and autograd wiring"""
+    from metal_flash_attention_amd import torch_binding as tb
+    B, H, R, C, D = 2, 2, 200, 264, 128
+    g = torch.Generator(device="cuda").manual_seed(21)
+    q, k, v = (torch.randn(B, H, n, D, generator=g, device="cuda").to(dtype).requires_grad_(True) for n in (R, C, C))
+
+    def f(q, k, v):
+        return tb.flash_attention_op(q * 1.0, k, v, causal=True).float().square().sum()
+
+    loss = torch.compile(f, backend="aot_eager", fullgraph=True)(q, k, v)
+    loss.backward()
+    qr, kr, vr, orf = reference(q, k, v, True)
+    ref_loss = orf.square().sum()
+    ref_loss.backward()
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    assert abs(loss.item() - ref_loss.item()) < tol * max(1.0, abs(ref_loss.item()))
+    for got, ref, name in ((q.grad, qr.grad, "dQ"), (k.grad, kr.grad, "dK"), (v.grad, vr.grad, "dV")):
+        assert (got.float() - ref).abs().max().item() < (5e-4 if dtype == torch.float32 else 8e-2), name
+    torch.library.opcheck(torch.ops.mfa.attention_forward, (q.detach(), k.detach(), v.detach(), False, False),
+                          test_utils=("test_schema", "test_faketensor"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 @pytest.mark.parametrize("causal", [False, True])

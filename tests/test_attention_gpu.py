@@ -263,6 +263,60 @@ def test_forward_16bit_multi_head(heads, batches):
         assert np.abs(L[i] - ref["L"]).max() < 1e-3, i
 
 
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("heads,batches,N", [(5, 3, 1280), (8, 5, 1024), (1, 9, 1800), (16, 20, 600)])
+def test_persistent_forward_block_table(heads, batches, N, causal, low_mid):
+    """The persistent form of the D <= 128 forward kernel (attn_fwd16_p4p) on grids that exercise its block table: several
+    blocks per workgroup, head counts that are / are not multiples of 8 (the two branches of fwd16_decode_block), odd numbers of
+    row blocks (causal: a middle block that is its own pair), ragged last row blocks, more workgroups than compute units;
+    interleaved heads ([B, N, H, D] storage viewed per head), every head against the oracle."""
+    import torch
+    D = 128
+    nets = [Network(NetworkDescriptor(N, N, D), seed=1700 + i) for i in range(heads * batches)]
+    desc = make_desc(N, N, D, low_in=True, low_mid=low_mid, in_type=P.BF16)
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+
+    def pack16(name):     # [B][N][H][D]: heads interleaved, leading dimension H * D
+        a = np.stack([getattr(n, name) for n in nets]).reshape(batches, heads, N, D).transpose(0, 2, 1, 3)
+        return torch.from_numpy((np.ascontiguousarray(a).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+
+    mem = desc.memoryPrecisions
+    bufs = {Op.Q: pack16("Q"), Op.K: pack16("K"), Op.V: pack16("V"),
+            Op.O: torch.full((batches, N, heads, D), float("nan"), device="cuda"),
+            Op.L: torch.zeros((batches, heads, N), device="cuda", dtype=torch.float16 if mem[Op.L] == P.FP16 else torch.float32)}
+    hs = {Op.Q: D, Op.K: D, Op.V: D, Op.O: D, Op.L: N}
+    bs = {Op.Q: N * heads * D, Op.K: N * heads * D, Op.V: N * heads * D, Op.O: N * heads * D, Op.L: heads * N}
+    ld = {Op.Q: heads * D, Op.K: heads * D, Op.V: heads * D, Op.O: heads * D}
+    kw = dict(row=N, column=N, heads=heads, batches=batches, headStrides=hs, batchStrides=bs, leadingDimensions=ld, causal=causal)
+    assert kernel.launchForm(bufs, **kw).startswith("attn_fwd16_p4p (persistent")
+    kernel.dispatch(bufs, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    torch.cuda.synchronize()
+    O = bufs[Op.O].cpu().numpy().transpose(0, 2, 1, 3).reshape(heads * batches, N, D)
+    L = bufs[Op.L].float().cpu().numpy().reshape(heads * batches, N) / np.float32(harness.LOG2E)
+    step = max(1, len(nets) // 12)          # the oracle checks a spread of heads (all blocks of a head share its code path)
+    for i in list(range(0, len(nets), step)) + [len(nets) - 1]:
+        net = nets[i]
+        round_inputs(net, desc)
+        ref = net.run(backward=False, causal=causal)
+        assert np.abs(O[i] - ref["O"]).max() < 1.5e-2, i
+        assert np.abs(L[i] - ref["L"]).max() < (7e-3 if low_mid else 1e-3), i
+    assert not np.isnan(O).any()
+
+
+def test_persistent_forward_full_size_causal_mixed():
+    """N = 4096, D = 128, causal, mixed-precision mode: the causal streams of the persistent kernel at bench.py's size"""
+    R = 4096
+    net = Network(NetworkDescriptor(R, R, 128), seed=3)
+    desc = make_desc(R, R, 128, low_in=True, low_mid=True, in_type=P.BF16)
+    run = harness.DeviceRun(desc, net, run_backward=False, causal=True)
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(backward=False, causal=True)
+    assert np.abs(got["O"] - ref["O"]).max() < 5e-3 and np.abs(got["L"] - ref["L"]).max() < 7e-3
+    assert all(run.tails_ok[k] for k in ("O", "L"))
+
+
 def test_forward_16bit_unaligned_launch_falls_back_to_general_kernel():
     """A leading dimension that breaks the 16-byte chunking must still give right answers (the
     kernel object keeps the general code object for such launches)."""

@@ -304,6 +304,36 @@ def test_persistent_forward_block_table(heads, batches, N, causal, low_mid):
     assert not np.isnan(O).any()
 
 
+def test_persistent_forward_more_blocks_than_the_table_holds():
+    """66,000 row blocks on 256 compute units: a workgroup's share (258) would not fit the 255-entry block table, so the launch
+    takes more workgroups than compute units (a multiple of 8, for the head -> XCD affinity); spot heads against the oracle"""
+    import torch
+    R, C, D, H, B = 256, 128, 128, 33000, 2
+    desc = make_desc(R, C, D, low_in=True, low_mid=True, in_type=P.BF16)
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    q = torch.randn((B, H, R, D), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    k = torch.randn((B, H, C, D), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    v = torch.randn((B, H, C, D), generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)
+    o = torch.full((B, H, R, D), float("nan"), device="cuda")
+    l = torch.zeros((B, H, R), device="cuda", dtype=torch.float16)
+    bufs = {Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}
+    hs = {Op.Q: R * D, Op.K: C * D, Op.V: C * D, Op.O: R * D, Op.L: R}
+    bs = {op: x * H for op, x in hs.items()}
+    kw = dict(row=R, column=C, heads=H, batches=B, headStrides=hs, batchStrides=bs)
+    assert kernel.launchForm(bufs, **kw).startswith("attn_fwd16_p4p (persistent")
+    kernel.dispatch(bufs, stream=torch.cuda.current_stream().cuda_stream, **kw)
+    torch.cuda.synchronize()
+    assert not torch.isnan(o).any().item()
+    for b, h in ((0, 0), (0, 255), (0, 256), (1, 17), (1, H - 1), (0, 32999), (1, 16384)):
+        net = Network(NetworkDescriptor(R, C, D), seed=0)
+        net.Q, net.K, net.V = (x[b, h].float().cpu().numpy() for x in (q, k, v))
+        net.invalidate()
+        ref = net.run(backward=False)
+        assert np.abs(o[b, h].cpu().numpy() - ref["O"]).max() < 1.5e-2, (b, h)
+        assert np.abs(l[b, h].float().cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 7e-3, (b, h)
+
+
 def test_persistent_forward_full_size_causal_mixed():
     """N = 4096, D = 128, causal, mixed-precision mode: the causal streams of the persistent kernel at bench.py's size"""
     R = 4096

@@ -147,6 +147,14 @@ def test_merged_block_switch_experiment(C):
     _check(2, 512, C, cfg=p4pgen.VARIANTS["BF16_FOLD_L16_MERGE"], seed=14, dma_mode="early", order=(3, 2, 1, 0))
 
 
+@pytest.mark.parametrize("C", [128, 449])
+def test_fused_tail_experiment(C):
+    """developer stream (no gain on the GPU, kept as a record): the epilogue's per-block work dealt out between the last tile's
+    P V products, which run in (head-dimension block, key step, row block) order"""
+    _check(3, 256, C, cfg=p4pgen.VARIANTS["BF16_FOLD_L16_FUSE"], seed=15)
+    _check(2, 300, C, cfg=p4pgen.VARIANTS["BF16_FOLD_L16_FUSE"], seed=16, dma_mode="early", stores="early", order=(3, 2, 1, 0))
+
+
 def test_stream_file_is_current():
     """csrc/attn_fwd16_p4p_stream.inc is what tools/p4pgen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4p_stream.inc")

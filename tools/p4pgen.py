@@ -73,7 +73,7 @@ IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qre
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb)
         self.o16, self.l16 = o16, l16
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
@@ -86,6 +86,15 @@ class PCfg(Cfg):
         # registers halve (+2.6 k)
         self.merge = merge
         assert not (merge and causal)
+        # fuse (dense streams; developer experiment that did NOT pay, profiles/r03_p4p_fused_tail.txt: the LDS round trips and
+        # store issues stall the products they sit between as long as they take on their own): the last tile's P V products run
+        # in (head-dimension block, key step, row block) order, so that a
+        # 32 x 32 block of O^T is complete after every fourth product; its share of the epilogue (accumulator reads, 1 / l, the
+        # trip through LDS, four stores) is dealt out as fillers of the products that follow instead of running behind them.
+        # Causal streams keep the separate epilogue: their waves reach the last tile at different times, and the barrier in
+        # front of the LDS staging must be the same barrier for every wave
+        self.fuse = 0 if fuse is None else fuse
+        assert not (self.fuse and (causal or merge))
         # pprof (developer builds, exact-scale streams only: their -m blocks v168.. are free): shader-clock sums per segment of
         # the block loop in v168..v183, written to O[first row of the wave's last block][0:16] when the workgroup ends
         self.pprof = pprof
@@ -331,14 +340,18 @@ class PStream(Stream):
                 self.emit("v_accvgpr_write_b32", A(Q_BASE + 4 * n + w), [x])
         self.lds_flush()
 
-    def epilogue(self):
-        """O /= l (+Source.swift:165-171) and L = m + log2 l (+Caching.swift:373-377), straight from the registers"""
-        cfg = self.cfg
-        self.emit("s_nop", None, [I(15)], note="the last accumulating MFMAs leave the matrix pipe")
-        self.emit("s_nop", None, [I(7)])
+    EPI_LTOT, EPI_INV = (T_MX, T_MX + 1), (T_MN, T_MN + 1)
+    EPI_WA, EPI_RA, EPI_VO = [T_CORR, T_CORR + 1, T_LB, T_LB + 1], T_MASKV, T_TL   # (re-initialised by the next block / dead after the loop)
+
+    def epi_prepare(self):
+        """what the per-block work of the epilogue needs: resources of O and L, l of the row (half swap), 1 / l, the LDS staging
+        addresses.  O leaves through a 4 KiB slice of LDS per wave (its share of the V image the ring is not using: the one after
+        V'(0)'s), one 32 x 32 block at a time: lane = row with four consecutive columns per register group goes in (16-byte
+        chunks, chunk index XOR row & 7), lane = (row & 7, chunk) comes out -- eight lanes then cover one 128-byte line of a row
+        and a store instruction touches 8 lines instead of 32 (measured: 3.4 k instead of 9.0 k clocks per block for the 32 stores)"""
         self.desc("tres", "ob", "nreco")
         self.desc("lres", "lb", "nrecl")
-        ltot, inv, ta, tb = (T_MX, T_MX + 1), (T_MN, T_MN + 1), V(T_SW), V(T_SW + 1)
+        ltot, inv, ta, tb = self.EPI_LTOT, self.EPI_INV, V(T_SW), V(T_SW + 1)
         for rb in range(2):
             lt, iv = V(ltot[rb]), V(inv[rb])
             self.emit("v_mov_b32", ta, [VN("l%d" % rb)])
@@ -353,12 +366,7 @@ class PStream(Stream):
             self.emit("v_fma_f32", iv, [ta, iv, iv])                   # r += e r
             self.emit("v_cmp_lt_f32", VCC, [F(1e-30), lt])
             self.emit("v_cndmask_b32", iv, [I(0), iv, VCC])            # a row without keys: O = 0
-        # O leaves through a 4 KiB slice of LDS per wave (its share of the V image the ring is not using: the one after V'(0)'s),
-        # one 32 x 32 block at a time: lane = row with four consecutive columns per register group goes in (16-byte chunks,
-        # chunk index XOR row & 7), lane = (row & 7, chunk) comes out -- eight lanes then cover one 128-byte line of a row and a
-        # store instruction touches 8 lines instead of 32 (measured: 3.4 k instead of 9.0 k clocks per block for the 32 stores)
-        vo = V(T_TL)
-        wa, ra = [T_CORR, T_CORR + 1, T_LB, T_LB + 1], T_MASKV     # (re-initialised by the next block / dead after the loop)
+        wa, ra = self.EPI_WA, self.EPI_RA
         self.emit("s_add_u32", s("t2"), [SN("vwr"), I(VSLOT)])
         self.emit("s_cmp_ge_u32", None, [s("t2"), SN("t1")])
         self.emit("s_cselect_b32", s("t2"), [SN("ldsv"), s("t2")])
@@ -370,53 +378,66 @@ class PStream(Stream):
                 self.emit("v_add_u32", V(wa[g]), [s("t2"), VN("ewa")])
         self.emit("v_add_u32", V(ra), [s("t2"), VN("era")])
         self.emit("s_lshl_b32", s("t4"), [SN("ldo"), I(3)])          # eight rows
-        pending = None
 
-        def stores(blk):
-            rb, db, dst, ids = blk
-            self.lds_need(ids[-1])
+    def epi_block_work(self, blocks, regs):
+        """the per-block work as a list of (position in `blocks`, closure) in execution order: accumulator reads, 1 / l, four
+        ds_write_b128, four ds_read_b128, and -- one block later, behind the counted wait for those reads -- four stores.
+        blocks: (rb, db) in processing order; regs(i) -> (source registers, destination registers) of the i-th block."""
+        cfg = self.cfg
+        wa, ra, vo, inv = self.EPI_WA, self.EPI_RA, V(self.EPI_VO), self.EPI_INV
+        work = []
+
+        def stores(i, rb, db, dst, ids):
+            out = [(i, lambda: self.lds_need(ids[-1]))]
             for k in range(4):
                 if k == 0:
-                    self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
+                    out.append((i, lambda: self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])))
                     if rb:
-                        self.emit("s_add_u32", s("t0"), [s("t0"), I(32)])
-                    self.emit("s_mul_i32", s("t0"), [s("t0"), SN("ldo")])
+                        out.append((i, lambda: self.emit("s_add_u32", s("t0"), [s("t0"), I(32)])))
+                    out.append((i, lambda: self.emit("s_mul_i32", s("t0"), [s("t0"), SN("ldo")])))
                 else:
-                    self.emit("s_add_u32", s("t0"), [s("t0"), s("t4")])
-                self.emit("v_add_u32_e64", vo, [VN("ov%d" % db), s("t0")], clamp=1)
+                    out.append((i, lambda: self.emit("s_add_u32", s("t0"), [s("t0"), s("t4")])))
+                out.append((i, lambda: self.emit("v_add_u32_e64", vo, [VN("ov%d" % db), s("t0")], clamp=1)))
                 if cfg.o16:
-                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k), [V(dst + 4 * k), V(dst + 4 * k + 1)])
-                    self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k + 1), [V(dst + 4 * k + 2), V(dst + 4 * k + 3)])
-                    self.emit("buffer_store_dwordx2", None, [V(dst + 4 * k, 2), vo, s("tres", 4)], offset=0)
+                    out.append((i, lambda k=k: self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k), [V(dst + 4 * k), V(dst + 4 * k + 1)])))
+                    out.append((i, lambda k=k: self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k + 1), [V(dst + 4 * k + 2), V(dst + 4 * k + 3)])))
+                    out.append((i, lambda k=k: self.emit("buffer_store_dwordx2", None, [V(dst + 4 * k, 2), vo, s("tres", 4)], offset=0)))
                 else:
-                    self.emit("buffer_store_dwordx4", None, [V(dst + 4 * k, 4), vo, s("tres", 4)], offset=0)
+                    out.append((i, lambda k=k: self.emit("buffer_store_dwordx4", None, [V(dst + 4 * k, 4), vo, s("tres", 4)], offset=0)))
+            return out
 
-        for b in range(8):
-            rb, db = divmod(b, 4)
-            # staging registers: four 16-register sets each way (an instruction reads its registers when it issues); the merged
-            # block switch has the odd tiles' score registers only (the even ones hold the next block's tile 0): two sets
-            if cfg.merge:
-                src, dst = S_BASE[1] + 16 * (b & 1), S_BASE[1] + 32 + 16 * (b & 1)
-            else:
-                src, dst = S_BASE[0] + 16 * (b & 3), S_BASE[1] + 16 * (b & 3)
+        pending = None
+        for i, (rb, db) in enumerate(blocks):
+            src, dst = regs(i)
+            b = 4 * rb + db
             for r in range(16):
-                self.emit("v_accvgpr_read_b32", V(src + r), [A(O_BASE + 16 * b + r)])
+                work.append((i, lambda r=r, src=src, b=b: self.emit("v_accvgpr_read_b32", V(src + r), [A(O_BASE + 16 * b + r)])))
             if cfg.merge:       # the next block's first phase multiplied K Q^T beside this block's softmax: O is zeroed here
                 for r in range(16):
-                    self.emit("v_accvgpr_write_b32", A(O_BASE + 16 * b + r), [I(0)])
+                    work.append((i, lambda r=r, b=b: self.emit("v_accvgpr_write_b32", A(O_BASE + 16 * b + r), [I(0)])))
             for r in range(16):
-                self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])
+                work.append((i, lambda r=r, src=src, rb=rb: self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])))
             for g in range(4):
-                self.lds_write("ds_write_b128", V(wa[g]), V(src + 4 * g, 4), 0)
-            ids = [self.lds_read("ds_read_b128", V(dst + 4 * k, 4), V(ra), 1024 * k, note="O(%d,%d) rows %d.." % (rb, db, 8 * k)) for k in range(4)]
+                work.append((i, lambda g=g, src=src: self.lds_write("ds_write_b128", V(wa[g]), V(src + 4 * g, 4), 0)))
+            ids = []
+            if pending is not None and regs(i)[1] == pending[3]:     # one destination set: the previous block's stores go first
+                work += stores(*pending)
+                pending = None
+            for k in range(4):
+                work.append((i, lambda k=k, dst=dst, ids=ids, rb=rb, db=db: ids.append(
+                    self.lds_read("ds_read_b128", V(dst + 4 * k, 4), V(ra), 1024 * k, note="O(%d,%d) rows %d.." % (rb, db, 8 * k)))))
             if pending is not None:
-                stores(pending)
-            pending = (rb, db, dst, ids)
-        stores(pending)
-        self.lds_flush()
+                work += stores(*pending)
+            pending = (i, rb, db, dst, ids)
+        work += stores(*pending)
+        return work
+
+    def epi_finish(self):
+        cfg = self.cfg
+        vo = V(self.EPI_VO)
         for rb in range(2):
             x = V(T_SW + rb)
-            self.emit("v_log_f32", x, [V(ltot[rb])])
+            self.emit("v_log_f32", x, [V(self.EPI_LTOT[rb])])
             self.emit("s_nop", None, [I(0)], note="trans -> VALU")
             self.emit("v_add_f32", x, [VN("m%d" % rb), x])
             self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
@@ -429,6 +450,72 @@ class PStream(Stream):
                 self.emit("buffer_store_short", None, [x, vo, s("lres", 4)], offset=0)
             else:
                 self.emit("buffer_store_dword", None, [x, vo, s("lres", 4)], offset=0)
+
+    def epilogue(self):
+        """O /= l (+Source.swift:165-171) and L = m + log2 l (+Caching.swift:373-377), straight from the registers"""
+        cfg = self.cfg
+        self.emit("s_nop", None, [I(15)], note="the last accumulating MFMAs leave the matrix pipe")
+        self.emit("s_nop", None, [I(7)])
+        self.epi_prepare()
+        # staging registers: four 16-register sets each way (an instruction reads its registers when it issues); the merged
+        # block switch has the odd tiles' score registers only (the even ones hold the next block's tile 0): two sets
+        if cfg.merge:
+            regs = lambda i: (S_BASE[1] + 16 * (i & 1), S_BASE[1] + 32 + 16 * (i & 1))
+        else:
+            regs = lambda i: (S_BASE[0] + 16 * (i & 3), S_BASE[1] + 16 * (i & 3))
+        for _, fn in self.epi_block_work([(b // 4, b % 4) for b in range(8)], regs):
+            fn()
+        self.lds_flush()
+        self.epi_finish()
+
+    def fused_tail(self):
+        """dense streams, behind the last (odd) tile: softmax finish, then P V with the epilogue dealt out between the products"""
+        cfg = self.cfg
+        lastpar, par = 1, 0
+        vids = self.phase_a(par, mfma=False, softmax=True, zero_o=False)       # softmax finish + V^T fragments 0..7 (ring)
+        # V^T fragments 8..15 have no ring slot to wait for: they go to registers that are dead behind the last tile (FOLD: the -m
+        # start blocks; exact-scale streams: their free registers and the rescale temporaries)
+        spare = [CM_BASE + 4 * k for k in range(8)] if cfg.fold else [CM_BASE + 8 + 4 * k for k in range(6)] + [p4gen.T_RS, p4gen.T_RS + 4]
+        if cfg.pprof:     # (the clock sums live in the exact-scale streams' free registers: the fragments take half of the staging area)
+            spare = [S_BASE[0] + 32 + 4 * k for k in range(8)]
+        for f in range(8, 16):
+            u, db = divmod(f, 4)
+            for h in range(2):
+                self.lds_read("ds_read_b64_tr_b16", V(spare[f - 8] + 2 * h, 2), V(p4gen.T_VADDR), (db * 64 + 16 * u) * 64 + h * 8 * 64,
+                              note="V^T f%d.%d" % (f, h))
+        self.lds_flush()
+        for rb in range(2):
+            self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
+        self.emit("s_barrier")       # every wave is done with the V image O is staged in (last read in phase B(nt-1))
+        self.epi_prepare()
+        regs = lambda i: (S_BASE[0] + 16 * (i & 1), S_BASE[0] + 32 + 16 * (i & 1))   # the even tiles' score registers are free
+        if cfg.pprof:
+            regs = lambda i: (S_BASE[0], S_BASE[0] + 16)
+        blocks = [(rb, db) for db in range(4) for rb in range(2)]                     # completion order
+        work = self.epi_block_work(blocks, regs)
+        # products in (db, u, rb) order: block (rb, db) is complete behind product 8 db + 6 + rb; its work may start two products later
+        fill = [[] for _ in range(32)]
+        for db in range(3):
+            mine = [fn for i, fn in work if i // 2 == db]
+            gaps = list(range(8 * (db + 1) + 1, 8 * (db + 2)))
+            for n, fn in enumerate(mine):
+                fill[gaps[n * len(gaps) // len(mine)]].append(fn)
+        rest = [fn for i, fn in work if i // 2 == 3]
+        self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
+        for g in range(32):
+            db, u, rb = g // 8, (g % 8) // 2, g % 2
+            f = 4 * u + db
+            afrag = p4gen.vf_frag(f) if f < 8 else V(spare[f - 8], 4)
+            self.mfma(p4gen.o_acc(rb, db), afrag, p4gen.p_frag(lastpar, rb, u), p4gen.o_acc(rb, db))
+            for fn in fill[g]:
+                fn()
+        self.pstamp("tail")
+        self.emit("s_nop", None, [I(15)], note="the last accumulating MFMAs leave the matrix pipe")
+        self.emit("s_nop", None, [I(7)])
+        for fn in rest:
+            fn()
+        self.lds_flush()
+        self.epi_finish()
 
     def emit_outofline(self):
         mine = [x for x in self.outofline if x[0] in ("ksw", "vsw", "qsw")]
@@ -490,8 +577,8 @@ class PStream(Stream):
         self.outofline = []
         self.xe_pending = []
         self.first_tiles = False
-        blk_lbl, loop, end_even, end_odd, done, fin, nonext, epi = (
-            self.newlabel(x) for x in ("BLOCK", "LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN", "NONEXT", "EPI"))
+        blk_lbl, loop, end_even, end_odd, done, fin, nonext, after_epi = (
+            self.newlabel(x) for x in ("BLOCK", "LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN", "NONEXT", "AFTEREPI"))
         # ---- once per workgroup
         for ks in range(8):
             self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
@@ -590,6 +677,10 @@ class PStream(Stream):
                 self.phase_b(0, mfma=True, softmax=False, vids=vids)
                 self.emit("s_branch", None, [], target=done)
                 self.label(plain)
+            if cfg.fuse and lastpar == 1:       # (a dense block ends behind an odd tile: its count is even)
+                self.fused_tail()
+                self.emit("s_branch", None, [], target=after_epi)
+                continue
             vids = self.phase_a(lastpar ^ 1, mfma=False, softmax=True, zero_o=False)
             self.lds_flush()
             self.emit("s_nop", None, [I(1)], note="freshly packed P -> MFMA operand")
@@ -614,6 +705,7 @@ class PStream(Stream):
         for rb in range(2):
             self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
         self.epilogue()
+        self.label(after_epi)
         self.pstamp("epilogue")
         if cfg.pprof:
             acc = V(PROF_ACC + PROF_NAMES.index("blocks"))
@@ -696,8 +788,9 @@ VARIANTS = {
     "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1),
     "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
     "BF16_FOLD_L16_MERGE": PCfg("bf16", 8, fold=1, l16=1, merge=1),   # developer builds only: merged block switch (lost)
+    "BF16_FOLD_L16_FUSE": PCfg("bf16", 8, fold=1, l16=1, fuse=1),     # developer builds only: epilogue dealt out under the last P V (no gain)
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof and not c.merge)
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof and not c.merge and not c.fuse)
 
 
 def write_inc(path):

@@ -705,7 +705,8 @@ class PStream(Stream):
         for rb in range(2):
             self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
         self.epilogue()
-        self.label(after_epi)
+        if cfg.fuse:
+            self.label(after_epi)
         self.pstamp("epilogue")
         if cfg.pprof:
             acc = V(PROF_ACC + PROF_NAMES.index("blocks"))

@@ -70,7 +70,7 @@ template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f)
 }
 
 template <typename T, int D, int NW, int RB, int THR, int PRE, int ABL = 0, int RING = 3, bool SPLIT = false,
-          bool CAUSAL = false, int VD = 0, bool SPARSE = false>
+          bool CAUSAL = false, int VD = 0, bool SPARSE = false, int TR = 0>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
@@ -89,9 +89,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // barrier of iteration j: both have a whole iteration to land, and the second barrier of the register-staged
   // 2-stage ring (which published the tile written during step A) is not needed.
   constexpr bool KV32 = LDMA && RING == 2;
+  // TR != 0: operands stored transposed ([D][sequence], transposeState of AttentionKernelDescriptor.swift:28-42, read in place
+  // like AttentionKernel.swift:189-204 does -- no scratch).  Bit 0 = K, bit 1 = V: compile-time, because the LDS image keeps
+  // the orientation of the source (16-byte chunks = 8 consecutive KEYS of one head-dimension element) and the two read recipes
+  // change places: K^T is read like V (sub-images of 32 keys, ds_read_b64_tr_b16), V^T like K (rows of 64 keys, ds_read_b128).
+  // Bit 2 alone = only Q / O may be transposed: those two are honoured at run time (a.op[].transposed) by every TR kernel,
+  // outside the loop (Q^T: gathered 16-bit loads, once; O^T: stores straight from the accumulators, whose lanes are
+  // consecutive rows).  The causal mask is a run-time flag of these kernels (one code object per transposition pattern).
+  constexpr bool KT = (TR & 1) != 0, VT = (TR & 2) != 0;
+  static_assert(TR == 0 || (!LDMA && PRE == 0 && !SPLIT && !SPARSE && CAUSAL && RB == 1 && (VD & ~2) == 0),
+                "transposed operands: register-staged schedule, fragment reads left to hipcc");
   static_assert(!LDMA || (VPIPE && (RING == 3 || RING == 2) && PRE >= 1 && !KPAD && RB == 1 && NKS % 4 == 0),
                 "LDMA: grouped-read schedule");
-  constexpr int ROWB = D * 2 + (KPAD ? 16 : 0), KTILE = BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
+  constexpr int ROWB = D * 2 + ((KPAD && !KT) ? 16 : 0), KTILE = KT ? BC * D * 2 : BC * ROWB, TILE = BC * D * 2, STAGE = KTILE + TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   // byte offset of K image `stage`; of the stage base the V addressing (which includes + KTILE) starts from
   auto koffs = [](int stage) { return KV32 ? stage * KTILE : stage * STAGE; };
@@ -117,12 +127,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
                  ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
 
+  const bool qT = TR != 0 && a.op[SLOT_Q].transposed != 0, oT = TR != 0 && a.op[SLOT_O].transposed != 0;
   const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
-      operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)R * ldq2, 0x00020000);
+      operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)(qT ? Dr : R) * ldq2, 0x00020000);
   const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(
-      operand_base(a.op[SLOT_K], head, batch), 0, (uint32_t)C * ldk2, 0x00020000);
+      operand_base(a.op[SLOT_K], head, batch), 0, (uint32_t)(KT ? Dr : C) * ldk2, 0x00020000);
   const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(
-      operand_base(a.op[SLOT_V], head, batch), 0, (uint32_t)C * ldv2, 0x00020000);
+      operand_base(a.op[SLOT_V], head, batch), 0, (uint32_t)(VT ? Dr : C) * ldv2, 0x00020000);
   constexpr uint32_t OOB = 0xFFFFFF00u;
 
   // ---- Q fragments (B operand of S^T = K Q^T), cached in registers for the whole kernel
@@ -134,6 +145,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     for (int s = 0; s < NKS; ++s) {
       const int d0 = 16 * s + 8 * hi;
       const uint32_t off = (d0 < Dr && r0 + b * 32 + q < R) ? rowoff + d0 * 2 : OOB;
+      if constexpr (TR != 0) {
+        // K^T fragments come out of the transposing read with the contraction index in the order of a 32 x 32 accumulator
+        // block's registers -- elements 4 hi + {0..3, 8..11} of a 16-element step instead of 8 hi + {0..7} -- so Q follows
+        auto elem = [&](int i) { return KT ? 16 * s + 4 * hi + (i & 3) + 8 * (i >> 2) : d0 + i; };
+        if (qT) {   // Q^T: the lane's eight elements lie one leading dimension apart; lanes are consecutive rows
+          uint16_t e[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            e[i] = __builtin_amdgcn_raw_buffer_load_b16(
+                qres, (elem(i) < Dr && r0 + b * 32 + q < R) ? (uint32_t)elem(i) * ldq2 + (uint32_t)(r0 + b * 32 + q) * 2 : OOB, 0, 0);
+          const u32x4 w = {e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
+                           e[6] | ((uint32_t)e[7] << 16)};
+          qf[b][s] = __builtin_bit_cast(v8, w);
+          continue;
+        }
+        if constexpr (KT) {
+          const bool rowok = r0 + b * 32 + q < R;
+          const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(qres, (elem(0) < Dr && rowok) ? rowoff + elem(0) * 2 : OOB, 0, 0);
+          const u32x2 up = __builtin_amdgcn_raw_buffer_load_b64(qres, (elem(4) < Dr && rowok) ? rowoff + elem(4) * 2 : OOB, 0, 0);
+          const u32x4 w = {lo[0], lo[1], up[0], up[1]};
+          qf[b][s] = __builtin_bit_cast(v8, w);
+          continue;
+        }
+      }
       qf[b][s] = __builtin_bit_cast(v8, __builtin_amdgcn_raw_buffer_load_b128(qres, off, 0, 0));
     }
   }
@@ -143,7 +178,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;   // (SPARSE: first tile of the current run)
   // CAUSAL (extension): row r sees key c iff c <= r + (C - R); the workgroup stops at the tile that holds
   // the last key its last row may see, tiles that cross the diagonal are masked element-wise.
-  const int coff = C - R;
+  const int coff = (TR != 0 && !a.causal) ? 0x3FFFFFFF : C - R;   // TR kernels: the mask is a run-time flag (never reached without it)
   int tiles_visible = tiles_total;
   if constexpr (CAUSAL) {
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * RB * 32)) - 1;
@@ -154,7 +189,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // ---- K/V staging: global -> VGPR -> LDS (LDS-DMA staging measured 12 % slower)
   uint32_t koff[NCH], voff[NCH], klds[NCH], vlds[NCH];
   uint32_t kbase0[SPARSE ? NCH : 1], vbase0[SPARSE ? NCH : 1];   // SPARSE: offsets of tile 0, koff/voff restart per run
-  const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
+  const uint32_t kinc = KT ? BC * 2 : BC * ldk2, vinc = VT ? BC * 2 : BC * ldv2;
+  // transposed tiles: chunk id = 8 consecutive keys (8 tc .. 8 tc + 7 of the tile) of head-dimension element id / 8; the tile
+  // advances ALONG the rows, so the end of the sequence is not the end of the buffer: lcol / wcol = first key of the tile
+  // requested / written next, chunks that begin at or beyond C are not fetched (zeros), the one chunk that straddles C
+  // (C % 8 != 0) is cut to size before V^T is written (P = 0 there, but 0 x whatever the padding holds is not 0)
+  const int tc8 = (tid & 7) * 8;
+  int lcol = tile0 * BC, wcol = tile0 * BC;
+  // rows of a transposed operand that do not begin on 16-byte boundaries (leading dimension = an odd sequence length, say):
+  // the chunk is gathered by eight 16-bit loads instead of one 128-bit load -- slower, but still the matrix-core kernel
+  const bool kGather = KT && (((uintptr_t)operand_base(a.op[SLOT_K], head, batch) | ldk2) & 15) != 0;
+  const bool vGather = VT && (((uintptr_t)operand_base(a.op[SLOT_V], head, batch) | ldv2) & 15) != 0;
+  auto gather_chunk = [&](const __amdgpu_buffer_rsrc_t &res, uint32_t off, int col) {   // keys col .. col + 7 of one row
+    uint16_t e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_raw_buffer_load_b16(res, (col + i < C) ? off + 2 * i : OOB, 0, 0);
+    const u32x4 w = {e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
+                     e[6] | ((uint32_t)e[7] << 16)};
+    return w;
+  };
+  static_assert(TR == 0 || NT % 8 == 0, "");
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int id = tid + i * NT;
@@ -162,6 +216,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const bool valid = c * 8 < Dr;
     koff[i] = valid ? (tile0 * BC + row) * ldk2 + c * 16 : OOB;
     voff[i] = valid ? (tile0 * BC + row) * ldv2 + c * 16 : OOB;
+    if constexpr (KT) koff[i] = (id / 8 < Dr) ? (uint32_t)(id / 8) * ldk2 + (uint32_t)(tile0 * BC + tc8) * 2 : OOB;
+    if constexpr (VT) voff[i] = (id / 8 < Dr) ? (uint32_t)(id / 8) * ldv2 + (uint32_t)(tile0 * BC + tc8) * 2 : OOB;
     if constexpr (LDMA) {   // 16-byte position p of the image -> the chunk stored there
       const int p = (wave * NCH + i) * 64 + lane;
       const int krow = p / CPR, kc = (p % CPR) ^ kswz_mask<D>(krow);
@@ -171,6 +227,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     }
     klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
     vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+    // K^T image: [2 blocks of 32 keys][D elements][64 bytes]; V^T image: [D elements][64 keys], chunks XOR-swizzled
+    if constexpr (KT) klds[i] = (((id & 7) >> 2) * D + id / 8) * 64 + (id & 3) * 16;
+    if constexpr (VT) vlds[i] = KTILE + (id / 8) * 128 + kswz<64>(id / 8, id & 7) * 16;
     if constexpr (SPARSE) {
       kbase0[i] = valid ? row * ldk2 + c * 16 : OOB;
       vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
@@ -208,13 +267,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto issue_dma = [&](int stage) { issue_dma_k(stage); issue_dma_v(stage); };
   auto issue_loads = [&]() {
     if constexpr (!LDMA) {
+      const bool inside = lcol + tc8 < C;   // (transposed tiles only)
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, koff[i], 0, 0);
-        vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, voff[i], 0, 0);
+        if (KT && kGather) kreg[i] = gather_chunk(kres, koff[i], lcol + tc8);
+        else kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(kres, (KT && !inside) ? OOB : koff[i], 0, 0);
+        if (VT && vGather) vreg[i] = gather_chunk(vres, voff[i], lcol + tc8);
+        else vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, (VT && !inside) ? OOB : voff[i], 0, 0);
         koff[i] = __builtin_elementwise_add_sat(koff[i], kinc);
         voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
       }
+      lcol += BC;
     }
   };
   auto stage_part = [&](int stage, int i0, int i1) {   // write chunks [i0, i1) of tile j+1, then request them for tile j+2
@@ -237,6 +300,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto write_tiles = [&](int stage) {
     if constexpr (!LDMA) {
       char *base = smem + stage * STAGE;
+      if constexpr (VT) {
+        const int nv = C - wcol - tc8;   // keys of this lane's chunks inside the sequence
+        if (nv > 0 && nv < 8) {
+#pragma unroll
+          for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const uint32_t keep = (2 * w + 1 < nv) ? 0xFFFFFFFFu : (2 * w < nv) ? 0x0000FFFFu : 0u;
+              vreg[i][w] &= keep;
+            }
+        }
+        wcol += BC;
+      }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
@@ -252,10 +328,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 
   // S^T for the 32 keys of half `kb` of the tile in `stage`: one K fragment feeds RB MFMAs
   auto qk = [&](int stage, int kb, f32x16 (&s)[RB]) {
-    const char *Ks = smem + koffs(stage) + kb * 32 * ROWB;
+    const char *Ks = smem + koffs(stage) + (KT ? kb * D * 64 + (vtr_off - KTILE) : kb * 32 * ROWB);
 #pragma unroll
     for (int t = 0; t < NKS; ++t) {
-      const v8 kf = NOLDS ? qf[0][(t + 1) % NKS] : *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
+      v8 kf;
+      if constexpr (KT) {   // key = 32 kb + lane % 32, elements 16 t + 8 hi ..: rows 16 t .. of sub-image kb
+        const char *kp = Ks + 16 * t * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(kp + 8 * 64));
+        kf = __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+      } else {
+        kf = NOLDS ? qf[0][(t + 1) % NKS] : *reinterpret_cast<const v8 *>(Ks + kread[ABL == 3 ? 0 : t]);
+      }
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
         if (t == 0) {
@@ -362,10 +446,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int db = 0; db < NDB; ++db) {
-        const char *vp = Vs + (db * BC + 16 * u) * 64;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
-        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
-        const v8 vf = NOLDS ? qf[0][(2 * db + u) % NKS] : __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        v8 vf;
+        if constexpr (VT) {
+          // element 32 db + lane % 32; keys in the order P^T holds them (registers of an accumulator block): 4 hi + {0..3} of
+          // the step's first 8-key chunk, then of its second
+          const int vrow = 32 * db + q;
+          const char *vr = smem + voffs(stage) + KTILE + vrow * 128 + 8 * hi;
+          const u32x2 lo = *reinterpret_cast<const u32x2 *>(vr + kswz<64>(vrow, 4 * kb + 2 * u) * 16);
+          const u32x2 up = *reinterpret_cast<const u32x2 *>(vr + kswz<64>(vrow, 4 * kb + 2 * u + 1) * 16);
+          const u32x4 w = {lo[0], lo[1], up[0], up[1]};
+          vf = __builtin_bit_cast(v8, w);
+        } else {
+          const char *vp = Vs + (db * BC + 16 * u) * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));
+          const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp + 8 * 64));
+          vf = NOLDS ? qf[0][(2 * db + u) % NKS] : __builtin_bit_cast(v8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
 #pragma unroll
         for (int b = 0; b < RB; ++b) o[b][db] = F::mfma(vf, pf[b][u], o[b][db]);
       }
@@ -732,13 +828,35 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     const float l_tot = half_swap_add(l[b]) + 1.401298464e-45f;
     const float inv = SPLIT ? 1.0f : (l_tot > 1e-30f ? 1.0f / l_tot : 0.f);   // a row may see no key at all (block mask, empty batch entry)
     float *orow = Os + (b * 32 + q) * OLD;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
-            make_float4(o[b][db][4 * g] * inv, o[b][db][4 * g + 1] * inv, o[b][db][4 * g + 2] * inv, o[b][db][4 * g + 3] * inv);
     const int64_t row = r0 + b * 32 + q;
+    bool stored = false;
+    if constexpr (TR != 0) {
+      if (oT) {   // O^T ([D][R]): register r of block db is element 32 db + crow(r, hi) of the lane's row -- lanes = consecutive rows
+        const int prec = a.op[SLOT_O].precision;
+        const uint32_t esz = prec == PREC_FP32 ? 4u : 2u, ldo = (uint32_t)a.op[SLOT_O].ld;
+        const __amdgpu_buffer_rsrc_t ores =
+            __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_O], head, batch), 0, (uint32_t)Dr * ldo * esz, 0x00020000);
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = 32 * db + crow(r, hi);
+            const uint32_t off = (d < Dr && row < R) ? ((uint32_t)d * ldo + (uint32_t)row) * esz : OOB;
+            const float val = o[b][db][r] * inv;
+            if (prec == PREC_FP32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ores, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b16((uint16_t)pack16<T>(val, 0.f), ores, off, 0, 0);
+          }
+        stored = true;
+      }
+    }
+    if (!stored) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
+              make_float4(o[b][db][4 * g] * inv, o[b][db][4 * g + 1] * inv, o[b][db][4 * g + 2] * inv, o[b][db][4 * g + 3] * inv);
+    }
     if (hi == 0 && row < R) {
       if constexpr (SPLIT) {
         grid.wsML[(slab + row) * 2] = m[b];
@@ -754,7 +872,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     if constexpr (SPLIT)
       store_block_rows<T, D>(Os + b * 32 * OLD, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr,
                              r0 + 32 * b, R, Dr, lane);
-    else
+    else if (!oT)
       store_block_rows<T, D>(Os + b * 32 * OLD, operand_base(a.op[SLOT_O], head, batch), a.op[SLOT_O].precision,
                              (uint32_t)a.op[SLOT_O].ld, r0 + 32 * b, R, Dr, lane);
   }

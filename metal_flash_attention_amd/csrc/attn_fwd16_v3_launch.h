@@ -75,4 +75,41 @@ static void fill_with_split(VariantInfo *v, const char *name) {
   v->causal = true;
 }
 
+// transposed operands read in place (TR of attn_fwd16_v3.h): one code object per pattern of (K, V); Q / O and the causal mask
+// are run-time flags of these kernels.  No column-parallel or block-sparse siblings: such launches stay row-parallel /
+// go to the general kernel.
+template <typename T, int D, int NW, int RING, int VD, int TR>
+static void launch_v3_tr(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  hipLaunchKernelGGL((attn_fwd16_v3<T, D, NW, 1, 8, 0, 0, RING, false, true, VD, false, TR>), dim3(grid.x * grid.y * grid.z),
+                     dim3(NW * 64), (fwd16v3_lds_bytes<D, NW, 1, RING, VD>()), stream, args, g);
+}
+
+template <typename T, int D, int NW, int RING, int VD, int TR>
+static void fill_tr(VariantInfo *v, const char *name) {
+  *v = VariantInfo();
+  v->func = reinterpret_cast<const void *>(&attn_fwd16_v3<T, D, NW, 1, 8, 0, 0, RING, false, true, VD, false, TR>);
+  v->name = name;
+  v->parallelization = NW * 32;
+  v->traversal = 32;
+  v->headBlock = D;
+  v->threads = NW * 64;
+  v->ldsBytes = fwd16v3_lds_bytes<D, NW, 1, RING, VD>();
+  v->cacheLeft = true;
+  v->cacheSecond = true;
+  v->causal = true;
+  v->transposedInPlace = true;
+  v->launch = &launch_v3_tr<T, D, NW, RING, VD, TR>;
+}
+
+// pattern: bit 0 = K transposed, bit 1 = V transposed (Q / O: any)
+#define MFA_FWD16_V3_TR_BUCKET(T, TNAME, D, NW, RING, VD, GEOM)                                                                   \
+  switch (pattern) {                                                                                                               \
+    case 0: fill_tr<T, D, NW, RING, VD, 4>(out, "attn_fwd16v3_" TNAME "_d" #D "_" GEOM "_thr8_tr"); return true;                 \
+    case 1: fill_tr<T, D, NW, RING, VD, 5>(out, "attn_fwd16v3_" TNAME "_d" #D "_" GEOM "_thr8_tr_k"); return true;               \
+    case 2: fill_tr<T, D, NW, RING, VD, 6>(out, "attn_fwd16v3_" TNAME "_d" #D "_" GEOM "_thr8_tr_v"); return true;               \
+    case 3: fill_tr<T, D, NW, RING, VD, 7>(out, "attn_fwd16v3_" TNAME "_d" #D "_" GEOM "_thr8_tr_kv"); return true;              \
+    default: return false;                                                                                                         \
+  }
+
 } // namespace mfa

@@ -1,0 +1,15 @@
+// attn_fwd16_v3_tr_d160.hip -- the 16-bit forward kernel (attn_fwd16_v3.h) for operands stored transposed, read in place: head-dimension
+// bucket 160.  Register-staged ring, fragment reads left to hipcc.
+#include "attn_fwd16_v3_launch.h"
+
+namespace mfa {
+
+bool fwd16_v3_tr_variant_d160(int precision, int D, int pattern, VariantInfo *out) {
+  if (D == 160) {
+    if (precision == PREC_BF16) { MFA_FWD16_V3_TR_BUCKET(__bf16, "bf16", 160, 4, 3, 2, "w4x32") }
+    if (precision == PREC_FP16) { MFA_FWD16_V3_TR_BUCKET(_Float16, "f16", 160, 4, 3, 2, "w4x32") }
+  }
+  return false;
+}
+
+} // namespace mfa

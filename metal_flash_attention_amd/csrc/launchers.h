@@ -18,6 +18,7 @@ struct VariantInfo {
   bool cacheSecond = false;     // the second of them alone (dO / V); fill code sets it = cacheLeft unless a variant splits the pair
   bool pagedAccumulators = false;   // accumulators paged through the output buffers (any-D kernels, attn_paged.h); else in registers
   bool causal = false;          // the code object implements the causal mask itself (general kernels: always)
+  bool transposedInPlace = false;   // reads / writes transposed operands where they lie, whatever their alignment (attn_fwd16_v3.h, TR)
   void (*launch)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;
   // dense / causal launches that `launch` / `launchCausal` hand to another code object (the persistent form of the D <= 128
   // forward kernel): its name for such a launch, nullptr when the variant's own kernel runs (mfa_attention_kernel_launch_form)
@@ -78,6 +79,12 @@ bool dkv16_rs_variant(int precision, int gprecision, int D, int impl, VariantInf
 // objects run on zero-padded chunks (0.576 vs 0.499 ms, 0.885 vs 0.781 ms) and are not built; dK/dV wins at 96 (1.02 vs 1.18 ms)
 bool fwd16_v3_variant_d160(int precision, VariantInfo *out);
 bool fwd16_v3_variant_d192(int precision, VariantInfo *out);
+// operands stored transposed, read in place (TR kernels of attn_fwd16_v3.h): pattern bit 0 = K, bit 1 = V transposed (Q / O: any)
+bool fwd16_v3_tr_variant_d64(int precision, int D, int pattern, VariantInfo *out);   // buckets 32, 64
+bool fwd16_v3_tr_variant_d128(int precision, int D, int pattern, VariantInfo *out);
+bool fwd16_v3_tr_variant_d160(int precision, int D, int pattern, VariantInfo *out);
+bool fwd16_v3_tr_variant_d192(int precision, int D, int pattern, VariantInfo *out);
+bool fwd16_v3_tr_variant_d256(int precision, int D, int pattern, VariantInfo *out);
 bool dq16_variant_d160(int precision, int gprecision, VariantInfo *out);
 bool dq16_variant_d192(int precision, int gprecision, VariantInfo *out);
 bool dkv16_rs_variant_d96(int precision, int gprecision, VariantInfo *out);

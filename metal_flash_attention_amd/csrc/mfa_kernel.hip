@@ -127,11 +127,21 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
   VariantInfo v;
   bool relayout = false;
   if (type == MFA_FORWARD) {
-    // transposed operands (transposeState): the matrix-core kernels read row-major tiles; with a workspace the launch
-    // re-lays the transposed operands out (an HBM-bound pass, attn_relayout below), without one it runs the general kernel
-    relayout = kdesc->transposeState[MFA_Q] || kdesc->transposeState[MFA_K] || kdesc->transposeState[MFA_V] || kdesc->transposeState[MFA_O];
+    // transposed operands (transposeState, AttentionKernelDescriptor.swift:28-42): the forward kernel has code objects that
+    // read and write them in place, like the reference (AttentionKernel.swift:189-204) -- one per pattern of (K, V), Q and O
+    // are run-time flags of those (attn_fwd16_v3.h, TR).  No workspace, no re-layout pass.
+    const bool transposedOperands = kdesc->transposeState[MFA_Q] || kdesc->transposeState[MFA_K] || kdesc->transposeState[MFA_V] || kdesc->transposeState[MFA_O];
     const int b16 = bucket16(D, B16_FORWARD);
-    if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
+    if (transposedOperands && same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
+      const int pattern = (kdesc->transposeState[MFA_K] ? 1 : 0) | (kdesc->transposeState[MFA_V] ? 2 : 0);
+      switch (b16) {
+        case 32: case 64: add(fwd16_v3_tr_variant_d64(pq, b16, pattern, &v), v); break;
+        case 128: add(fwd16_v3_tr_variant_d128(pq, b16, pattern, &v), v); break;
+        case 160: add(fwd16_v3_tr_variant_d160(pq, b16, pattern, &v), v); break;
+        case 192: add(fwd16_v3_tr_variant_d192(pq, b16, pattern, &v), v); break;
+        default: add(fwd16_v3_tr_variant_d256(pq, b16, pattern, &v), v); break;
+      }
+    } else if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
       VariantInfo v3;
       bool have3 = false;
       switch (b16) {
@@ -359,13 +369,16 @@ static bool meets_fast_requirements(const mfa_attention_kernel *kernel, const Ke
     if (!slot_used(type, slot) || slot == SLOT_L || slot == SLOT_D) continue;
     const OperandView &v = args.op[slot];
     const int64_t per16 = 16 / (v.precision == PREC_FP32 ? 4 : 2);  // elements per 16 bytes
-    if ((reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
-    if (v.ld % per16 || v.headStride % per16 || v.batchStride % per16) return false;
+    // (transposed views: the kernels that read them in place gather what is not 16-byte aligned)
+    const bool anyAlignment = v.transposed && kernel->variant.transposedInPlace;
+    if (!anyAlignment && (reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
+    if (!anyAlignment && (v.ld % per16 || v.headStride % per16 || v.batchStride % per16)) return false;
     // these kernels address one (head, batch) slice through a buffer descriptor with 32-bit byte
     // offsets (prefetch may run two tiles past the end): larger slices use the general kernels
     const bool rowOperand = (slot == SLOT_Q || slot == SLOT_O || slot == SLOT_dO || slot == SLOT_dQ);
     const uint64_t seq = rowOperand ? args.R : args.C;
-    const uint64_t bytes = (seq + 192) * (uint64_t)v.ld * (v.precision == PREC_FP32 ? 4u : 2u);
+    // (transposed views, forward only: D rows of `ld` elements; the prefetch runs two tiles = 128 elements along the last row)
+    const uint64_t bytes = (v.transposed ? ((uint64_t)args.D * (uint64_t)v.ld + 192) : (seq + 192) * (uint64_t)v.ld) * (v.precision == PREC_FP32 ? 4u : 2u);
     if (bytes >= 0xFF000000ull) return false;
   }
   return true;

@@ -663,29 +663,95 @@ def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("tr", [(True, True, True, True), (False, True, False, False), (False, False, True, True), (True, False, False, False)])
 @pytest.mark.parametrize("shape", [(300, 449, 128), (130, 200, 64), (200, 150, 256), (257, 129, 104)])
-def test_transposed_operands_reach_the_matrix_cores_through_a_workspace(shape, tr, low_mid):
-    """transposeState (AttentionKernelDescriptor.swift:30-41) with 16-bit inputs: given a workspace, every transposed operand
-    is re-laid out row-major (inputs before, outputs after the launch) and the 16-bit matrix-core code object runs; without
-    one the general kernel reads the transposed buffers in place.  Both agree with the oracle; the canary tails stay intact."""
+def test_transposed_operands_reach_the_matrix_cores(shape, tr, low_mid):
+    """transposeState (AttentionKernelDescriptor.swift:30-41) with 16-bit inputs.  Forward: a code object per pattern of (K, V)
+    reads and writes the transposed operands IN PLACE (AttentionKernel.swift:189-204: no scratch) -- no workspace, whatever the
+    leading dimensions (rows that are not 16-byte aligned are gathered).  Backward: given a workspace, every transposed operand
+    is re-laid out row-major (inputs before, outputs after the launch) and the 16-bit matrix-core code object runs; without one
+    the general kernel reads the transposed buffers in place.  All agree with the oracle; the canary tails stay intact."""
     R, C, D = shape
     net = Network(NetworkDescriptor(R, C, D), seed=R + 3 * C + D)
     desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.BF16, tr=tr)
     run = harness.DeviceRun(desc, net)
-    for k in run.kernels.values():
-        assert k.needsWorkspaceForFastPath and not k.variant.startswith("attn_generic") and k.fallbackVariant.startswith("attn_generic")
+    for t, k in run.kernels.items():
+        assert not k.variant.startswith("attn_generic") and k.fallbackVariant.startswith("attn_generic")
+        if t == AttentionKernelType.forward:
+            assert not k.needsWorkspaceForFastPath and k.variant.startswith("attn_fwd16v3_bf16") and "_tr" in k.variant, k.variant
+            assert k.workspaceSize(row=R, column=C) == 0
+            form = k.launchForm(run.buffers, row=R, column=C)
+            assert form.startswith("attn_fwd16v3_bf16") and "_tr" in form, form     # what really runs, without a workspace
+        else:
+            assert k.needsWorkspaceForFastPath
     got = run.execute(with_workspace=True)
-    assert all(v > 0 for v in run.workspace_bytes.values()), run.workspace_bytes
+    assert all(v > 0 for t, v in run.workspace_bytes.items() if t != AttentionKernelType.forward), run.workspace_bytes
     round_inputs(net, desc)
     ref = net.run()
     failures, report = harness.compare(ref, got, TOL_MIXED)
     assert not failures, (failures, [k.variant for k in run.kernels.values()])
     assert all(run.tails_ok.values()), run.tails_ok
     run2 = harness.DeviceRun(desc, net)
-    slow = run2.execute()                      # no workspace: general kernels
+    slow = run2.execute()                      # no workspace: the same forward kernel, general backward kernels
     failures, report = harness.compare(ref, slow, TOL_MIXED)
     assert not failures, failures
-    for name in ("O", "dQ", "dK", "dV"):       # the two paths differ by the 16-bit rounding of P and dS only
+    assert np.array_equal(got["O"], slow["O"]) and np.array_equal(got["L"], slow["L"])
+    for name in ("dQ", "dK", "dV"):            # the two paths differ by the 16-bit rounding of P and dS only
         assert np.abs(got[name] - slow[name]).max() < 3e-2, name
+
+
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+@pytest.mark.parametrize("pattern", range(1, 16))
+def test_forward_reads_every_transposition_pattern_in_place(pattern, in_type):
+    """All fifteen patterns of transposed (Q, K, V, O), head dimensions of every forward bucket, ragged edges (R, C not multiples
+    of the 32-row / 64-key tiles; C % 8 != 0 cuts a 16-byte chunk of K^T / V^T), 16-bit and FP32 O, causal and not: the forward
+    kernel runs its in-place code object (no workspace) and agrees with the oracle on the rounded inputs."""
+    tr = tuple(bool(pattern & (1 << i)) for i in range(4))
+    shapes = [(77, 203, 32), (130, 200, 64), (257, 129, 104), (96, 331, 128), (100, 140, 160), (65, 270, 192), (200, 150, 256)]
+    R, C, D = shapes[pattern % len(shapes)]
+    for causal, low_out in ((False, pattern % 2 == 0), (True, pattern % 3 == 0)):
+        if causal:
+            R = min(R, C)
+        net = Network(NetworkDescriptor(R, C, D), seed=pattern + D)
+        desc = make_desc(R, C, D, low_in=True, in_type=in_type, tr=tr)
+        desc.lowPrecisionOutputs = low_out
+        run = harness.DeviceRun(desc, net, run_backward=False, causal=causal)
+        k = run.kernels[AttentionKernelType.forward]
+        assert "_tr" in k.variant and not k.needsWorkspaceForFastPath, k.variant
+        got = run.execute()
+        round_inputs(net, desc)
+        ref = net.run(backward=False, causal=causal)
+        failures, report = harness.compare(ref, got, dict(O=1.5e-2 if not low_out else 3e-2, L=2e-3))
+        assert not failures, (failures, k.variant, tr, (R, C, D), causal)
+        assert all(run.tails_ok.values()), run.tails_ok
+
+
+def test_transposed_rows_with_poisoned_padding():
+    """K^T / V^T with a leading dimension beyond the sequence length (16-byte aligned rows) whose padding holds NaN, C % 8 != 0:
+    the chunk that straddles the end of the sequence is cut to size (0 x NaN would poison O), chunks beyond it are never
+    fetched.  Q^T / O^T with padded rows as well; the padding of O^T keeps its poison."""
+    import torch
+    R, C, D = 150, 203, 128
+    ldq, ldk = 160, 208
+    net = Network(NetworkDescriptor(R, C, D), seed=9)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=(True, True, True, True))
+    round_inputs(net, desc)
+    kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+    assert "_tr_kv" in kernel.variant and not kernel.needsWorkspaceForFastPath
+
+    def dev_t(x, ld):   # [seq][D] fp32 (bf16-representable) -> bf16 bits [D][ld], padding = NaN
+        out = np.full((D, ld), 0x7FC0, np.uint16)
+        out[:, :x.shape[0]] = (np.ascontiguousarray(x.T).view(np.uint32) >> 16).astype(np.uint16)
+        return torch.from_numpy(out.view(np.int16)).cuda()
+    bufs = {Op.Q: dev_t(net.Q, ldq), Op.K: dev_t(net.K, ldk), Op.V: dev_t(net.V, ldk),
+            Op.O: torch.full((D, ldq), float("nan"), device="cuda"), Op.L: torch.full((R,), float("nan"), device="cuda")}
+    lds = {Op.Q: ldq, Op.K: ldk, Op.V: ldk, Op.O: ldq}
+    assert "_tr_kv" in kernel.launchForm(bufs, row=R, column=C, leadingDimensions=lds)
+    kernel.dispatch(bufs, row=R, column=C, leadingDimensions=lds, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = net.run(backward=False)
+    o = bufs[Op.O].cpu().numpy()
+    assert np.abs(o[:, :R].T - ref["O"]).max() < 1.5e-2
+    assert np.isnan(o[:, R:]).all(), "padding columns of the transposed O were written"
+    assert np.abs(bufs[Op.L].cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 2e-3
 
 
 def test_transposed_outputs_with_lengths_leave_the_padding_alone():
@@ -697,7 +763,7 @@ def test_transposed_outputs_with_lengths_leave_the_padding_alone():
     rlen, clen = [200, 77], [333, 100]
     desc = make_desc(Rmax, Cmax, D, low_in=True, in_type=P.BF16, tr=(False, False, False, True))
     kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
-    assert kernel.needsWorkspaceForFastPath
+    assert not kernel.needsWorkspaceForFastPath and kernel.variant.endswith("_tr"), kernel.variant   # (round 3: written in place by the matrix-core kernel)
     rng = np.random.default_rng(5)
     host = {n: round_trip(rng.standard_normal((B, H, Rmax if n == "Q" else Cmax, D)).astype(np.float32), int(P.BF16)) for n in ("Q", "K", "V")}
     dev = lambda x: torch.from_numpy((np.ascontiguousarray(x).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()

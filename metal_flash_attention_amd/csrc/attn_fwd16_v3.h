@@ -229,7 +229,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
     // K^T image: [2 blocks of 32 keys][D elements][64 bytes]; V^T image: [D elements][64 keys], chunks XOR-swizzled
     if constexpr (KT) klds[i] = (((id & 7) >> 2) * D + id / 8) * 64 + (id & 3) * 16;
-    if constexpr (VT) vlds[i] = KTILE + (id / 8) * 128 + kswz<64>(id / 8, id & 7) * 16;
+    // (within a 16-key step the keys are stored in the order P^T holds them -- 4 h + {0..3, 8..11} in chunk 2 u + h -- so that
+    // one ds_read_b128 is a fragment: the lane's chunk goes out as two halves, vlds = where keys +0..3 go, keys +4..7 one
+    // chunk further)
+    if constexpr (VT) vlds[i] = KTILE + (id / 8) * 128 + (id & 1) * 8;
     if constexpr (SPARSE) {
       kbase0[i] = valid ? row * ldk2 + c * 16 : OOB;
       vbase0[i] = valid ? row * ldv2 + c * 16 : OOB;
@@ -316,7 +319,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         *reinterpret_cast<u32x4 *>(base + klds[i]) = kreg[i];
-        *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+        if constexpr (VT) {
+          const int vrow = (tid + i * NT) / 8, c2 = tid & 6;   // chunks c2, c2 + 1 hold the step's keys
+          const u32x2 lo = {vreg[i][0], vreg[i][1]}, up = {vreg[i][2], vreg[i][3]};
+          *reinterpret_cast<u32x2 *>(base + vlds[i] + kswz<64>(vrow, c2) * 16) = lo;
+          *reinterpret_cast<u32x2 *>(base + vlds[i] + kswz<64>(vrow, c2 + 1) * 16) = up;
+        } else {
+          *reinterpret_cast<u32x4 *>(base + vlds[i]) = vreg[i];
+        }
       }
     }
   };
@@ -448,14 +458,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
       for (int db = 0; db < NDB; ++db) {
         v8 vf;
         if constexpr (VT) {
-          // element 32 db + lane % 32; keys in the order P^T holds them (registers of an accumulator block): 4 hi + {0..3} of
-          // the step's first 8-key chunk, then of its second
+          // element 32 db + lane % 32; keys in the order P^T holds them (registers of an accumulator block): the image is written
+          // that way (write_tiles)
           const int vrow = 32 * db + q;
-          const char *vr = smem + voffs(stage) + KTILE + vrow * 128 + 8 * hi;
-          const u32x2 lo = *reinterpret_cast<const u32x2 *>(vr + kswz<64>(vrow, 4 * kb + 2 * u) * 16);
-          const u32x2 up = *reinterpret_cast<const u32x2 *>(vr + kswz<64>(vrow, 4 * kb + 2 * u + 1) * 16);
-          const u32x4 w = {lo[0], lo[1], up[0], up[1]};
-          vf = __builtin_bit_cast(v8, w);
+          vf = *reinterpret_cast<const v8 *>(smem + voffs(stage) + KTILE + vrow * 128 + kswz<64>(vrow, 4 * kb + 2 * u + hi) * 16);
         } else {
           const char *vp = Vs + (db * BC + 16 * u) * 64;
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(vp));

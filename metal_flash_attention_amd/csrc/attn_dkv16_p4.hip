@@ -10,7 +10,18 @@ static void launch_dkv_p4(dim3 grid, hipStream_t stream, const KernelArgs &args)
   hipLaunchKernelGGL((attn_dkv16_p4<T, STREAM, CAUSAL>), dim3(grid.x * grid.y * grid.z), dim3(256), dkv4::LDS_BYTES, stream, args, g);
 }
 
-// `v` arrives filled by dkv16_rs_variant: split and block-sparse launches keep the role-split kernel's code objects
+// row-parallel launch: the 32-row steps in `splits` pieces (SPLIT of attn_dkv16_p4.h), then the sums of the dV and dK slabs
+template <typename T, int STREAM>
+static void launch_dkv_p4_split(dim3 grid, uint32_t splits, float *ws, float *, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, ws, nullptr};
+  hipLaunchKernelGGL((attn_dkv16_p4<T, STREAM, false, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), dkv4::LDS_BYTES, stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.C;
+  const float *dk_slabs = ws + (uint64_t)splits * rows * args.D;   // dV slabs first, then dK slabs
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dV, args.C, (const float *)ws);
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dK, args.C, dk_slabs);
+}
+
+// `v` arrives filled by dkv16_rs_variant: block-sparse launches and causal row-parallel ones keep the role-split kernel's code objects
 template <typename T, int STREAM> static void fill_dkv_p4(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dkv16_p4<T, STREAM, false>);
   v->name = name;
@@ -26,6 +37,11 @@ template <typename T, int STREAM> static void fill_dkv_p4(VariantInfo *v, const 
   v->launchCausal = &launch_dkv_p4<T, STREAM, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16_p4<T, STREAM, true>);
   v->causal = true;
+  v->launchSplitCausal = v->launchSplit;   // (the role-split kernel's)
+  v->launchSplit = &launch_dkv_p4_split<T, STREAM>;
+  v->funcSplit = reinterpret_cast<const void *>(&attn_dkv16_p4<T, STREAM, false, true>);
+  v->splitParallelization = 256;
+  v->splitTarget = 256;   // one workgroup per compute unit (512 registers per lane)
 }
 
 // precision: Q, K, V and dO (one 16-bit type); lprec / dprec: storage types of L and D.  The streams exist for the two

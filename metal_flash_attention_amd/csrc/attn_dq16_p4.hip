@@ -10,8 +10,18 @@ static void launch_dq_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) 
   hipLaunchKernelGGL((attn_dq16_p4<T, STREAM, CAUSAL, TG>), dim3(grid.x * grid.y * grid.z), dim3(256), dq4::LDS_BYTES, stream, args, g);
 }
 
-// `v` arrives filled by dq16_variant (eight waves x 32 rows, the same 256 rows per workgroup): split and block-sparse
-// launches keep that kernel's code objects
+// column-parallel launch: the key tiles in `splits` pieces (SPLIT of attn_dq16_p4.h), then the sum of the slabs
+template <typename T, int STREAM, typename TG>
+static void launch_dq_p4_split(dim3 grid, uint32_t splits, float *ws, float *, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, ws, nullptr};
+  hipLaunchKernelGGL((attn_dq16_p4<T, STREAM, false, TG, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), dq4::LDS_BYTES, stream,
+                     args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dQ, args.R, (const float *)ws);
+}
+
+// `v` arrives filled by dq16_variant (eight waves x 32 rows, the same 256 rows per workgroup): block-sparse launches and
+// causal column-parallel ones keep that kernel's code objects
 template <typename T, int STREAM, typename TG = T> static void fill_dq_p4(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, false, TG>);
   v->name = name;
@@ -26,6 +36,11 @@ template <typename T, int STREAM, typename TG = T> static void fill_dq_p4(Varian
   v->launchCausal = &launch_dq_p4<T, STREAM, true, TG>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, true, TG>);
   v->causal = true;
+  v->launchSplitCausal = v->launchSplit;   // (the eight-wave kernel's)
+  v->launchSplit = &launch_dq_p4_split<T, STREAM, TG>;
+  v->funcSplit = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, false, TG, true>);
+  v->splitParallelization = 256;
+  v->splitTarget = 256;   // one workgroup per compute unit (512 registers per lane)
 }
 
 // impl 0: Q as stored, softmax scale in fp32 (descriptors that keep the attention matrix in FP32 registers); impl 10: Q

@@ -10,6 +10,8 @@ struct VariantInfo {
   uint16_t parallelization = 0; // rows (fwd, dQ) or columns (dK/dV) per workgroup
   uint16_t siblingParallelization = 0;   // the same for launchSparse / launchSplit when they belong to another kernel (0: equal)
   uint16_t splitTarget = 0;     // workgroups a traversal-parallel launch aims at (0: 512 = two per compute unit)
+  uint16_t splitParallelization = 0;   // rows / columns per workgroup of launchSplit when it is the variant's own kernel again and
+                                       // only launchSplitCausal / launchSparse belong to the sibling (0: as the sibling)
   uint16_t traversal = 0;       // columns (fwd, dQ) or rows (dK/dV) per main-loop step
   uint16_t headBlock = 0;       // padded head dimension the code object is unrolled for
   uint32_t threads = 0;         // work-items per workgroup
@@ -27,6 +29,8 @@ struct VariantInfo {
   // caller's workspace, then the combine kernel); nullptr if the variant has none
   void (*launchSplit)(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream,
                       const KernelArgs &args) = nullptr;
+  // causal traversal-parallel launches, when they belong to another kernel than launchSplit (nullptr: launchSplit takes both)
+  void (*launchSplitCausal)(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) = nullptr;
   // separate code object implementing the causal mask (the unmasked loop bodies stay branch-free);
   // nullptr when `launch` handles the flag itself (general kernels) or the variant has no mask
   void (*launchCausal)(dim3 grid, hipStream_t stream, const KernelArgs &args) = nullptr;

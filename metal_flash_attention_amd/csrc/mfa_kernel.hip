@@ -621,8 +621,8 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   // block-sparse and split launches may belong to a sibling kernel with its own workgroup shape (attn_dkv16_p4 keeps those of
   // attn_dkv16_rs)
   const uint32_t sibPar = plan->variant->siblingParallelization ? plan->variant->siblingParallelization : plan->variant->parallelization;
-  const uint32_t sibBlocks = (par + sibPar - 1) / sibPar;
-  if (args->mask && plan->variant->launchSparse && !plan->useFallback) blocks = sibBlocks;
+  const uint32_t siblingBlocks = (par + sibPar - 1) / sibPar;
+  if (args->mask && plan->variant->launchSparse && !plan->useFallback) blocks = siblingBlocks;
   if ((uint64_t)blocks * heads * batches > 0x7FFFFFFFull) return fail(MFA_ERR_INVALID_ARGUMENT, "grid too large");
   plan->grid = dim3(blocks, heads, batches);
   plan->splits = 1;
@@ -632,6 +632,9 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
   const bool splittable = !plan->useFallback && !kernel->relayout && plan->variant->launchSplit && !args->rowLen && !args->colLen && !args->mask &&
                           (type != MFA_FORWARD || !args->causal);
   if (splittable) {
+    // (the hand-placed backward kernels split dense launches themselves; causal ones stay with their siblings)
+    const bool ownSplit = plan->variant->splitParallelization && !(args->causal && plan->variant->launchSplitCausal);
+    const uint32_t sibBlocks = ownSplit ? (par + plan->variant->splitParallelization - 1) / plan->variant->splitParallelization : siblingBlocks;
     const uint32_t s = choose_splits((uint64_t)sibBlocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column,
                                      plan->variant->splitTarget ? plan->variant->splitTarget : 512);
     if (s > 1) {
@@ -647,6 +650,10 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
     }
   }
   return MFA_OK;
+}
+
+static auto split_launcher(const LaunchPlan &plan) -> decltype(plan.variant->launchSplit) {
+  return (plan.args.causal && plan.variant->launchSplitCausal) ? plan.variant->launchSplitCausal : plan.variant->launchSplit;
 }
 
 static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const LaunchPlan &plan) {
@@ -682,7 +689,7 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   if (st != MFA_OK) return st;
   for (int i = 0; i < plan.nRelayouts; ++i)
     if (!plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], (hipStream_t)stream);
-  if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, (hipStream_t)stream, plan.args);
+  if (plan.splits > 1) split_launcher(plan)(plan.grid, plan.splits, plan.wsO, plan.wsML, (hipStream_t)stream, plan.args);
   else if (plan.args.mask && plan.variant->launchSparse) plan.variant->launchSparse(plan.grid, (hipStream_t)stream, plan.args);
   else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, (hipStream_t)stream, plan.args);
   else plan.variant->launch(plan.grid, (hipStream_t)stream, plan.args);
@@ -705,6 +712,7 @@ mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, 
     text += std::string(plan.variant->name) + " (general kernel: the launch does not meet the requirements of " + kernel->variant.name + ")";
   } else if (plan.splits > 1) {
     text += std::string(plan.variant->name) + " column-parallel x" + std::to_string(plan.splits) + " + combine";
+    if (plan.args.causal && plan.variant->launchSplitCausal) text += " (pieces by the sibling kernel)";
   } else {
     const bool sparse = plan.args.mask && plan.variant->launchSparse;
     const char *form = (!sparse && plan.variant->launchForm) ? plan.variant->launchForm(plan.args) : nullptr;
@@ -729,7 +737,9 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
   if (params->rowLengths || params->columnLengths || params->blockMask || (type == MFA_FORWARD && params->causal)) return MFA_OK;
   const uint32_t heads = params->heads ? params->heads : 1, batches = params->batches ? params->batches : 1;
   const uint32_t par = (type == MFA_BACKWARD_KEY_VALUE) ? params->column : params->row;
-  const uint32_t wgPar = kernel->variant.siblingParallelization ? kernel->variant.siblingParallelization : kernel->variant.parallelization;
+  const bool ownSplit = kernel->variant.splitParallelization && !(params->causal && kernel->variant.launchSplitCausal);
+  const uint32_t wgPar = ownSplit ? kernel->variant.splitParallelization
+                                  : kernel->variant.siblingParallelization ? kernel->variant.siblingParallelization : kernel->variant.parallelization;
   const uint32_t blocks = (par + wgPar - 1) / wgPar;
   const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? params->row : params->column,
                                    kernel->variant.splitTarget ? kernel->variant.splitTarget : 512);
@@ -755,7 +765,7 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   auto go = [&]() {
     for (int i = 0; i < plan.nRelayouts; ++i)
       if (!plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], s);
-    if (plan.splits > 1) plan.variant->launchSplit(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);
+    if (plan.splits > 1) split_launcher(plan)(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);
     else if (plan.args.mask && plan.variant->launchSparse) plan.variant->launchSparse(plan.grid, s, plan.args);
     else if (plan.args.causal && plan.variant->launchCausal) plan.variant->launchCausal(plan.grid, s, plan.args);
     else plan.variant->launch(plan.grid, s, plan.args);

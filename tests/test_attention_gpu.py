@@ -798,7 +798,8 @@ def test_backward_16bit_matches_general_kernels(monkeypatch):
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
     fast = harness.DeviceRun(desc, net).execute()
     run = harness.DeviceRun(make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=(False, False, True, False)), net)
-    assert all("generic" in k.fallbackVariant and k.needsWorkspaceForFastPath for k in run.kernels.values())   # no workspace below
+    for t, k in run.kernels.items():   # no workspace below: general backward kernels (the forward kernel reads V^T in place)
+        assert "generic" in k.fallbackVariant and k.needsWorkspaceForFastPath == (t != AttentionKernelType.forward), (t, k.variant)
     slow = run.execute()
     for name in ("D", "dQ", "dK", "dV"):
         assert np.abs(fast[name] - slow[name]).max() < 2e-2, name
@@ -1173,6 +1174,10 @@ def test_backward_split_matches_unsplit_and_oracle(shape, causal):
         for op in outputs:   # poison this kernel's outputs: the split path must rewrite all of them
             run.buffers[op][: run.buffers[op].numel() // 2].fill_(0x7F)
         k.dispatch(run.buffers, row=R, column=C, stream=stream, causal=causal, workspace=ws)
+        form = k.launchForm(run.buffers, row=R, column=C, causal=causal, workspace=ws)
+        assert "column-parallel x" in form, form
+        # the hand-placed kernels (D <= 128) cut dense launches into pieces themselves; causal ones belong to their siblings
+        assert ("sibling" in form) == (causal and "p4" in k.variant), form
     torch.cuda.synchronize()
     got = run.results()
     # the unsplit launch of the 128 bucket is the four-wave hand-placed kernel, the split one its 8 x 32 / role-split sibling:

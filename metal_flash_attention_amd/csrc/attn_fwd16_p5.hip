@@ -11,7 +11,16 @@ static void launch_p5(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   hipLaunchKernelGGL((attn_fwd16_p5<T, STREAM, CAUSAL>), dim3(groups * grid.y * grid.z), dim3(256), p5::LDS_BYTES, stream, args, g);
 }
 
-// `v` arrives filled by fwd16_v3_variant (D = 256: four waves x 32 rows): split and block-sparse launches keep its code objects
+// column-parallel launch (few-workgroup problems: one head, long sequences): pieces of the key range, then the combine pass
+template <typename T, int STREAM>
+static void launch_p5_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
+  hipLaunchKernelGGL((attn_fwd16_p5<T, STREAM, false, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), p5::LDS_BYTES, stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
+  hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
+}
+
+// `v` arrives filled by fwd16_v3_variant (D = 256: four waves x 32 rows): block-sparse launches keep its code objects
 template <typename T, int STREAM> static void fill_p5(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_fwd16_p5<T, STREAM, false>);
   v->name = name;
@@ -27,6 +36,10 @@ template <typename T, int STREAM> static void fill_p5(VariantInfo *v, const char
   v->launchCausal = &launch_p5<T, STREAM, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_p5<T, STREAM, true>);
   v->causal = true;
+  v->launchSplit = &launch_p5_split<T, STREAM>;
+  v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_p5<T, STREAM, false, true>);
+  v->splitParallelization = 256;
+  v->splitTarget = 256;   // one workgroup per compute unit
 }
 
 // impl 0 = scale applied in fp32; impl 10 = FOLD (see attn_fwd16_p4.hip); 1000 + stream index: developer streams

@@ -859,7 +859,7 @@ def test_backward_reference_low_precision_mix_on_matrix_cores(shape, low_mid):
 # ---- column-parallel ("split-KV") forward through a caller-provided workspace ------------------
 @pytest.mark.parametrize("shape,heads", [((4096, 4096, 64), 1), ((4096, 4096, 128), 1), ((300, 3000, 128), 2),
                                          ((129, 8200, 64), 1), ((64, 16384, 128), 1), ((300, 3000, 256), 1),
-                                         ((129, 4200, 32), 2)])
+                                         ((129, 4200, 32), 2), ((300, 3000, 192), 1), ((200, 4100, 160), 2), ((520, 2100, 256), 1)])
 def test_forward_split_kv_matches_unsplit_and_oracle(shape, heads):
     """Same answer with and without the workspace (to the rounding of a different summation order),
     and both within the tight forward bounds of the oracle."""
@@ -881,6 +881,9 @@ def test_forward_split_kv_matches_unsplit_and_oracle(shape, heads):
     for ws in (None, torch.empty(need + 64, dtype=torch.uint8, device="cuda")):
         o = torch.full((heads, R, D), float("nan"), device="cuda")
         l = torch.zeros((heads, R), device="cuda")
+        if ws is not None:   # the hand-placed kernels (D > 64) cut the key range themselves
+            form = kernel.launchForm({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=heads, headStrides=hs, workspace=ws)
+            assert "column-parallel x" in form and form.startswith(kernel.variant), (form, kernel.variant)
         kernel.dispatch({Op.Q: q, Op.K: k, Op.V: v, Op.O: o, Op.L: l}, row=R, column=C, heads=heads,
                         headStrides=hs, stream=torch.cuda.current_stream().cuda_stream, workspace=ws)
         torch.cuda.synchronize()

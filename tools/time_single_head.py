@@ -9,7 +9,7 @@ from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, Att
                                        AttentionOperand as Op, GEMMOperandPrecision as P)
 FLOPS = {KT.forward: 4.0, KT.backwardQuery: 6.0, KT.backwardKeyValue: 8.0}
 mixed = "--mixed" in sys.argv
-for N, D in ((4096, 64), (4096, 128), (8192, 128), (16384, 128), (16384, 64)):
+for N, D in ((4096, 64), (4096, 128), (8192, 128), (16384, 128), (16384, 64), (8192, 256), (16384, 256)):
     desc = AttentionDescriptor(); desc.lowPrecisionInputs = True; desc.lowPrecisionInputType = P.BF16
     desc.lowPrecisionIntermediates = mixed
     desc.matrixDimensions = (N, N, D); desc.transposeState = (False,) * 4

@@ -34,8 +34,9 @@
  *   - FP16 Q, K, V with BF16 dO (the reference's own low-precision mix), backwardKeyValue, D <= 128: the two products that
  *     read dO run in BF16 -- V is rounded to BF16 once per workgroup and P is packed to BF16 for dV -- while S and dK stay
  *     FP16; the other kernels convert dO to FP16 instead (exact in FP16's range).
- *   - Transposed operands (transposeState) run on the 16-bit matrix cores only when the launch is given a workspace
- *     (mfa_attention_kernel_needs_workspace_for_fast_path); without one the fp32-arithmetic kernels serve them.
+ *   - Transposed operands (transposeState): the forward kernel reads and writes them in place on the 16-bit matrix cores
+ *     (any leading dimension); the backward kernels run on the matrix cores only when the launch is given a workspace
+ *     (mfa_attention_kernel_needs_workspace_for_fast_path), without one the fp32-arithmetic kernels serve them.
  *   - Head dimensions: any.  16-bit matrix-core code objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic
  *     kernels whatever the storage type, accumulators in registers; D > 384 (beyond the reference's tables, which fall through
  *     to their last row, +Parameters.swift:60-65) runs D-blocked kernels that page the accumulators through the output
@@ -185,11 +186,14 @@ const char *mfa_attention_kernel_variant(const mfa_attention_kernel *kernel);
 /* name of the general (fp32-arithmetic) code object that serves the launches the selected variant cannot take (misaligned
  * pointers or strides, transposed operands without a workspace ...); "" if the selected variant is the general one */
 const char *mfa_attention_kernel_fallback_variant(const mfa_attention_kernel *kernel);
-/* Transposed operands (transposeState, AttentionKernelDescriptor.swift:30-41) and the 16-bit matrix-core kernels: those
- * read row-major tiles, so a launch with `workspace` first re-lays every transposed operand out into the workspace (one
- * HBM-bound pass per operand, 2 x sequence x D x size bytes; transposed outputs are written back the same way) and then
- * runs the matrix-core code object; without a workspace the general kernel reads the transposed operands in place.
- * Non-zero = this kernel is in that situation (size the workspace with mfa_attention_kernel_workspace_size). */
+/* Transposed operands (transposeState, AttentionKernelDescriptor.swift:30-41) and the 16-bit matrix-core kernels.
+ * FORWARD: code objects that read Q^T, K^T, V^T and write O^T where they lie (AttentionKernel.swift:189-204: no scratch),
+ * one per pattern of (K, V) and head-dimension bucket; rows that are not 16-byte aligned (an odd sequence length as the
+ * leading dimension) are gathered element-wise -- slower, never the fp32-arithmetic kernel.  This function returns 0.
+ * BACKWARD (dQ, dK/dV): those kernels read row-major tiles, so a launch with `workspace` first re-lays every transposed
+ * operand out into the workspace (one HBM-bound pass per operand, 2 x sequence x D x size bytes; transposed outputs are written
+ * back the same way) and then runs the matrix-core code object; without a workspace the general kernel reads the transposed
+ * operands in place.  Non-zero = this kernel is in that situation (size the workspace with mfa_attention_kernel_workspace_size). */
 int mfa_attention_kernel_needs_workspace_for_fast_path(const mfa_attention_kernel *kernel);
 /* The descriptor as the selected code object really executes it: the Swift struct lets callers
  * request any block dimensions / cache state (AttentionKernelDescriptor.swift:9-13); a
@@ -216,7 +220,7 @@ typedef struct mfa_launch_params {
    * traversal-parallel: forward and backwardQuery cut the key range, backwardKeyValue the row range;
    * the pieces' partial results (forward: un-normalised O, m, l; backward: fp32 gradient slabs) go to
    * this scratch and a second small kernel merges them -- no atomics.  NULL (default) = never split.
-   * Second use: row-major copies of transposed operands for the matrix-core kernels (see
+   * Second use: row-major copies of transposed operands for the backward matrix-core kernels (see
    * mfa_attention_kernel_needs_workspace_for_fast_path; such launches are not split; 256-byte aligned).
    * Size it with mfa_attention_kernel_workspace_size.  Contents need no initialisation. */
   void *workspace;

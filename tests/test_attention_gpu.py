@@ -1195,6 +1195,62 @@ def test_backward_split_matches_unsplit_and_oracle(shape, causal):
     assert all(run.tails_ok.values())
 
 
+@pytest.mark.parametrize("shape,heads", [((1024, 1024, 128), 2), ((4096, 4096, 128), 1), ((300, 449, 64), 3)])
+def test_launches_are_capturable_in_a_hip_graph(shape, heads):
+    """The three launches of a training step -- persistent forward, hand-placed backward, and (one head) their column-parallel
+    pieces + combine passes through a workspace -- captured into ONE hipGraph on a side stream and replayed: the library makes
+    no allocation, no synchronisation and no host-side decision that depends on device data, so a replay on new inputs gives
+    what eager launches give, bit for bit."""
+    import torch
+    R, C, D = shape
+    desc = make_desc(R, C, D, low_in=True, low_mid=True, in_type=P.BF16)
+    kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in AttentionKernelType}
+    prec = desc.memoryPrecisions
+    tdt = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
+    seq = {Op.Q: R, Op.K: C, Op.V: C, Op.O: R, Op.dO: R, Op.dV: C, Op.dK: C, Op.dQ: R}
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+
+    def fresh_inputs(bufs):
+        for op in (Op.Q, Op.K, Op.V, Op.dO):
+            bufs[op].copy_((torch.randn((heads, seq[op], D), generator=g, device="cuda") * (0.1 if op == Op.dO else 1)).to(tdt[prec[op]]))
+    bufs = {op: torch.zeros((heads, n, D), device="cuda", dtype=tdt[prec[op]]) for op, n in seq.items()}
+    bufs[Op.L] = torch.zeros((heads, R), device="cuda", dtype=tdt[prec[Op.L]])
+    bufs[Op.D] = torch.zeros((heads, R), device="cuda", dtype=tdt[prec[Op.D]])
+    hs = {op: n * D for op, n in seq.items()}
+    hs[Op.L] = hs[Op.D] = R
+    ws = {t: torch.empty(max(k.workspaceSize(row=R, column=C, heads=heads), 256), dtype=torch.uint8, device="cuda") for t, k in kernels.items()}
+
+    def step(stream):
+        for t in (AttentionKernelType.forward, AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):
+            kernels[t].dispatch(bufs, row=R, column=C, heads=heads, headStrides=hs, stream=stream, workspace=ws[t])
+    outs = (Op.O, Op.L, Op.D, Op.dQ, Op.dK, Op.dV)
+    fresh_inputs(bufs)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(side.cuda_stream)   # warm-up outside the capture (first launch of a code object raises its LDS limit)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step(torch.cuda.current_stream().cuda_stream)
+    for round_ in range(2):
+        fresh_inputs(bufs)
+        for op in outs:
+            bufs[op].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        replayed = {op: bufs[op].clone() for op in outs}
+        for op in outs:
+            bufs[op].zero_()
+        step(torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for op in outs:
+            assert torch.equal(replayed[op].view(torch.uint8), bufs[op].view(torch.uint8)), (op, round_)
+        assert torch.isfinite(bufs[Op.O].float()).all() and bufs[Op.dQ].float().abs().max() > 0
+    if heads == 1 and R >= 4096:
+        assert all("column-parallel" in kernels[t].launchForm(bufs, row=R, column=C, heads=heads, headStrides=hs, workspace=ws[t]) for t in kernels)
+
+
 # ---- head dimensions above 256 (the reference's large-D rows, +Parameters.swift:77-285; accumulator paging of
 # +Accumulate.swift:449-467 re-derived: accumulators stay in the 512 registers, the left-hand operands leave them) ----
 @pytest.mark.parametrize("shape", [(200, 200, 320), (130, 130, 384), (77, 150, 384), (33, 260, 264), (100, 64, 352)])

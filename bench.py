@@ -93,8 +93,8 @@ WORKLOADS = {
                                    types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwdbwd_bf16_d128_mixed": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True,
                                    types=("forward", "backwardQuery", "backwardKeyValue")),
-    # the headline shape with Q, K, V, O stored transposed ([D][N]): with a workspace the launch re-lays them out (an
-    # HBM-bound pass per operand) and runs the same matrix-core kernel
+    # the headline shape with Q, K, V, O stored transposed ([D][N]): read and written in place by the matrix-core kernel's
+    # transposed code object (round 3; round 2: re-layout passes through a workspace)
     "fwd_bf16_d128_transposed": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), low_mid=True,
                                      tr=(True, True, True, True)),
     "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),

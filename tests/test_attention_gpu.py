@@ -754,29 +754,39 @@ def test_transposed_rows_with_poisoned_padding():
     assert np.abs(bufs[Op.L].cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 2e-3
 
 
-def test_transposed_outputs_with_lengths_leave_the_padding_alone():
-    """Transposed O ([D][Rmax] per head) + per-batch lengths + a workspace: the write-back of a row-major output copy would
-    overwrite the caller's padding columns with uninitialised workspace bytes (the matrix-core kernels never write padding
-    rows), so such launches run on the general kernel in place.  Padding must keep its poison, the rest equals the oracle."""
+@pytest.mark.parametrize("tr", [(False, False, False, True), (True, True, True, True), (False, True, False, True)])
+def test_transposed_operands_with_lengths_leave_the_padding_alone(tr):
+    """Transposed operands ([D][max sequence] per head) + per-batch lengths (padded batches): keys beyond a batch entry's length
+    are neither multiplied nor summed although they lie INSIDE the rows of K^T / V^T (poison there), padding columns of O^T keep
+    their poison (the kernel stores only rows < length), the rest equals the oracle.  (Round 2 sent such launches to the general
+    kernel: a re-laid-out output copy would have overwritten the padding.)"""
     import torch
-    B, H, Rmax, Cmax, D = 2, 2, 200, 333, 128
+    B, H, Rmax, Cmax, D = 2, 2, 200, 336, 128
     rlen, clen = [200, 77], [333, 100]
-    desc = make_desc(Rmax, Cmax, D, low_in=True, in_type=P.BF16, tr=(False, False, False, True))
+    tq, tk, tv, to = tr
+    desc = make_desc(Rmax, Cmax, D, low_in=True, in_type=P.BF16, tr=tr)
     kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
-    assert not kernel.needsWorkspaceForFastPath and kernel.variant.endswith("_tr"), kernel.variant   # (round 3: written in place by the matrix-core kernel)
+    assert not kernel.needsWorkspaceForFastPath and "_tr" in kernel.variant, kernel.variant
     rng = np.random.default_rng(5)
     host = {n: round_trip(rng.standard_normal((B, H, Rmax if n == "Q" else Cmax, D)).astype(np.float32), int(P.BF16)) for n in ("Q", "K", "V")}
-    dev = lambda x: torch.from_numpy((np.ascontiguousarray(x).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
-    bufs = {Op.Q: dev(host["Q"]), Op.K: dev(host["K"]), Op.V: dev(host["V"]),
-            Op.O: torch.full((B, H, D, Rmax), float("nan"), device="cuda"), Op.L: torch.full((B, H, Rmax), float("nan"), device="cuda")}
+
+    def dev(name, transposed):
+        bits = (np.ascontiguousarray(host[name]).view(np.uint32) >> 16).astype(np.uint16)
+        lens = rlen if name == "Q" else clen
+        for b in range(B):   # poison beyond each batch entry's length
+            bits[b, :, lens[b]:, :] = 0x7FC0
+        if transposed:
+            bits = np.ascontiguousarray(bits.transpose(0, 1, 3, 2))
+        return torch.from_numpy(bits.view(np.int16)).cuda()
+    bufs = {Op.Q: dev("Q", tq), Op.K: dev("K", tk), Op.V: dev("V", tv),
+            Op.O: torch.full((B, H, D, Rmax) if to else (B, H, Rmax, D), float("nan"), device="cuda"),
+            Op.L: torch.full((B, H, Rmax), float("nan"), device="cuda")}
     hs = {Op.Q: Rmax * D, Op.K: Cmax * D, Op.V: Cmax * D, Op.O: Rmax * D, Op.L: Rmax}
     bs = {op: v * H for op, v in hs.items()}
-    need = kernel.workspaceSize(row=Rmax, column=Cmax, heads=H, batches=B)
-    ws = torch.full((need + 256,), 0x7F, dtype=torch.uint8, device="cuda")     # garbage a write-back would expose
-    kernel.dispatch(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs, workspace=ws,
-                    stream=torch.cuda.current_stream().cuda_stream,
-                    rowLengths=torch.tensor(rlen, dtype=torch.int32, device="cuda"),
-                    columnLengths=torch.tensor(clen, dtype=torch.int32, device="cuda"))
+    args = dict(row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                rowLengths=torch.tensor(rlen, dtype=torch.int32, device="cuda"), columnLengths=torch.tensor(clen, dtype=torch.int32, device="cuda"))
+    assert "_tr" in kernel.launchForm(bufs, **args)
+    kernel.dispatch(bufs, stream=torch.cuda.current_stream().cuda_stream, **args)
     torch.cuda.synchronize()
     o = bufs[Op.O].cpu().numpy()
     for b in range(B):
@@ -786,8 +796,28 @@ def test_transposed_outputs_with_lengths_leave_the_padding_alone():
             net.Q, net.K, net.V = (np.ascontiguousarray(host[n][b, h, :(R if n == "Q" else C)]) for n in ("Q", "K", "V"))
             net.invalidate()
             ref = net.run(backward=False)
-            assert np.abs(o[b, h][:, :R].T - ref["O"]).max() < 1.5e-2
-            assert np.isnan(o[b, h][:, R:]).all(), "padding columns of the transposed O were written"
+            got = o[b, h].T if to else o[b, h]
+            assert np.abs(got[:R] - ref["O"]).max() < 1.5e-2, (b, h)
+            assert np.isnan(got[R:]).all(), "padding rows of O were written"
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_headline_shape_transposed_in_place(causal):
+    """N = 4096, D = 128, BF16, every operand transposed (`bench.py --workload fwd_bf16_d128_transposed`), one head: the in-place
+    code object against the oracle on the rounded inputs, O and L."""
+    R = C = 4096
+    D = 128
+    net = Network(NetworkDescriptor(R, C, D), seed=77)
+    desc = make_desc(R, C, D, low_in=True, low_mid=True, in_type=P.BF16, tr=(True,) * 4)
+    run = harness.DeviceRun(desc, net, run_backward=False, causal=causal)
+    k = run.kernels[AttentionKernelType.forward]
+    assert k.variant == "attn_fwd16v3_bf16_d128_w8x32_thr8_tr_kv" and not k.needsWorkspaceForFastPath
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(backward=False, causal=causal)
+    failures, report = harness.compare(ref, got, dict(O=1.5e-2, L=7e-3))
+    assert not failures, failures
+    assert all(run.tails_ok.values())
 
 
 def test_backward_16bit_matches_general_kernels(monkeypatch):

@@ -136,7 +136,12 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       const int pattern = (kdesc->transposeState[MFA_K] ? 1 : 0) | (kdesc->transposeState[MFA_V] ? 2 : 0);
       switch (b16) {
         case 32: case 64: add(fwd16_v3_tr_variant_d64(pq, b16, pattern, &v), v); break;
-        case 128: add(fwd16_v3_tr_variant_d128(pq, b16, pattern, &v), v); break;
+        case 128: {
+          bool have = fwd16_v3_tr_variant_d128(pq, b16, pattern, &v);
+          if (have && pattern == 3) fwd16_p4_tr_variant(pq, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
+          add(have, v);
+          break;
+        }
         case 160: add(fwd16_v3_tr_variant_d160(pq, b16, pattern, &v), v); break;
         case 192: add(fwd16_v3_tr_variant_d192(pq, b16, pattern, &v), v); break;
         default: add(fwd16_v3_tr_variant_d256(pq, b16, pattern, &v), v); break;

@@ -100,6 +100,22 @@ def test_causal_per_wave_bounds_and_skip_loop(name, dma_mode, order):
     assert len(set(w.count["s_barrier"] for w in wg.waves)) == 1
 
 
+@pytest.mark.parametrize("name", list(p4gen.TR_STREAMS))
+@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3))])
+def test_transposed_streams(name, dma_mode, order):
+    """K and V handed over TRANSPOSED ([128][C], whole tiles): the images keep the source orientation and the read recipes change
+    places (K^T fragments by transposing reads, Q in their element order; V^T 8 bytes at a time from swizzled rows) -- tile counts
+    across the ring's wrap, ragged row blocks, causal with per-wave bounds and the skip loop, a forced rescale, DMA landing
+    early / late with the waves in either order."""
+    cfg = p4gen.VARIANTS[name]
+    for R, C, rblk, causal in ((256, 64, 0, False), (256, 448, 0, False), (200, 320, 0, False), (512, 512, 1, True), (300, 448, 1, True),
+                               (700, 1024, 2, True)):
+        _check(R, C, rblk=rblk, causal=causal, cfg=cfg, dma_mode=dma_mode, order=order, seed=21)
+    wg = _check(256, 448, cfg=cfg, dma_mode=dma_mode, order=order, spike=(5, 300, 3.0), seed=22, tol_o=1.2e-2)
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 128   # the rescale section ran
+    assert wg.waves[0].count.get("ds_read_b128", 0) == 0 and wg.waves[0].count["ds_read_b64"] > 0
+
+
 def test_fold_stream_very_negative_scores():
     """every score far below zero: the first tile must still set m to the true maximum (m starts at 0 in FOLD streams)"""
     rng = np.random.default_rng(3)
@@ -109,6 +125,15 @@ def test_fold_stream_very_negative_scores():
     O, L, _ = p4sim.run_block(q, k, v, 0, cfg=FOLD)
     Oref, Lref = p4sim.reference(q, k, v)
     assert np.isfinite(O).all() and np.abs(O - Oref).max() < 2e-2 and np.abs(L - Lref).max() < 0.2
+
+
+def test_rendered_memory_instructions_keep_their_offsets():
+    """the model executes the instruction list, the GPU the rendered text: every LDS read's immediate offset must be in it
+    (a plain ds_read_b64 once went out without -- every head-dimension block but the first read the wrong rows)"""
+    for name in ("BF16_THR8", "BF16_FOLD_TR"):
+        for ins in p4gen.Stream(p4gen.VARIANTS[name]).build():
+            if ins.op.startswith("ds_read") and ins.mod.get("offset"):
+                assert ("offset:%d" % ins.mod["offset"]) in p4gen.render_one(ins), p4gen.render_one(ins)
 
 
 def test_stream_file_is_current():

@@ -59,7 +59,7 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64):
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64, tr=0):
         """fold: Q arrives pre-multiplied by log2(e)/sqrt(D) and the running maximum is subtracted INSIDE the matrix pipe (an
         extra k-step whose A operand is -1.0 and whose B operand carries m as a bf16/f16 pair): no s * scale2 - m per
         score; xb = scores per tile exponentiated in phase B already (FOLD streams only)."""
@@ -74,6 +74,16 @@ class Cfg:
         self.dma = dma
         # timing-only ablations (WRONG RESULTS; developer builds): fillers left out of the steady-state phases
         self.abl = frozenset(abl)
+        # tr = 1: K and V stored TRANSPOSED ([D][keys], transposeState; attn_fwd16_p4_tr.h): the LDS images keep the orientation of
+        # the source -- a 16-byte chunk is 8 consecutive KEYS of one head-dimension element -- and the two read recipes change
+        # places.  K^T image: [2 blocks of 32 keys][128 elements][64 bytes], a fragment = two ds_read_b64_tr_b16 (rows 16 ks + 8 h
+        # of block kb); they return the contraction index in the order of an accumulator block's registers (4 hi + {0..3, 8..11}),
+        # so the kernel stores the Q fragments in that order.  V^T image: [128 elements][64 keys], chunks XOR-swizzled by
+        # (element & 7); P^T holds its keys in that register order anyway, so a fragment's halves are the 8 bytes at 8 hi of
+        # chunks 2 u and 2 u + 1: two ds_read_b64 through eight address registers (the K fragment addresses' registers, which the
+        # one K^T base does not need), recomputed per tile from the ring position.  The LDS-DMA pieces are the same instructions:
+        # where a chunk comes from is the kernel's business (lane offsets, 128 bytes per tile).
+        self.tr = tr
 
 
 # ---------------------------------------------------------------- tiny IR
@@ -242,6 +252,9 @@ class Stream:
         vids = {}
         if softmax:
             self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of tile j-1")
+            if cfg.tr:
+                for c in range(8):   # (the ring position is a multiple of 16 KiB: the XOR only meets the swizzle bits)
+                    self.emit("v_xor_b32", V(T_KADDR + c), [I(c << 4), V(T_VADDR)])
         mlist = self.qk_list(par)
         ng = len(mlist)
         g0 = (ng - 32) // 2          # element pair i is exponentiated in gap g0 + i and packed one gap later
@@ -303,6 +316,8 @@ class Stream:
         """V^T read i (0..31): fragment f = i // 2 = 4 u + db, half i % 2 (keys +0..3 / +8..11 of the 16-key group)"""
         f, h = divmod(i, 2)
         u, db = divmod(f, 4)
+        if self.cfg.tr:   # element 32 db + lane % 32 of the [128][64 keys] image: 8 bytes of chunk 2 u + h
+            return self.lds_read("ds_read_b64", vf_half(f, h), V(T_KADDR + 2 * u + h), db * 32 * 128, note="V^T f%d.%d" % (f, h))
         off = (db * 64 + 16 * u) * 64 + h * 8 * 64
         return self.lds_read("ds_read_b64_tr_b16", vf_half(f, h), V(T_VADDR), off, note="V^T f%d.%d" % (f, h))
 
@@ -464,6 +479,11 @@ class Stream:
 
     def k_read(self, slot, i):
         kb, ks = divmod(i, 8)
+        if self.cfg.tr:   # rows 16 ks (+ 8) of key block kb of the [2][128][64 bytes] image
+            for h in range(2):
+                self.lds_read("ds_read_b64_tr_b16", A(K_BASE + 4 * (8 * kb + ks) + 2 * h, 2), VN("kbase"),
+                              slot * KSLOT + (kb * 128 + 16 * ks + 8 * h) * 64, note="K^T(%d,%d).%d" % (kb, ks, h))
+            return
         self.lds_read("ds_read_b128", k_frag(kb, ks), V(T_KADDR + ks), slot * KSLOT + kb * 8192, note="K(%d,%d)" % (kb, ks))
 
     def vrd_advance(self):   # the V^T read base of this tile is already in T_VADDR
@@ -574,7 +594,8 @@ class Stream:
         self.emit("s_waitcnt", None, [], vmcnt=4)
         self.emit("s_barrier")
         for ks in range(8):
-            self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
+            if not self.cfg.tr:
+                self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
         for rb in range(2):
             self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
@@ -705,7 +726,7 @@ def render_one(ins, suffix="%="):
         return "%s %s, %s, %s, 0 offen" % (op, fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
     if op == "buffer_store_dwordx4":     # s = (four data registers, per-lane byte offset, buffer resource)
         return "buffer_store_dwordx4 %s, %s, %s, 0 offen" % (fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
-    if op in ("ds_read_b128", "ds_read_b64_tr_b16"):
+    if op in ("ds_read_b128", "ds_read_b64", "ds_read_b64_tr_b16"):
         return "%s %s, %s offset:%d" % (op, fmt(ins.d), fmt(ins.s[0]), m["offset"])
     if op == "v_fma_f32":
         return "v_fma_f32 %s, %s, %s, -%s" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
@@ -743,12 +764,18 @@ def write_inc(path):
     lines.append("// X(name, folds Q scale and running maximum into the matrix pipe, stamps the shader clock)")
     lines.append("#define MFA_P4_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.prof))
+        if not cfg.tr:
+            lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.prof))
+    lines.append("")
+    lines.append("// streams of attn_fwd16_p4_tr (K and V stored transposed): X(name, folds)")
+    lines.append("#define MFA_P4_TR_STREAM_LIST(X) \\")
+    for name in TR_STREAMS:
+        lines.append("  X(%s, %d) \\" % (name, VARIANTS[name].fold))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates: MFA_FWD16_IMPL=p4:<1000 + index>")
     lines.append("#define MFA_P4_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        if name not in PRODUCT_STREAMS and cfg.dtype == "bf16":
+        if name not in PRODUCT_STREAMS and cfg.dtype == "bf16" and not cfg.tr:
             lines.append("  X(%s) \\" % name)
     lines.append("")
     lines.append("")
@@ -757,8 +784,9 @@ def write_inc(path):
         ins = st.build()
         txt = render(ins)
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
-        lines.append("// %s: dtype=%s thr=%g xe=%d xf=%d order_a=%s pad=%d prof=%d fold=%d xb=%d dma=%s -- %d instructions, %d matrix instructions"
-                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.xf, cfg.order_a, cfg.pad, cfg.prof, cfg.fold, cfg.xb, cfg.dma, len(txt), n_mfma))
+        lines.append("// %s: dtype=%s thr=%g xe=%d xf=%d order_a=%s pad=%d prof=%d fold=%d xb=%d dma=%s%s -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.xf, cfg.order_a, cfg.pad, cfg.prof, cfg.fold, cfg.xb, cfg.dma,
+                        " tr=1" if cfg.tr else "", len(txt), n_mfma))
         lines.append("#define MFA_P4_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)
@@ -780,6 +808,10 @@ VARIANTS = {
     "F16_FOLD": Cfg("f16", 8, fold=1, xb=40),
     "BF16_FOLD_XB24": Cfg("bf16", 8, fold=1, xb=24),
     "BF16_FOLD_PROF": Cfg("bf16", 8, fold=1, xb=40, prof=1),
+    "BF16_THR8_TR": Cfg("bf16", 8, 0, tr=1),
+    "F16_THR8_TR": Cfg("f16", 8, 0, tr=1),
+    "BF16_FOLD_TR": Cfg("bf16", 8, fold=1, xb=40, tr=1),
+    "F16_FOLD_TR": Cfg("f16", 8, fold=1, xb=40, tr=1),
     "ABL_EXPA": Cfg("bf16", 8, fold=1, prof=1, abl=("expa",)),
     "ABL_SUMPACK": Cfg("bf16", 8, fold=1, prof=1, abl=("sum", "pack")),
     "ABL_VREADA": Cfg("bf16", 8, fold=1, prof=1, abl=("vreada",)),
@@ -793,6 +825,7 @@ VARIANTS = {
 }
 
 PRODUCT_STREAMS = ("BF16_THR8", "F16_THR8", "BF16_THR0", "BF16_FOLD", "F16_FOLD")
+TR_STREAMS = ("BF16_THR8_TR", "F16_THR8_TR", "BF16_FOLD_TR", "F16_FOLD_TR")   # product too: their own list (attn_fwd16_p4_tr.h)
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

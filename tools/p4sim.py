@@ -239,6 +239,13 @@ class Workgroup:
             for t in dests:
                 w.poison.add(t)
             w.lds_q.append((dests, data.T.copy()))
+        elif op == "ds_read_b64":
+            addr = w.rd(s[0]) + m["offset"]
+            data = self.lds_read(addr, 8).copy().view(np.uint32)      # [64][2]
+            dests = w.regs(d)
+            for t in dests:
+                w.poison.add(t)
+            w.lds_q.append((dests, data.T.copy()))
         elif op == "ds_read_b64_tr_b16":
             addr = (w.rd(s[0]) + m["offset"]).astype(np.int64)
             raw = self.lds_read(addr, 8).copy().view(np.uint16)       # [64 lanes][4 elements] at each lane's address
@@ -417,15 +424,22 @@ class Workgroup:
 
 
 def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 1, 2, 3), scale=None, stream=None):
-    """One 256-row block: q [R][128], k / v [C][128] as uint16 bf16 bit patterns.  Returns O [256][128] f32, L [256]."""
+    """One 256-row block: q [R][128], k / v [C][128] as uint16 bf16 bit patterns.  Returns O [256][128] f32, L [256].
+    cfg.tr: K and V are handed to the stream TRANSPOSED ([128][C] in memory, C % 64 == 0), as attn_fwd16_p4_tr.h does."""
     cfg = cfg or Cfg()
+    tr = bool(getattr(cfg, "tr", 0))
     f16 = cfg.dtype == "f16"
     R, C, D = q.shape[0], k.shape[0], 128
     assert q.shape[1] == D
     instrs = stream if stream is not None else Stream(cfg).build()
     wg = Workgroup(instrs, dma_mode)
     kb, vb, qb = k.reshape(-1).view(np.uint8), v.reshape(-1).view(np.uint8), q.reshape(-1).view(np.uint8)
+    if tr:
+        assert C % 64 == 0, "the transposed streams take whole tiles"
+        kb, vb = np.ascontiguousarray(k.T).reshape(-1).view(np.uint8), np.ascontiguousarray(v.T).reshape(-1).view(np.uint8)
     ld2 = D * 2
+    ldt2 = C * 2                     # leading dimension of K^T / V^T, bytes
+    knrec = D * ldt2 if tr else C * ld2
     nt_total = (C + 63) // 64
     coff = C - R
     nt = nt_total
@@ -451,7 +465,11 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
                 for l in range(64):
                     row = r0 + b * 32 + int(qq[l])
                     d0 = 16 * s + 8 * int(hi[l])
-                    if row < R:
+                    if row < R and tr:   # elements 4 hi + {0..3, 8..11} of the step: the order the K^T fragments arrive in
+                        d0 = 16 * s + 4 * int(hi[l])
+                        chunk = np.concatenate([qb[row * ld2 + d0 * 2: row * ld2 + d0 * 2 + 8],
+                                                qb[row * ld2 + (d0 + 8) * 2: row * ld2 + (d0 + 8) * 2 + 8]]).view(np.uint32)
+                    elif row < R:
                         chunk = qb[row * ld2 + d0 * 2: row * ld2 + d0 * 2 + 16].view(np.uint32)
                     else:
                         chunk = np.zeros(4, np.uint32)
@@ -463,8 +481,12 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             p = (wave * 4 + i) * 64 + lane
             krow, kc = p >> 4, (p & 15) ^ ((p >> 4) & 15)
             vkey, vc = (p >> 2) & 63, (p >> 8) * 4 + (p & 3)
-            koff.append((krow * ld2 + kc * 16).astype(np.uint32))
-            voff.append((vkey * ld2 + vc * 16).astype(np.uint32))
+            if tr:   # K^T image [2 blocks of 32 keys][128 elements][4 chunks]; V^T image [128 elements][8 chunks ^ (element & 7)]
+                koff.append((((p >> 2) & 127) * ldt2 + ((p >> 9) * 32 + (p & 3) * 8) * 2).astype(np.uint32))
+                voff.append(((p >> 3) * ldt2 + ((p & 7) ^ ((p >> 3) & 7)) * 16).astype(np.uint32))
+            else:
+                koff.append((krow * ld2 + kc * 16).astype(np.uint32))
+                voff.append((vkey * ld2 + vc * 16).astype(np.uint32))
 
         def dma(buf, nrec, off, ldsbase):
             data = np.zeros((64, 16), np.uint8)
@@ -474,15 +496,15 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
                     data[l] = buf[o:o + 16]
             wg.lds_write16(ldsbase + 16 * np.arange(64), data)
 
-        kinc = vinc = 64 * ld2
+        kinc = vinc = 128 if tr else 64 * ld2
         for i in range(4):
-            dma(kb, C * ld2, koff[i], 0 * KSLOT + (wave * 4 + i) * 1024)
+            dma(kb, knrec, koff[i], 0 * KSLOT + (wave * 4 + i) * 1024)
             koff[i] = np.minimum(koff[i].astype(np.uint64) + kinc, 0xFFFFFFFF).astype(np.uint32)
         for i in range(4):
-            dma(vb, C * ld2, voff[i], VBASE + (wave * 4 + i) * 1024)
+            dma(vb, knrec, voff[i], VBASE + (wave * 4 + i) * 1024)
             voff[i] = np.minimum(voff[i].astype(np.uint64) + vinc, 0xFFFFFFFF).astype(np.uint32)
         for i in range(4):
-            dma(kb, C * ld2, koff[i], 1 * KSLOT + (wave * 4 + i) * 1024)
+            dma(kb, knrec, koff[i], 1 * KSLOT + (wave * 4 + i) * 1024)
             koff[i] = np.minimum(koff[i].astype(np.uint64) + kinc, 0xFFFFFFFF).astype(np.uint32)
         w.vm_q = [(None, None)] * 12
         n16 = lane & 15
@@ -494,6 +516,9 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             "kbase": (qq * 256 + ((hi ^ (qq & 15)) << 4)).astype(np.uint32),
             "vbase": (VBASE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32),
         })
+        if tr:   # K^T: the transposing-read lane term; V^T: row lane % 32, the swizzle's XOR mask, + 8 hi
+            w.vn["kbase"] = (((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32)
+            w.vn["vbase"] = (VBASE + qq * 128 + ((qq & 7) << 4) + 8 * hi).astype(np.uint32)
         for i in range(4):
             w.vn["koff%d" % i], w.vn["voff%d" % i] = koff[i], voff[i]
         for b in range(2):
@@ -506,7 +531,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         if causal:   # tiles this wave's own rows can see
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 64 + 1)) if wlast >= r0 else 1
-        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
+        w.sn.update({"kres": (kb, knrec), "vres": (vb, knrec), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
                      "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "maskfrom": maskfrom})
     wg.run(order)
     O = np.zeros((256, D), np.float32)

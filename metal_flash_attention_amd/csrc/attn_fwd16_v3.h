@@ -202,8 +202,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   const bool vGather = VT && (((uintptr_t)operand_base(a.op[SLOT_V], head, batch) | ldv2) & 15) != 0;
   auto gather_chunk = [&](const __amdgpu_buffer_rsrc_t &res, uint32_t off, int col) {   // keys col .. col + 7 of one row
     uint16_t e[8];
+    const bool row = off < OOB;   // (rows beyond the head dimension: their offset saturates at 2^32 - 1 as the tiles advance,
+                                  // and + 2 i would wrap into the buffer)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_raw_buffer_load_b16(res, (col + i < C) ? off + 2 * i : OOB, 0, 0);
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_raw_buffer_load_b16(res, (row && col + i < C) ? off + 2 * i : OOB, 0, 0);
     const u32x4 w = {e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
                      e[6] | ((uint32_t)e[7] << 16)};
     return w;

@@ -754,6 +754,26 @@ def test_transposed_rows_with_poisoned_padding():
     assert np.abs(bufs[Op.L].cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 2e-3
 
 
+def test_transposed_gather_never_wraps_into_the_buffer():
+    """K^T with rows that are not 16-byte aligned (odd C: gathered 16-bit loads) and a head dimension below its bucket (D = 72 in
+    128): the image rows beyond D are fetched at offsets that SATURATE as the tiles advance -- adding the element offset to
+    2^32 - 1 once wrapped into the buffer and read it at odd byte addresses (found by tools/fuzz_shapes.py --transposed: 5 of 240).
+    K^T starts with bit patterns 0x807F (tiny negative numbers) whose bytes, read one byte off, are +Inf: 0 x Inf = NaN everywhere."""
+    import torch
+    R, C, D = 150, 507, 72
+    net = Network(NetworkDescriptor(R, C, D), seed=12)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=(False, True, False, False))
+    round_inputs(net, desc)
+    net.K[:32, 0] = np.array([0x807F0000], np.uint32).view(np.float32)[0]
+    net.invalidate()
+    run = harness.DeviceRun(desc, net, run_backward=False)
+    assert run.kernels[AttentionKernelType.forward].variant.endswith("_tr_k")
+    got = run.execute()
+    ref = net.run(backward=False)
+    failures, report = harness.compare(ref, got, dict(O=1.5e-2, L=2e-3))
+    assert not failures and np.isfinite(got["O"]).all(), failures
+
+
 @pytest.mark.parametrize("tr", [(False, False, False, True), (True, True, True, True), (False, True, False, True)])
 def test_transposed_operands_with_lengths_leave_the_padding_alone(tr):
     """Transposed operands ([D][max sequence] per head) + per-batch lengths (padded batches): keys beyond a batch entry's length

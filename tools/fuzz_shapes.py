@@ -2,7 +2,11 @@
 """developer check: random (R, C, D, causal, precision mode, 16-bit type) problems through all three kernels against the oracle
 with the reference's mixed tolerances (and a tighter gradient bound); prints every failure, exits non-zero if there is one.
 
-  python tools/fuzz_shapes.py [cases] [seed]
+  python tools/fuzz_shapes.py [cases] [seed] [--transposed]
+
+--transposed: forward only, a random non-empty pattern of transposed (Q, K, V, O) per problem (transposeState), sequence lengths
+that are multiples of 64 / of 8 / odd in equal parts -- the hand-placed stream on K^T + V^T, the 8 x 32 kernel's in-place code
+objects with aligned rows, and their gather path.
 """
 import os, sys
 import numpy as np
@@ -14,8 +18,10 @@ from test_attention_gpu import make_desc, round_inputs, TOL_MIXED, TOL_MIXED_SHO
 from metal_flash_attention_amd import GEMMOperandPrecision as P
 from oracle import Network, NetworkDescriptor
 
-cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+transposed = "--transposed" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+cases = int(argv[0]) if len(argv) > 0 else 120
+rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
 bad = 0
 seen = {}
 for i in range(cases):
@@ -25,20 +31,36 @@ for i in range(cases):
     C = int(rng.integers(R if causal else 1, 900))
     low_mid = bool(rng.integers(2))
     in_type = P.BF16 if rng.integers(2) else P.FP16
+    tr = (False,) * 4
+    if transposed:
+        tr = tuple(bool(b) for b in rng.integers(2, size=4))
+        if not any(tr):
+            tr = (True, True, True, True)
+        g = (64, 8, 1)[i % 3]
+        R, C = max(g, R // g * g), max(g, C // g * g)
+        if causal and C < R:
+            C = R
     net = Network(NetworkDescriptor(R, C, D), seed=1000 + i)
-    desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type)
-    run = harness.DeviceRun(desc, net, causal=causal)
+    desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=tr)
+    if transposed:
+        desc.lowPrecisionOutputs = bool(rng.integers(2))
+    run = harness.DeviceRun(desc, net, causal=causal, run_backward=not transposed)
     got = run.execute()
     round_inputs(net, desc)
-    ref = net.run(causal=causal)
-    failures, report = harness.compare(ref, got, TOL_MIXED_SHORT if C <= 20 else TOL_MIXED)
-    variants = [k.variant for k in run.kernels.values()]
+    ref = net.run(causal=causal, backward=not transposed)
+    tol = TOL_MIXED_SHORT if C <= 20 else TOL_MIXED
+    if transposed:
+        tol = {k: v for k, v in tol.items() if k in ("O", "L")}
+    failures, report = harness.compare(ref, got, tol)
+    variants = [k.launchForm(run.buffers, row=R, column=C, causal=causal).split(" (")[0] if transposed else k.variant for k in run.kernels.values()]
     for v in variants:
         seen[v] = seen.get(v, 0) + 1
-    ok = not failures and all(run.tails_ok.values()) and all(np.isfinite(got[n]).all() for n in ("O", "dQ", "dK", "dV"))
+    outs = ("O",) if transposed else ("O", "dQ", "dK", "dV")
+    tails = {k: v for k, v in run.tails_ok.items() if not transposed or k in ("O", "L")}
+    ok = not failures and all(tails.values()) and all(np.isfinite(got[n]).all() for n in outs)
     if not ok:
         bad += 1
-        print("FAIL", (R, C, D), "causal" if causal else "dense", "mixed" if low_mid else "fp32mid", in_type.name, failures, run.tails_ok, variants)
+        print("FAIL", (R, C, D), "causal" if causal else "dense", "mixed" if low_mid else "fp32mid", in_type.name, tr, failures, tails, variants)
 print(f"{cases - bad} of {cases} random problems within the reference's mixed tolerances")
 for v, n in sorted(seen.items()):
     print(f"  {n:4d} x {v}")

@@ -754,6 +754,37 @@ def test_transposed_rows_with_poisoned_padding():
     assert np.abs(bufs[Op.L].cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 2e-3
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_transposed_multi_head_batches(causal):
+    """Heads and batch entries of transposed operands ([batch][head][D][sequence]) through strides: the hand-placed stream on
+    K^T / V^T (whole aligned tiles) and, with one more key, the 8 x 32 kernel's gather path -- every head against the oracle."""
+    import torch
+    B, H, D = 2, 3, 128
+    for R, C, stream in ((320, 512, True), (320, 513, False)):
+        desc = make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=(True, True, True, True))
+        kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+        rng = np.random.default_rng(R + C)
+        host = {n: round_trip(rng.standard_normal((B, H, R if n == "Q" else C, D)).astype(np.float32), int(P.BF16)) for n in ("Q", "K", "V")}
+        dev = lambda x: torch.from_numpy((np.ascontiguousarray(x.transpose(0, 1, 3, 2)).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+        bufs = {Op.Q: dev(host["Q"]), Op.K: dev(host["K"]), Op.V: dev(host["V"]),
+                Op.O: torch.full((B, H, D, R), float("nan"), device="cuda"), Op.L: torch.full((B, H, R), float("nan"), device="cuda")}
+        hs = {Op.Q: R * D, Op.K: C * D, Op.V: C * D, Op.O: R * D, Op.L: R}
+        bs = {op: v * H for op, v in hs.items()}
+        args = dict(row=R, column=C, heads=H, batches=B, headStrides=hs, batchStrides=bs, causal=causal)
+        assert kernel.launchForm(bufs, **args).startswith("attn_fwd16_p4_tr" if stream else "attn_fwd16v3")
+        kernel.dispatch(bufs, stream=torch.cuda.current_stream().cuda_stream, **args)
+        torch.cuda.synchronize()
+        o, l = bufs[Op.O].cpu().numpy(), bufs[Op.L].cpu().numpy()
+        for b in range(B):
+            for h in range(H):
+                net = Network(NetworkDescriptor(R, C, D), seed=0)
+                net.Q, net.K, net.V = (np.ascontiguousarray(host[n][b, h]) for n in ("Q", "K", "V"))
+                net.invalidate()
+                ref = net.run(backward=False, causal=causal)
+                assert np.abs(o[b, h].T - ref["O"]).max() < 1.5e-2, (b, h, stream)
+                assert np.abs(l[b, h] / np.float32(harness.LOG2E) - ref["L"]).max() < 2e-3, (b, h, stream)
+
+
 def test_transposed_gather_never_wraps_into_the_buffer():
     """K^T with rows that are not 16-byte aligned (odd C: gathered 16-bit loads) and a head dimension below its bucket (D = 72 in
     128): the image rows beyond D are fetched at offsets that SATURATE as the tiles advance -- adding the element offset to

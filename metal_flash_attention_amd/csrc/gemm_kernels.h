@@ -337,7 +337,7 @@ __global__ __launch_bounds__(WR * WC * 64) void gemm_16(const GemmArgs g) {
     else return __builtin_bit_cast(v8, __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3));
   };
   constexpr int FRAG_OPS = MT * (AKM ? 1 : 2) + NT * (BKM ? 1 : 2);   // LDS instructions per k-step of fragment reads
-  static_assert(MT == 4 && NT == 2 || !DMA, "frag_wait lists the fragments of a 4 x 2 wave tile");
+  static_assert((MT == 4 && NT == 2) || !DMA, "frag_wait lists the fragments of a 4 x 2 wave tile");
   // s_waitcnt with the A fragments as in/out operands, then an empty asm that lists the B fragments (asm volatile
   // statements keep their order): no consumer of either can be scheduled above the wait
   auto frag_wait = [&](AsmFrag (&a)[MT], AsmFrag (&b)[NT], auto more) {

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
 #define MFA_P4_DMA(res, dst, off) __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (lds_ptr)(dst), 16, off, 0, 0, 0)
 #else
-#define MFA_P4_DMA(res, dst, off) ((void)(res), (void)(dst))
+#define MFA_P4_DMA(res, dst, off) ((void)(res), (void)(dst), (void)(off))
 #endif
   // ---- Q tile of the wave (64 rows) by LDS-DMA into an image of its own behind the first tiles: row-major Q in a K-tile-shaped
   // image ([64 rows][16 chunks ^ (row & 15)]), Q^T in a K^T-shaped one ([2 blocks of 32 rows][128 elements][64 bytes])

@@ -5,12 +5,15 @@
 // The traversal is the same generated statement with two read recipes exchanged (tools/p4gen.py, Cfg.tr): the LDS images keep the
 // orientation of the source -- a 16-byte LDS-DMA chunk is 8 consecutive KEYS of one head-dimension element --
 //   K^T image [2 blocks of 32 keys][128 elements][64 bytes]        read with ds_read_b64_tr_b16 (as V is in the row-major kernel)
-//   V^T image [128 elements][64 keys], chunks ^ (element & 7)       read 8 bytes at a time (P^T holds its keys 4 hi + {0..3, 8..11})
+//   V^T image [128 elements][64 keys], chunks ^ (element >> 1 & 7)  read 8 bytes at a time (P^T holds its keys 4 hi + {0..3, 8..11};
+//                                                                   sixteen lanes = sixteen rows land on 32 distinct banks)
 // and which chunk lands where is decided here, by the lane offsets of the LDS-DMA pieces (128 bytes further per tile).  The
 // transposing read returns the contraction index of S^T = K Q^T in that register order too, so the Q fragments are stored in it.
-// What the tile walk cannot do in place: zero the keys of a PARTIAL last tile (the end of the sequence is not the end of the
-// buffer) -- launches with column % 64 != 0, per-batch lengths, rows of K^T / V^T / Q^T that are not 16-byte aligned, or a block
-// mask run on the 8 x 32 kernel's transposed code object instead (attn_fwd16_v3.h, TR), which the launcher falls back to.
+// The tile advances ALONG the rows, so the end of the sequence is not the end of the buffer: the workgroup's last V^T tile is
+// fetched through lane offsets of its own (vlast: out of bounds = zeros for chunks at or beyond key C; P is 0 there, but
+// 0 x whatever follows the sequence is not), the scores of what follows K^T's keys are replaced by the edge mask.  Chunks cannot
+// be cut: launches with column % 8 != 0, rows of K^T / V^T / Q^T that are not 16-byte aligned, per-batch lengths or a block mask
+// run on the 8 x 32 kernel's transposed code object instead (attn_fwd16_v3.h, TR), which the launcher falls back to.
 // Verified on the lane-exact model like the other streams (tools/p4sim.py run_block with cfg.tr, tests/test_p4_stream.py).
 #pragma once
 #include "attn_fwd16_p4.h"
@@ -29,6 +32,20 @@ constexpr bool stream_folds(int s) {
 }
 
 }  // namespace p4tr
+
+// the statement of attn_fwd16_p4 plus the last tile's V^T offsets
+#define MFA_P4TR_TRAVERSE(STREAM)                                                                                        \
+  asm volatile(STREAM                                                                                                    \
+               : [m0] "+v"(m0), [m1] "+v"(m1), [l0] "+v"(l0), [l1] "+v"(l1), [koff0] "+v"(koff[0]), [koff1] "+v"(koff[1]), \
+                 [koff2] "+v"(koff[2]), [koff3] "+v"(koff[3]), [voff0] "+v"(voff[0]), [voff1] "+v"(voff[1]),               \
+                 [voff2] "+v"(voff[2]), [voff3] "+v"(voff[3]), [j] "=&s"(tj), [vrd] "=&s"(tvrd), [vwr] "=&s"(tvwr),       \
+                 [pend] "=&s"(tpend), [t0] "=&s"(tt0), [t1] "=&s"(tt1), [pa] "=&s"(tpa), [pw] "=&s"(tpw),                 \
+                 [pb] "=&s"(tpb), [plast] "=&s"(tplast), [sv] "=&s"(tsv), [ptime] "=&s"(tptime), [selv] "=&s"(tselv)       \
+               : [kbase] "v"(kbase), [vbase] "v"(vbase), [lim0] "v"(lim0), [lim1] "v"(lim1), [onesw] "v"(onesw),          \
+                 [vlast0] "v"(vlast[0]), [vlast1] "v"(vlast[1]), [vlast2] "v"(vlast[2]), [vlast3] "v"(vlast[3]),          \
+                 [kres] "s"(kdesc), [vres] "s"(vdesc), [nt] "s"(nt), [wnt] "s"(wnt), [scale2] "s"(a.scale2), [kinc] "s"(kinc), \
+                 [vinc] "s"(vinc), [ldsk] "s"(ldsk), [ldsv] "s"(ldsv), [maskfrom] "s"(maskfrom), [ntm2] "s"(ntm2)           \
+               : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_P4_OWNED_VGPRS)
 
 // T: __bf16 or _Float16 (must match the stream); CAUSAL only selects the block order and the bounds (as attn_fwd16_p4)
 template <typename T, int STREAM, bool CAUSAL>
@@ -59,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
     if (pass == 1 && rblk0 == grid.rowBlocks - 1 - rblk0) break;
     if (pass == 1) __syncthreads();
   }
-  const int R = a.R, C = a.C;   // (no per-batch lengths here; C % 64 == 0)
+  const int R = a.R, C = a.C;   // (no per-batch lengths here; C % 8 == 0)
   if ((int64_t)rblk * GROWS >= R) continue;
   const int64_t r0 = (int64_t)rblk * GROWS + wave * WROWS;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2,
@@ -99,8 +116,8 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   }
   asm volatile("" ::: "memory");   // keep the Q loads ahead of the DMA pieces in the memory queue
 
-  // ---- traversal range (whole tiles only)
-  const int tiles_total = C / BC;
+  // ---- traversal range
+  const int tiles_total = (C + BC - 1) / BC;
   const int coff = C - R;   // CAUSAL (extension): row r sees key c iff c <= r + (C - R)
   int nt = tiles_total;
   if constexpr (CAUSAL) {
@@ -113,8 +130,10 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
     wnt = wlast >= r0 ? (int)max((int64_t)1, min((int64_t)nt, (wlast + coff) / BC + 1)) : 1;
     wnt = __builtin_amdgcn_readfirstlane(wnt);
   }
+  const bool ragged = (C & (BC - 1)) != 0 && nt == tiles_total;   // only the globally last tile is partial
   const int minlim = CAUSAL ? (int)min((int64_t)C - 1, r0 + coff) : C - 1;
-  const int maskfrom = CAUSAL ? (minlim + 1) / BC : nt;
+  const int maskfrom = (CAUSAL || ragged) ? (minlim + 1) / BC : nt;
+  const int ntm2 = nt - 2;
   int lim0 = C - 1, lim1 = C - 1;
   if constexpr (CAUSAL) {
     lim0 = (int)min((int64_t)C - 1, r0 + q + coff);
@@ -124,15 +143,17 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   lim1 -= 4 * hi;
 
   // ---- LDS-DMA staging: piece i of wave w fills 16-byte positions (4 w + i) * 64 + lane of an image
-  uint32_t koff[4], voff[4];
+  uint32_t koff[4], voff[4], vlast[4];
   const uint32_t kinc = BC * 2, vinc = BC * 2;   // a tile further = 64 keys along every row
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = (wave * 4 + i) * 64 + lane;
     const int kd = (p >> 2) & 127, kkey = (p >> 9) * 32 + (p & 3) * 8;
-    const int vd = p >> 3, vkey = ((p & 7) ^ (vd & 7)) * 8;
+    const int vd = p >> 3, vkey = ((p & 7) ^ ((vd >> 1) & 7)) * 8;
     koff[i] = (kd < Dr) ? (uint32_t)kd * ldk2 + kkey * 2 : OOB;
     voff[i] = (vd < Dr) ? (uint32_t)vd * ldv2 + vkey * 2 : OOB;
+    // the workgroup's last tile: chunks at or beyond key C are not fetched
+    vlast[i] = (vd < Dr && vkey + BC * (nt - 1) < C) ? voff[i] + (uint32_t)(nt - 1) * vinc : OOB;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // K(0) -> K image 0
@@ -141,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // V(0) -> V image 0
-    MFA_P4_DMA(vres, smem + VBASE + (wave * 4 + i) * 1024, voff[i]);
+    MFA_P4_DMA(vres, smem + VBASE + (wave * 4 + i) * 1024, nt == 1 ? vlast[i] : voff[i]);
     voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
   }
 #pragma unroll
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   const int n16 = lane & 15;
   const uint32_t trlane = ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
   const uint32_t kbase = lds0 + trlane;
-  const uint32_t vbase = lds0 + VBASE + q * 128 + ((q & 7) << 4) + 8 * hi;
+  const uint32_t vbase = lds0 + VBASE + q * 128 + (((q >> 1) & 7) << 4) + 8 * hi;
   const uint32_t ldsk = lds0 + wave * 4096, ldsv = lds0 + VBASE + wave * 4096;
 
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the wave's own Q image has landed; the 12 K / V pieces stay in flight
@@ -189,8 +210,8 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   const uint32_t onesw = hi ? 0u : (__is_same(T, __bf16) ? 0xBF80BF80u : 0xBC00BC00u);   // -1.0 in k-slots 0, 1
   {
     uint32_t tj, tvrd, tvwr, tpend, tt0, tt1, tplast, tpa, tpw, tpb;
-    uint64_t tsv, tptime;
-#define MFA_P4TR_RUN(name, fold) if constexpr (STREAM == p4tr::S_##name) MFA_P4_TRAVERSE(MFA_P4_STREAM_##name);
+    uint64_t tsv, tptime, tselv;
+#define MFA_P4TR_RUN(name, fold) if constexpr (STREAM == p4tr::S_##name) MFA_P4TR_TRAVERSE(MFA_P4_STREAM_##name);
     MFA_P4_TR_STREAM_LIST(MFA_P4TR_RUN)
 #undef MFA_P4TR_RUN
   }

@@ -5,10 +5,10 @@
 
 namespace mfa {
 
-// what the tile walk of attn_fwd16_p4_tr needs (its header): whole 64-key tiles, no per-batch lengths, no block mask, 16-byte
-// aligned rows of K^T, V^T and (if transposed) Q^T, row-major Q as the row-major kernel wants it
+// what the tile walk of attn_fwd16_p4_tr needs (its header): whole 16-byte chunks of keys, no per-batch lengths, no block mask,
+// 16-byte aligned rows of K^T, V^T and (if transposed) Q^T, row-major Q as the row-major kernel wants it
 static bool p4_tr_takes(const KernelArgs &a) {
-  if (a.C % 64 != 0 || a.rowLen || a.colLen || a.mask) return false;
+  if (a.C % 8 != 0 || a.rowLen || a.colLen || a.mask) return false;
   auto aligned = [](const OperandView &v) {
     return ((reinterpret_cast<uintptr_t>(v.ptr) | (uint64_t)v.ld * 2 | (uint64_t)v.headStride * 2 | (uint64_t)v.batchStride * 2) & 15) == 0;
   };

@@ -877,11 +877,14 @@ def test_headline_shape_transposed_in_place(causal):
 @pytest.mark.parametrize("qo", [(False, False), (True, False), (False, True), (True, True)])
 def test_hand_placed_stream_on_transposed_keys_and_values(qo, low_mid, in_type):
     """K^T and V^T in whole, 16-byte aligned tiles at D <= 128: the hand-placed stream reads them in place (attn_fwd16_p4_tr.h: the
-    images keep the source orientation, the read recipes change places), Q and O either way; ragged row blocks, head dimensions
-    below the bucket, causal, 16-bit O, both scale modes.  Launches it cannot take (column % 64 != 0) stay with the 8 x 32 kernel's
-    transposed code object -- same answers."""
+    images keep the source orientation, the read recipes change places), Q and O either way; ragged row blocks and last tiles,
+    head dimensions below the bucket, causal, 16-bit O, both scale modes.  Launches it cannot take (rows that are not 16-byte
+    aligned) stay with the 8 x 32 kernel's transposed code object -- same answers."""
     for (R, C, D), causal, low_out in (((296, 448, 128), False, False), ((256, 64, 128), False, True), ((200, 320, 104), True, False),
-                                       ((696, 1024, 80), True, True), ((136, 2048, 128), False, False)):   # (rows of Q^T: 16-byte aligned)
+                                       ((696, 1024, 80), True, True), ((136, 2048, 128), False, False),   # (rows of Q^T: 16-byte aligned)
+                                       # partial last tiles (whole 16-byte chunks of keys): the last V^T tile through its own offsets
+                                       ((296, 456, 128), False, False), ((256, 40, 128), False, True), ((200, 328, 104), True, False),
+                                       ((696, 1000, 80), True, True), ((64, 72, 128), True, False)):
         net = Network(NetworkDescriptor(R, C, D), seed=R + C)
         desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=(qo[0], True, True, qo[1]))
         desc.lowPrecisionOutputs = low_out
@@ -895,8 +898,8 @@ def test_hand_placed_stream_on_transposed_keys_and_values(qo, low_mid, in_type):
         failures, report = harness.compare(ref, got, dict(O=3e-2 if low_out else 1.5e-2, L=7e-3 if low_mid else 2e-3))
         assert not failures, (failures, (R, C, D), causal, form)
         assert all(run.tails_ok.values())
-    # a partial last tile, or rows of Q^T that do not begin on 16-byte boundaries: the 8 x 32 kernel
-    for R, C in ((256, 200),) + (((300, 448),) if qo[0] else ()):
+    # rows of K^T / V^T (or Q^T) that do not begin on 16-byte boundaries: the 8 x 32 kernel
+    for R, C in ((256, 201),) + (((300, 448),) if qo[0] else ()):
         desc = make_desc(R, C, 128, low_in=True, low_mid=low_mid, in_type=in_type, tr=(qo[0], True, True, qo[1]))
         run = harness.DeviceRun(desc, Network(NetworkDescriptor(R, C, 128), seed=1), run_backward=False)
         form = run.kernels[AttentionKernelType.forward].launchForm(run.buffers, row=R, column=C)

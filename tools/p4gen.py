@@ -79,7 +79,7 @@ class Cfg:
         # places.  K^T image: [2 blocks of 32 keys][128 elements][64 bytes], a fragment = two ds_read_b64_tr_b16 (rows 16 ks + 8 h
         # of block kb); they return the contraction index in the order of an accumulator block's registers (4 hi + {0..3, 8..11}),
         # so the kernel stores the Q fragments in that order.  V^T image: [128 elements][64 keys], chunks XOR-swizzled by
-        # (element & 7); P^T holds its keys in that register order anyway, so a fragment's halves are the 8 bytes at 8 hi of
+        # (element >> 1) & 7 (sixteen lanes = sixteen rows then land on 32 distinct banks); P^T holds its keys in that register order anyway, so a fragment's halves are the 8 bytes at 8 hi of
         # chunks 2 u and 2 u + 1: two ds_read_b64 through eight address registers (the K fragment addresses' registers, which the
         # one K^T base does not need), recomputed per tile from the ring position.  The LDS-DMA pieces are the same instructions:
         # where a chunk comes from is the kernel's business (lane offsets, 128 bytes per tile).
@@ -373,6 +373,8 @@ class Stream:
                 if not (mfma and "kread" in cfg.abl):
                     at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
             # LDS-DMA: K(j+2) pieces in gaps 20..23, V(j+1) pieces 24..27; their offsets advance in gaps 28..31
+            if cfg.tr and cfg.dma == "b":
+                at(24, lambda: self.last_v_tile())
             for i in range(4 if cfg.dma == "b" and not (mfma and "dma" in cfg.abl) else 0):
                 at(20 + i, lambda i=i: self.dma_piece("k", par, i))
                 at(24 + i, lambda i=i: self.dma_piece("v", par, i))
@@ -503,6 +505,16 @@ class Stream:
         else:              # V(j+1) -> V image (j + 1) % 3
             self.emit("s_add_u32", M0, [SN("vwr"), I(i * 1024)])
             self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), SN("vres", 4)])
+
+    def last_v_tile(self):
+        """transposed streams, in front of the pieces of V(j+1): the tile advances ALONG the rows of V^T, so the end of the
+        sequence is not the end of the buffer -- the workgroup's LAST tile is fetched through offsets of its own (vlast: out
+        of bounds, i.e. zeros, for chunks at or beyond key C; P is 0 there, but 0 x whatever follows the sequence is not).  The
+        run-ahead tiles behind it are never read."""
+        self.emit("s_cmp_eq_u32", None, [SN("j"), SN("ntm2")])
+        self.emit("s_cselect_b64", SN("selv", 2), [I(-1), I(0)])
+        for i in range(4):
+            self.emit("v_cndmask_b32_e64", VN("voff%d" % i), [VN("voff%d" % i), VN("vlast%d" % i), SN("selv", 2)])
 
     def mask_section(self, par, after_mfma):
         """edge masks on the fresh score tile: key c of row r is visible iff c <= lim[r] (lim = min(C - 1, causal limit))"""
@@ -659,6 +671,8 @@ class Stream:
                 self.vwr_update()
                 for i in range(4):
                     self.dma_piece("k", par, i)
+                if self.cfg.tr:
+                    self.last_v_tile()
                 for i in range(4):
                     self.dma_piece("v", par, i)
                 for i in range(4):
@@ -746,6 +760,8 @@ def render_one(ins, suffix="%="):
         return "%s_e32 vcc, %s, %s" % (op, fmt(ins.s[0]), fmt(ins.s[1]))
     if op == "v_cndmask_b32":
         return "v_cndmask_b32_e32 %s, %s, %s, vcc" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
+    if op == "v_cndmask_b32_e64":   # d = mask ? s1 : s0, the mask a scalar register pair
+        return "v_cndmask_b32_e64 %s, %s, %s, %s" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
     ops = [fmt(ins.d)] if ins.d is not None else []
     ops += [fmt(x) for x in ins.s]
     return "%s %s" % (op, ", ".join(ops))

@@ -389,6 +389,10 @@ class Workgroup:
             w.scc = int((w.srd(s[0]) & 0xFFFFFFFF) >= (w.srd(s[1]) & 0xFFFFFFFF))
         elif op == "s_cmp_eq_u32":
             w.scc = int((w.srd(s[0]) & 0xFFFFFFFF) == (w.srd(s[1]) & 0xFFFFFFFF))
+        elif op == "s_cselect_b64":
+            w.sn[d[1]] = np.full(64, bool(w.srd(s[0]) if w.scc else w.srd(s[1])))
+        elif op == "v_cndmask_b32_e64":
+            w.wr(d, np.where(w.sn[s[2][1]], w.rd(s[1]), w.rd(s[0])))
         elif op == "s_cselect_b32":
             w.swr(d, w.srd(s[0]) if w.scc else w.srd(s[1]))
         elif op == "s_mov_b64":
@@ -423,9 +427,10 @@ class Workgroup:
             alive = states[0]
 
 
-def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 1, 2, 3), scale=None, stream=None):
+def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 1, 2, 3), scale=None, stream=None, tr_pad=0):
     """One 256-row block: q [R][128], k / v [C][128] as uint16 bf16 bit patterns.  Returns O [256][128] f32, L [256].
-    cfg.tr: K and V are handed to the stream TRANSPOSED ([128][C] in memory, C % 64 == 0), as attn_fwd16_p4_tr.h does."""
+    cfg.tr: K and V are handed to the stream TRANSPOSED ([128][C + tr_pad] in memory, C % 8 == 0; the padding columns hold NaN:
+    what follows the sequence in a row must neither be multiplied nor summed), as attn_fwd16_p4_tr.h does."""
     cfg = cfg or Cfg()
     tr = bool(getattr(cfg, "tr", 0))
     f16 = cfg.dtype == "f16"
@@ -435,10 +440,12 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
     wg = Workgroup(instrs, dma_mode)
     kb, vb, qb = k.reshape(-1).view(np.uint8), v.reshape(-1).view(np.uint8), q.reshape(-1).view(np.uint8)
     if tr:
-        assert C % 64 == 0, "the transposed streams take whole tiles"
-        kb, vb = np.ascontiguousarray(k.T).reshape(-1).view(np.uint8), np.ascontiguousarray(v.T).reshape(-1).view(np.uint8)
+        assert C % 8 == 0, "the transposed streams take whole 16-byte chunks"
+        nan16 = 0x7E00 if f16 else 0x7FC0
+        kt, vt = (np.concatenate([x.T, np.full((D, tr_pad), nan16, np.uint16)], axis=1) for x in (k, v))
+        kb, vb = np.ascontiguousarray(kt).reshape(-1).view(np.uint8), np.ascontiguousarray(vt).reshape(-1).view(np.uint8)
     ld2 = D * 2
-    ldt2 = C * 2                     # leading dimension of K^T / V^T, bytes
+    ldt2 = (C + tr_pad) * 2          # leading dimension of K^T / V^T, bytes
     knrec = D * ldt2 if tr else C * ld2
     nt_total = (C + 63) // 64
     coff = C - R
@@ -481,9 +488,9 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             p = (wave * 4 + i) * 64 + lane
             krow, kc = p >> 4, (p & 15) ^ ((p >> 4) & 15)
             vkey, vc = (p >> 2) & 63, (p >> 8) * 4 + (p & 3)
-            if tr:   # K^T image [2 blocks of 32 keys][128 elements][4 chunks]; V^T image [128 elements][8 chunks ^ (element & 7)]
+            if tr:   # K^T image [2 blocks of 32 keys][128 elements][4 chunks]; V^T image [128 elements][8 chunks ^ (element >> 1 & 7)]
                 koff.append((((p >> 2) & 127) * ldt2 + ((p >> 9) * 32 + (p & 3) * 8) * 2).astype(np.uint32))
-                voff.append(((p >> 3) * ldt2 + ((p & 7) ^ ((p >> 3) & 7)) * 16).astype(np.uint32))
+                voff.append(((p >> 3) * ldt2 + ((p & 7) ^ ((p >> 4) & 7)) * 16).astype(np.uint32))
             else:
                 koff.append((krow * ld2 + kc * 16).astype(np.uint32))
                 voff.append((vkey * ld2 + vc * 16).astype(np.uint32))
@@ -497,11 +504,18 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             wg.lds_write16(ldsbase + 16 * np.arange(64), data)
 
         kinc = vinc = 128 if tr else 64 * ld2
+        vlast = []
+        if tr:   # offsets of the workgroup's LAST tile: chunks at or beyond key C are not fetched (zeros)
+            for i in range(4):
+                p = (wave * 4 + i) * 64 + lane
+                key0 = ((p & 7) ^ ((p >> 4) & 7)) * 8 + 64 * (nt - 1)
+                vlast.append(np.where(key0 < C, voff[i].astype(np.uint64) + (nt - 1) * vinc, OOB).astype(np.uint32))
+                w.vn["vlast%d" % i] = vlast[i]
         for i in range(4):
             dma(kb, knrec, koff[i], 0 * KSLOT + (wave * 4 + i) * 1024)
             koff[i] = np.minimum(koff[i].astype(np.uint64) + kinc, 0xFFFFFFFF).astype(np.uint32)
         for i in range(4):
-            dma(vb, knrec, voff[i], VBASE + (wave * 4 + i) * 1024)
+            dma(vb, knrec, vlast[i] if tr and nt == 1 else voff[i], VBASE + (wave * 4 + i) * 1024)
             voff[i] = np.minimum(voff[i].astype(np.uint64) + vinc, 0xFFFFFFFF).astype(np.uint32)
         for i in range(4):
             dma(kb, knrec, koff[i], 1 * KSLOT + (wave * 4 + i) * 1024)
@@ -518,7 +532,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         })
         if tr:   # K^T: the transposing-read lane term; V^T: row lane % 32, the swizzle's XOR mask, + 8 hi
             w.vn["kbase"] = (((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32)
-            w.vn["vbase"] = (VBASE + qq * 128 + ((qq & 7) << 4) + 8 * hi).astype(np.uint32)
+            w.vn["vbase"] = (VBASE + qq * 128 + (((qq >> 1) & 7) << 4) + 8 * hi).astype(np.uint32)
         for i in range(4):
             w.vn["koff%d" % i], w.vn["voff%d" % i] = koff[i], voff[i]
         for b in range(2):
@@ -532,7 +546,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 64 + 1)) if wlast >= r0 else 1
         w.sn.update({"kres": (kb, knrec), "vres": (vb, knrec), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
-                     "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "maskfrom": maskfrom})
+                     "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "maskfrom": maskfrom, "ntm2": nt - 2})
     wg.run(order)
     O = np.zeros((256, D), np.float32)
     L = np.zeros(256, np.float32)

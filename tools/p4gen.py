@@ -250,19 +250,23 @@ class Stream:
         cfg = self.cfg
         prev = par ^ 1
         vids = {}
-        if softmax:
+        if softmax and not cfg.tr:   # (transposed streams: phase B of the previous tile has left the eight V^T addresses)
             self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of tile j-1")
-            if cfg.tr:
-                for c in range(8):   # (the ring position is a multiple of 16 KiB: the XOR only meets the swizzle bits)
-                    self.emit("v_xor_b32", V(T_KADDR + c), [I(c << 4), V(T_VADDR)])
         mlist = self.qk_list(par)
         ng = len(mlist)
         g0 = (ng - 32) // 2          # element pair i is exponentiated in gap g0 + i and packed one gap later
         v0 = g0 + 12                 # V^T fragments 0..7 (16 reads) in gaps v0 .. v0 + 15: they land before the barrier
         pending_pack = None
+        k_late = None
         for g in range(ng):
             if mfma:
+                if g == 16 and k_late is not None:
+                    self.lds_need(k_late)    # the K^T fragments of key block 1 requested in gaps 0..7
                 self.mfma(*mlist[g])
+            if cfg.tr and mfma and softmax and g < 8:
+                # transposed streams: a K^T fragment is two reads -- the second key block's are requested here, where phase B
+                # of the previous tile left them out (they are first multiplied sixteen matrix instructions from now)
+                k_late = self.k_read(par, 8 + g)
             if zero_o and g < 32:
                 for i in range(4):
                     self.emit("v_accvgpr_write_b32", A(O_BASE + 4 * g + i), [I(0)])
@@ -368,8 +372,8 @@ class Stream:
                             at(g, lambda e=e: self.fma_op(par, e))
                             e += 1
                 assert e == 64
-            # K(j+1) fragments -> a[192:255], one per gap 12..27
-            for i in range(16):
+            # K(j+1) fragments -> a[192:255], one per gap 12..27 (transposed streams: key block 0 here, block 1 in phase A)
+            for i in range(8 if cfg.tr else 16):
                 if not (mfma and "kread" in cfg.abl):
                     at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
             # LDS-DMA: K(j+2) pieces in gaps 20..23, V(j+1) pieces 24..27; their offsets advance in gaps 28..31
@@ -383,6 +387,12 @@ class Stream:
             if cfg.dma == "b":
                 at(0, lambda: self.vwr_update())
             at(1, lambda: self.vrd_advance())
+            if cfg.tr:
+                # the eight V^T chunk addresses of the tile phase A reads next (vrd has just advanced to it; the last V^T read of
+                # THIS phase is in gap 17; the ring position is a multiple of 16 KiB: the XOR only meets the swizzle bits)
+                at(18, lambda: self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of the next phase A"))
+                for c in range(8):
+                    at(18 + c, lambda c=c: self.emit("v_xor_b32", V(T_KADDR + c), [I(c << 4), V(T_VADDR)]))
             if getattr(self, "persistent", False):   # tools/p4pgen.py: the last tiles' LDS-DMA pieces belong to the next block
                 self.b_hook(at, par, mfma)
         for g in range(32):
@@ -483,9 +493,9 @@ class Stream:
         kb, ks = divmod(i, 8)
         if self.cfg.tr:   # rows 16 ks (+ 8) of key block kb of the [2][128][64 bytes] image
             for h in range(2):
-                self.lds_read("ds_read_b64_tr_b16", A(K_BASE + 4 * (8 * kb + ks) + 2 * h, 2), VN("kbase"),
-                              slot * KSLOT + (kb * 128 + 16 * ks + 8 * h) * 64, note="K^T(%d,%d).%d" % (kb, ks, h))
-            return
+                rid = self.lds_read("ds_read_b64_tr_b16", A(K_BASE + 4 * (8 * kb + ks) + 2 * h, 2), VN("kbase"),
+                                    slot * KSLOT + (kb * 128 + 16 * ks + 8 * h) * 64, note="K^T(%d,%d).%d" % (kb, ks, h))
+            return rid
         self.lds_read("ds_read_b128", k_frag(kb, ks), V(T_KADDR + ks), slot * KSLOT + kb * 8192, note="K(%d,%d)" % (kb, ks))
 
     def vrd_advance(self):   # the V^T read base of this tile is already in T_VADDR

@@ -84,6 +84,9 @@ class Cfg:
         # one K^T base does not need), recomputed per tile from the ring position.  The LDS-DMA pieces are the same instructions:
         # where a chunk comes from is the kernel's business (lane offsets, 128 bytes per tile).
         self.tr = tr
+        # ksplit: the second key block's K fragments are requested in the first gaps of phase A (they are first multiplied sixteen
+        # matrix instructions later) instead of in phase B of the previous tile, the longer phase.  Always with tr (32 reads).
+        self.ksplit = 1 if tr else 0
 
 
 # ---------------------------------------------------------------- tiny IR
@@ -263,7 +266,7 @@ class Stream:
                 if g == 16 and k_late is not None:
                     self.lds_need(k_late)    # the K^T fragments of key block 1 requested in gaps 0..7
                 self.mfma(*mlist[g])
-            if cfg.tr and mfma and softmax and g < 8:
+            if cfg.ksplit and mfma and softmax and g < 8:
                 # transposed streams: a K^T fragment is two reads -- the second key block's are requested here, where phase B
                 # of the previous tile left them out (they are first multiplied sixteen matrix instructions from now)
                 k_late = self.k_read(par, 8 + g)
@@ -373,7 +376,7 @@ class Stream:
                             e += 1
                 assert e == 64
             # K(j+1) fragments -> a[192:255], one per gap 12..27 (transposed streams: key block 0 here, block 1 in phase A)
-            for i in range(8 if cfg.tr else 16):
+            for i in range(8 if cfg.ksplit else 16):
                 if not (mfma and "kread" in cfg.abl):
                     at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
             # LDS-DMA: K(j+2) pieces in gaps 20..23, V(j+1) pieces 24..27; their offsets advance in gaps 28..31
@@ -496,7 +499,7 @@ class Stream:
                 rid = self.lds_read("ds_read_b64_tr_b16", A(K_BASE + 4 * (8 * kb + ks) + 2 * h, 2), VN("kbase"),
                                     slot * KSLOT + (kb * 128 + 16 * ks + 8 * h) * 64, note="K^T(%d,%d).%d" % (kb, ks, h))
             return rid
-        self.lds_read("ds_read_b128", k_frag(kb, ks), V(T_KADDR + ks), slot * KSLOT + kb * 8192, note="K(%d,%d)" % (kb, ks))
+        return self.lds_read("ds_read_b128", k_frag(kb, ks), V(T_KADDR + ks), slot * KSLOT + kb * 8192, note="K(%d,%d)" % (kb, ks))
 
     def vrd_advance(self):   # the V^T read base of this tile is already in T_VADDR
         self.emit("s_add_u32", SN("vrd"), [SN("vrd"), I(VSLOT)])

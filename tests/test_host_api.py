@@ -256,6 +256,32 @@ def test_parameter_table_row_selects_the_code_object():
         mfa.resetParameterFiles()
 
 
+def test_transposed_descriptors_select_the_in_place_forward_code_objects():
+    """transposeState with 16-bit inputs (no GPU needed to plan): the forward kernel has a code object per pattern of (K, V) and
+    head-dimension bucket that reads / writes the operands where they lie -- no workspace; the backward kernels keep the
+    re-layout path (workspace) with the general kernel behind it; FP32 inputs run the general kernel, which reads any layout."""
+    suffix = {(False, False): "_tr", (True, False): "_tr_k", (False, True): "_tr_v", (True, True): "_tr_kv"}
+    for D, bucket in ((24, 32), (64, 64), (72, 128), (128, 128), (136, 160), (192, 192), (200, 256), (256, 256)):
+        for in_type, tname in ((P.BF16, "bf16"), (P.FP16, "f16")):
+            for (tk, tv), suf in suffix.items():
+                for tq, to in ((True, False), (False, True)):
+                    if not (tq or tk or tv or to):
+                        continue
+                    d = _desc(dims=(512, 512, D), low_in=True, in_type=in_type, tr=(tq, tk, tv, to))
+                    k = AttentionKernel(d.kernelDescriptor(T.forward))
+                    assert k.variant.startswith("attn_fwd16v3_%s_d%d_" % (tname, bucket)) and k.variant.endswith(suf), (D, k.variant)
+                    assert not k.needsWorkspaceForFastPath and k.workspaceSize(row=512, column=512) == 0
+                    assert k.fallbackVariant.startswith("attn_generic")
+    d = _desc(dims=(512, 512, 128), low_in=True, in_type=P.BF16, tr=(False, True, True, False))
+    for t in (T.backwardQuery, T.backwardKeyValue):
+        k = AttentionKernel(d.kernelDescriptor(t))
+        assert k.needsWorkspaceForFastPath and k.workspaceSize(row=512, column=512) > 0 and not k.variant.startswith("attn_generic")
+    k = AttentionKernel(_desc(dims=(512, 512, 128), tr=(True, True, True, True)).kernelDescriptor(T.forward))   # FP32 inputs
+    assert k.variant.startswith("attn_generic") and not k.needsWorkspaceForFastPath
+    k = AttentionKernel(_desc(dims=(512, 512, 260), low_in=True, in_type=P.BF16, tr=(True,) * 4).kernelDescriptor(T.forward))   # D > 256
+    assert k.variant.startswith("attn_generic")
+
+
 def test_low_precision_intermediates_select_the_folded_scale_stream():
     """S and P in FP32 registers (lowPrecisionIntermediates = false): the scale is applied in fp32 per score; with
     lowPrecisionIntermediates the reference itself keeps S / P in 16 bits (+Precisions.swift:149-215) and the kernel may

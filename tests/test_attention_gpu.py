@@ -581,6 +581,46 @@ def test_fuzz_random_problems(case):
     assert all(np.isfinite(got[n]).all() for n in ("O", "dQ", "dK", "dV")), variants
 
 
+def _fuzz_transposed_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        D = int(rng.choice([8, 40, 64, 72, 96, 104, 112, 120, 128, 136, 152, 160, 176, 192, 200, 232, 256]))
+        causal = bool(rng.integers(2))
+        R = int(rng.integers(1, 700))
+        C = int(rng.integers(R if causal else 1, 900))
+        tr = tuple(bool(b) for b in rng.integers(2, size=4))
+        if not any(tr):
+            tr = (True,) * 4
+        g = (64, 8, 1)[i % 3]       # whole tiles / whole 16-byte chunks / anything: stream, aligned rows, gathered rows
+        R, C = max(g, R // g * g), max(g, C // g * g)
+        if causal and C < R:
+            C = R
+        out.append((i, R, C, D, causal, bool(rng.integers(2)), "BF16" if rng.integers(2) else "FP16", tr, bool(rng.integers(2))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_transposed_cases(45, seed=5), ids=lambda c: "%d-%dx%dx%d-%s-%s" % (
+    c[0], c[1], c[2], c[3], "causal" if c[4] else "dense", "".join("T" if t else "n" for t in c[7])))
+def test_fuzz_random_transposed_problems(case):
+    """A seeded slice of tools/fuzz_shapes.py --transposed (the mode that found the gather wrap): random problems with a random
+    non-empty pattern of transposed (Q, K, V, O), forward, against the oracle; O and L, canary tails, no NaN."""
+    i, R, C, D, causal, low_mid, in_type, tr, low_out = case
+    net = Network(NetworkDescriptor(R, C, D), seed=2000 + i)
+    desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P[in_type], tr=tr)
+    desc.lowPrecisionOutputs = low_out
+    run = harness.DeviceRun(desc, net, causal=causal, run_backward=False)
+    k = run.kernels[AttentionKernelType.forward]
+    assert "_tr" in k.variant or D % 8 != 0, k.variant
+    got = run.execute()
+    round_inputs(net, desc)
+    ref = net.run(causal=causal, backward=False)
+    tol = TOL_MIXED_SHORT if C <= 20 else TOL_MIXED
+    failures, report = harness.compare(ref, got, {n: tol[n] for n in ("O", "L")})
+    assert not failures, (failures, k.variant, k.launchForm(run.buffers, row=R, column=C, causal=causal))
+    assert run.tails_ok["O"] and run.tails_ok["L"] and np.isfinite(got["O"]).all()
+
+
 def test_size_independent_properties_at_full_size():
     """Properties that need no oracle: (i) V = 1 gives O = 1 exactly up to rounding (rows of P sum to
     one); (ii) permuting the keys (rows of K and V together) leaves O and L unchanged up to

@@ -1,6 +1,7 @@
-// attn_fwd16_p4_tr.h -- the hand-placed forward kernel (attn_fwd16_p4.h: four waves x 64 rows, one wave per SIMD) for K and V stored
-// TRANSPOSED ([D][keys], transposeState of AttentionKernelDescriptor.swift:28-42, read where they lie like
-// AttentionKernel.swift:189-204); Q and O either way (run-time flags, outside the statement).
+// attn_fwd16_p4_tr.h -- the hand-placed forward kernel (attn_fwd16_p4.h: four waves x 64 rows, one wave per SIMD) for K and / or V
+// stored TRANSPOSED ([D][keys], transposeState of AttentionKernelDescriptor.swift:28-42, read where they lie like
+// AttentionKernel.swift:189-204): a stream family per pattern (both, K alone, V alone); Q and O either way (run-time flags,
+// outside the statement).
 //
 // The traversal is the same generated statement with two read recipes exchanged (tools/p4gen.py, Cfg.tr): the LDS images keep the
 // orientation of the source -- a 16-byte LDS-DMA chunk is 8 consecutive KEYS of one head-dimension element --
@@ -21,14 +22,21 @@
 namespace mfa {
 namespace p4tr {
 
-#define MFA_P4TR_ENUM(name, fold) S_##name,
+#define MFA_P4TR_ENUM(name, fold, pattern) S_##name,
 enum : int { MFA_P4_TR_STREAM_LIST(MFA_P4TR_ENUM) S_COUNT };
 #undef MFA_P4TR_ENUM
 constexpr bool stream_folds(int s) {
-#define MFA_P4TR_FOLDS(name, fold) if (s == S_##name) return fold != 0;
+#define MFA_P4TR_FOLDS(name, fold, pattern) if (s == S_##name) return fold != 0;
   MFA_P4_TR_STREAM_LIST(MFA_P4TR_FOLDS)
 #undef MFA_P4TR_FOLDS
   return false;
+}
+// bit 0 = K, bit 1 = V stored transposed
+constexpr int stream_pattern(int s) {
+#define MFA_P4TR_PATTERN(name, fold, pattern) if (s == S_##name) return pattern;
+  MFA_P4_TR_STREAM_LIST(MFA_P4TR_PATTERN)
+#undef MFA_P4TR_PATTERN
+  return 0;
 }
 
 }  // namespace p4tr
@@ -40,7 +48,8 @@ constexpr bool stream_folds(int s) {
                  [koff2] "+v"(koff[2]), [koff3] "+v"(koff[3]), [voff0] "+v"(voff[0]), [voff1] "+v"(voff[1]),               \
                  [voff2] "+v"(voff[2]), [voff3] "+v"(voff[3]), [j] "=&s"(tj), [vrd] "=&s"(tvrd), [vwr] "=&s"(tvwr),       \
                  [pend] "=&s"(tpend), [t0] "=&s"(tt0), [t1] "=&s"(tt1), [pa] "=&s"(tpa), [pw] "=&s"(tpw),                 \
-                 [pb] "=&s"(tpb), [plast] "=&s"(tplast), [sv] "=&s"(tsv), [ptime] "=&s"(tptime), [selv] "=&s"(tselv)       \
+                 [pb] "=&s"(tpb), [plast] "=&s"(tplast), [sv] "=&s"(tsv), [ptime] "=&s"(tptime), [selv] "=&s"(tselv),      \
+                 [vta] "=&v"(tvta), [vtb] "=&v"(tvtb)                                                                    \
                : [kbase] "v"(kbase), [vbase] "v"(vbase), [lim0] "v"(lim0), [lim1] "v"(lim1), [onesw] "v"(onesw),          \
                  [vlast0] "v"(vlast[0]), [vlast1] "v"(vlast[1]), [vlast2] "v"(vlast[2]), [vlast3] "v"(vlast[3]),          \
                  [kres] "s"(kdesc), [vres] "s"(vdesc), [nt] "s"(nt), [wnt] "s"(wnt), [scale2] "s"(a.scale2), [kinc] "s"(kinc), \
@@ -54,6 +63,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   using p4tr::stream_folds;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 128, BC = 64, NKS = 8, NDB = 4, WROWS = 64, GROWS = 256;
+  constexpr bool KT = (p4tr::stream_pattern(STREAM) & 1) != 0, VT = (p4tr::stream_pattern(STREAM) & 2) != 0;
   typedef __attribute__((address_space(3))) s16x4 *lds_tr_ptr;
 
   const int tid = threadIdx.x;
@@ -84,11 +94,12 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   const char *kptr = operand_base(a.op[SLOT_K], head, batch), *vptr = operand_base(a.op[SLOT_V], head, batch);
   const __amdgpu_buffer_rsrc_t qres = __builtin_amdgcn_make_buffer_rsrc(
       operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)(qT ? Dr : R) * ldq2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kptr), 0, (uint32_t)Dr * ldk2, 0x00020000);
-  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vptr), 0, (uint32_t)Dr * ldv2, 0x00020000);
+  const uint32_t knrec = (uint32_t)(KT ? Dr : C) * ldk2, vnrec = (uint32_t)(VT ? Dr : C) * ldv2;
+  const __amdgpu_buffer_rsrc_t kres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(kptr), 0, knrec, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vres = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(vptr), 0, vnrec, 0x00020000);
   const uint64_t kaddr = (uint64_t)(uintptr_t)kptr, vaddr = (uint64_t)(uintptr_t)vptr;
-  const u32x4 kdesc = {(uint32_t)kaddr, (uint32_t)(kaddr >> 32) & 0xFFFFu, (uint32_t)Dr * ldk2, 0x00020000u};
-  const u32x4 vdesc = {(uint32_t)vaddr, (uint32_t)(vaddr >> 32) & 0xFFFFu, (uint32_t)Dr * ldv2, 0x00020000u};
+  const u32x4 kdesc = {(uint32_t)kaddr, (uint32_t)(kaddr >> 32) & 0xFFFFu, knrec, 0x00020000u};
+  const u32x4 vdesc = {(uint32_t)vaddr, (uint32_t)(vaddr >> 32) & 0xFFFFu, vnrec, 0x00020000u};
   constexpr uint32_t OOB = 0xFFFFFF00u;
 
   typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -143,17 +154,30 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   lim1 -= 4 * hi;
 
   // ---- LDS-DMA staging: piece i of wave w fills 16-byte positions (4 w + i) * 64 + lane of an image
+  // (an operand that is NOT transposed keeps the row-major kernel's images: K rows with the chunk index ^ (row & 15), V in
+  // sub-images of 32 elements; 64 rows further per tile, zeros past the end of the buffer)
   uint32_t koff[4], voff[4], vlast[4];
-  const uint32_t kinc = BC * 2, vinc = BC * 2;   // a tile further = 64 keys along every row
+  const uint32_t kinc = KT ? BC * 2 : BC * ldk2, vinc = VT ? BC * 2 : BC * ldv2;   // transposed: a tile further = 64 keys along every row
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int p = (wave * 4 + i) * 64 + lane;
-    const int kd = (p >> 2) & 127, kkey = (p >> 9) * 32 + (p & 3) * 8;
-    const int vd = p >> 3, vkey = ((p & 7) ^ ((vd >> 1) & 7)) * 8;
-    koff[i] = (kd < Dr) ? (uint32_t)kd * ldk2 + kkey * 2 : OOB;
-    voff[i] = (vd < Dr) ? (uint32_t)vd * ldv2 + vkey * 2 : OOB;
-    // the workgroup's last tile: chunks at or beyond key C are not fetched
-    vlast[i] = (vd < Dr && vkey + BC * (nt - 1) < C) ? voff[i] + (uint32_t)(nt - 1) * vinc : OOB;
+    if constexpr (KT) {
+      const int kd = (p >> 2) & 127, kkey = (p >> 9) * 32 + (p & 3) * 8;
+      koff[i] = (kd < Dr) ? (uint32_t)kd * ldk2 + kkey * 2 : OOB;
+    } else {
+      const int krow = p >> 4, kc = (p & 15) ^ (krow & 15);
+      koff[i] = (kc * 8 < Dr) ? krow * ldk2 + kc * 16 : OOB;
+    }
+    if constexpr (VT) {
+      const int vd = p >> 3, vkey = ((p & 7) ^ ((vd >> 1) & 7)) * 8;
+      voff[i] = (vd < Dr) ? (uint32_t)vd * ldv2 + vkey * 2 : OOB;
+      // the workgroup's last tile: chunks at or beyond key C are not fetched
+      vlast[i] = (vd < Dr && vkey + BC * (nt - 1) < C) ? voff[i] + (uint32_t)(nt - 1) * vinc : OOB;
+    } else {
+      const int vkey = (p >> 2) & 63, vc = (p >> 8) * 4 + (p & 3);
+      voff[i] = (vc * 8 < Dr) ? vkey * ldv2 + vc * 16 : OOB;
+      vlast[i] = voff[i];   // (not read by these streams)
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // K(0) -> K image 0
@@ -162,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // V(0) -> V image 0
-    MFA_P4_DMA(vres, smem + VBASE + (wave * 4 + i) * 1024, nt == 1 ? vlast[i] : voff[i]);
+    MFA_P4_DMA(vres, smem + VBASE + (wave * 4 + i) * 1024, (VT && nt == 1) ? vlast[i] : voff[i]);
     voff[i] = __builtin_elementwise_add_sat(voff[i], vinc);
   }
 #pragma unroll
@@ -177,27 +201,40 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   const uint32_t lds0 = lds_addr(smem);
   const int n16 = lane & 15;
   const uint32_t trlane = ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2;
-  const uint32_t kbase = lds0 + trlane;
-  const uint32_t vbase = lds0 + VBASE + q * 128 + (((q >> 1) & 7) << 4) + 8 * hi;
+  const uint32_t kbase = KT ? lds0 + trlane : lds0 + q * 256 + ((hi ^ (q & 15)) << 4);
+  const uint32_t vbase = VT ? lds0 + VBASE + q * 128 + (((q >> 1) & 7) << 4) + 8 * hi : lds0 + VBASE + trlane;
   const uint32_t ldsk = lds0 + wave * 4096, ldsv = lds0 + VBASE + wave * 4096;
 
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // the wave's own Q image has landed; the 12 K / V pieces stay in flight
-  // Q fragments (B operand of S^T = K Q^T: lane = row) in the order the K^T fragments hold the contraction index: elements
-  // 16 s + 4 hi + {0..3, 8..11} -> a[128:191]
+  // Q fragments (B operand of S^T = K Q^T: lane = row) -> a[128:191], in the order the K fragments hold the contraction index:
+  // with K^T elements 16 s + 4 hi + {0..3, 8..11} (what a transposing read of the Q^T image returns, two 8-byte reads of the
+  // row-major one), with row-major K elements 16 s + 8 hi + {0..7} (one 16-byte read; of the Q^T image: the two transposing
+  // reads of rows 8 hi and 8 hi + 4 hold them as 4 hi' + {0..3} -- lanes exchange nothing, the image is simply read at
+  // element 16 s + 8 hi + 4 (lane's read half) through per-half lane terms)
   static_for<2>([&](auto bc) {
     static_for<NKS>([&](auto sc) {
       constexpr int b = decltype(bc)::value, s = decltype(sc)::value;
       u32x4 qx;
       if (qT) {
-        const char *qp = qimg + (b * 128 + 16 * s) * 64 + trlane;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(qp));
-        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(qp + 8 * 64));
-        qx = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
-      } else {
+        if constexpr (KT) {
+          const char *qp = qimg + (b * 128 + 16 * s) * 64 + trlane;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(qp));
+          const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(qp + 8 * 64));
+          qx = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+        } else {
+          // elements 16 s + 8 hi + {0..3} and + {4..7}: rows (n16 >> 2) + 8 hi (+ 4) of the image instead of (n16 >> 2) + 4 hi (+ 8)
+          const char *qp = qimg + (b * 128 + 16 * s) * 64 + trlane + 4 * hi * 64;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(qp));
+          const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(qp + 4 * 64));
+          qx = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+      } else if constexpr (KT) {
         const char *qrow = qimg + (b * 32 + q) * 256 + 8 * hi;
         const u32x2 lo = *reinterpret_cast<const u32x2 *>(qrow + (((2 * s) ^ (q & 15)) << 4));
         const u32x2 up = *reinterpret_cast<const u32x2 *>(qrow + (((2 * s + 1) ^ (q & 15)) << 4));
         qx = u32x4{lo[0], lo[1], up[0], up[1]};
+      } else {
+        qx = *reinterpret_cast<const u32x4 *>(qimg + (b * 32 + q) * 256 + (((2 * s + hi) ^ (q & 15)) << 4));
       }
       if constexpr (stream_folds(STREAM)) acc_write4<Q_BASE + 4 * (b * 8 + s)>(scale16x8<T>(qx, a.scale2));
       else acc_write4<Q_BASE + 4 * (b * 8 + s)>(qx);
@@ -209,9 +246,9 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
   float m0 = M_INIT, m1 = M_INIT, l0 = 0.f, l1 = 0.f;
   const uint32_t onesw = hi ? 0u : (__is_same(T, __bf16) ? 0xBF80BF80u : 0xBC00BC00u);   // -1.0 in k-slots 0, 1
   {
-    uint32_t tj, tvrd, tvwr, tpend, tt0, tt1, tplast, tpa, tpw, tpb;
+    uint32_t tj, tvrd, tvwr, tpend, tt0, tt1, tplast, tpa, tpw, tpb, tvta, tvtb;
     uint64_t tsv, tptime, tselv;
-#define MFA_P4TR_RUN(name, fold) if constexpr (STREAM == p4tr::S_##name) MFA_P4TR_TRAVERSE(MFA_P4_STREAM_##name);
+#define MFA_P4TR_RUN(name, fold, pattern) if constexpr (STREAM == p4tr::S_##name) MFA_P4TR_TRAVERSE(MFA_P4_STREAM_##name);
     MFA_P4_TR_STREAM_LIST(MFA_P4TR_RUN)
 #undef MFA_P4TR_RUN
   }

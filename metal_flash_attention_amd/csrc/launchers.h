@@ -89,9 +89,9 @@ bool fwd16_v3_tr_variant_d128(int precision, int D, int pattern, VariantInfo *ou
 bool fwd16_v3_tr_variant_d160(int precision, int D, int pattern, VariantInfo *out);
 bool fwd16_v3_tr_variant_d192(int precision, int D, int pattern, VariantInfo *out);
 bool fwd16_v3_tr_variant_d256(int precision, int D, int pattern, VariantInfo *out);
-// (K, V) both transposed at D <= 128: launches of whole, aligned tiles run the hand-placed stream (attn_fwd16_p4_tr.h); `out` arrives
-// filled by fwd16_v3_tr_variant_d128, whose kernel keeps the others
-bool fwd16_p4_tr_variant(int precision, bool fold, VariantInfo *out);
+// K and / or V transposed at D <= 128 (pattern: bit 0 = K, bit 1 = V): launches of whole chunks of aligned rows run the hand-placed
+// stream (attn_fwd16_p4_tr.h); `out` arrives filled by fwd16_v3_tr_variant_d128, whose kernel keeps the others
+bool fwd16_p4_tr_variant(int precision, int pattern, bool fold, VariantInfo *out);
 bool dq16_variant_d160(int precision, int gprecision, VariantInfo *out);
 bool dq16_variant_d192(int precision, int gprecision, VariantInfo *out);
 bool dkv16_rs_variant_d96(int precision, int gprecision, VariantInfo *out);

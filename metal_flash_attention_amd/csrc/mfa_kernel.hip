@@ -138,7 +138,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         case 32: case 64: add(fwd16_v3_tr_variant_d64(pq, b16, pattern, &v), v); break;
         case 128: {
           bool have = fwd16_v3_tr_variant_d128(pq, b16, pattern, &v);
-          if (have && pattern == 3) fwd16_p4_tr_variant(pq, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
+          if (have && pattern != 0) fwd16_p4_tr_variant(pq, pattern, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
           add(have, v);
           break;
         }

@@ -794,6 +794,32 @@ def test_transposed_rows_with_poisoned_padding():
     assert np.abs(bufs[Op.L].cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 2e-3
 
 
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("kv", [(True, False), (False, True)])
+def test_hand_placed_stream_with_one_transposed_operand(kv, low_mid, in_type):
+    """K^T alone or V^T alone (aligned rows, D <= 128): the stream family of that pattern; Q / O both ways, ragged last tiles,
+    head dimensions below the bucket, causal, 16-bit O."""
+    for (R, C, D), causal, low_out, (tq, to) in (((296, 456, 128), False, False, (False, False)), ((256, 40, 128), False, True, (True, True)),
+                                                 ((200, 328, 104), True, False, (True, False)), ((696, 1000, 80), True, True, (False, True)),
+                                                 ((136, 2048, 128), False, False, (True, True))):
+        net = Network(NetworkDescriptor(R, C, D), seed=R + C + 1)
+        desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=(tq, kv[0], kv[1], to))
+        desc.lowPrecisionOutputs = low_out
+        run = harness.DeviceRun(desc, net, run_backward=False, causal=causal)
+        k = run.kernels[AttentionKernelType.forward]
+        form = k.launchForm(run.buffers, row=R, column=C, causal=causal)
+        which = "transposed K" if kv[0] else "transposed V"
+        assert k.variant.endswith("_tr_k" if kv[0] else "_tr_v") and form.startswith("attn_fwd16_p4_tr") and which in form and \
+            ("folded" in form) == low_mid, (k.variant, form)
+        got = run.execute()
+        round_inputs(net, desc)
+        ref = net.run(backward=False, causal=causal)
+        failures, report = harness.compare(ref, got, dict(O=3e-2 if low_out else 1.5e-2, L=7e-3 if low_mid else 2e-3))
+        assert not failures, (failures, (R, C, D), causal, form)
+        assert all(run.tails_ok.values())
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_transposed_multi_head_batches(causal):
     """Heads and batch entries of transposed operands ([batch][head][D][sequence]) through strides: the hand-placed stream on

@@ -100,7 +100,19 @@ def test_causal_per_wave_bounds_and_skip_loop(name, dma_mode, order):
     assert len(set(w.count["s_barrier"] for w in wg.waves)) == 1
 
 
-@pytest.mark.parametrize("name", list(p4gen.TR_STREAMS))
+@pytest.mark.parametrize("name", [n for n in p4gen.TR_STREAMS if n.endswith("_TRK") or n.endswith("_TRV")])
+def test_streams_with_one_transposed_operand(name):
+    """K^T alone / V^T alone: the same exchange for that operand only (V^T alone: the step's two chunk addresses in scratch
+    registers, K keeps its eight); ragged last tiles with NaN behind the sequence, causal, a forced rescale."""
+    cfg = p4gen.VARIANTS[name]
+    for R, C, rblk, causal, mode in ((256, 456, 0, False, "late"), (512, 520, 1, True, "early"), (200, 64, 0, False, "late")):
+        _check(R, C, rblk=rblk, causal=causal, cfg=cfg, dma_mode=mode, order=(3, 2, 1, 0) if mode == "early" else (0, 1, 2, 3), seed=31, tr_pad=8)
+    wg = _check(256, 448, cfg=cfg, spike=(5, 300, 3.0), seed=32, tol_o=1.2e-2, tr_pad=16)
+    assert wg.waves[0].count.get("v_accvgpr_read_b32", 0) >= 128   # the rescale section ran
+    assert (wg.waves[0].count.get("ds_read_b128", 0) == 0) == bool(cfg.kt) and (wg.waves[0].count.get("ds_read_b64", 0) > 0) == bool(cfg.vt)
+
+
+@pytest.mark.parametrize("name", [n for n in p4gen.TR_STREAMS if n.endswith("_TR")])
 @pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3))])
 def test_transposed_streams(name, dma_mode, order):
     """K and V handed over TRANSPOSED ([128][C], whole tiles): the images keep the source orientation and the read recipes change

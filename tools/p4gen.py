@@ -60,6 +60,7 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "
 
 class Cfg:
     def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64, tr=0):
+        """tr: bit 0 = K, bit 1 = V stored transposed (attn_fwd16_p4_tr.h)"""
         """fold: Q arrives pre-multiplied by log2(e)/sqrt(D) and the running maximum is subtracted INSIDE the matrix pipe (an
         extra k-step whose A operand is -1.0 and whose B operand carries m as a bf16/f16 pair): no s * scale2 - m per
         score; xb = scores per tile exponentiated in phase B already (FOLD streams only)."""
@@ -83,10 +84,14 @@ class Cfg:
         # chunks 2 u and 2 u + 1: two ds_read_b64 through eight address registers (the K fragment addresses' registers, which the
         # one K^T base does not need), recomputed per tile from the ring position.  The LDS-DMA pieces are the same instructions:
         # where a chunk comes from is the kernel's business (lane offsets, 128 bytes per tile).
+        # Either operand alone (tr = 1: K^T, tr = 2: V^T) is the same exchange for that operand; with V^T alone the K fragment
+        # addresses keep their eight registers and the V^T chunk addresses of a 16-key step are computed in two scratch registers
+        # in front of the step's first read (vta / vtb, operands of the statement).
         self.tr = tr
+        self.kt, self.vt = tr & 1, (tr >> 1) & 1
         # ksplit: the second key block's K fragments are requested in the first gaps of phase A (they are first multiplied sixteen
-        # matrix instructions later) instead of in phase B of the previous tile, the longer phase.  Always with tr (32 reads).
-        self.ksplit = 1 if tr else 0
+        # matrix instructions later) instead of in phase B of the previous tile, the longer phase.  Always with K^T (32 reads).
+        self.ksplit = 1 if self.kt else 0
 
 
 # ---------------------------------------------------------------- tiny IR
@@ -253,7 +258,7 @@ class Stream:
         cfg = self.cfg
         prev = par ^ 1
         vids = {}
-        if softmax and not cfg.tr:   # (transposed streams: phase B of the previous tile has left the eight V^T addresses)
+        if softmax and cfg.tr != 3:   # (K^T + V^T: phase B of the previous tile has left the eight V^T addresses)
             self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of tile j-1")
         mlist = self.qk_list(par)
         ng = len(mlist)
@@ -323,8 +328,13 @@ class Stream:
         """V^T read i (0..31): fragment f = i // 2 = 4 u + db, half i % 2 (keys +0..3 / +8..11 of the 16-key group)"""
         f, h = divmod(i, 2)
         u, db = divmod(f, 4)
-        if self.cfg.tr:   # element 32 db + lane % 32 of the [128][64 keys] image: 8 bytes of chunk 2 u + h
-            return self.lds_read("ds_read_b64", vf_half(f, h), V(T_KADDR + 2 * u + h), db * 32 * 128, note="V^T f%d.%d" % (f, h))
+        if self.cfg.vt:   # element 32 db + lane % 32 of the [128][64 keys] image: 8 bytes of chunk 2 u + h
+            if self.cfg.kt:
+                return self.lds_read("ds_read_b64", vf_half(f, h), V(T_KADDR + 2 * u + h), db * 32 * 128, note="V^T f%d.%d" % (f, h))
+            if db == 0 and h == 0:   # the step's two chunk addresses (the XOR only meets the swizzle bits of the read base)
+                self.emit("v_xor_b32", VN("vta"), [I((2 * u) << 4), V(T_VADDR)])
+                self.emit("v_xor_b32", VN("vtb"), [I((2 * u + 1) << 4), V(T_VADDR)])
+            return self.lds_read("ds_read_b64", vf_half(f, h), VN("vtb" if h else "vta"), db * 32 * 128, note="V^T f%d.%d" % (f, h))
         off = (db * 64 + 16 * u) * 64 + h * 8 * 64
         return self.lds_read("ds_read_b64_tr_b16", vf_half(f, h), V(T_VADDR), off, note="V^T f%d.%d" % (f, h))
 
@@ -380,7 +390,7 @@ class Stream:
                 if not (mfma and "kread" in cfg.abl):
                     at(12 + i, lambda i=i: self.k_read(par ^ 1, i))
             # LDS-DMA: K(j+2) pieces in gaps 20..23, V(j+1) pieces 24..27; their offsets advance in gaps 28..31
-            if cfg.tr and cfg.dma == "b":
+            if cfg.vt and cfg.dma == "b":
                 at(24, lambda: self.last_v_tile())
             for i in range(4 if cfg.dma == "b" and not (mfma and "dma" in cfg.abl) else 0):
                 at(20 + i, lambda i=i: self.dma_piece("k", par, i))
@@ -390,7 +400,7 @@ class Stream:
             if cfg.dma == "b":
                 at(0, lambda: self.vwr_update())
             at(1, lambda: self.vrd_advance())
-            if cfg.tr:
+            if cfg.tr == 3:
                 # the eight V^T chunk addresses of the tile phase A reads next (vrd has just advanced to it; the last V^T read of
                 # THIS phase is in gap 17; the ring position is a multiple of 16 KiB: the XOR only meets the swizzle bits)
                 at(18, lambda: self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of the next phase A"))
@@ -494,7 +504,7 @@ class Stream:
 
     def k_read(self, slot, i):
         kb, ks = divmod(i, 8)
-        if self.cfg.tr:   # rows 16 ks (+ 8) of key block kb of the [2][128][64 bytes] image
+        if self.cfg.kt:   # rows 16 ks (+ 8) of key block kb of the [2][128][64 bytes] image
             for h in range(2):
                 rid = self.lds_read("ds_read_b64_tr_b16", A(K_BASE + 4 * (8 * kb + ks) + 2 * h, 2), VN("kbase"),
                                     slot * KSLOT + (kb * 128 + 16 * ks + 8 * h) * 64, note="K^T(%d,%d).%d" % (kb, ks, h))
@@ -619,7 +629,7 @@ class Stream:
         self.emit("s_waitcnt", None, [], vmcnt=4)
         self.emit("s_barrier")
         for ks in range(8):
-            if not self.cfg.tr:
+            if not self.cfg.kt:
                 self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
         for rb in range(2):
             self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
@@ -684,7 +694,7 @@ class Stream:
                 self.vwr_update()
                 for i in range(4):
                     self.dma_piece("k", par, i)
-                if self.cfg.tr:
+                if self.cfg.vt:
                     self.last_v_tile()
                 for i in range(4):
                     self.dma_piece("v", par, i)
@@ -796,10 +806,10 @@ def write_inc(path):
         if not cfg.tr:
             lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.prof))
     lines.append("")
-    lines.append("// streams of attn_fwd16_p4_tr (K and V stored transposed): X(name, folds)")
+    lines.append("// streams of attn_fwd16_p4_tr (K and / or V stored transposed): X(name, folds, pattern: bit 0 = K, bit 1 = V)")
     lines.append("#define MFA_P4_TR_STREAM_LIST(X) \\")
     for name in TR_STREAMS:
-        lines.append("  X(%s, %d) \\" % (name, VARIANTS[name].fold))
+        lines.append("  X(%s, %d, %d) \\" % (name, VARIANTS[name].fold, VARIANTS[name].tr))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates: MFA_FWD16_IMPL=p4:<1000 + index>")
     lines.append("#define MFA_P4_DEV_STREAM_LIST(X) \\")
@@ -815,7 +825,7 @@ def write_inc(path):
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
         lines.append("// %s: dtype=%s thr=%g xe=%d xf=%d order_a=%s pad=%d prof=%d fold=%d xb=%d dma=%s%s -- %d instructions, %d matrix instructions"
                      % (name, cfg.dtype, cfg.thr, cfg.xe, cfg.xf, cfg.order_a, cfg.pad, cfg.prof, cfg.fold, cfg.xb, cfg.dma,
-                        " tr=1" if cfg.tr else "", len(txt), n_mfma))
+                        " tr=%d" % cfg.tr if cfg.tr else "", len(txt), n_mfma))
         lines.append("#define MFA_P4_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)
@@ -837,10 +847,18 @@ VARIANTS = {
     "F16_FOLD": Cfg("f16", 8, fold=1, xb=40),
     "BF16_FOLD_XB24": Cfg("bf16", 8, fold=1, xb=24),
     "BF16_FOLD_PROF": Cfg("bf16", 8, fold=1, xb=40, prof=1),
-    "BF16_THR8_TR": Cfg("bf16", 8, 0, tr=1),
-    "F16_THR8_TR": Cfg("f16", 8, 0, tr=1),
-    "BF16_FOLD_TR": Cfg("bf16", 8, fold=1, xb=40, tr=1),
-    "F16_FOLD_TR": Cfg("f16", 8, fold=1, xb=40, tr=1),
+    "BF16_THR8_TR": Cfg("bf16", 8, 0, tr=3),
+    "F16_THR8_TR": Cfg("f16", 8, 0, tr=3),
+    "BF16_FOLD_TR": Cfg("bf16", 8, fold=1, xb=40, tr=3),
+    "F16_FOLD_TR": Cfg("f16", 8, fold=1, xb=40, tr=3),
+    "BF16_THR8_TRK": Cfg("bf16", 8, 0, tr=1),
+    "F16_THR8_TRK": Cfg("f16", 8, 0, tr=1),
+    "BF16_FOLD_TRK": Cfg("bf16", 8, fold=1, xb=40, tr=1),
+    "F16_FOLD_TRK": Cfg("f16", 8, fold=1, xb=40, tr=1),
+    "BF16_THR8_TRV": Cfg("bf16", 8, 0, tr=2),
+    "F16_THR8_TRV": Cfg("f16", 8, 0, tr=2),
+    "BF16_FOLD_TRV": Cfg("bf16", 8, fold=1, xb=40, tr=2),
+    "F16_FOLD_TRV": Cfg("f16", 8, fold=1, xb=40, tr=2),
     "ABL_EXPA": Cfg("bf16", 8, fold=1, prof=1, abl=("expa",)),
     "ABL_SUMPACK": Cfg("bf16", 8, fold=1, prof=1, abl=("sum", "pack")),
     "ABL_VREADA": Cfg("bf16", 8, fold=1, prof=1, abl=("vreada",)),
@@ -854,7 +872,8 @@ VARIANTS = {
 }
 
 PRODUCT_STREAMS = ("BF16_THR8", "F16_THR8", "BF16_THR0", "BF16_FOLD", "F16_FOLD")
-TR_STREAMS = ("BF16_THR8_TR", "F16_THR8_TR", "BF16_FOLD_TR", "F16_FOLD_TR")   # product too: their own list (attn_fwd16_p4_tr.h)
+TR_STREAMS = ("BF16_THR8_TR", "F16_THR8_TR", "BF16_FOLD_TR", "F16_FOLD_TR", "BF16_THR8_TRK", "F16_THR8_TRK", "BF16_FOLD_TRK",
+              "F16_FOLD_TRK", "BF16_THR8_TRV", "F16_THR8_TRV", "BF16_FOLD_TRV", "F16_FOLD_TRV")   # product too: their own list (attn_fwd16_p4_tr.h)
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

@@ -433,6 +433,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
     what follows the sequence in a row must neither be multiplied nor summed), as attn_fwd16_p4_tr.h does."""
     cfg = cfg or Cfg()
     tr = bool(getattr(cfg, "tr", 0))
+    ktr, vtr = bool(getattr(cfg, "kt", 0)), bool(getattr(cfg, "vt", 0))
     f16 = cfg.dtype == "f16"
     R, C, D = q.shape[0], k.shape[0], 128
     assert q.shape[1] == D
@@ -443,10 +444,14 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         assert C % 8 == 0, "the transposed streams take whole 16-byte chunks"
         nan16 = 0x7E00 if f16 else 0x7FC0
         kt, vt = (np.concatenate([x.T, np.full((D, tr_pad), nan16, np.uint16)], axis=1) for x in (k, v))
-        kb, vb = np.ascontiguousarray(kt).reshape(-1).view(np.uint8), np.ascontiguousarray(vt).reshape(-1).view(np.uint8)
+        if ktr:
+            kb = np.ascontiguousarray(kt).reshape(-1).view(np.uint8)
+        if vtr:
+            vb = np.ascontiguousarray(vt).reshape(-1).view(np.uint8)
     ld2 = D * 2
     ldt2 = (C + tr_pad) * 2          # leading dimension of K^T / V^T, bytes
-    knrec = D * ldt2 if tr else C * ld2
+    knrec = D * ldt2 if ktr else C * ld2
+    vnrec = D * ldt2 if vtr else C * ld2
     nt_total = (C + 63) // 64
     coff = C - R
     nt = nt_total
@@ -472,7 +477,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
                 for l in range(64):
                     row = r0 + b * 32 + int(qq[l])
                     d0 = 16 * s + 8 * int(hi[l])
-                    if row < R and tr:   # elements 4 hi + {0..3, 8..11} of the step: the order the K^T fragments arrive in
+                    if row < R and ktr:   # elements 4 hi + {0..3, 8..11} of the step: the order the K^T fragments arrive in
                         d0 = 16 * s + 4 * int(hi[l])
                         chunk = np.concatenate([qb[row * ld2 + d0 * 2: row * ld2 + d0 * 2 + 8],
                                                 qb[row * ld2 + (d0 + 8) * 2: row * ld2 + (d0 + 8) * 2 + 8]]).view(np.uint32)
@@ -488,11 +493,14 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             p = (wave * 4 + i) * 64 + lane
             krow, kc = p >> 4, (p & 15) ^ ((p >> 4) & 15)
             vkey, vc = (p >> 2) & 63, (p >> 8) * 4 + (p & 3)
-            if tr:   # K^T image [2 blocks of 32 keys][128 elements][4 chunks]; V^T image [128 elements][8 chunks ^ (element >> 1 & 7)]
+            # K^T image [2 blocks of 32 keys][128 elements][4 chunks]; V^T image [128 elements][8 chunks ^ (element >> 1 & 7)]
+            if ktr:
                 koff.append((((p >> 2) & 127) * ldt2 + ((p >> 9) * 32 + (p & 3) * 8) * 2).astype(np.uint32))
-                voff.append(((p >> 3) * ldt2 + ((p & 7) ^ ((p >> 4) & 7)) * 16).astype(np.uint32))
             else:
                 koff.append((krow * ld2 + kc * 16).astype(np.uint32))
+            if vtr:
+                voff.append(((p >> 3) * ldt2 + ((p & 7) ^ ((p >> 4) & 7)) * 16).astype(np.uint32))
+            else:
                 voff.append((vkey * ld2 + vc * 16).astype(np.uint32))
 
         def dma(buf, nrec, off, ldsbase):
@@ -503,9 +511,9 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
                     data[l] = buf[o:o + 16]
             wg.lds_write16(ldsbase + 16 * np.arange(64), data)
 
-        kinc = vinc = 128 if tr else 64 * ld2
+        kinc, vinc = 128 if ktr else 64 * ld2, 128 if vtr else 64 * ld2
         vlast = []
-        if tr:   # offsets of the workgroup's LAST tile: chunks at or beyond key C are not fetched (zeros)
+        if vtr:   # offsets of the workgroup's LAST tile: chunks at or beyond key C are not fetched (zeros)
             for i in range(4):
                 p = (wave * 4 + i) * 64 + lane
                 key0 = ((p & 7) ^ ((p >> 4) & 7)) * 8 + 64 * (nt - 1)
@@ -515,7 +523,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             dma(kb, knrec, koff[i], 0 * KSLOT + (wave * 4 + i) * 1024)
             koff[i] = np.minimum(koff[i].astype(np.uint64) + kinc, 0xFFFFFFFF).astype(np.uint32)
         for i in range(4):
-            dma(vb, knrec, vlast[i] if tr and nt == 1 else voff[i], VBASE + (wave * 4 + i) * 1024)
+            dma(vb, vnrec, vlast[i] if vtr and nt == 1 else voff[i], VBASE + (wave * 4 + i) * 1024)
             voff[i] = np.minimum(voff[i].astype(np.uint64) + vinc, 0xFFFFFFFF).astype(np.uint32)
         for i in range(4):
             dma(kb, knrec, koff[i], 1 * KSLOT + (wave * 4 + i) * 1024)
@@ -530,9 +538,11 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             "kbase": (qq * 256 + ((hi ^ (qq & 15)) << 4)).astype(np.uint32),
             "vbase": (VBASE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32),
         })
-        if tr:   # K^T: the transposing-read lane term; V^T: row lane % 32, the swizzle's XOR mask, + 8 hi
+        if ktr:   # K^T: the transposing-read lane term
             w.vn["kbase"] = (((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32)
+        if vtr:   # V^T: row lane % 32, the swizzle's XOR mask, + 8 hi
             w.vn["vbase"] = (VBASE + qq * 128 + (((qq >> 1) & 7) << 4) + 8 * hi).astype(np.uint32)
+            w.vn["vta"] = w.vn["vtb"] = np.zeros(64, np.uint32)
         for i in range(4):
             w.vn["koff%d" % i], w.vn["voff%d" % i] = koff[i], voff[i]
         for b in range(2):
@@ -545,7 +555,7 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         if causal:   # tiles this wave's own rows can see
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 64 + 1)) if wlast >= r0 else 1
-        w.sn.update({"kres": (kb, knrec), "vres": (vb, knrec), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
+        w.sn.update({"kres": (kb, knrec), "vres": (vb, vnrec), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": kinc, "vinc": vinc,
                      "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "maskfrom": maskfrom, "ntm2": nt - 2})
     wg.run(order)
     O = np.zeros((256, D), np.float32)

@@ -68,6 +68,20 @@ def test_d64_ring_discipline(dma_mode, order):
     _check(256, 448, cfg=V["D64_BF16_FOLD"], causal=True, dma_mode=dma_mode, order=order, seed=3)
 
 
+@pytest.mark.parametrize("name", sorted(dq4gen.TR_VARIANTS))
+@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3))])
+def test_transposed_key_value_streams(name, dma_mode, order):
+    """K and V handed over TRANSPOSED ([128][C], whole tiles): the images keep the source orientation and the two read recipes
+    change roles -- K / V row fragments by transposing reads (Q' and dO in their element order), K^T fragments as two 8-byte
+    reads in the order dS' holds its keys.  Model-verified streams (no kernel behind them yet): tile counts
+    across two ring wraps, ragged row blocks, causal with per-wave bounds and the skip loop, DMA early / late, waves in either
+    order."""
+    cfg = dq4gen.TR_VARIANTS[name]
+    for R, C, rblk, causal in ((256, 64, 0, False), (256, 576, 0, False), (200, 320, 0, False), (512, 512, 1, True), (300, 448, 1, True)):
+        wg = _check(R, C, rblk=rblk, causal=causal, cfg=cfg, seed=11, dma_mode=dma_mode, order=order)
+    assert wg.waves[0].count.get("ds_read_b128", 0) == 0 and wg.waves[0].count["ds_read_b64"] > 0
+
+
 def test_stream_file_is_current():
     """csrc/attn_dq16_p4_stream.inc is what tools/dq4gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_dq16_p4_stream.inc")

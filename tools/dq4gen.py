@@ -58,11 +58,21 @@ IN_S = ["kres", "vres", "nt", "wnt", "kinc", "vinc", "wr0", "ringend", "maskfrom
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", prof=0, exact=0, abl=(), D=128, defer=None):
+    def __init__(self, dtype="bf16", prof=0, exact=0, abl=(), D=128, defer=None, tr=0):
         """exact: Q stays as stored, -L arrives divided by log2(e)/sqrt(D) and the scale is applied in fp32 before the exp2
         (one packed multiply per two scores more); otherwise Q arrives pre-multiplied, rounded to the 16-bit type"""
         self.dtype, self.prof, self.exact, self.abl, self.D = dtype, prof, exact, frozenset(abl), D
         self.defer = (D == 64) if defer is None else defer     # dQ update of a tile's second key block beside the next tile
+        # tr (D = 128; model-verified, NOT yet behind a kernel -- DESIGN.md 10.4): K and V stored TRANSPOSED ([D][keys]).  The
+        # images keep the source orientation -- [2 blocks of 32 keys][128 elements][64 bytes], chunks ^ (element >> 2) & 3: the
+        # same two read recipes with their roles exchanged.  K and V ROW fragments (A of S' and dP') come from transposing reads
+        # (addresses ka0 / ka1: rows + 0 / + 8 of a 16-element step), which return the contraction index in the order of an
+        # accumulator block's registers (4 hi + {0..3, 8..11}): the kernel stores the Q' and dO fragments in that order.  K^T
+        # fragments (A of dQ^T += K^T dS'^T) are two 8-byte reads of the lane's element row, chunks 2 u and 2 u + 1 at 8 hi
+        # (dS' holds its keys in that register order): four addresses ta0..ta3 instead of two.  Whole tiles only (C % 64 == 0):
+        # a masked score makes dS' = 0, but 0 x what follows the sequence in a row of V^T / K^T is not.
+        self.tr = tr
+        assert not (tr and D != 128)
 
 
 def st_blk(rb, kb):
@@ -104,6 +114,19 @@ class Stream(_P4Stream):
 
     # fragment i of a tile: 0..7 K rows kb0 | 8..15 V rows kb0 | 16..23 K rows kb1 | 24..31 V rows kb1 | 32..39 K^T kb0 | 40..47 K^T kb1
     def frag_read(self, i):
+        if self.cfg.tr:
+            if i < 32:       # rows 16 ks (+ 8) of key block kb's sub-image
+                kb, isv, ks = i // 16, (i // 8) & 1, i % 8
+                off = (VIMG if isv else 0) + kb * 8192 + ks * 1024
+                self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ka0"), off, note="%s^T rows kb%d ks%d" % ("V" if isv else "K", kb, ks))
+                self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ka1"), off)
+            else:            # element row 32 db + lane % 32 of sub-image kb: 8 bytes of chunks 2 u, 2 u + 1
+                kb, r = divmod(i - 32, 8)
+                u, db = divmod(r, 4)
+                off = kb * 8192 + db * 2048
+                self.lds_read("ds_read_b64", af_half(i, 0), VN("ta%d" % (2 * u)), off, note="K kb%d u%d db%d" % (kb, u, db))
+                self.frag_rid[i] = self.lds_read("ds_read_b64", af_half(i, 1), VN("ta%d" % (2 * u + 1)), off)
+            return
         if i < 32:
             kb, isv, ks = i // 16, (i // 8) & 1, i % 8
             off = (VIMG if isv else 0) + (ks >> 1) * 4096 + kb * 2048
@@ -249,7 +272,7 @@ class Stream(_P4Stream):
         def seam():
             self.emit("s_waitcnt", None, [], vmcnt=8 if "dma" not in cfg.abl else 0)
             self.emit("s_barrier")
-            self.addr_advance(["ta0", "ta1"])
+            self.addr_advance(["ta0", "ta1", "ta2", "ta3"] if cfg.tr else ["ta0", "ta1"])
         at(88, seam)
         for i in range(4):
             at(89 + 2 * i, lambda i=i: self.frag_read(i))
@@ -477,9 +500,10 @@ class Stream(_P4Stream):
             self.emit("s_mov_b32", SN("plast"), [("vcc_lo",)])
         loop, skip, done, fin = (self.newlabel(x) for x in ("LOOP", "SKIP", "DONE", "FIN"))
         self.label(loop)
-        head_out = self.lds_issued - self.lds_done
+        head_out, head_gap = self.lds_issued - self.lds_done, self.lds_issued - self.frag_rid[0]
         tile()
-        assert self.lds_issued - self.frag_rid[0] == 3 and self.lds_issued - self.lds_done <= head_out, "loop-carried LDS queue state"
+        assert head_gap == (6 if cfg.tr else 3) and self.lds_issued - self.frag_rid[0] == head_gap and \
+            self.lds_issued - self.lds_done <= head_out, "loop-carried LDS queue state"
         self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         self.emit("s_cmp_lt_i32", None, [SN("j"), SN("wnt")])
         self.emit("s_cbranch_scc1", None, [], target=loop)
@@ -521,13 +545,18 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.D))
     lines.append("")
+    lines.append("// transposed K / V (model-verified, no kernel yet): X(name, applies the softmax scale in fp32)")
+    lines.append("#define MFA_DQ4_TR_STREAM_LIST(X) \\")
+    for name, cfg in TR_VARIANTS.items():
+        lines.append("  X(%s, %d) \\" % (name, cfg.exact))
+    lines.append("")
     lines.append("#define MFA_DQ4_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if cfg.prof:
             lines.append("  X(%s) \\" % name)
     lines.append("")
     lines.append("")
-    for name, cfg in VARIANTS.items():
+    for name, cfg in list(VARIANTS.items()) + list(TR_VARIANTS.items()):
         ins = Stream(cfg).build()
         txt = render(ins)
         lines.append("// %s: dtype=%s prof=%d exact=%d D=%d -- %d instructions" % (name, cfg.dtype, cfg.prof, cfg.exact, cfg.D, len(txt)))
@@ -558,6 +587,13 @@ VARIANTS = {
     "ABL_MULPACK": Cfg("bf16", prof=1, abl=("mulpack",)),
     "ABL_READS": Cfg("bf16", prof=1, abl=("reads",)),
     "ABL_ALL": Cfg("bf16", prof=1, abl=("dma", "exp", "mulpack", "reads")),
+}
+
+TR_VARIANTS = {
+    "BF16_FOLD_TR": Cfg("bf16", tr=1),
+    "F16_FOLD_TR": Cfg("f16", tr=1),
+    "BF16_EXACT_TR": Cfg("bf16", exact=1, tr=1),
+    "F16_EXACT_TR": Cfg("f16", exact=1, tr=1),
 }
 
 if __name__ == "__main__":

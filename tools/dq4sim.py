@@ -43,6 +43,11 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
     wg = Workgroup(instrs, dma_mode)
     ld2 = D * 2
     kb_, vb_ = k.reshape(-1).view(np.uint8), v.reshape(-1).view(np.uint8)
+    tr = bool(getattr(cfg, "tr", 0))
+    if tr:   # K^T, V^T: [D][C] in memory
+        assert C % 64 == 0 and D == 128
+        kb_, vb_ = np.ascontiguousarray(k.T).reshape(-1).view(np.uint8), np.ascontiguousarray(v.T).reshape(-1).view(np.uint8)
+    ldt2 = C * 2
     scale = np.float32(1.0) / np.sqrt(np.float32(D))
     scale2 = np.float32(LOG2E) * scale
     coff = C - R
@@ -66,7 +71,11 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
                     for l in range(64):
                         row = r0 + b * 32 + int(qq[l])
                         d0 = 16 * s_ + 8 * int(hi[l])
-                        chunk = src[row, d0:d0 + 8].view(np.uint32) if row < R else np.zeros(4, np.uint32)
+                        if tr and row < R:   # elements 4 hi + {0..3, 8..11} of the step: the order the transposing reads return
+                            d0 = 16 * s_ + 4 * int(hi[l])
+                            chunk = np.concatenate([src[row, d0:d0 + 4], src[row, d0 + 8:d0 + 12]]).view(np.uint32)
+                        else:
+                            chunk = src[row, d0:d0 + 8].view(np.uint32) if row < R else np.zeros(4, np.uint32)
                         for t in range(4):
                             w.a[base + 4 * (b * 8 + s_) + t][l] = chunk[t]
         koff, voff = [], []
@@ -74,6 +83,12 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
             p = (wave * pw + i) * 64 + lane
             db, key, slot = p >> 8, (p >> 2) & 63, p & 3
             chunk = db * 4 + (slot ^ ((key >> 2) & 3))
+            if tr:   # image [2 blocks of 32 keys][128 elements][4 chunks of 8 keys ^ (element >> 2) & 3]
+                d_ = (p >> 2) & 127
+                src_off = d_ * ldt2 + ((p >> 9) * 32 + ((p & 3) ^ ((d_ >> 2) & 3)) * 8) * 2
+                koff.append(src_off.astype(np.uint32))
+                voff.append(src_off.astype(np.uint32))
+                continue
             koff.append((key * ld2 + chunk * 16).astype(np.uint32))
             voff.append((key * ld2 + chunk * 16).astype(np.uint32))
         trow = (n16 >> 2) + 4 * hi
@@ -94,6 +109,10 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
             "ta0": (trow * 64 + ((tchunk ^ (hi & 3)) * 16) + thalf * 8).astype(np.uint32),
             "ta1": ((trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8).astype(np.uint32),
         })
+        if tr:
+            ta = [(qq * 64 + ((c ^ ((qq >> 2) & 3)) * 16) + 8 * hi).astype(np.uint32) for c in range(4)]
+            w.vn.update({"ka0": w.vn["ta0"], "ka1": w.vn["ta1"]})          # rows + 0 / + 8 of a 16-element step (transposing reads)
+            w.vn.update({"ta%d" % c: ta[c] for c in range(4)})
         for i in range(4):
             oob = np.full(64, 0xFFFFFF00, np.uint32)
             w.vn["koff%d" % i], w.vn["voff%d" % i] = (koff[i], voff[i]) if i < pw else (oob, oob)
@@ -103,7 +122,8 @@ def run_block(q, k, v, do, L, Dt, rblk=0, cfg=None, causal=False, dma_mode="late
         if causal:
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 64 + 1)) if wlast >= r0 else 1
-        w.sn.update({"kres": (kb_, C * ld2), "vres": (vb_, C * ld2), "nt": nt, "wnt": wnt, "kinc": 64 * ld2, "vinc": 64 * ld2,
+        w.sn.update({"kres": (kb_, C * ld2), "vres": (vb_, C * ld2), "nt": nt, "wnt": wnt,
+                     "kinc": 128 if tr else 64 * ld2, "vinc": 128 if tr else 64 * ld2,
                      "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom, "scale2x2": float(scale2)})
     wg.run(order)
     dQ = np.zeros((256, D), np.float32)

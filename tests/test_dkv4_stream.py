@@ -61,6 +61,20 @@ def test_exact_stream_is_closer():
     assert e_exact[1] < 0.5 * e_fold[1]
 
 
+@pytest.mark.parametrize("name", sorted(dkv4gen.TR_VARIANTS))
+@pytest.mark.parametrize("dma_mode,order", [("early", (3, 2, 1, 0)), ("late", (0, 1, 2, 3))])
+def test_transposed_query_gradient_streams(name, dma_mode, order):
+    """Q and dO handed over TRANSPOSED ([128][R], whole 32-row steps): a step's tile in the source orientation is the same
+    [4][32][64 bytes] image with the two read recipes' roles exchanged -- Q / dO row fragments by transposing reads (K' and V in
+    their element order), dO^T / Q^T fragments as two 8-byte reads in the order P and dS' hold their rows.  Model-verified streams
+    (no kernel behind them yet): step counts across two ring wraps, ragged key blocks, causal, DMA early / late,
+    waves in either order."""
+    cfg = dkv4gen.TR_VARIANTS[name]
+    for R, C, cblk, causal in ((32, 256, 0, False), (320, 256, 0, False), (96, 200, 0, False), (512, 512, 1, True), (288, 448, 1, True)):
+        wg = _check(R, C, cblk=cblk, causal=causal, cfg=cfg, seed=12, dma_mode=dma_mode, order=order)
+    assert wg.waves[0].count.get("ds_read_b128", 0) == 32 and wg.waves[0].count["ds_read_b64"] > 0   # (b128: the K' / V hand-over only)
+
+
 def test_stream_file_is_current():
     """csrc/attn_dkv16_p4_stream.inc is what tools/dkv4gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_dkv16_p4_stream.inc")

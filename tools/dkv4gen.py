@@ -64,7 +64,7 @@ IN_S = ["qres", "gres", "lres", "dres", "nsteps", "rscale", "qinc", "ginc", "ldi
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", prof=0, abl=(), exact=0, gdtype=None, D=128):
+    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", prof=0, abl=(), exact=0, gdtype=None, D=128, tr=0):
         """dtype: type of Q, K, V, dO and of the packed P / dS'; lprec / dprec: storage types of L and D.
         exact: K stays as stored and the softmax scale is applied in fp32, P = exp2(scale2 * (Q K^T - L / scale2)) (one packed
         multiply per two scores more); otherwise K arrives pre-multiplied by scale2, rounded to the 16-bit type."""
@@ -79,6 +79,15 @@ class Cfg:
         # one LDS-DMA piece per wave and operand tile; the register map keeps its D = 128 positions)
         self.D, self.nks, self.ndb = D, D // 16, D // 32
         assert D in (64, 128)
+        # tr (D = 128; model-verified, NOT yet behind a kernel -- DESIGN.md 10.4): Q and dO stored TRANSPOSED ([D][rows]).  A step's
+        # tile in the source orientation is [128 elements][32 rows x 2 bytes] = the same [4][32][64 bytes] image with the roles
+        # of its two read recipes exchanged: Q / dO ROW fragments (A of S' and dP') by transposing reads (addresses ra0 / ra1 =
+        # rows + 0 / + 8 of a 16-element step; the contraction index arrives in accumulator-register order, so the kernel parks
+        # the K' and V fragments in that order), dO^T / Q^T fragments (A of dV^T and dK^T) as two 8-byte reads of the lane's
+        # element row, chunks 2 u and 2 u + 1 at 8 hi (P and dS' hold their rows in that order): four addresses ta0..ta3.
+        # Whole steps only (R % 32 == 0): rows beyond R are no longer zeros read past the end of a buffer.
+        self.tr = tr
+        assert not (tr and D != 128)
         self.abl = frozenset(abl)
 
 
@@ -141,6 +150,18 @@ class Stream(_P4Stream):
         """issue the LDS read(s) of ring fragment i of the current step (addresses: ra* row reads, ta* transposing reads)"""
         if self.cfg.D == 64:
             return self.frag_read64(i)
+        if self.cfg.tr:
+            if i < 16:      # rows 16 (ks & 1) (+ 8) of sub-image ks >> 1
+                ks = i % 8
+                off = (0 if i < 8 else GIMG) + (ks >> 1) * 2048 + (ks & 1) * 1024
+                self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ra0"), off, note="%s^T rows ks%d" % ("Q" if i < 8 else "dO", ks))
+                self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ra1"), off)
+            else:           # element row 32 db + lane % 32: 8 bytes of chunks 2 u, 2 u + 1
+                u, db = divmod(i % 8, 4)
+                off = (GIMG if i < 24 else 0) + db * 2048
+                self.lds_read("ds_read_b64", af_half(i, 0), VN("ta%d" % (2 * u)), off, note="%s u%d db%d" % ("dO" if i < 24 else "Q", u, db))
+                self.frag_rid[i] = self.lds_read("ds_read_b64", af_half(i, 1), VN("ta%d" % (2 * u + 1)), off)
+            return
         if i < 16:          # row fragment ks of Q (i < 8) or dO: 16 bytes at chunk (2 ks + hi) ^ swizzle of row (lane & 31)
             ks = i % 8
             img = 0 if i < 8 else GIMG
@@ -355,7 +376,7 @@ class Stream(_P4Stream):
         def seam():
             self.emit("s_waitcnt", None, [], vmcnt=4 if "dma" not in cfg.abl else 0)
             self.emit("s_barrier")
-            self.addr_advance(["ta0", "ta1"])
+            self.addr_advance(["ta0", "ta1", "ta2", "ta3"] if cfg.tr else ["ta0", "ta1"])
         at(60, seam)
         conv = self.ld_convert_ops()
         for n, fn in enumerate(conv):
@@ -551,7 +572,8 @@ class Stream(_P4Stream):
         head_issued = self.lds_issued
         head_outstanding = self.lds_issued - self.lds_done
         self.step()
-        assert self.lds_issued - self.lds_done <= 4 and self.lds_issued - self.frag_rid[0] == 3, "loop-carried LDS queue state"
+        assert self.lds_issued - self.lds_done <= (8 if cfg.tr else 4) and self.lds_issued - self.frag_rid[0] == (6 if cfg.tr else 3), \
+            "loop-carried LDS queue state"
         if head_outstanding < self.lds_issued - self.lds_done:
             raise AssertionError("the loop head assumes fewer reads in flight than the back edge leaves")
         del head_issued
@@ -577,8 +599,13 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.mix, cfg.D))
     lines.append("")
+    lines.append("// transposed Q / dO (model-verified, no kernel yet): X(name, applies the softmax scale in fp32)")
+    lines.append("#define MFA_DKV4_TR_STREAM_LIST(X) \\")
+    for name, cfg in TR_VARIANTS.items():
+        lines.append("  X(%s, %d) \\" % (name, cfg.exact))
     lines.append("")
-    for name, cfg in VARIANTS.items():
+    lines.append("")
+    for name, cfg in list(VARIANTS.items()) + list(TR_VARIANTS.items()):
         ins = Stream(cfg).build()
         txt = render(ins)
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
@@ -609,6 +636,12 @@ VARIANTS = {
     "D64_F16_DOBF16_F32": Cfg("f16", "f32", "f32", exact=1, gdtype="bf16", D=64),
 }
 PRODUCT_STREAMS = ("BF16_MIXED", "F16_MIXED", "BF16_F32", "F16_F32", "F16_DOBF16_MIXED", "F16_DOBF16_F32")
+TR_VARIANTS = {
+    "BF16_MIXED_TR": Cfg("bf16", "f16", "bf16", tr=1),
+    "F16_MIXED_TR": Cfg("f16", "f16", "bf16", tr=1),
+    "BF16_F32_TR": Cfg("bf16", "f32", "f32", exact=1, tr=1),
+    "F16_F32_TR": Cfg("f16", "f32", "f32", exact=1, tr=1),
+}
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

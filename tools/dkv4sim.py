@@ -66,6 +66,11 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
     wg = Workgroup(instrs, dma_mode)
     ld2 = D * 2
     qb, gb = q.reshape(-1).view(np.uint8), do.reshape(-1).view(np.uint8)
+    tr = bool(getattr(cfg, "tr", 0))
+    if tr:   # Q^T, dO^T: [D][R] in memory
+        assert R % 32 == 0 and D == 128
+        qb, gb = np.ascontiguousarray(q.T).reshape(-1).view(np.uint8), np.ascontiguousarray(do.T).reshape(-1).view(np.uint8)
+    ldt2 = R * 2
     lbuf, lesz = store_prec(L, cfg.lprec)
     dbuf, desz = store_prec(Dt, cfg.dprec)
     assert lesz == desz
@@ -97,7 +102,10 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
             for l in range(64):
                 col = c0 + 64 * wave + 32 * kb_ + int(kc[l])
                 d0 = 16 * ks + 8 * int(hi[l])
-                if col < C:
+                if col < C and tr:   # elements 4 hi + {0..3, 8..11}: the order the transposing reads of Q^T / dO^T return
+                    d0 = 16 * ks + 4 * int(hi[l])
+                    data[l] = np.concatenate([src[col, d0:d0 + 4], src[col, d0 + 8:d0 + 12]]).view(np.uint8)
+                elif col < C:
                     data[l] = src[col, d0:d0 + 8].view(np.uint8)
             wg.lds_write16(back + i * 1024 + 16 * lane, data)
         # DMA source offsets: piece i of wave w fills 16-byte positions (2 w + i) * 64 + lane of a tile
@@ -106,6 +114,10 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
             p = (pw * wave + i) * 64 + lane
             db, row, slot = p >> 7, (p >> 2) & 31, p & 3
             chunk = db * 4 + (slot ^ ((row >> 2) & 3))
+            if tr:   # image [128 elements][4 chunks of 8 rows ^ (element >> 2) & 3]
+                d_ = p >> 2
+                offs.append((d_ * ldt2 + (row_first + ((p & 3) ^ ((d_ >> 2) & 3)) * 8) * 2).astype(np.uint32))
+                continue
             offs.append(np.where((i < pw) & (chunk * 8 < D), (row_first + row) * ld2 + chunk * 16, 0xFFFFFF00).astype(np.uint32))
         trow = (n16 >> 2) + 4 * hi
         tchunk = 2 * ((lane >> 4) & 1) + ((n16 & 3) >> 1)
@@ -121,11 +133,16 @@ def run_block(q, k, v, do, L, Dt, cblk=0, cfg=None, causal=False, dma_mode="late
             "tk": ((c0 + 64 * wave + kc) - coff - 4 * hi - row_first).astype(np.int64).astype(np.uint32),
             "kvback": (back + 16 * lane).astype(np.uint32),
         })
+        if tr:
+            ta = [(kc * 64 + ((c ^ ((kc >> 2) & 3)) * 16) + 8 * hi).astype(np.uint32) for c in range(4)]
+            w.vn.update({"ra0": w.vn["ta0"], "ra1": w.vn["ta1"]})          # rows + 0 / + 8 of a 16-element step (transposing reads)
+            w.vn.update({"ta%d" % c: ta[c] for c in range(4)})
         maskuntil = 0
         if causal:   # steps whose rows do not all see this wave's last key
             maskuntil = max(0, -(-(c0 + 64 * wave + 63 - coff - row_first) // 32))
         w.sn.update({"qres": (qb, R * ld2), "gres": (gb, R * ld2), "lres": (lbuf, R * lesz), "dres": (dbuf, R * desz),
-                     "nsteps": nsteps, "rscale": float(np.float32(0.5 if cfg.mix else 1.0) / scale), "qinc": 32 * ld2, "ginc": 32 * ld2,
+                     "nsteps": nsteps, "rscale": float(np.float32(0.5 if cfg.mix else 1.0) / scale),
+                     "qinc": 64 if tr else 32 * ld2, "ginc": 64 if tr else 32 * ld2,
                      "ldinc": 32 * lesz, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskuntil": maskuntil,
                      "rscale2": float(np.float32(0.5 if cfg.mix else 1.0) / (scale2 if cfg.exact else np.float32(1.0))), "scale2x2": float(scale2)})
     wg.run(order)

@@ -58,6 +58,22 @@ def test_every_compiled_variant(name):
     _check(256, 320, cfg=V[name], causal=True, seed=6)
 
 
+@pytest.mark.parametrize("name", ["D256_BF16_THR8_TR", "D256_F16_FOLD_TR", "D192_BF16_FOLD_TR", "D160_F16_THR8_TR"])
+def test_transposed_key_value_streams(name):
+    """K and V handed over TRANSPOSED ([D][C], whole 32-key steps): a step's tile in the source orientation is the same
+    [D/32][32][64 bytes] image with the two read recipes' roles exchanged -- K row fragments by transposing reads (Q' parked in their
+    element order), V^T fragments as two 8-byte reads in the order P^T holds its keys.  Model-verified streams (no kernel behind them
+    yet): step counts across two ring wraps, ragged row blocks, causal with per-wave bounds, a forced rescale, DMA
+    early / late with the waves in either order."""
+    cfg = f256gen.TR_VARIANTS[name]
+    for R, C, rblk, causal, mode in ((256, 32, 0, False, "late"), (256, 288, 0, False, "early"), (200, 160, 0, False, "late"),
+                                     (512, 512, 1, True, "early")):
+        wg = _check(R, C, rblk=rblk, causal=causal, cfg=cfg, seed=14, dma_mode=mode, order=(3, 2, 1, 0) if mode == "early" else (0, 1, 2, 3))
+    _check(256, 160, cfg=cfg, spike=(5, 100, 3.0), seed=15, tol_o=1.2e-2)
+    # (b128 reads: only the Q' fragments taken over from LDS at the start)
+    assert wg.waves[0].count.get("ds_read_b128", 0) == 2 * cfg.nks and wg.waves[0].count["ds_read_b64"] > 0
+
+
 def test_stream_file_is_current():
     """csrc/attn_fwd16_p5_stream.inc is what tools/f256gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p5_stream.inc")

@@ -56,7 +56,7 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "wr0", "ringend",
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, prof=0, abl=(), D=256, xbp=0):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, prof=0, abl=(), D=256, xbp=0, tr=0):
         """D: head-dimension bucket of the code object (160, 192 or 256): D / 16 k-steps per score block, D / 32 blocks of O^T
         per row block; the register map keeps its D = 256 positions (smaller buckets leave the tail of the Q' and O ranges unused)"""
         self.dtype, self.thr, self.fold, self.prof, self.abl = dtype, float(thr), fold, prof, frozenset(abl)
@@ -67,6 +67,12 @@ class Cfg:
         # tools/p4gen.py.  xbp: pairs of scores per row block pair whose exp2 already runs in phase B (behind the decision)
         self.cinit = bool(fold) and self.nks <= 12
         self.xbp = xbp
+        # tr (model-verified, NOT yet behind a kernel -- DESIGN.md 10.4): K and V stored TRANSPOSED ([D][keys]).  A step's tile in
+        # the source orientation is [D elements][32 keys x 2 bytes] = the same [D/32][32][64 bytes] image with the roles of its
+        # two read recipes exchanged: K row fragments by transposing reads (ka0 / ka1 = rows + 0 / + 8 of a 16-element step; the
+        # kernel parks the Q' fragments in the element order they return), V^T fragments as two 8-byte reads of the lane's
+        # element row, chunks 2 u and 2 u + 1 at 8 hi (four addresses ta0..ta3).  Whole steps only (C % 32 == 0).
+        self.tr = tr
         assert D % 32 == 0 and (self.nks + 2 * self.ndb) % 4 == 0
 
 
@@ -110,6 +116,17 @@ class Stream(_P4Stream):
     # ---- fragment i of a step: 0..nks-1 K rows (k-step i) of the step's own tile, then 2 ndb V^T fragments (u, db) of the PREVIOUS tile
     def frag_read(self, i):
         nks, ndb = self.cfg.nks, self.cfg.ndb
+        if self.cfg.tr:
+            if i < nks:
+                off = (i >> 1) * 2048 + (i & 1) * 1024
+                self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ka0"), off, note="K^T rows ks%d" % i)
+                self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ka1"), off)
+            else:
+                u, db = divmod(i - nks, ndb)
+                off = VIMG + db * 2048
+                self.lds_read("ds_read_b64", af_half(i, 0), VN("ta%d" % (2 * u)), off, note="V u%d db%d" % (u, db))
+                self.frag_rid[i] = self.lds_read("ds_read_b64", af_half(i, 1), VN("ta%d" % (2 * u + 1)), off)
+            return
         if i < nks:
             self.frag_rid[i] = self.lds_read("ds_read_b128", af(i), VN("ka%d" % (i & 1)), (i >> 1) * 2048, note="K rows ks%d" % i)
         else:
@@ -265,7 +282,8 @@ class Stream(_P4Stream):
             for i in range(4):
                 at(seam_gap + 1 + 2 * i, lambda i=i: self.frag_read(i))
             # the V^T addresses move once the last fragment of this step is requested (gap seam_gap - 1)
-            at(seam_gap + 2, lambda: [self.emit("v_add_u32", VN(n), [SN("deltav"), VN(n)]) for n in ("ta0", "ta1")])
+            at(seam_gap + 2, lambda: [self.emit("v_add_u32", VN(n), [SN("deltav"), VN(n)])
+                                      for n in (("ta0", "ta1", "ta2", "ta3") if cfg.tr else ("ta0", "ta1"))])
         for g in range(nb):
             if mfma:
                 u, db, rb = g // (2 * ndb), (g % (2 * ndb)) // 2, g % 2
@@ -525,8 +543,13 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.fold, cfg.prof, cfg.D))
     lines.append("")
+    lines.append("// transposed K / V (model-verified, no kernel yet): X(name, folds, head-dimension bucket)")
+    lines.append("#define MFA_P5_TR_STREAM_LIST(X) \\")
+    for name, cfg in TR_VARIANTS.items():
+        lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.D))
     lines.append("")
-    for name, cfg in VARIANTS.items():
+    lines.append("")
+    for name, cfg in list(VARIANTS.items()) + list(TR_VARIANTS.items()):
         ins = Stream(cfg).build()
         txt = render(ins)
         lines.append("// %s: dtype=%s thr=%g fold=%d prof=%d -- %d instructions" % (name, cfg.dtype, cfg.thr, cfg.fold, cfg.prof, len(txt)))
@@ -551,6 +574,12 @@ for _d in (192, 160):       # the head-dimension buckets between 128 and 256
     for _t in ("bf16", "f16"):
         VARIANTS["D%d_%s_THR8" % (_d, _t.upper())] = Cfg(_t, D=_d)
         VARIANTS["D%d_%s_FOLD" % (_d, _t.upper())] = Cfg(_t, fold=1, D=_d)
+
+TR_VARIANTS = {}
+for _d in (256, 192, 160):
+    for _t in ("bf16", "f16"):
+        TR_VARIANTS["D%d_%s_THR8_TR" % (_d, _t.upper())] = Cfg(_t, D=_d, tr=1)
+        TR_VARIANTS["D%d_%s_FOLD_TR" % (_d, _t.upper())] = Cfg(_t, fold=1, D=_d, tr=1)
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

@@ -20,6 +20,11 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
     instrs = stream if stream is not None else Stream(cfg).build()
     wg = Workgroup(instrs, dma_mode)
     kb, vb = k.reshape(-1).view(np.uint8), v.reshape(-1).view(np.uint8)
+    tr = bool(getattr(cfg, "tr", 0))
+    if tr:   # K^T, V^T: [D][C] in memory
+        assert C % 32 == 0
+        kb, vb = np.ascontiguousarray(k.T).reshape(-1).view(np.uint8), np.ascontiguousarray(v.T).reshape(-1).view(np.uint8)
+    ldt2 = C * 2
     ld2 = D * 2
     nt_total = (C + 31) // 32
     coff = C - R
@@ -44,7 +49,10 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             for l in range(64):
                 row = r0 + 32 * rb + int(qq[l])
                 d0 = 16 * ks + 8 * int(hi[l])
-                if row < R:
+                if row < R and tr:   # elements 4 hi + {0..3, 8..11}: the order the transposing reads of K^T return
+                    d0 = 16 * ks + 4 * int(hi[l])
+                    data[l] = np.concatenate([q[row, d0:d0 + 4], q[row, d0 + 8:d0 + 12]]).view(np.uint8)
+                elif row < R:
                     data[l] = q[row, d0:d0 + 8].view(np.uint8)
             wg.lds_write16(back + i * 1024 + 16 * lane, data)
         koff = []
@@ -52,6 +60,10 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             p = (wave * pw + i) * 64 + lane
             db, key, slot = p >> 7, (p >> 2) & 31, p & 3
             chunk = db * 4 + (slot ^ ((key >> 2) & 3))
+            if tr:   # image [D elements][4 chunks of 8 keys ^ (element >> 2) & 3]
+                d_ = p >> 2
+                koff.append(np.where(d_ < D, d_ * ldt2 + ((p & 3) ^ ((d_ >> 2) & 3)) * 16, 0xFFFFFF00).astype(np.uint32))
+                continue
             koff.append(np.where(chunk * 8 < D, key * ld2 + chunk * 16, 0xFFFFFF00).astype(np.uint32))
         while len(koff) < 4:
             koff.append(np.full(64, 0xFFFFFF00, np.uint32))
@@ -68,6 +80,10 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             "ta1": ((RING - 1) * STAGE + (trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8).astype(np.uint32),
             "qback": (back + 16 * lane).astype(np.uint32),
         })
+        if tr:
+            vstart = (RING - 1) * STAGE          # the V addresses start one stage behind, like ta0 / ta1 above
+            w.vn.update({"ka0": (w.vn["ta0"] - vstart).astype(np.uint32), "ka1": (w.vn["ta1"] - vstart).astype(np.uint32)})
+            w.vn.update({"ta%d" % c: (vstart + qq * 64 + ((c ^ ((qq >> 2) & 3)) * 16) + 8 * hi).astype(np.uint32) for c in range(4)})
         for i in range(4):
             w.vn["koff%d" % i], w.vn["voff%d" % i] = koff[i].copy(), koff[i].copy()
         for b in range(2):
@@ -80,8 +96,8 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         if causal:
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 32 + 1)) if wlast >= r0 else 1
-        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": 32 * ld2,
-                     "vinc": 32 * ld2, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom})
+        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": 64 if tr else 32 * ld2,
+                     "vinc": 64 if tr else 32 * ld2, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom})
     wg.run(order)
     O = np.zeros((256, D), np.float32)
     L = np.zeros(256, np.float32)

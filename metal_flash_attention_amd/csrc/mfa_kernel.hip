@@ -690,6 +690,18 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   LaunchPlan plan;
   mfa_status st = prepare_launch(kernel, buffers, params, &plan);
   if (st != MFA_OK) return st;
+#ifdef MFA_DEV_VARIANTS
+  // developer library, MFA_BWD16_TR=1: a transposed backward launch without a workspace tries the kernels that read the
+  // operands in place (attn_bwd16_p4_tr.hip; not in the product library until they have been measured)
+  if (plan.useFallback && kernel->relayout && kernel->desc.type != MFA_FORWARD && std::getenv("MFA_BWD16_TR") &&
+      bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, (hipStream_t)stream,
+                         kernel->desc.registerPrecisions[MFA_P] > MFA_FP32)) {
+    hipError_t derr = hipGetLastError();
+    if (std::strcmp(std::getenv("MFA_BWD16_TR"), "verbose") == 0)
+      std::fprintf(stderr, "mfa: %s on transposed operands in place\n", kernel->desc.type == MFA_BACKWARD_QUERY ? "attn_dq16_p4_tr" : "attn_dkv16_p4_tr");
+    return derr == hipSuccess ? MFA_OK : hip_fail(derr, "attn_bwd16_p4_tr");
+  }
+#endif
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
   for (int i = 0; i < plan.nRelayouts; ++i)

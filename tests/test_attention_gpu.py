@@ -820,6 +820,30 @@ def test_hand_placed_stream_with_one_transposed_operand(kv, low_mid, in_type):
         assert all(run.tails_ok.values())
 
 
+@needs_dev_library
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("causal", [False, True])
+def test_developer_backward_kernels_read_transposed_operands_in_place(causal, low_mid, monkeypatch, capfd, in_type=P.BF16):
+    """Developer library, MFA_BWD16_TR: the backward streams on transposed operands (K^T / V^T in backwardQuery, Q^T / dO^T in
+    backwardKeyValue; whole tiles, aligned rows) without a workspace -- model-verified streams behind developer-only kernels
+    (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h), not in the product library until measured.  Every operand transposed; results
+    against the oracle at the reference's mixed tolerances.  (BF16: with FP16 inputs the reference's descriptors store dO in BF16,
+    a mix these streams do not have yet.)"""
+    monkeypatch.setenv("MFA_BWD16_TR", "verbose")
+    for R, C, D in ((320, 448, 128), (256, 256, 104)):
+        net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
+        desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=(True, True, True, True))
+        run = harness.DeviceRun(desc, net, causal=causal)
+        got = run.execute()                      # no workspace
+        err = capfd.readouterr().err
+        assert "attn_dq16_p4_tr" in err and "attn_dkv16_p4_tr" in err, err
+        round_inputs(net, desc)
+        ref = net.run(causal=causal)
+        failures, report = harness.compare(ref, got, TOL_MIXED)
+        assert not failures, (failures, (R, C, D))
+        assert all(run.tails_ok.values()), run.tails_ok
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_transposed_multi_head_batches(causal):
     """Heads and batch entries of transposed operands ([batch][head][D][sequence]) through strides: the hand-placed stream on

@@ -101,6 +101,8 @@ bool dkv16_rs_variant_d192(int precision, int gprecision, VariantInfo *out);
 #ifdef MFA_DEV_VARIANTS
 // developer build: backward kernels that read transposed operands in place (attn_bwd16_p4_tr.hip); false = not such a launch
 bool bwd16_p4_tr_launch(int type, const KernelArgs &args, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold);
+// developer build: hand-placed forward kernel on transposed K / V at 128 < D <= 256 (attn_fwd16_p5_tr.hip)
+bool fwd16_p5_tr_launch(const KernelArgs &args, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold);
 #endif
 
 } // namespace mfa

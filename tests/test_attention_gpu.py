@@ -844,6 +844,31 @@ def test_developer_backward_kernels_read_transposed_operands_in_place(causal, lo
         assert all(run.tails_ok.values()), run.tails_ok
 
 
+@needs_dev_library
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("causal", [False, True])
+def test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions(causal, low_mid, monkeypatch, capfd):
+    """Developer library, MFA_FWD16_P5_TR: the hand-placed forward stream of the 160 / 192 / 256 buckets on K^T / V^T in place
+    (attn_fwd16_p5_tr.h; whole 32-key steps, aligned rows) -- model-verified streams behind a developer-only kernel, the product
+    library keeps the 8 x 32 kernel's transposed code object there until both have been timed.  Q / O row-major and transposed,
+    a head dimension inside each bucket and on its edge; against the oracle at the product tolerances of that path."""
+    monkeypatch.setenv("MFA_FWD16_P5_TR", "verbose")
+    for (R, C, D), in_type, tr in (((320, 448, 256), P.BF16, (True, True, True, True)), ((300, 352, 152), P.BF16, (False, True, True, False)),
+                                   ((256, 288, 192), P.FP16, (False, True, True, True)), ((264, 320, 232), P.FP16, (True, True, True, False))):
+        net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
+        desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=tr)
+        run = harness.DeviceRun(desc, net, run_backward=False, causal=causal)
+        got = run.execute()
+        err = capfd.readouterr().err
+        assert "attn_fwd16_p5_tr" in err, (err, (R, C, D))
+        round_inputs(net, desc)
+        ref = net.run(backward=False, causal=causal)
+        low_out = desc.memoryPrecisions[Op.O] != P.FP32
+        failures, report = harness.compare(ref, got, dict(O=3e-2 if low_out else 1.5e-2, L=7e-3 if low_mid else 2e-3))
+        assert not failures, (failures, (R, C, D), tr)
+        assert all(run.tails_ok.values()), run.tails_ok
+
+
 @pytest.mark.parametrize("causal", [False, True])
 def test_transposed_multi_head_batches(causal):
     """Heads and batch entries of transposed operands ([batch][head][D][sequence]) through strides: the hand-placed stream on

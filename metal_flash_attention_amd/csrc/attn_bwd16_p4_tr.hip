@@ -16,15 +16,15 @@ template <typename Kernel> static bool raise_lds(Kernel kernel, int bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
 }
 
-template <typename T, int STREAM> static bool launch_dq_tr(const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream) {
+template <typename T, int STREAM, typename TG = T> static bool launch_dq_tr(const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream) {
   const uint32_t blocks = (a.R + 255) / 256;
   Fwd16Grid g{blocks, heads, batches};
   if (a.causal) {
-    if (!raise_lds(&attn_dq16_p4_tr<T, STREAM, true>, dq4::LDS_BYTES)) return false;
-    hipLaunchKernelGGL((attn_dq16_p4_tr<T, STREAM, true>), dim3(blocks * heads * batches), dim3(256), dq4::LDS_BYTES, stream, a, g);
+    if (!raise_lds(&attn_dq16_p4_tr<T, STREAM, true, TG>, dq4::LDS_BYTES)) return false;
+    hipLaunchKernelGGL((attn_dq16_p4_tr<T, STREAM, true, TG>), dim3(blocks * heads * batches), dim3(256), dq4::LDS_BYTES, stream, a, g);
   } else {
-    if (!raise_lds(&attn_dq16_p4_tr<T, STREAM, false>, dq4::LDS_BYTES)) return false;
-    hipLaunchKernelGGL((attn_dq16_p4_tr<T, STREAM, false>), dim3(blocks * heads * batches), dim3(256), dq4::LDS_BYTES, stream, a, g);
+    if (!raise_lds(&attn_dq16_p4_tr<T, STREAM, false, TG>, dq4::LDS_BYTES)) return false;
+    hipLaunchKernelGGL((attn_dq16_p4_tr<T, STREAM, false, TG>), dim3(blocks * heads * batches), dim3(256), dq4::LDS_BYTES, stream, a, g);
   }
   return true;
 }
@@ -45,13 +45,16 @@ template <typename T, int STREAM> static bool launch_dkv_tr(const KernelArgs &a,
 // type: 1 = backwardQuery, 2 = backwardKeyValue (mfa_kernel_type); fold: the descriptor keeps the attention matrix in 16-bit registers
 bool bwd16_p4_tr_launch(int type, const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold) {
   const int p = a.op[SLOT_Q].precision;
-  if (p == PREC_FP32 || a.op[SLOT_K].precision != p || a.op[SLOT_V].precision != p || a.op[SLOT_dO].precision != p) return false;
+  const int pg = a.op[SLOT_dO].precision;
+  const bool gmix = p == PREC_FP16 && pg == PREC_BF16;   // the reference's own mix: FP16 Q, K, V with BF16 dO (+Precisions.swift:13-17)
+  if (p == PREC_FP32 || a.op[SLOT_K].precision != p || a.op[SLOT_V].precision != p || (pg != p && !gmix)) return false;
   if (a.rowLen || a.colLen || a.mask || a.D <= 64 || a.D > 128 || a.D % 8) return false;
   if (a.causal && a.C < a.R) return false;
   if (type == 1) {
     if (!a.op[SLOT_K].transposed || !a.op[SLOT_V].transposed || a.C % 64 != 0) return false;
     if (!rows_aligned(a.op[SLOT_K]) || !rows_aligned(a.op[SLOT_V])) return false;
     if (p == PREC_BF16) return fold ? launch_dq_tr<__bf16, dq4tr::S_BF16_FOLD_TR>(a, heads, batches, stream) : launch_dq_tr<__bf16, dq4tr::S_BF16_EXACT_TR>(a, heads, batches, stream);
+    if (gmix) return fold ? launch_dq_tr<_Float16, dq4tr::S_F16_FOLD_TR, __bf16>(a, heads, batches, stream) : launch_dq_tr<_Float16, dq4tr::S_F16_EXACT_TR, __bf16>(a, heads, batches, stream);
     return fold ? launch_dq_tr<_Float16, dq4tr::S_F16_FOLD_TR>(a, heads, batches, stream) : launch_dq_tr<_Float16, dq4tr::S_F16_EXACT_TR>(a, heads, batches, stream);
   }
   if (!a.op[SLOT_Q].transposed || !a.op[SLOT_dO].transposed || a.R % 32 != 0) return false;
@@ -60,6 +63,7 @@ bool bwd16_p4_tr_launch(int type, const KernelArgs &a, uint32_t heads, uint32_t 
   const bool mixed = lp == PREC_FP16 && dp == PREC_BF16, f32 = lp == PREC_FP32 && dp == PREC_FP32;
   if (!mixed && !f32) return false;
   if (p == PREC_BF16) return mixed ? launch_dkv_tr<__bf16, dkv4tr::S_BF16_MIXED_TR>(a, heads, batches, stream) : launch_dkv_tr<__bf16, dkv4tr::S_BF16_F32_TR>(a, heads, batches, stream);
+  if (gmix) return mixed ? launch_dkv_tr<_Float16, dkv4tr::S_F16_DOBF16_MIXED_TR>(a, heads, batches, stream) : launch_dkv_tr<_Float16, dkv4tr::S_F16_DOBF16_F32_TR>(a, heads, batches, stream);
   return mixed ? launch_dkv_tr<_Float16, dkv4tr::S_F16_MIXED_TR>(a, heads, batches, stream) : launch_dkv_tr<_Float16, dkv4tr::S_F16_F32_TR>(a, heads, batches, stream);
 }
 

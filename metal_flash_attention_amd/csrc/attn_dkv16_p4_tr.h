@@ -15,13 +15,20 @@
 namespace mfa {
 namespace dkv4tr {
 
-#define MFA_DKV4TR_ENUM(name, exact) S_##name,
+#define MFA_DKV4TR_ENUM(name, exact, mix) S_##name,
 enum : int { MFA_DKV4_TR_STREAM_LIST(MFA_DKV4TR_ENUM) S_COUNT };
 #undef MFA_DKV4TR_ENUM
 constexpr bool stream_exact(int s) {
-#define MFA_DKV4TR_EXACT(name, exact) if (s == S_##name) return exact != 0;
+#define MFA_DKV4TR_EXACT(name, exact, mix) if (s == S_##name) return exact != 0;
   MFA_DKV4_TR_STREAM_LIST(MFA_DKV4TR_EXACT)
 #undef MFA_DKV4TR_EXACT
+  return false;
+}
+// dO^T is BF16 next to FP16 Q^T, K, V (the reference's own low-precision mix; see stream_mix in attn_dkv16_p4.h)
+constexpr bool stream_mix(int s) {
+#define MFA_DKV4TR_MIX(name, exact, mix) if (s == S_##name) return mix != 0;
+  MFA_DKV4_TR_STREAM_LIST(MFA_DKV4TR_MIX)
+#undef MFA_DKV4TR_MIX
   return false;
 }
 
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_dkv16_p4_tr(const KernelArgs a, cons
   using namespace dkv4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = 128, NKS = 8, NDB = 4, WKEYS = 64, GKEYS = 256, BR = 32, PW = 2;
-  constexpr bool EXACT = dkv4tr::stream_exact(STREAM);
+  constexpr bool EXACT = dkv4tr::stream_exact(STREAM), MIX = dkv4tr::stream_mix(STREAM);
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,7 +98,8 @@ __global__ __launch_bounds__(256) void attn_dkv16_p4_tr(const KernelArgs a, cons
         const u32x4 vx = load16x8(vres, vT, ldv2, col, s);
         if constexpr (EXACT) *reinterpret_cast<u32x4 *>(back + (kb * 8 + s) * 1024) = kx;
         else *reinterpret_cast<u32x4 *>(back + (kb * 8 + s) * 1024) = p4::scale16x8<T>(kx, a.scale2);
-        *reinterpret_cast<u32x4 *>(back + (16 + kb * 8 + s) * 1024) = vx;
+        if constexpr (MIX) *reinterpret_cast<u32x4 *>(back + (16 + kb * 8 + s) * 1024) = __builtin_bit_cast(u32x4, convert_chunk<__bf16, T>(vx));
+        else *reinterpret_cast<u32x4 *>(back + (16 + kb * 8 + s) * 1024) = vx;
       }
     }
   }
@@ -142,15 +150,16 @@ __global__ __launch_bounds__(256) void attn_dkv16_p4_tr(const KernelArgs a, cons
   for (int c = 0; c < 4; ++c) ta[c] = lds0 + kc * 64 + ((c ^ ((kc >> 2) & 3)) * 16) + 8 * hi;
   const uint32_t kvback = lds0 + wave * 32768 + lane * 16;
   const uint32_t wr0 = lds0 + wave * (PW * 1024), ringend = lds0 + RING_BYTES;
-  const uint32_t onesw = hi ? 0u : (__is_same(T, __bf16) ? 0xBF80BF80u : 0xBC00BC00u);
+  const uint32_t onesw = hi ? 0u : (MIX ? 0xC000C000u : (__is_same(T, __bf16) ? 0xBF80BF80u : 0xBC00BC00u));   // (mix: -2.0, one pattern for both types)
   const int tk = (int)(c0 + kc - coff - 4 * hi - row_first);
-  const float rscale = 1.0f / a.scale, rscale2 = EXACT ? 1.0f / a.scale2 : 1.0f;
+  constexpr float half = MIX ? 0.5f : 1.0f;
+  const float rscale = half / a.scale, rscale2 = EXACT ? half / a.scale2 : half;
   const uint64_t scale2x2 = (uint64_t)__builtin_bit_cast(uint32_t, a.scale2) * 0x100000001ull;
 
   {
     uint32_t tj, tstg, tdelta, twr, tt0, tt1, tplast, tpa, tpb, tpc, tpd;
     uint64_t tptime;
-#define MFA_DKV4TR_RUN(name, exact) if constexpr (STREAM == dkv4tr::S_##name) MFA_DKV4TR_TRAVERSE(MFA_DKV4_STREAM_##name);
+#define MFA_DKV4TR_RUN(name, exact, mix) if constexpr (STREAM == dkv4tr::S_##name) MFA_DKV4TR_TRAVERSE(MFA_DKV4_STREAM_##name);
     MFA_DKV4_TR_STREAM_LIST(MFA_DKV4TR_RUN)
 #undef MFA_DKV4TR_RUN
   }

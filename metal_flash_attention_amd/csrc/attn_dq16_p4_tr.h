@@ -41,7 +41,7 @@ constexpr bool stream_exact(int s) {
                  [scale2x2] "s"(scale2x2)                                                                                \
                : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_DQ4_OWNED_VGPRS)
 
-template <typename T, int STREAM, bool CAUSAL>
+template <typename T, int STREAM, bool CAUSAL, typename TG = T>
 __global__ __launch_bounds__(256) void attn_dq16_p4_tr(const KernelArgs a, const Fwd16Grid grid) {
   using namespace dq4;
   typedef Frag16<T> F;
@@ -115,14 +115,14 @@ __global__ __launch_bounds__(256) void attn_dq16_p4_tr(const KernelArgs a, const
       constexpr int s = decltype(sc)::value;
       const u32x4 qx = load16x8(qres, qT, ldq2, row, s);
       const u32x4 gx = load16x8(gres, gT, ldg2, row, s);
-      const v8 g8 = __builtin_bit_cast(v8, gx);
+      const v8 g8 = convert_chunk<T, TG>(gx);   // (TG = __bf16 next to _Float16 Q / K / V: the reference's own mix, converted when loaded)
       float o[8];
       load_o8(row, s, o);
 #pragma unroll
       for (int i = 0; i < 8; ++i) dterm[b] += (float)g8[i] * o[i];
       if constexpr (EXACT) p4::acc_write4<Q_BASE + 4 * (b * 8 + s)>(qx);
       else p4::acc_write4<Q_BASE + 4 * (b * 8 + s)>(p4::scale16x8<T>(qx, a.scale2));
-      p4::acc_write4<G_BASE + 4 * (b * 8 + s)>(gx);
+      p4::acc_write4<G_BASE + 4 * (b * 8 + s)>(__builtin_bit_cast(u32x4, g8));
     });
   });
   float negl[2], negd[2];

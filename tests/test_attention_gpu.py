@@ -823,12 +823,14 @@ def test_hand_placed_stream_with_one_transposed_operand(kv, low_mid, in_type):
 @needs_dev_library
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
-def test_developer_backward_kernels_read_transposed_operands_in_place(causal, low_mid, monkeypatch, capfd, in_type=P.BF16):
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+def test_developer_backward_kernels_read_transposed_operands_in_place(causal, low_mid, in_type, monkeypatch, capfd):
     """Developer library, MFA_BWD16_TR: the backward streams on transposed operands (K^T / V^T in backwardQuery, Q^T / dO^T in
     backwardKeyValue; whole tiles, aligned rows) without a workspace -- model-verified streams behind developer-only kernels
     (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h), not in the product library until measured.  Every operand transposed; results
-    against the oracle at the reference's mixed tolerances.  (BF16: with FP16 inputs the reference's descriptors store dO in BF16,
-    a mix these streams do not have yet.)"""
+    against the oracle at the reference's mixed tolerances.  With FP16 inputs the reference's descriptors store dO in BF16
+    (+Precisions.swift:13-17): backwardQuery converts the fragments when it loads them, backwardKeyValue runs the two products
+    that read dO^T in BF16 (streams F16_DOBF16_*_TR)."""
     monkeypatch.setenv("MFA_BWD16_TR", "verbose")
     for R, C, D in ((320, 448, 128), (256, 256, 104)):
         net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)

@@ -62,12 +62,13 @@ def test_exact_stream_is_closer():
 
 
 @pytest.mark.parametrize("name,dma_mode,order", [("BF16_MIXED_TR", "early", (3, 2, 1, 0)), ("BF16_F32_TR", "late", (0, 1, 2, 3)),
-                                                 ("F16_MIXED_TR", "late", (0, 1, 2, 3)), ("F16_F32_TR", "early", (3, 2, 1, 0))])
+                                                 ("F16_MIXED_TR", "late", (0, 1, 2, 3)), ("F16_F32_TR", "early", (3, 2, 1, 0)),
+                                                 ("F16_DOBF16_MIXED_TR", "early", (0, 1, 2, 3)), ("F16_DOBF16_F32_TR", "late", (3, 2, 1, 0))])
 def test_transposed_query_gradient_streams(name, dma_mode, order):
     """Q and dO handed over TRANSPOSED ([128][R], whole 32-row steps): a step's tile in the source orientation is the same
     [4][32][64 bytes] image with the two read recipes' roles exchanged -- Q / dO row fragments by transposing reads (K' and V in
-    their element order), dO^T / Q^T fragments as two 8-byte reads in the order P and dS' hold their rows.  Model-verified streams
-    (no kernel behind them yet): step counts across two ring wraps, ragged key blocks, causal, DMA early / late,
+    their element order), dO^T / Q^T fragments as two 8-byte reads in the order P and dS' hold their rows; with BF16 dO^T next to FP16
+    operands the two products that read it run in BF16.  Model-verified streams (developer kernels only): step counts across two ring wraps, ragged key blocks, causal, DMA early / late,
     waves in either order."""
     cfg = dkv4gen.TR_VARIANTS[name]
     for R, C, cblk, causal in ((32, 256, 0, False), (320, 256, 0, False), (96, 200, 0, False), (512, 512, 1, True), (288, 448, 1, True)):

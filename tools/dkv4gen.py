@@ -599,10 +599,10 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.prof, cfg.exact, cfg.mix, cfg.D))
     lines.append("")
-    lines.append("// transposed Q / dO (model-verified, no kernel yet): X(name, applies the softmax scale in fp32)")
+    lines.append("// transposed Q / dO (developer kernels only): X(name, applies the softmax scale in fp32, dO is BF16 next to FP16 Q / K / V)")
     lines.append("#define MFA_DKV4_TR_STREAM_LIST(X) \\")
     for name, cfg in TR_VARIANTS.items():
-        lines.append("  X(%s, %d) \\" % (name, cfg.exact))
+        lines.append("  X(%s, %d, %d) \\" % (name, cfg.exact, int(cfg.mix)))
     lines.append("")
     lines.append("")
     for name, cfg in list(VARIANTS.items()) + list(TR_VARIANTS.items()):
@@ -641,6 +641,8 @@ TR_VARIANTS = {
     "F16_MIXED_TR": Cfg("f16", "f16", "bf16", tr=1),
     "BF16_F32_TR": Cfg("bf16", "f32", "f32", exact=1, tr=1),
     "F16_F32_TR": Cfg("f16", "f32", "f32", exact=1, tr=1),
+    "F16_DOBF16_MIXED_TR": Cfg("f16", "f16", "bf16", gdtype="bf16", tr=1),   # (the two products that read dO^T run in BF16)
+    "F16_DOBF16_F32_TR": Cfg("f16", "f32", "f32", exact=1, gdtype="bf16", tr=1),
 }
 
 if __name__ == "__main__":

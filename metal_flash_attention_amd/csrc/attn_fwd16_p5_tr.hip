@@ -1,52 +1,81 @@
-// attn_fwd16_p5_tr.hip -- DEVELOPER BUILD ONLY: launcher of the hand-placed forward kernel for transposed K and V at the
-// head-dimension buckets 160 / 192 / 256 (attn_fwd16_p5_tr.h).  Reached from mfa_attention_kernel_launch when the developer
-// library runs with MFA_FWD16_P5_TR=1 (the product library launches the 8 x 32 kernel's transposed code object there);
-// false = not a launch this kernel takes.
+// attn_fwd16_p5_tr.hip -- DEVELOPER BUILD ONLY (DEV_ONLY_HIP in the Makefile) until the product library's evidence is re-taken
+// with it: instantiations of the hand-placed forward kernel for transposed K and V at the head-dimension
+// buckets 160 / 192 / 256 (attn_fwd16_p5_tr.h) and the launcher that prefers it over the 8 x 32 kernel's transposed code object
+// when the launch is whole 32-key steps of aligned rows -- the same arrangement as attn_fwd16_p4_tr.hip at D <= 128.
+#include <cstdlib>
+#include <cstring>
 #include "attn_fwd16_p5_tr.h"
 #include "launchers.h"
 
 namespace mfa {
 
-static bool rows_aligned16(const OperandView &v) {
-  return ((reinterpret_cast<uintptr_t>(v.ptr) | (uint64_t)v.ld * 2 | (uint64_t)v.headStride * 2 | (uint64_t)v.batchStride * 2) & 15) == 0;
-}
+typedef void (*LaunchFn)(dim3 grid, hipStream_t stream, const KernelArgs &args);
+// the launcher of the code object `out` arrived with (fwd16_v3_tr_variant_dNN, pattern K^T + V^T): one per (type, stream)
+template <typename T, int STREAM> struct P5TrFallback { static LaunchFn launch; };
+template <typename T, int STREAM> LaunchFn P5TrFallback<T, STREAM>::launch = nullptr;
 
-template <typename T, int STREAM> static bool launch_p5_tr(const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream) {
-  const uint32_t blocks = (a.R + 255) / 256;
-  Fwd16Grid g{blocks, heads, batches};
-  auto raise = [](const void *f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, p5::LDS_BYTES) == hipSuccess; };
-  if (a.causal) {
-    if (!raise(reinterpret_cast<const void *>(&attn_fwd16_p5_tr<T, STREAM, true>))) return false;
-    hipLaunchKernelGGL((attn_fwd16_p5_tr<T, STREAM, true>), dim3((blocks + 1) / 2 * heads * batches), dim3(256), p5::LDS_BYTES, stream, a, g);
-  } else {
-    if (!raise(reinterpret_cast<const void *>(&attn_fwd16_p5_tr<T, STREAM, false>))) return false;
-    hipLaunchKernelGGL((attn_fwd16_p5_tr<T, STREAM, false>), dim3(blocks * heads * batches), dim3(256), p5::LDS_BYTES, stream, a, g);
-  }
-  return true;
-}
-
-// fold: the descriptor keeps the attention matrix in 16-bit registers (Q pre-multiplied by the softmax scale in the 16-bit type)
-bool fwd16_p5_tr_launch(const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold) {
-  const int p = a.op[SLOT_Q].precision;
-  if (p == PREC_FP32 || a.op[SLOT_K].precision != p || a.op[SLOT_V].precision != p) return false;
+// what the step walk of attn_fwd16_p5_tr needs (its header): K^T and V^T, no per-batch lengths, no block mask, whole 32-key
+// steps, 16-byte aligned rows of K^T / V^T (and of Q when it is row-major: its fragments are 8-byte loads; Q^T is gathered)
+static bool p5_tr_takes(const KernelArgs &a) {
+#ifdef MFA_DEV_VARIANTS
+  const char *knob = std::getenv("MFA_FWD16_P5_TR");   // developer library: MFA_FWD16_P5_TR=0 keeps the 8 x 32 code object (A/B runs)
+  if (knob && std::strcmp(knob, "0") == 0) return false;
+#endif
+  auto aligned = [](const OperandView &v) {
+    return ((reinterpret_cast<uintptr_t>(v.ptr) | (uint64_t)v.ld * 2 | (uint64_t)v.headStride * 2 | (uint64_t)v.batchStride * 2) & 15) == 0;
+  };
   if (a.rowLen || a.colLen || a.mask || a.D <= 128 || a.D > 256 || a.D % 8 || a.C % 32 || a.C == 0) return false;
   if (a.causal && a.C < a.R) return false;
   if (!a.op[SLOT_K].transposed || !a.op[SLOT_V].transposed) return false;
-  if (!rows_aligned16(a.op[SLOT_K]) || !rows_aligned16(a.op[SLOT_V])) return false;
-  if (!a.op[SLOT_Q].transposed && !rows_aligned16(a.op[SLOT_Q])) return false;
-  const int bucket = a.D <= 160 ? 160 : a.D <= 192 ? 192 : 256;
-#define MFA_P5TR_PICK(T, TN)                                                                                                  \
-  switch (bucket) {                                                                                                           \
-    case 160: return fold ? launch_p5_tr<T, p5tr::S_D160_##TN##_FOLD_TR>(a, heads, batches, stream)                            \
-                          : launch_p5_tr<T, p5tr::S_D160_##TN##_THR8_TR>(a, heads, batches, stream);                           \
-    case 192: return fold ? launch_p5_tr<T, p5tr::S_D192_##TN##_FOLD_TR>(a, heads, batches, stream)                            \
-                          : launch_p5_tr<T, p5tr::S_D192_##TN##_THR8_TR>(a, heads, batches, stream);                           \
-    default: return fold ? launch_p5_tr<T, p5tr::S_D256_##TN##_FOLD_TR>(a, heads, batches, stream)                             \
-                         : launch_p5_tr<T, p5tr::S_D256_##TN##_THR8_TR>(a, heads, batches, stream);                            \
+  if (!aligned(a.op[SLOT_K]) || !aligned(a.op[SLOT_V])) return false;
+  return a.op[SLOT_Q].transposed || aligned(a.op[SLOT_Q]);
+}
+
+template <typename T, int STREAM>
+static void launch_p5_tr(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if (!p5_tr_takes(args)) { P5TrFallback<T, STREAM>::launch(grid, stream, args); return; }
+  // grid arrives in the 8 x 32 kernel's row blocks (VariantInfo.parallelization); this kernel's are 256 rows
+  const uint32_t blocks = ((uint32_t)args.R + 255) / 256;
+  Fwd16Grid g{blocks, grid.y, grid.z};
+  if (args.causal) {
+    const uint32_t groups = (blocks + 1) / 2;   // one workgroup per pair of row blocks (last - i, i)
+    hipLaunchKernelGGL((attn_fwd16_p5_tr<T, STREAM, true>), dim3(groups * grid.y * grid.z), dim3(256), p5::LDS_BYTES, stream, args, g);
+  } else {
+    hipLaunchKernelGGL((attn_fwd16_p5_tr<T, STREAM, false>), dim3(blocks * grid.y * grid.z), dim3(256), p5::LDS_BYTES, stream, args, g);
   }
-  if (p == PREC_BF16) { MFA_P5TR_PICK(__bf16, BF16) }
-  MFA_P5TR_PICK(_Float16, F16)
-#undef MFA_P5TR_PICK
+}
+
+template <typename T, int STREAM> static const char *p5_tr_form(const KernelArgs &args) {
+  if (!p5_tr_takes(args)) return nullptr;
+  return p5tr::stream_folds(STREAM) ? "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed K / V; scale folded into Q)"
+                                     : "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed K / V)";
+}
+
+template <typename T, int STREAM> static void attach(VariantInfo *v) {
+  P5TrFallback<T, STREAM>::launch = v->launch;
+  v->launch = &launch_p5_tr<T, STREAM>;
+  v->launchForm = &p5_tr_form<T, STREAM>;
+  // (fields that only name code objects whose LDS limit must be raised before the first launch)
+  v->funcCausal = reinterpret_cast<const void *>(&attn_fwd16_p5_tr<T, STREAM, true>);
+  v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_p5_tr<T, STREAM, false>);
+  v->ldsBytes = v->ldsBytes > (uint32_t)p5::LDS_BYTES ? v->ldsBytes : (uint32_t)p5::LDS_BYTES;
+}
+
+// `out` arrives filled by fwd16_v3_tr_variant_d160 / _d192 / _d256 for the pattern K^T + V^T: launches the stream can take go to
+// it, the others stay.  fold: Q pre-multiplied by the softmax scale in the 16-bit type (mixed-precision descriptors)
+bool fwd16_p5_tr_variant(int precision, int bucket, bool fold, VariantInfo *out) {
+  if (!out->launch || out->launchCausal || out->launchSplit) return false;   // (the transposed code objects take the causal flag at run time and are never split)
+#define MFA_P5TR_ATTACH(T, TN)                                                                                               \
+  switch (bucket) {                                                                                                          \
+    case 160: if (fold) attach<T, p5tr::S_D160_##TN##_FOLD_TR>(out); else attach<T, p5tr::S_D160_##TN##_THR8_TR>(out); return true; \
+    case 192: if (fold) attach<T, p5tr::S_D192_##TN##_FOLD_TR>(out); else attach<T, p5tr::S_D192_##TN##_THR8_TR>(out); return true; \
+    case 256: if (fold) attach<T, p5tr::S_D256_##TN##_FOLD_TR>(out); else attach<T, p5tr::S_D256_##TN##_THR8_TR>(out); return true; \
+    default: return false;                                                                                                   \
+  }
+  if (precision == PREC_BF16) { MFA_P5TR_ATTACH(__bf16, BF16) }
+  if (precision == PREC_FP16) { MFA_P5TR_ATTACH(_Float16, F16) }
+#undef MFA_P5TR_ATTACH
+  return false;
 }
 
 } // namespace mfa

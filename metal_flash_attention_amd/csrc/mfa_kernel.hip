@@ -142,9 +142,15 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           add(have, v);
           break;
         }
-        case 160: add(fwd16_v3_tr_variant_d160(pq, b16, pattern, &v), v); break;
-        case 192: add(fwd16_v3_tr_variant_d192(pq, b16, pattern, &v), v); break;
-        default: add(fwd16_v3_tr_variant_d256(pq, b16, pattern, &v), v); break;
+        default: {
+          bool have = b16 == 160 ? fwd16_v3_tr_variant_d160(pq, b16, pattern, &v)
+                    : b16 == 192 ? fwd16_v3_tr_variant_d192(pq, b16, pattern, &v) : fwd16_v3_tr_variant_d256(pq, b16, pattern, &v);
+#ifdef MFA_DEV_VARIANTS   // (developer library until the product library's evidence is re-taken with it)
+          if (have && pattern == 3) fwd16_p5_tr_variant(pq, b16, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
+#endif
+          add(have, v);
+          break;
+        }
       }
     } else if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
       VariantInfo v3;
@@ -700,14 +706,6 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
     if (std::strcmp(std::getenv("MFA_BWD16_TR"), "verbose") == 0)
       std::fprintf(stderr, "mfa: %s on transposed operands in place\n", kernel->desc.type == MFA_BACKWARD_QUERY ? "attn_dq16_p4_tr" : "attn_dkv16_p4_tr");
     return derr == hipSuccess ? MFA_OK : hip_fail(derr, "attn_bwd16_p4_tr");
-  }
-  // developer library, MFA_FWD16_P5_TR=1: forward launches on transposed K / V at 128 < D <= 256 try the hand-placed stream
-  // (attn_fwd16_p5_tr.hip) before the 8 x 32 kernel's transposed code object
-  if (kernel->desc.type == MFA_FORWARD && plan.splits <= 1 && plan.nRelayouts == 0 && std::getenv("MFA_FWD16_P5_TR") &&
-      fwd16_p5_tr_launch(plan.args, plan.heads, plan.batches, (hipStream_t)stream, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32)) {
-    hipError_t derr = hipGetLastError();
-    if (std::strcmp(std::getenv("MFA_FWD16_P5_TR"), "verbose") == 0) std::fprintf(stderr, "mfa: attn_fwd16_p5_tr on transposed operands in place\n");
-    return derr == hipSuccess ? MFA_OK : hip_fail(derr, "attn_fwd16_p5_tr");
   }
 #endif
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);

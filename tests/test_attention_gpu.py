@@ -850,19 +850,23 @@ def test_developer_backward_kernels_read_transposed_operands_in_place(causal, lo
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
 def test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions(causal, low_mid, monkeypatch, capfd):
-    """Developer library, MFA_FWD16_P5_TR: the hand-placed forward stream of the 160 / 192 / 256 buckets on K^T / V^T in place
-    (attn_fwd16_p5_tr.h; whole 32-key steps, aligned rows) -- model-verified streams behind a developer-only kernel, the product
-    library keeps the 8 x 32 kernel's transposed code object there until both have been timed.  Q / O row-major and transposed,
-    a head dimension inside each bucket and on its edge; against the oracle at the product tolerances of that path."""
-    monkeypatch.setenv("MFA_FWD16_P5_TR", "verbose")
+    """Developer library: the hand-placed forward stream of the 160 / 192 / 256 buckets on K^T / V^T in place (attn_fwd16_p5_tr.h;
+    whole 32-key steps, aligned rows), attached to the transposed variants the way attn_fwd16_p4_tr is at D <= 128 -- the product
+    library keeps the 8 x 32 kernel's transposed code object there until its evidence is re-taken.  Q / O
+    row-major and transposed, a head dimension inside each bucket and on its edge; against the oracle at the product tolerances of
+    that path; MFA_FWD16_P5_TR=0 (A/B knob of the developer library) and a launch that is not whole steps keep the 8 x 32 object."""
     for (R, C, D), in_type, tr in (((320, 448, 256), P.BF16, (True, True, True, True)), ((300, 352, 152), P.BF16, (False, True, True, False)),
                                    ((256, 288, 192), P.FP16, (False, True, True, True)), ((264, 320, 232), P.FP16, (True, True, True, False))):
         net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
         desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=tr)
         run = harness.DeviceRun(desc, net, run_backward=False, causal=causal)
+        k = run.kernels[AttentionKernelType.forward]
+        form = k.launchForm(run.buffers, row=R, column=C, causal=causal)
+        assert k.variant.endswith("_tr_kv") and form.startswith("attn_fwd16_p5_tr") and ("folded" in form) == low_mid, (k.variant, form)
+        monkeypatch.setenv("MFA_FWD16_P5_TR", "0")
+        assert k.launchForm(run.buffers, row=R, column=C, causal=causal).startswith("attn_fwd16v3")
+        monkeypatch.delenv("MFA_FWD16_P5_TR")
         got = run.execute()
-        err = capfd.readouterr().err
-        assert "attn_fwd16_p5_tr" in err, (err, (R, C, D))
         round_inputs(net, desc)
         ref = net.run(backward=False, causal=causal)
         low_out = desc.memoryPrecisions[Op.O] != P.FP32

@@ -282,6 +282,36 @@ def test_transposed_descriptors_select_the_in_place_forward_code_objects():
     assert k.variant.startswith("attn_generic")
 
 
+def test_developer_library_routes_transposed_keys_and_values_at_large_head_dimensions_to_the_stream():
+    """Developer library only (MFA_LIBRARY=.../libmfa_hip_dev.so; skipped on the product library, which keeps the 8 x 32 kernel's
+    transposed code object at these buckets until its evidence is re-taken): K^T + V^T at the buckets
+    160 / 192 / 256 keep their variant, and a launch of whole 32-key steps of aligned rows is handed to attn_fwd16_p5_tr -- planned
+    without a GPU (host pointers only decide the alignment)."""
+    from metal_flash_attention_amd import _abi
+    if "libmfa_hip_dev" not in os.path.basename(_abi.library_path()):
+        pytest.skip("developer library")
+    torch = pytest.importorskip("torch")
+    N = 512
+    for D, bucket in ((136, 160), (192, 192), (200, 256), (256, 256)):
+        for low_mid in (False, True):
+            d = _desc(dims=(N, N, D), low_in=True, low_mid=low_mid, in_type=P.BF16, tr=(False, True, True, False))
+            k = AttentionKernel(d.kernelDescriptor(T.forward))
+            assert k.variant.startswith("attn_fwd16v3_bf16_d%d_" % bucket) and k.variant.endswith("_tr_kv")
+            for C, stream in ((512, True), (520, False), (32, True)):
+                b = {Op.Q: torch.zeros((N, D), dtype=torch.bfloat16), Op.K: torch.zeros((D, C), dtype=torch.bfloat16),
+                     Op.V: torch.zeros((D, C), dtype=torch.bfloat16), Op.O: torch.zeros((N, D)),
+                     Op.L: torch.zeros(N, dtype=torch.float16 if low_mid else torch.float32)}
+                form = k.launchForm(b, row=N, column=C)
+                assert form.startswith("attn_fwd16_p5_tr" if stream else "attn_fwd16v3"), (D, C, form)
+                assert not stream or ("folded" in form) == low_mid
+    # one operand transposed: no stream at these buckets yet
+    d = _desc(dims=(N, N, 256), low_in=True, in_type=P.BF16, tr=(False, True, False, False))
+    k = AttentionKernel(d.kernelDescriptor(T.forward))
+    b = {Op.Q: torch.zeros((N, 256), dtype=torch.bfloat16), Op.K: torch.zeros((256, N), dtype=torch.bfloat16),
+         Op.V: torch.zeros((N, 256), dtype=torch.bfloat16), Op.O: torch.zeros((N, 256)), Op.L: torch.zeros(N)}
+    assert k.launchForm(b, row=N, column=N).startswith("attn_fwd16v3")
+
+
 def test_low_precision_intermediates_select_the_folded_scale_stream():
     """S and P in FP32 registers (lowPrecisionIntermediates = false): the scale is applied in fp32 per score; with
     lowPrecisionIntermediates the reference itself keeps S / P in 16 bits (+Precisions.swift:149-215) and the kernel may

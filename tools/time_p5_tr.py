@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer library only (MFA_LIBRARY=.../libmfa_hip_dev.so): forward on K^T / V^T in place at the head-dimension buckets
 160 / 192 / 256 -- the 8 x 32 kernel's transposed code object (what the product library launches) against the hand-placed
-stream attn_fwd16_p5_tr (MFA_FWD16_P5_TR), same buffers, torch events around back-to-back launches on the current stream."""
+stream attn_fwd16_p5_tr (the developer library's choice; MFA_FWD16_P5_TR=0 turns it off), same buffers, torch events around back-to-back launches on the current stream."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,8 +27,8 @@ for N, D in ((8192, 256), (8192, 192), (8192, 160)):
         s = torch.cuda.current_stream().cuda_stream
         out, res = {}, {}
         for name in ("8x32", "stream"):
-            if name == "stream": os.environ["MFA_FWD16_P5_TR"] = "1"
-            else: os.environ.pop("MFA_FWD16_P5_TR", None)
+            if name == "stream": os.environ.pop("MFA_FWD16_P5_TR", None)
+            else: os.environ["MFA_FWD16_P5_TR"] = "0"    # the developer library's A/B knob: keep the 8 x 32 code object
             for _ in range(2): k.dispatch(b, stream=s, **args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -16,17 +16,17 @@
 namespace mfa {
 namespace p5tr {
 
-#define MFA_P5TR_ENUM(name, fold, d) S_##name,
+#define MFA_P5TR_ENUM(name, fold, d, pattern) S_##name,
 enum : int { MFA_P5_TR_STREAM_LIST(MFA_P5TR_ENUM) S_COUNT };
 #undef MFA_P5TR_ENUM
 constexpr bool stream_folds(int s) {
-#define MFA_P5TR_FOLDS(name, fold, d) if (s == S_##name) return fold != 0;
+#define MFA_P5TR_FOLDS(name, fold, d, pattern) if (s == S_##name) return fold != 0;
   MFA_P5_TR_STREAM_LIST(MFA_P5TR_FOLDS)
 #undef MFA_P5TR_FOLDS
   return false;
 }
 constexpr int stream_bucket(int s) {
-#define MFA_P5TR_BUCKET(name, fold, d) if (s == S_##name) return d;
+#define MFA_P5TR_BUCKET(name, fold, d, pattern) if (s == S_##name) return d;
   MFA_P5_TR_STREAM_LIST(MFA_P5TR_BUCKET)
 #undef MFA_P5TR_BUCKET
   return 256;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p5_tr(const KernelArgs a, cons
   if (nt > 0) {
     uint32_t tj, tstg, tdelta, tdeltav, twr, tpend, tt0, tt1, tplast, tpa, tpb;
     uint64_t tsv, tptime;
-#define MFA_P5TR_RUN(name, fold, d) if constexpr (STREAM == p5tr::S_##name) MFA_P5TR_TRAVERSE(MFA_P5_STREAM_##name);
+#define MFA_P5TR_RUN(name, fold, d, pattern) if constexpr (STREAM == p5tr::S_##name) MFA_P5TR_TRAVERSE(MFA_P5_STREAM_##name);
     MFA_P5_TR_STREAM_LIST(MFA_P5TR_RUN)
 #undef MFA_P5TR_RUN
   } else {   // no keys: O = 0

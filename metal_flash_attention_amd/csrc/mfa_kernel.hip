@@ -142,15 +142,19 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           add(have, v);
           break;
         }
+#ifdef MFA_DEV_VARIANTS   // (developer library until the product library's evidence is re-taken with it, DESIGN.md 10 item 4)
         default: {
           bool have = b16 == 160 ? fwd16_v3_tr_variant_d160(pq, b16, pattern, &v)
                     : b16 == 192 ? fwd16_v3_tr_variant_d192(pq, b16, pattern, &v) : fwd16_v3_tr_variant_d256(pq, b16, pattern, &v);
-#ifdef MFA_DEV_VARIANTS   // (developer library until the product library's evidence is re-taken with it, DESIGN.md 10 item 4)
           if (have && pattern == 3) fwd16_p5_tr_variant(pq, b16, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
-#endif
           add(have, v);
           break;
         }
+#else
+        case 160: add(fwd16_v3_tr_variant_d160(pq, b16, pattern, &v), v); break;
+        case 192: add(fwd16_v3_tr_variant_d192(pq, b16, pattern, &v), v); break;
+        default: add(fwd16_v3_tr_variant_d256(pq, b16, pattern, &v), v); break;
+#endif
       }
     } else if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
       VariantInfo v3;

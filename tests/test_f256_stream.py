@@ -74,6 +74,24 @@ def test_transposed_key_value_streams(name):
     assert wg.waves[0].count.get("ds_read_b128", 0) == 2 * cfg.nks and wg.waves[0].count["ds_read_b64"] > 0
 
 
+@pytest.mark.parametrize("name", ["D256_BF16_THR8_TRK", "D256_F16_FOLD_TRV", "D192_BF16_FOLD_TRK", "D160_F16_THR8_TRV",
+                                  "D160_BF16_FOLD_TRK", "D192_F16_THR8_TRV"])
+def test_streams_with_one_transposed_operand(name):
+    """K^T alone or V^T alone (Cfg.tr is a bit mask like tools/p4gen.py's): the halves of a step's fragment list are independent --
+    the transposed operand takes the exchanged read recipe (and, for V^T, four addresses), the other keeps the row-major one.
+    Model-only streams (f256gen.MODEL_ONLY_VARIANTS: not in the generated file until a kernel uses them)."""
+    cfg = f256gen.MODEL_ONLY_VARIANTS[name]
+    for R, C, rblk, causal, mode in ((256, 32, 0, False, "late"), (256, 288, 0, False, "early"), (200, 160, 0, False, "late"),
+                                     (512, 512, 1, True, "early")):
+        wg = _check(R, C, rblk=rblk, causal=causal, cfg=cfg, seed=16, dma_mode=mode, order=(3, 2, 1, 0) if mode == "early" else (0, 1, 2, 3))
+    _check(256, 160, cfg=cfg, spike=(5, 100, 3.0), seed=17, tol_o=1.2e-2)
+    count = wg.waves[0].count
+    if cfg.kt:     # K^T by transposing reads, V^T fragments of the row-major V too: no 16-byte read beyond the Q' hand-over
+        assert count.get("ds_read_b128", 0) == 2 * cfg.nks and "ds_read_b64" not in count
+    else:          # K rows 16 bytes at a time, V^T 8 bytes at a time: no transposing read at all
+        assert count["ds_read_b128"] > 2 * cfg.nks and count["ds_read_b64"] > 0 and "ds_read_b64_tr_b16" not in count
+
+
 def test_stream_file_is_current():
     """csrc/attn_fwd16_p5_stream.inc is what tools/f256gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p5_stream.inc")

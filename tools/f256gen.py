@@ -72,7 +72,9 @@ class Cfg:
         # two read recipes exchanged: K row fragments by transposing reads (ka0 / ka1 = rows + 0 / + 8 of a 16-element step; the
         # kernel parks the Q' fragments in the element order they return), V^T fragments as two 8-byte reads of the lane's
         # element row, chunks 2 u and 2 u + 1 at 8 hi (four addresses ta0..ta3).  Whole steps only (C % 32 == 0).
-        self.tr = tr
+        # tr is a bit mask like tools/p4gen.py's: bit 0 = K, bit 1 = V transposed -- the two halves of a step's fragment list are
+        # independent, an operand that is NOT transposed keeps the row-major recipe (and its two addresses).
+        self.tr, self.kt, self.vt = tr, bool(tr & 1), bool(tr & 2)
         assert D % 32 == 0 and (self.nks + 2 * self.ndb) % 4 == 0
 
 
@@ -116,16 +118,16 @@ class Stream(_P4Stream):
     # ---- fragment i of a step: 0..nks-1 K rows (k-step i) of the step's own tile, then 2 ndb V^T fragments (u, db) of the PREVIOUS tile
     def frag_read(self, i):
         nks, ndb = self.cfg.nks, self.cfg.ndb
-        if self.cfg.tr:
-            if i < nks:
-                off = (i >> 1) * 2048 + (i & 1) * 1024
-                self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ka0"), off, note="K^T rows ks%d" % i)
-                self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ka1"), off)
-            else:
-                u, db = divmod(i - nks, ndb)
-                off = VIMG + db * 2048
-                self.lds_read("ds_read_b64", af_half(i, 0), VN("ta%d" % (2 * u)), off, note="V u%d db%d" % (u, db))
-                self.frag_rid[i] = self.lds_read("ds_read_b64", af_half(i, 1), VN("ta%d" % (2 * u + 1)), off)
+        if i < nks and self.cfg.kt:
+            off = (i >> 1) * 2048 + (i & 1) * 1024
+            self.lds_read("ds_read_b64_tr_b16", af_half(i, 0), VN("ka0"), off, note="K^T rows ks%d" % i)
+            self.frag_rid[i] = self.lds_read("ds_read_b64_tr_b16", af_half(i, 1), VN("ka1"), off)
+            return
+        if i >= nks and self.cfg.vt:
+            u, db = divmod(i - nks, ndb)
+            off = VIMG + db * 2048
+            self.lds_read("ds_read_b64", af_half(i, 0), VN("ta%d" % (2 * u)), off, note="V u%d db%d" % (u, db))
+            self.frag_rid[i] = self.lds_read("ds_read_b64", af_half(i, 1), VN("ta%d" % (2 * u + 1)), off)
             return
         if i < nks:
             self.frag_rid[i] = self.lds_read("ds_read_b128", af(i), VN("ka%d" % (i & 1)), (i >> 1) * 2048, note="K rows ks%d" % i)
@@ -283,7 +285,7 @@ class Stream(_P4Stream):
                 at(seam_gap + 1 + 2 * i, lambda i=i: self.frag_read(i))
             # the V^T addresses move once the last fragment of this step is requested (gap seam_gap - 1)
             at(seam_gap + 2, lambda: [self.emit("v_add_u32", VN(n), [SN("deltav"), VN(n)])
-                                      for n in (("ta0", "ta1", "ta2", "ta3") if cfg.tr else ("ta0", "ta1"))])
+                                      for n in (("ta0", "ta1", "ta2", "ta3") if cfg.vt else ("ta0", "ta1"))])
         for g in range(nb):
             if mfma:
                 u, db, rb = g // (2 * ndb), (g % (2 * ndb)) // 2, g % 2
@@ -543,10 +545,10 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.fold, cfg.prof, cfg.D))
     lines.append("")
-    lines.append("// transposed K / V (model-verified, no kernel yet): X(name, folds, head-dimension bucket)")
+    lines.append("// transposed K and / or V (developer kernels only): X(name, folds, head-dimension bucket, pattern: bit 0 = K, bit 1 = V)")
     lines.append("#define MFA_P5_TR_STREAM_LIST(X) \\")
     for name, cfg in TR_VARIANTS.items():
-        lines.append("  X(%s, %d, %d) \\" % (name, cfg.fold, cfg.D))
+        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.fold, cfg.D, cfg.tr))
     lines.append("")
     lines.append("")
     for name, cfg in list(VARIANTS.items()) + list(TR_VARIANTS.items()):
@@ -578,8 +580,16 @@ for _d in (192, 160):       # the head-dimension buckets between 128 and 256
 TR_VARIANTS = {}
 for _d in (256, 192, 160):
     for _t in ("bf16", "f16"):
-        TR_VARIANTS["D%d_%s_THR8_TR" % (_d, _t.upper())] = Cfg(_t, D=_d, tr=1)
-        TR_VARIANTS["D%d_%s_FOLD_TR" % (_d, _t.upper())] = Cfg(_t, fold=1, D=_d, tr=1)
+        TR_VARIANTS["D%d_%s_THR8_TR" % (_d, _t.upper())] = Cfg(_t, D=_d, tr=3)
+        TR_VARIANTS["D%d_%s_FOLD_TR" % (_d, _t.upper())] = Cfg(_t, fold=1, D=_d, tr=3)
+# one operand transposed: verified on the model (tests/test_f256_stream.py), NOT written to the generated file until a kernel
+# uses them (~150 KB of text per stream)
+MODEL_ONLY_VARIANTS = {}
+for _d in (256, 192, 160):
+    for _t in ("bf16", "f16"):
+        for _sfx, _pat in (("TRK", 1), ("TRV", 2)):
+            MODEL_ONLY_VARIANTS["D%d_%s_THR8_%s" % (_d, _t.upper(), _sfx)] = Cfg(_t, D=_d, tr=_pat)
+            MODEL_ONLY_VARIANTS["D%d_%s_FOLD_%s" % (_d, _t.upper(), _sfx)] = Cfg(_t, fold=1, D=_d, tr=_pat)
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))

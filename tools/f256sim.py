@@ -20,10 +20,13 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
     instrs = stream if stream is not None else Stream(cfg).build()
     wg = Workgroup(instrs, dma_mode)
     kb, vb = k.reshape(-1).view(np.uint8), v.reshape(-1).view(np.uint8)
-    tr = bool(getattr(cfg, "tr", 0))
-    if tr:   # K^T, V^T: [D][C] in memory
+    kt, vt = bool(getattr(cfg, "tr", 0) & 1), bool(getattr(cfg, "tr", 0) & 2)
+    if kt or vt:   # K^T / V^T: [D][C] in memory
         assert C % 32 == 0
-        kb, vb = np.ascontiguousarray(k.T).reshape(-1).view(np.uint8), np.ascontiguousarray(v.T).reshape(-1).view(np.uint8)
+    if kt:
+        kb = np.ascontiguousarray(k.T).reshape(-1).view(np.uint8)
+    if vt:
+        vb = np.ascontiguousarray(v.T).reshape(-1).view(np.uint8)
     ldt2 = C * 2
     ld2 = D * 2
     nt_total = (C + 31) // 32
@@ -49,24 +52,23 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             for l in range(64):
                 row = r0 + 32 * rb + int(qq[l])
                 d0 = 16 * ks + 8 * int(hi[l])
-                if row < R and tr:   # elements 4 hi + {0..3, 8..11}: the order the transposing reads of K^T return
+                if row < R and kt:   # elements 4 hi + {0..3, 8..11}: the order the transposing reads of K^T return
                     d0 = 16 * ks + 4 * int(hi[l])
                     data[l] = np.concatenate([q[row, d0:d0 + 4], q[row, d0 + 8:d0 + 12]]).view(np.uint8)
                 elif row < R:
                     data[l] = q[row, d0:d0 + 8].view(np.uint8)
             wg.lds_write16(back + i * 1024 + 16 * lane, data)
-        koff = []
+        koff, koff_t = [], []     # lane offsets of the pieces of a row-major / a transposed tile
         for i in range(pw):
             p = (wave * pw + i) * 64 + lane
             db, key, slot = p >> 7, (p >> 2) & 31, p & 3
             chunk = db * 4 + (slot ^ ((key >> 2) & 3))
-            if tr:   # image [D elements][4 chunks of 8 keys ^ (element >> 2) & 3]
-                d_ = p >> 2
-                koff.append(np.where(d_ < D, d_ * ldt2 + ((p & 3) ^ ((d_ >> 2) & 3)) * 16, 0xFFFFFF00).astype(np.uint32))
-                continue
+            d_ = p >> 2               # transposed: image [D elements][4 chunks of 8 keys ^ (element >> 2) & 3]
+            koff_t.append(np.where(d_ < D, d_ * ldt2 + ((p & 3) ^ ((d_ >> 2) & 3)) * 16, 0xFFFFFF00).astype(np.uint32))
             koff.append(np.where(chunk * 8 < D, key * ld2 + chunk * 16, 0xFFFFFF00).astype(np.uint32))
         while len(koff) < 4:
             koff.append(np.full(64, 0xFFFFFF00, np.uint32))
+            koff_t.append(np.full(64, 0xFFFFFF00, np.uint32))
         trow = (n16 >> 2) + 4 * hi
         tchunk = 2 * ((lane >> 4) & 1) + ((n16 & 3) >> 1)
         thalf = (n16 & 3) & 1
@@ -80,12 +82,13 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
             "ta1": ((RING - 1) * STAGE + (trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8).astype(np.uint32),
             "qback": (back + 16 * lane).astype(np.uint32),
         })
-        if tr:
-            vstart = (RING - 1) * STAGE          # the V addresses start one stage behind, like ta0 / ta1 above
+        vstart = (RING - 1) * STAGE          # the V addresses start one stage behind, like ta0 / ta1 above
+        if kt:     # (the lane terms of a transposing read: what ta0 / ta1 are for a row-major V)
             w.vn.update({"ka0": (w.vn["ta0"] - vstart).astype(np.uint32), "ka1": (w.vn["ta1"] - vstart).astype(np.uint32)})
+        if vt:
             w.vn.update({"ta%d" % c: (vstart + qq * 64 + ((c ^ ((qq >> 2) & 3)) * 16) + 8 * hi).astype(np.uint32) for c in range(4)})
         for i in range(4):
-            w.vn["koff%d" % i], w.vn["voff%d" % i] = koff[i].copy(), koff[i].copy()
+            w.vn["koff%d" % i], w.vn["voff%d" % i] = (koff_t if kt else koff)[i].copy(), (koff_t if vt else koff)[i].copy()
         for b in range(2):
             row = r0 + b * 32 + qq
             lim = np.minimum(C - 1, row + coff) if causal else np.full(64, C - 1)
@@ -96,8 +99,8 @@ def run_block(q, k, v, rblk, cfg=None, causal=False, dma_mode="late", order=(0, 
         if causal:
             wlast = min(R, r0 + 64) - 1
             wnt = max(1, min(nt, (wlast + coff) // 32 + 1)) if wlast >= r0 else 1
-        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": 64 if tr else 32 * ld2,
-                     "vinc": 64 if tr else 32 * ld2, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom})
+        w.sn.update({"kres": (kb, C * ld2), "vres": (vb, C * ld2), "nt": nt, "wnt": wnt, "scale2": scale2, "kinc": 64 if kt else 32 * ld2,
+                     "vinc": 64 if vt else 32 * ld2, "wr0": wave * pw * 1024, "ringend": RING * STAGE, "maskfrom": maskfrom})
     wg.run(order)
     O = np.zeros((256, D), np.float32)
     L = np.zeros(256, np.float32)

@@ -97,6 +97,13 @@ WORKLOADS = {
     # transposed code object (round 3; round 2: re-layout passes through a workspace)
     "fwd_bf16_d128_transposed": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), low_mid=True,
                                      tr=(True, True, True, True)),
+    # BASELINE config 4's shape with Q, K, V, O transposed: the 8 x 32 kernel's transposed code object in the product library (slow at
+    # D > 128: DESIGN.md 10 item 4), the hand-placed stream attn_fwd16_p5_tr in the developer library; and the backward kernels on
+    # transposed operands (through the workspace in the product library)
+    "fwd_bf16_d256_transposed": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",), low_mid=True,
+                                     tr=(True, True, True, True)),
+    "fwdbwd_bf16_d128_transposed": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, tr=(True, True, True, True),
+                                        types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),
     "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
                                     types=("forward", "backwardQuery", "backwardKeyValue")),

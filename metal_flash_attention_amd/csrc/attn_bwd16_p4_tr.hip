@@ -1,7 +1,7 @@
 // attn_bwd16_p4_tr.hip -- DEVELOPER BUILD ONLY: launchers of the backward kernels that read transposed operands in place
-// (attn_dq16_p4_tr.h: K^T / V^T; attn_dkv16_p4_tr.h: Q^T / dO^T).  Reached from mfa_attention_kernel_launch when the developer
-// library runs with MFA_BWD16_TR=1 and a transposed backward launch carries no workspace (the product library takes the general
-// kernel there); false = the launch is not one these kernels take.
+// (attn_dq16_p4_tr.h: K^T / V^T; attn_dkv16_p4_tr.h: Q^T / dO^T).  Reached from mfa_attention_kernel_launch / _time / _launch_form of
+// the developer library when a transposed backward launch carries no workspace (the product library takes the general kernel
+// there); MFA_BWD16_TR=0 is the developer library's A/B knob; false / nullptr = the launch is not one these kernels take.
 #include "attn_dq16_p4_tr.h"
 #include "attn_dkv16_p4_tr.h"
 #include "launchers.h"
@@ -42,26 +42,43 @@ template <typename T, int STREAM> static bool launch_dkv_tr(const KernelArgs &a,
   return true;
 }
 
-// type: 1 = backwardQuery, 2 = backwardKeyValue (mfa_kernel_type); fold: the descriptor keeps the attention matrix in 16-bit registers
-bool bwd16_p4_tr_launch(int type, const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold) {
-  const int p = a.op[SLOT_Q].precision;
-  const int pg = a.op[SLOT_dO].precision;
-  const bool gmix = p == PREC_FP16 && pg == PREC_BF16;   // the reference's own mix: FP16 Q, K, V with BF16 dO (+Precisions.swift:13-17)
+// what the in-place kernels take (their headers): 16-bit operands of one type (dO may be BF16 next to FP16), 64 < D <= 128, no
+// per-batch lengths, no block mask; backwardQuery: K^T and V^T in whole 64-key tiles of aligned rows; backwardKeyValue: Q^T and dO^T
+// in whole 32-row steps of aligned rows, L / D stored as the reference stores them (FP16 + BF16, or both FP32)
+static bool takes(int type, const KernelArgs &a) {
+  const int p = a.op[SLOT_Q].precision, pg = a.op[SLOT_dO].precision;
+  const bool gmix = p == PREC_FP16 && pg == PREC_BF16;
   if (p == PREC_FP32 || a.op[SLOT_K].precision != p || a.op[SLOT_V].precision != p || (pg != p && !gmix)) return false;
   if (a.rowLen || a.colLen || a.mask || a.D <= 64 || a.D > 128 || a.D % 8) return false;
   if (a.causal && a.C < a.R) return false;
   if (type == 1) {
     if (!a.op[SLOT_K].transposed || !a.op[SLOT_V].transposed || a.C % 64 != 0) return false;
-    if (!rows_aligned(a.op[SLOT_K]) || !rows_aligned(a.op[SLOT_V])) return false;
-    if (p == PREC_BF16) return fold ? launch_dq_tr<__bf16, dq4tr::S_BF16_FOLD_TR>(a, heads, batches, stream) : launch_dq_tr<__bf16, dq4tr::S_BF16_EXACT_TR>(a, heads, batches, stream);
-    if (gmix) return fold ? launch_dq_tr<_Float16, dq4tr::S_F16_FOLD_TR, __bf16>(a, heads, batches, stream) : launch_dq_tr<_Float16, dq4tr::S_F16_EXACT_TR, __bf16>(a, heads, batches, stream);
-    return fold ? launch_dq_tr<_Float16, dq4tr::S_F16_FOLD_TR>(a, heads, batches, stream) : launch_dq_tr<_Float16, dq4tr::S_F16_EXACT_TR>(a, heads, batches, stream);
+    return rows_aligned(a.op[SLOT_K]) && rows_aligned(a.op[SLOT_V]);
   }
   if (!a.op[SLOT_Q].transposed || !a.op[SLOT_dO].transposed || a.R % 32 != 0) return false;
   if (!rows_aligned(a.op[SLOT_Q]) || !rows_aligned(a.op[SLOT_dO])) return false;
   const int lp = a.op[SLOT_L].precision, dp = a.op[SLOT_D].precision;
-  const bool mixed = lp == PREC_FP16 && dp == PREC_BF16, f32 = lp == PREC_FP32 && dp == PREC_FP32;
-  if (!mixed && !f32) return false;
+  return (lp == PREC_FP16 && dp == PREC_BF16) || (lp == PREC_FP32 && dp == PREC_FP32);
+}
+
+// the name a launch reports (mfa_attention_kernel_launch_form), nullptr = not a launch these kernels take
+const char *bwd16_p4_tr_form(int type, const KernelArgs &a) {
+  if (!takes(type, a)) return nullptr;
+  return type == 1 ? "attn_dq16_p4_tr (four waves x 64 rows, hand-placed stream on transposed K / V in place, no workspace)"
+                   : "attn_dkv16_p4_tr (four waves x 64 keys, hand-placed stream on transposed Q / dO in place, no workspace)";
+}
+
+// type: 1 = backwardQuery, 2 = backwardKeyValue (mfa_kernel_type); fold: the descriptor keeps the attention matrix in 16-bit registers
+bool bwd16_p4_tr_launch(int type, const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold) {
+  if (!takes(type, a)) return false;
+  const int p = a.op[SLOT_Q].precision;
+  const bool gmix = p == PREC_FP16 && a.op[SLOT_dO].precision == PREC_BF16;   // the reference's own mix: FP16 Q, K, V with BF16 dO (+Precisions.swift:13-17)
+  if (type == 1) {
+    if (p == PREC_BF16) return fold ? launch_dq_tr<__bf16, dq4tr::S_BF16_FOLD_TR>(a, heads, batches, stream) : launch_dq_tr<__bf16, dq4tr::S_BF16_EXACT_TR>(a, heads, batches, stream);
+    if (gmix) return fold ? launch_dq_tr<_Float16, dq4tr::S_F16_FOLD_TR, __bf16>(a, heads, batches, stream) : launch_dq_tr<_Float16, dq4tr::S_F16_EXACT_TR, __bf16>(a, heads, batches, stream);
+    return fold ? launch_dq_tr<_Float16, dq4tr::S_F16_FOLD_TR>(a, heads, batches, stream) : launch_dq_tr<_Float16, dq4tr::S_F16_EXACT_TR>(a, heads, batches, stream);
+  }
+  const bool mixed = a.op[SLOT_L].precision == PREC_FP16;
   if (p == PREC_BF16) return mixed ? launch_dkv_tr<__bf16, dkv4tr::S_BF16_MIXED_TR>(a, heads, batches, stream) : launch_dkv_tr<__bf16, dkv4tr::S_BF16_F32_TR>(a, heads, batches, stream);
   if (gmix) return mixed ? launch_dkv_tr<_Float16, dkv4tr::S_F16_DOBF16_MIXED_TR>(a, heads, batches, stream) : launch_dkv_tr<_Float16, dkv4tr::S_F16_DOBF16_F32_TR>(a, heads, batches, stream);
   return mixed ? launch_dkv_tr<_Float16, dkv4tr::S_F16_MIXED_TR>(a, heads, batches, stream) : launch_dkv_tr<_Float16, dkv4tr::S_F16_F32_TR>(a, heads, batches, stream);

@@ -671,6 +671,16 @@ static auto split_launcher(const LaunchPlan &plan) -> decltype(plan.variant->lau
   return (plan.args.causal && plan.variant->launchSplitCausal) ? plan.variant->launchSplitCausal : plan.variant->launchSplit;
 }
 
+#ifdef MFA_DEV_VARIANTS
+// developer library: does this launch go to the in-place backward kernels?  (MFA_BWD16_TR=0: never -- A/B runs against the general kernel)
+static bool dev_in_place_backward(const mfa_attention_kernel *kernel, const LaunchPlan &plan) {
+  if (!plan.useFallback || !kernel->relayout || kernel->desc.type == MFA_FORWARD) return false;
+  const char *knob = std::getenv("MFA_BWD16_TR");
+  if (knob && std::strcmp(knob, "0") == 0) return false;
+  return bwd16_p4_tr_form(kernel->desc.type, plan.args) != nullptr;
+}
+#endif
+
 static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const LaunchPlan &plan) {
   if (plan.variant->ldsBytes <= 64 * 1024) return MFA_OK;
   int device = 0;
@@ -701,13 +711,13 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   mfa_status st = prepare_launch(kernel, buffers, params, &plan);
   if (st != MFA_OK) return st;
 #ifdef MFA_DEV_VARIANTS
-  // developer library, MFA_BWD16_TR=1: a transposed backward launch without a workspace tries the kernels that read the
-  // operands in place (attn_bwd16_p4_tr.hip; not in the product library until they have been measured)
-  if (plan.useFallback && kernel->relayout && kernel->desc.type != MFA_FORWARD && std::getenv("MFA_BWD16_TR") &&
-      bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, (hipStream_t)stream,
-                         kernel->desc.registerPrecisions[MFA_P] > MFA_FP32)) {
+  // developer library (until the product library's evidence is re-taken with them): a transposed backward
+  // launch without a workspace goes to the kernels that read the operands in place when they take it (attn_bwd16_p4_tr.hip)
+  if (dev_in_place_backward(kernel, plan)) {
+    bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, (hipStream_t)stream, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32);
     hipError_t derr = hipGetLastError();
-    if (std::strcmp(std::getenv("MFA_BWD16_TR"), "verbose") == 0)
+    const char *knob = std::getenv("MFA_BWD16_TR");
+    if (knob && std::strcmp(knob, "verbose") == 0)
       std::fprintf(stderr, "mfa: %s on transposed operands in place\n", kernel->desc.type == MFA_BACKWARD_QUERY ? "attn_dq16_p4_tr" : "attn_dkv16_p4_tr");
     return derr == hipSuccess ? MFA_OK : hip_fail(derr, "attn_bwd16_p4_tr");
   }
@@ -735,6 +745,12 @@ mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, 
   if (st != MFA_OK) return st;
   std::string text;
   if (plan.nRelayouts) text += "attn_relayout x" + std::to_string(plan.nRelayouts) + " + ";
+#ifdef MFA_DEV_VARIANTS
+  if (dev_in_place_backward(kernel, plan)) {
+    std::snprintf(out, capacity, "%s", bwd16_p4_tr_form(kernel->desc.type, plan.args));
+    return MFA_OK;
+  }
+#endif
   if (plan.useFallback) {
     text += std::string(plan.variant->name) + " (general kernel: the launch does not meet the requirements of " + kernel->variant.name + ")";
   } else if (plan.splits > 1) {
@@ -790,6 +806,12 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   err = hipEventCreate(&stop);
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
   auto go = [&]() {
+#ifdef MFA_DEV_VARIANTS
+    if (dev_in_place_backward(kernel, plan)) {
+      bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, s, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32);
+      return;
+    }
+#endif
     for (int i = 0; i < plan.nRelayouts; ++i)
       if (!plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], s);
     if (plan.splits > 1) split_launcher(plan)(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);

@@ -825,9 +825,10 @@ def test_hand_placed_stream_with_one_transposed_operand(kv, low_mid, in_type):
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
 def test_developer_backward_kernels_read_transposed_operands_in_place(causal, low_mid, in_type, monkeypatch, capfd):
-    """Developer library, MFA_BWD16_TR: the backward streams on transposed operands (K^T / V^T in backwardQuery, Q^T / dO^T in
+    """Developer library: the backward streams on transposed operands (K^T / V^T in backwardQuery, Q^T / dO^T in
     backwardKeyValue; whole tiles, aligned rows) without a workspace -- model-verified streams behind developer-only kernels
-    (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h), not in the product library until measured.  Every operand transposed; results
+    (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h), the developer library's choice for such launches (launch form; MFA_BWD16_TR=0 keeps
+    the general kernel), not in the product library until its evidence is re-taken.  Every operand transposed; results
     against the oracle at the reference's mixed tolerances.  With FP16 inputs the reference's descriptors store dO in BF16
     (+Precisions.swift:13-17): backwardQuery converts the fragments when it loads them, backwardKeyValue runs the two products
     that read dO^T in BF16 (streams F16_DOBF16_*_TR)."""
@@ -836,6 +837,8 @@ def test_developer_backward_kernels_read_transposed_operands_in_place(causal, lo
         net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
         desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=(True, True, True, True))
         run = harness.DeviceRun(desc, net, causal=causal)
+        for t, name in ((AttentionKernelType.backwardQuery, "attn_dq16_p4_tr"), (AttentionKernelType.backwardKeyValue, "attn_dkv16_p4_tr")):
+            assert run.kernels[t].launchForm(run.buffers, row=R, column=C, causal=causal).startswith(name)
         got = run.execute()                      # no workspace
         err = capfd.readouterr().err
         assert "attn_dq16_p4_tr" in err and "attn_dkv16_p4_tr" in err, err

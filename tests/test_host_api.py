@@ -282,7 +282,7 @@ def test_transposed_descriptors_select_the_in_place_forward_code_objects():
     assert k.variant.startswith("attn_generic")
 
 
-def test_developer_library_routes_transposed_keys_and_values_at_large_head_dimensions_to_the_stream():
+def test_developer_library_routes_transposed_launches_to_the_in_place_streams():
     """Developer library only (MFA_LIBRARY=.../libmfa_hip_dev.so; skipped on the product library, which keeps the 8 x 32 kernel's
     transposed code object at these buckets until its evidence is re-taken): K^T + V^T at the buckets
     160 / 192 / 256 keep their variant, and a launch of whole 32-key steps of aligned rows is handed to attn_fwd16_p5_tr -- planned
@@ -304,6 +304,18 @@ def test_developer_library_routes_transposed_keys_and_values_at_large_head_dimen
                 form = k.launchForm(b, row=N, column=C)
                 assert form.startswith("attn_fwd16_p5_tr" if stream else "attn_fwd16v3"), (D, C, form)
                 assert not stream or ("folded" in form) == low_mid
+    # backward kernels, every operand transposed, no workspace: in place when whole tiles / steps of aligned rows (D in (64, 128])
+    for in_type in (P.BF16, P.FP16):
+        d = _desc(dims=(N, N, 128), low_in=True, low_mid=True, in_type=in_type, tr=(True,) * 4)
+        mem = d.memoryPrecisions
+        tt = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
+        for C, R, (fq, fkv) in ((512, 512, (True, True)), (520, 512, (False, True)), (512, 520, (True, False))):
+            b = {op: torch.zeros((128, R if op in (Op.Q, Op.O, Op.dO, Op.dQ) else C), dtype=tt[mem[op]])
+                 for op in (Op.Q, Op.K, Op.V, Op.O, Op.dO, Op.dQ, Op.dK, Op.dV)}
+            b[Op.L], b[Op.D] = torch.zeros(R, dtype=tt[mem[Op.L]]), torch.zeros(R, dtype=tt[mem[Op.D]])
+            for t, name, want in ((T.backwardQuery, "attn_dq16_p4_tr", fq), (T.backwardKeyValue, "attn_dkv16_p4_tr", fkv)):
+                form = AttentionKernel(d.kernelDescriptor(t)).launchForm(b, row=R, column=C)
+                assert form.startswith(name) == want, (in_type, R, C, t, form)
     # one operand transposed: no stream at these buckets yet
     d = _desc(dims=(N, N, 256), low_in=True, in_type=P.BF16, tr=(False, True, False, False))
     k = AttentionKernel(d.kernelDescriptor(T.forward))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer library only (MFA_LIBRARY=.../libmfa_hip_dev.so): the two backward kernels on transposed operands ([D][sequence]) --
 what the product library does (no workspace: the general kernels; with a workspace: copy to row-major, hand-placed kernel, copy
-back) against the developer kernels that read the operands in place (MFA_BWD16_TR; attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h).
+back) against the developer kernels that read the operands in place (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h; the developer
+library's choice for launches without a workspace, MFA_BWD16_TR=0 turns them off).
 Same buffers, torch events around back-to-back launches on the current stream."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +26,6 @@ for N, D, mixed in ((8192, 128, False), (8192, 128, True), (4096, 128, True)):
     args = dict(row=N, column=N, heads=H, batches=1, headStrides=hs, batchStrides={op: v * H for op, v in hs.items()})
     s = torch.cuda.current_stream().cuda_stream
     ks = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in KT}
-    os.environ.pop("MFA_BWD16_TR", None)
     ks[KT.forward].dispatch(b, stream=s, **args)
 
     def timed(k, iters, **kw):
@@ -41,13 +41,13 @@ for N, D, mixed in ((8192, 128, False), (8192, 128, True), (4096, 128, True)):
         ws = torch.empty(max(need, 256), dtype=torch.uint8, device="cuda")
         fl = FLOPS[t] * N * N * D * H
         res, out = {}, {}
+        os.environ["MFA_BWD16_TR"] = "0"           # the developer library's A/B knob: what the product library launches
         res["general"] = timed(k, 2)
+        os.environ.pop("MFA_BWD16_TR", None)
         res["workspace"] = timed(k, 10, workspace=ws)
         out["workspace"] = [b[o].float().clone() for o in outs]
-        os.environ["MFA_BWD16_TR"] = "1"
         res["in place"] = timed(k, 10)
         out["in place"] = [b[o].float().clone() for o in outs]
-        os.environ.pop("MFA_BWD16_TR", None)
         diff = max((x - y).abs().max().item() for x, y in zip(out["workspace"], out["in place"]))
         print(f"N={N} D={D} H={H} {'mixed' if mixed else 'fp32 '} {t.name:17s}: " +
               "   ".join(f"{n} {v:8.3f} ms ({fl/v/1e9:6.1f} TF)" for n, v in res.items()) +

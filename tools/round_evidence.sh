@@ -1,0 +1,41 @@
+#!/bin/bash
+# The evidence of a round in ONE gpurun call on the round's LAST product library (what profiles/rNN_final/ holds):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'ROUND=r04 bash tools/round_evidence.sh'
+# then copy gpurun_out/${ROUND}_final/ to profiles/${ROUND}_final/ and commit profiles/traffic.json (profile_pmc.sh rewrites it with
+# the library's SHA-256: bench.py reports `traffic` only for the library that hash belongs to -- any later change of a product
+# translation unit needs this call again).  ~20 GPU-minutes with the full GPU suite; FAST=1 skips the suite and the side workloads.
+cd "$(dirname "$0")/.." || exit 1
+ROUND=${ROUND:-rXX}
+OUT=gpurun_out/${ROUND}_final
+mkdir -p "$OUT"
+sha256sum metal_flash_attention_amd/libmfa_hip.so > "$OUT/library.sha256"
+if [ -z "$FAST" ]; then
+  timeout 1100 python -m pytest tests -q -m gpu 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
+  tail -3 "$OUT/pytest_gpu.txt"
+fi
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.txt" 2>&1; tail -1 "$OUT/smoke.txt"
+timeout 300 python bench.py 2> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_default.json"; cut -c1-300 "$OUT/bench_default.json"
+# kernel trace + the separate PMC passes of the headline (MI355X_MICROARCH.md's recipe), summary + traffic.json
+ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof.log" 2>&1; tail -25 "$OUT/prof.log" | head -40
+if [ -z "$FAST" ]; then
+  for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_1head \
+           fwd_bf16_d256 fwd_bf16_d256_mixed fwdbwd_bf16_d128 fwdbwd_bf16_d128_mixed fwdbwd_bf16_d128_causal fwdbwd_bf16_d128_transposed \
+           fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128; do
+    timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_$w.json"
+  done
+  timeout 200 python bench.py --workload c1_cpu 2>/dev/null | tail -1 > "$OUT/bench_c1_cpu.json"
+  timeout 300 python bench.py --gpus 2 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_2ranks_one_gpu.json"
+  python - <<PY
+import json, glob
+for f in sorted(glob.glob("$OUT/bench_*.json")):
+    try:
+        d = json.load(open(f)); print(f.split("bench_")[1][:-5], d.get("ms_per_step"), d.get("value"), (d.get("roofline") or {}).get("frac"))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
+  timeout 200 python tools/bucket_perf.py --mixed 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed.txt"
+  timeout 200 python tools/bucket_perf.py 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_fp32mid.txt"
+  timeout 200 python tools/time_single_head.py 2>&1 | grep -v amdgpu.ids > "$OUT/single_head.txt"
+  timeout 300 python tools/fuzz_shapes.py 120 1 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_120_seed1.txt"; grep "random problems" "$OUT/fuzz_120_seed1.txt"
+  timeout 300 python tools/fuzz_shapes.py 120 2 --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_120_seed2.txt"; grep "random problems" "$OUT/fuzz_transposed_120_seed2.txt"
+fi

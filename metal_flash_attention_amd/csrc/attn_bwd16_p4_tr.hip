@@ -2,6 +2,9 @@
 // (attn_dq16_p4_tr.h: K^T / V^T; attn_dkv16_p4_tr.h: Q^T / dO^T).  Reached from mfa_attention_kernel_launch / _time / _launch_form of
 // the developer library when a transposed backward launch carries no workspace (the product library takes the general kernel
 // there); MFA_BWD16_TR=0 is the developer library's A/B knob; false / nullptr = the launch is not one these kernels take.
+#include <mutex>
+#include <set>
+#include <utility>
 #include "attn_dq16_p4_tr.h"
 #include "attn_dkv16_p4_tr.h"
 #include "launchers.h"
@@ -12,8 +15,19 @@ static bool rows_aligned(const OperandView &v) {
   return ((reinterpret_cast<uintptr_t>(v.ptr) | (uint64_t)v.ld * 2 | (uint64_t)v.headStride * 2 | (uint64_t)v.batchStride * 2) & 15) == 0;
 }
 
+// the large-LDS attribute of a code object, once per (kernel, device): launches stay free of driver calls after the first one
+// (what a hipGraph capture needs; the product library keeps such a mask per kernel object, ensure_lds_attribute in mfa_kernel.hip)
 template <typename Kernel> static bool raise_lds(Kernel kernel, int bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  static std::mutex guard;
+  static std::set<std::pair<const void *, int>> done;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return false;
+  const std::pair<const void *, int> key(reinterpret_cast<const void *>(kernel), device);
+  std::lock_guard<std::mutex> lock(guard);
+  if (done.count(key)) return true;
+  if (hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done.insert(key);
+  return true;
 }
 
 template <typename T, int STREAM, typename TG = T> static bool launch_dq_tr(const KernelArgs &a, uint32_t heads, uint32_t batches, hipStream_t stream) {

@@ -61,8 +61,12 @@ def fuzz_p4p(rng):
     # streams, of Q' = Q log2(e) / sqrt(D): scores off by 2^-9 |s|) are not averaged out, |dO| reaches 4-5.3e-3 where the seeded
     # matrix's 4e-3 holds from a few dozen keys on (found by this tool: seed 3 cases 72, 287, 365, all BF16_FOLD_L16_CAUSAL, R = C)
     tol_o = 1e-2 if (cfg.causal and cfg.dtype == "bf16" and not cfg.o16) else None
-    t._check(H, R, C, cfg=cfg, seed=int(rng.integers(1 << 30)), stores=str(rng.choice(["early", "late"])), tol_o=tol_o, **m)
-    return name, H, R, C
+    if tol_o is None and cfg.fold and cfg.dtype == "bf16" and not cfg.o16:
+        tol_o = 8e-3   # dense, folded scale: Q' rounded to 8 bits moves peaked rows by up to 5.3e-3 (seed 8 cases 61, 275; seeded matrix: 4e-3)
+    D = int(rng.choice([128, 128, 128, 120, 104, 96, 80, 72]))     # head dimensions below the bucket: chunks beyond D fetched out of range
+    kw = dict(D=D, ld=128) if D < 128 else {}
+    t._check(H, R, C, cfg=cfg, seed=int(rng.integers(1 << 30)), stores=str(rng.choice(["early", "late"])), tol_o=tol_o, **m, **kw)
+    return name, H, R, C, D
 
 
 def fuzz_p5(rng):

@@ -2,11 +2,14 @@
 """developer check: random (R, C, D, causal, precision mode, 16-bit type) problems through all three kernels against the oracle
 with the reference's mixed tolerances (and a tighter gradient bound); prints every failure, exits non-zero if there is one.
 
-  python tools/fuzz_shapes.py [cases] [seed] [--transposed]
+  python tools/fuzz_shapes.py [cases] [seed] [--transposed [--backward] [--workspace]]
 
 --transposed: forward only, a random non-empty pattern of transposed (Q, K, V, O) per problem (transposeState), sequence lengths
 that are multiples of 64 / of 8 / odd in equal parts -- the hand-placed stream on K^T + V^T, the 8 x 32 kernel's in-place code
 objects with aligned rows, and their gather path.
+--backward (with --transposed): all three kernels on the transposed operands (the gradients follow their operands), without a
+workspace unless --workspace -- the general kernels in the product library, the in-place backward kernels where the developer
+library has them (MFA_LIBRARY=.../libmfa_hip_dev.so), the re-layout path with --workspace.
 """
 import os, sys
 import numpy as np
@@ -19,6 +22,8 @@ from metal_flash_attention_amd import GEMMOperandPrecision as P
 from oracle import Network, NetworkDescriptor
 
 transposed = "--transposed" in sys.argv
+backward = not transposed or "--backward" in sys.argv
+with_workspace = "--workspace" in sys.argv
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 cases = int(argv[0]) if len(argv) > 0 else 120
 rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
@@ -44,19 +49,19 @@ for i in range(cases):
     desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=tr)
     if transposed:
         desc.lowPrecisionOutputs = bool(rng.integers(2))
-    run = harness.DeviceRun(desc, net, causal=causal, run_backward=not transposed)
-    got = run.execute()
+    run = harness.DeviceRun(desc, net, causal=causal, run_backward=backward)
+    got = run.execute(with_workspace=with_workspace)
     round_inputs(net, desc)
-    ref = net.run(causal=causal, backward=not transposed)
+    ref = net.run(causal=causal, backward=backward)
     tol = TOL_MIXED_SHORT if C <= 20 else TOL_MIXED
-    if transposed:
+    if not backward:
         tol = {k: v for k, v in tol.items() if k in ("O", "L")}
     failures, report = harness.compare(ref, got, tol)
     variants = [k.launchForm(run.buffers, row=R, column=C, causal=causal).split(" (")[0] if transposed else k.variant for k in run.kernels.values()]
     for v in variants:
         seen[v] = seen.get(v, 0) + 1
-    outs = ("O",) if transposed else ("O", "dQ", "dK", "dV")
-    tails = {k: v for k, v in run.tails_ok.items() if not transposed or k in ("O", "L")}
+    outs = ("O", "dQ", "dK", "dV") if backward else ("O",)
+    tails = {k: v for k, v in run.tails_ok.items() if backward or k in ("O", "L")}
     ok = not failures and all(tails.values()) and all(np.isfinite(got[n]).all() for n in outs)
     if not ok:
         bad += 1

@@ -10,26 +10,40 @@
 // aligned, per-batch lengths or a block mask are not taken (the launcher returns false and the 8 x 32 kernel's transposed code
 // object runs, attn_fwd16_v3.h TR).  The product library launches that code object for every such problem until this kernel has
 // been timed against it.
+// One transposed operand (K^T alone, V^T alone): the halves of a step's fragment list are independent (tools/f256gen.py, Cfg.tr as a
+// bit mask) -- the transposed operand takes the exchanged recipe, the other keeps attn_fwd16_p5.h's; those 24 streams are generated
+// at build time (attn_fwd16_p5_tr1_stream.inc, `make DEV=1`), model-verified like the others, NOT yet run on a GPU.
 #pragma once
 #include "attn_fwd16_p5.h"
+#include "attn_fwd16_p5_tr1_stream.inc"
+
+// K^T + V^T (tracked streams) first: their enumerators -- and so the names of their code objects -- do not move
+#define MFA_P5TR_ALL_STREAMS(X) MFA_P5_TR_STREAM_LIST(X) MFA_P5_TR1_STREAM_LIST(X)
 
 namespace mfa {
 namespace p5tr {
 
 #define MFA_P5TR_ENUM(name, fold, d, pattern) S_##name,
-enum : int { MFA_P5_TR_STREAM_LIST(MFA_P5TR_ENUM) S_COUNT };
+enum : int { MFA_P5TR_ALL_STREAMS(MFA_P5TR_ENUM) S_COUNT };
 #undef MFA_P5TR_ENUM
 constexpr bool stream_folds(int s) {
 #define MFA_P5TR_FOLDS(name, fold, d, pattern) if (s == S_##name) return fold != 0;
-  MFA_P5_TR_STREAM_LIST(MFA_P5TR_FOLDS)
+  MFA_P5TR_ALL_STREAMS(MFA_P5TR_FOLDS)
 #undef MFA_P5TR_FOLDS
   return false;
 }
 constexpr int stream_bucket(int s) {
 #define MFA_P5TR_BUCKET(name, fold, d, pattern) if (s == S_##name) return d;
-  MFA_P5_TR_STREAM_LIST(MFA_P5TR_BUCKET)
+  MFA_P5TR_ALL_STREAMS(MFA_P5TR_BUCKET)
 #undef MFA_P5TR_BUCKET
   return 256;
+}
+// bit 0 = K, bit 1 = V stored transposed
+constexpr int stream_pattern(int s) {
+#define MFA_P5TR_PATTERN(name, fold, d, pattern) if (s == S_##name) return pattern;
+  MFA_P5TR_ALL_STREAMS(MFA_P5TR_PATTERN)
+#undef MFA_P5TR_PATTERN
+  return 3;
 }
 
 }  // namespace p5tr
@@ -57,6 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p5_tr(const KernelArgs a, cons
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D = p5tr::stream_bucket(STREAM), BC = 32, NKS = D / 16, NDB = D / 32, WROWS = 64, GROWS = 256;
   constexpr int PW = (D + 63) / 64;   // LDS-DMA pieces per wave and operand tile (D elements x 32 keys x 2 bytes, 1 KiB each, four waves)
+  constexpr bool KT = (p5tr::stream_pattern(STREAM) & 1) != 0, VT = (p5tr::stream_pattern(STREAM) & 2) != 0;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,12 +103,12 @@ __global__ __launch_bounds__(256) void attn_fwd16_p5_tr(const KernelArgs a, cons
       operand_base(a.op[SLOT_Q], head, batch), 0, (uint32_t)(qT ? Dr : R) * ldq2, 0x00020000);
   const uint64_t kaddr = (uint64_t)(uintptr_t)kptr, vaddr = (uint64_t)(uintptr_t)vptr;
   auto uni = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
-  const u32x4 kdesc = {uni((uint32_t)kaddr), uni((uint32_t)(kaddr >> 32) & 0xFFFFu), uni((uint32_t)Dr * ldk2), 0x00020000u};
-  const u32x4 vdesc = {uni((uint32_t)vaddr), uni((uint32_t)(vaddr >> 32) & 0xFFFFu), uni((uint32_t)Dr * ldv2), 0x00020000u};
+  const u32x4 kdesc = {uni((uint32_t)kaddr), uni((uint32_t)(kaddr >> 32) & 0xFFFFu), uni((uint32_t)(KT ? Dr : C) * ldk2), 0x00020000u};
+  const u32x4 vdesc = {uni((uint32_t)vaddr), uni((uint32_t)(vaddr >> 32) & 0xFFFFu), uni((uint32_t)(VT ? Dr : C) * ldv2), 0x00020000u};
   constexpr uint32_t OOB = 0xFFFFFF00u;
 
-  // ---- Q' fragments (B operand of S^T = K Q'^T: lane = row), in the order the transposing reads of K^T return the contraction
-  // index: elements 16 s + 4 hi + {0..3, 8..11}; parked in LDS for the statement
+  // ---- Q' fragments (B operand of S^T = K Q'^T: lane = row), in the order the K fragments hold the contraction index: with K^T
+  // elements 16 s + 4 hi + {0..3, 8..11} (what its transposing reads return), with row-major K 16 s + 8 hi + {0..7}; parked in LDS
   {
     char *back = smem + wave * 32768 + lane * 16;
 #pragma unroll
@@ -101,22 +116,24 @@ __global__ __launch_bounds__(256) void attn_fwd16_p5_tr(const KernelArgs a, cons
       const int64_t row = r0 + b * 32 + q;
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
-        const int d0 = 16 * s + 4 * hi;
+        const int d0 = KT ? 16 * s + 4 * hi : 16 * s + 8 * hi;
         u32x4 x;
         if (qT) {   // Q^T [D][R]: one element per load (consecutive lanes = consecutive rows)
           uint32_t e[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            const int d = d0 + (i & 3) + 8 * (i >> 2);
+            const int d = KT ? d0 + (i & 3) + 8 * (i >> 2) : d0 + i;
             const uint32_t off = (d < Dr && row < R) ? (uint32_t)d * ldq2 + (uint32_t)row * 2 : OOB;
             e[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(qres, off, 0, 0);
           }
           x = u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-        } else {
+        } else if constexpr (KT) {
           const uint32_t rowoff = (uint32_t)row * ldq2;
           const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(qres, (d0 < Dr && row < R) ? rowoff + d0 * 2 : OOB, 0, 0);
           const u32x2 up = __builtin_amdgcn_raw_buffer_load_b64(qres, (d0 + 8 < Dr && row < R) ? rowoff + (d0 + 8) * 2 : OOB, 0, 0);
           x = u32x4{lo[0], lo[1], up[0], up[1]};
+        } else {
+          x = __builtin_amdgcn_raw_buffer_load_b128(qres, (d0 < Dr && row < R) ? (uint32_t)row * ldq2 + d0 * 2 : OOB, 0, 0);
         }
         if constexpr (stream_folds(STREAM)) *reinterpret_cast<u32x4 *>(back + (b * NKS + s) * 1024) = p4::scale16x8<T>(x, a.scale2);
         else *reinterpret_cast<u32x4 *>(back + (b * NKS + s) * 1024) = x;
@@ -150,26 +167,40 @@ __global__ __launch_bounds__(256) void attn_fwd16_p5_tr(const KernelArgs a, cons
   lim1 -= 4 * hi;
 
   // ---- LDS-DMA staging: piece i of wave w fills 16-byte positions (PW w + i) * 64 + lane of an image
-  // ([D elements][4 chunks of 8 keys], chunk index ^ (element >> 2) & 3); a step further = 32 keys along every row
+  // (transposed operand: [D elements][4 chunks of 8 keys], chunk index ^ (element >> 2) & 3, a step further = 32 keys along every
+  // row; row-major operand: attn_fwd16_p5.h's [D/32][32 keys][4 chunks], chunk swizzled by (key >> 2) & 3, 32 rows further)
   uint32_t koff[4], voff[4];
-  const uint32_t kinc = BC * 2, vinc = BC * 2;
+  const uint32_t kinc = KT ? BC * 2 : BC * ldk2, vinc = VT ? BC * 2 : BC * ldv2;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {   // (the stream uses the first PW of them)
     const int p = (wave * PW + i) * 64 + lane;
     const int d = p >> 2, chunk = (p & 3) ^ ((d >> 2) & 3);
-    koff[i] = (i < PW && d < Dr) ? (uint32_t)d * ldk2 + chunk * 16 : OOB;
-    voff[i] = (i < PW && d < Dr) ? (uint32_t)d * ldv2 + chunk * 16 : OOB;
+    const int rkey = (p >> 2) & 31, rchunk = (p >> 7) * 4 + ((p & 3) ^ ((rkey >> 2) & 3));
+    if constexpr (KT) koff[i] = (i < PW && d < Dr) ? (uint32_t)d * ldk2 + chunk * 16 : OOB;
+    else koff[i] = (i < PW && rchunk * 8 < Dr) ? rkey * ldk2 + rchunk * 16 : OOB;
+    if constexpr (VT) voff[i] = (i < PW && d < Dr) ? (uint32_t)d * ldv2 + chunk * 16 : OOB;
+    else voff[i] = (i < PW && rchunk * 8 < Dr) ? rkey * ldv2 + rchunk * 16 : OOB;
   }
   const uint32_t lds0 = lds_addr(smem);
   const int n16 = lane & 15;
-  // transposing reads of the K^T image: rows (n16 >> 2) + 4 hi and + 8 of a 16-element step
+  // lane terms of a transposing read (K^T image; or the V image of a row-major V): rows (n16 >> 2) + 4 hi and + 8 of a 16-element step
   const int trow = (n16 >> 2) + 4 * hi, tchunk = 2 * ((lane >> 4) & 1) + ((n16 & 3) >> 1), thalf = (n16 & 3) & 1;
-  uint32_t ka0 = lds0 + trow * 64 + ((tchunk ^ (hi & 3)) * 16) + thalf * 8;
-  uint32_t ka1 = lds0 + (trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8;
+  const uint32_t tr0 = trow * 64 + ((tchunk ^ (hi & 3)) * 16) + thalf * 8, tr1 = (trow + 8) * 64 + ((tchunk ^ ((hi + 2) & 3)) * 16) + thalf * 8;
+  uint32_t ka0, ka1;
+  if constexpr (KT) {
+    ka0 = lds0 + tr0;
+    ka1 = lds0 + tr1;
+  } else {   // row-major K: the lane's key row, 16 bytes of k-step 2 t + hi (attn_fwd16_p5.h)
+    ka0 = lds0 + q * 64 + ((hi ^ ((q >> 2) & 3)) * 16);
+    ka1 = lds0 + q * 64 + (((2 + hi) ^ ((q >> 2) & 3)) * 16);
+  }
   // V^T: row lane % 32 of a 32-element block, chunk c (keys 8 c + 4 hi + {0..3}); one step behind K: the ring's last stage
   uint32_t ta[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) ta[c] = lds0 + (RING - 1) * STAGE + q * 64 + ((c ^ ((q >> 2) & 3)) * 16) + 8 * hi;
+  for (int c = 0; c < 4; ++c) {
+    if constexpr (VT) ta[c] = lds0 + (RING - 1) * STAGE + q * 64 + ((c ^ ((q >> 2) & 3)) * 16) + 8 * hi;
+    else ta[c] = c == 0 ? lds0 + (RING - 1) * STAGE + tr0 : c == 1 ? lds0 + (RING - 1) * STAGE + tr1 : 0u;   // (two addresses; ta2 / ta3 unused)
+  }
   const uint32_t qback = lds0 + wave * 32768 + lane * 16;
   const uint32_t wr0 = lds0 + wave * (PW * 1024), ringend = lds0 + RING_BYTES;
 
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p5_tr(const KernelArgs a, cons
     uint32_t tj, tstg, tdelta, tdeltav, twr, tpend, tt0, tt1, tplast, tpa, tpb;
     uint64_t tsv, tptime;
 #define MFA_P5TR_RUN(name, fold, d, pattern) if constexpr (STREAM == p5tr::S_##name) MFA_P5TR_TRAVERSE(MFA_P5_STREAM_##name);
-    MFA_P5_TR_STREAM_LIST(MFA_P5TR_RUN)
+    MFA_P5TR_ALL_STREAMS(MFA_P5TR_RUN)
 #undef MFA_P5TR_RUN
   } else {   // no keys: O = 0
     static_for<64>([&](auto ic) { p4::acc_write4<4 * decltype(ic)::value>(u32x4{0u, 0u, 0u, 0u}); });

@@ -2,6 +2,10 @@
 // with it: instantiations of the hand-placed forward kernel for transposed K and V at the head-dimension
 // buckets 160 / 192 / 256 (attn_fwd16_p5_tr.h) and the launcher that prefers it over the 8 x 32 kernel's transposed code object
 // when the launch is whole 32-key steps of aligned rows -- the same arrangement as attn_fwd16_p4_tr.hip at D <= 128.
+// GPU status (end of round 3): the K^T + V^T kernels passed their parity test and were timed (profiles/r03_dev_transposed_streams.txt)
+// BEFORE attn_fwd16_p5_tr.h learned the one-operand patterns -- hipcc compiles them a few instructions differently since (same
+// statement, same lane constants); the K^T-only / V^T-only kernels have not run on a GPU yet.  First call of the next round:
+// tests/test_attention_gpu.py::test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions.
 #include <cstdlib>
 #include <cstring>
 #include "attn_fwd16_p5_tr.h"
@@ -10,13 +14,14 @@
 namespace mfa {
 
 typedef void (*LaunchFn)(dim3 grid, hipStream_t stream, const KernelArgs &args);
-// the launcher of the code object `out` arrived with (fwd16_v3_tr_variant_dNN, pattern K^T + V^T): one per (type, stream)
+// the launcher of the code object `out` arrived with (fwd16_v3_tr_variant_dNN of the same pattern): one per (type, stream)
 template <typename T, int STREAM> struct P5TrFallback { static LaunchFn launch; };
 template <typename T, int STREAM> LaunchFn P5TrFallback<T, STREAM>::launch = nullptr;
 
-// what the step walk of attn_fwd16_p5_tr needs (its header): K^T and V^T, no per-batch lengths, no block mask, whole 32-key
-// steps, 16-byte aligned rows of K^T / V^T (and of Q when it is row-major: its fragments are 8-byte loads; Q^T is gathered)
-static bool p5_tr_takes(const KernelArgs &a) {
+// what the step walk of attn_fwd16_p5_tr needs (its header): K / V transposed as the stream's pattern says (bit 0 = K, bit 1 = V),
+// no per-batch lengths, no block mask, whole 32-key steps, 16-byte aligned rows of K and V in either orientation (and of Q when
+// it is row-major: its fragments are 8- or 16-byte loads; Q^T is gathered)
+static bool p5_tr_takes(const KernelArgs &a, int pattern) {
 #ifdef MFA_DEV_VARIANTS
   const char *knob = std::getenv("MFA_FWD16_P5_TR");   // developer library: MFA_FWD16_P5_TR=0 keeps the 8 x 32 code object (A/B runs)
   if (knob && std::strcmp(knob, "0") == 0) return false;
@@ -26,14 +31,14 @@ static bool p5_tr_takes(const KernelArgs &a) {
   };
   if (a.rowLen || a.colLen || a.mask || a.D <= 128 || a.D > 256 || a.D % 8 || a.C % 32 || a.C == 0) return false;
   if (a.causal && a.C < a.R) return false;
-  if (!a.op[SLOT_K].transposed || !a.op[SLOT_V].transposed) return false;
-  if (!aligned(a.op[SLOT_K]) || !aligned(a.op[SLOT_V])) return false;
+  if ((a.op[SLOT_K].transposed != 0) != ((pattern & 1) != 0) || (a.op[SLOT_V].transposed != 0) != ((pattern & 2) != 0)) return false;
+  if (!aligned(a.op[SLOT_K]) || !aligned(a.op[SLOT_V])) return false;   // (16-byte chunks of either orientation)
   return a.op[SLOT_Q].transposed || aligned(a.op[SLOT_Q]);
 }
 
 template <typename T, int STREAM>
 static void launch_p5_tr(dim3 grid, hipStream_t stream, const KernelArgs &args) {
-  if (!p5_tr_takes(args)) { P5TrFallback<T, STREAM>::launch(grid, stream, args); return; }
+  if (!p5_tr_takes(args, p5tr::stream_pattern(STREAM))) { P5TrFallback<T, STREAM>::launch(grid, stream, args); return; }
   // grid arrives in the 8 x 32 kernel's row blocks (VariantInfo.parallelization); this kernel's are 256 rows
   const uint32_t blocks = ((uint32_t)args.R + 255) / 256;
   Fwd16Grid g{blocks, grid.y, grid.z};
@@ -46,7 +51,14 @@ static void launch_p5_tr(dim3 grid, hipStream_t stream, const KernelArgs &args) 
 }
 
 template <typename T, int STREAM> static const char *p5_tr_form(const KernelArgs &args) {
-  if (!p5_tr_takes(args)) return nullptr;
+  constexpr int PATTERN = p5tr::stream_pattern(STREAM);
+  if (!p5_tr_takes(args, PATTERN)) return nullptr;
+  if (PATTERN == 1)
+    return p5tr::stream_folds(STREAM) ? "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed K; scale folded into Q)"
+                                       : "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed K)";
+  if (PATTERN == 2)
+    return p5tr::stream_folds(STREAM) ? "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed V; scale folded into Q)"
+                                       : "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed V)";
   return p5tr::stream_folds(STREAM) ? "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed K / V; scale folded into Q)"
                                      : "attn_fwd16_p5_tr (four waves x 64 rows, 32-key steps, hand-placed stream on transposed K / V)";
 }
@@ -61,20 +73,31 @@ template <typename T, int STREAM> static void attach(VariantInfo *v) {
   v->ldsBytes = v->ldsBytes > (uint32_t)p5::LDS_BYTES ? v->ldsBytes : (uint32_t)p5::LDS_BYTES;
 }
 
-// `out` arrives filled by fwd16_v3_tr_variant_d160 / _d192 / _d256 for the pattern K^T + V^T: launches the stream can take go to
-// it, the others stay.  fold: Q pre-multiplied by the softmax scale in the 16-bit type (mixed-precision descriptors)
-bool fwd16_p5_tr_variant(int precision, int bucket, bool fold, VariantInfo *out) {
+// `out` arrives filled by fwd16_v3_tr_variant_d160 / _d192 / _d256 for `pattern` (bit 0 = K, bit 1 = V transposed; 0 = only Q / O:
+// nothing to do): launches the stream can take go to it, the others stay.  fold: Q pre-multiplied by the softmax scale in the 16-bit
+// type (mixed-precision descriptors)
+bool fwd16_p5_tr_variant(int precision, int bucket, int pattern, bool fold, VariantInfo *out) {
   if (!out->launch || out->launchCausal || out->launchSplit) return false;   // (the transposed code objects take the causal flag at run time and are never split)
-#define MFA_P5TR_ATTACH(T, TN)                                                                                               \
-  switch (bucket) {                                                                                                          \
-    case 160: if (fold) attach<T, p5tr::S_D160_##TN##_FOLD_TR>(out); else attach<T, p5tr::S_D160_##TN##_THR8_TR>(out); return true; \
-    case 192: if (fold) attach<T, p5tr::S_D192_##TN##_FOLD_TR>(out); else attach<T, p5tr::S_D192_##TN##_THR8_TR>(out); return true; \
-    case 256: if (fold) attach<T, p5tr::S_D256_##TN##_FOLD_TR>(out); else attach<T, p5tr::S_D256_##TN##_THR8_TR>(out); return true; \
-    default: return false;                                                                                                   \
+#define MFA_P5TR_ATTACH1(T, TN, B, SFX) { if (fold) attach<T, p5tr::S_D##B##_##TN##_FOLD_##SFX>(out); else attach<T, p5tr::S_D##B##_##TN##_THR8_##SFX>(out); return true; }
+#define MFA_P5TR_ATTACH(T, TN, SFX)                \
+  switch (bucket) {                                \
+    case 160: MFA_P5TR_ATTACH1(T, TN, 160, SFX)    \
+    case 192: MFA_P5TR_ATTACH1(T, TN, 192, SFX)    \
+    case 256: MFA_P5TR_ATTACH1(T, TN, 256, SFX)    \
+    default: return false;                         \
   }
-  if (precision == PREC_BF16) { MFA_P5TR_ATTACH(__bf16, BF16) }
-  if (precision == PREC_FP16) { MFA_P5TR_ATTACH(_Float16, F16) }
+#define MFA_P5TR_PATTERNS(T, TN)                   \
+  switch (pattern) {                               \
+    case 1: MFA_P5TR_ATTACH(T, TN, TRK)            \
+    case 2: MFA_P5TR_ATTACH(T, TN, TRV)            \
+    case 3: MFA_P5TR_ATTACH(T, TN, TR)             \
+    default: return false;                         \
+  }
+  if (precision == PREC_BF16) { MFA_P5TR_PATTERNS(__bf16, BF16) }
+  if (precision == PREC_FP16) { MFA_P5TR_PATTERNS(_Float16, F16) }
+#undef MFA_P5TR_PATTERNS
 #undef MFA_P5TR_ATTACH
+#undef MFA_P5TR_ATTACH1
   return false;
 }
 

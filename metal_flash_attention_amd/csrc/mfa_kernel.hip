@@ -146,7 +146,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         default: {
           bool have = b16 == 160 ? fwd16_v3_tr_variant_d160(pq, b16, pattern, &v)
                     : b16 == 192 ? fwd16_v3_tr_variant_d192(pq, b16, pattern, &v) : fwd16_v3_tr_variant_d256(pq, b16, pattern, &v);
-          if (have && pattern == 3) fwd16_p5_tr_variant(pq, b16, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
+          if (have && pattern != 0) fwd16_p5_tr_variant(pq, b16, pattern, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v);
           add(have, v);
           break;
         }

@@ -859,13 +859,17 @@ def test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head
     row-major and transposed, a head dimension inside each bucket and on its edge; against the oracle at the product tolerances of
     that path; MFA_FWD16_P5_TR=0 (A/B knob of the developer library) and a launch that is not whole steps keep the 8 x 32 object."""
     for (R, C, D), in_type, tr in (((320, 448, 256), P.BF16, (True, True, True, True)), ((300, 352, 152), P.BF16, (False, True, True, False)),
-                                   ((256, 288, 192), P.FP16, (False, True, True, True)), ((264, 320, 232), P.FP16, (True, True, True, False))):
+                                   ((256, 288, 192), P.FP16, (False, True, True, True)), ((264, 320, 232), P.FP16, (True, True, True, False)),
+                                   # one operand transposed (streams generated at build time; written after the round's last GPU call)
+                                   ((320, 448, 256), P.BF16, (False, True, False, False)), ((300, 352, 152), P.FP16, (True, False, True, True)),
+                                   ((256, 288, 192), P.BF16, (True, True, False, True)), ((264, 320, 232), P.FP16, (False, False, True, False))):
         net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
         desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type, tr=tr)
         run = harness.DeviceRun(desc, net, run_backward=False, causal=causal)
         k = run.kernels[AttentionKernelType.forward]
         form = k.launchForm(run.buffers, row=R, column=C, causal=causal)
-        assert k.variant.endswith("_tr_kv") and form.startswith("attn_fwd16_p5_tr") and ("folded" in form) == low_mid, (k.variant, form)
+        suffix = {(True, True): "_tr_kv", (True, False): "_tr_k", (False, True): "_tr_v"}[(tr[1], tr[2])]
+        assert k.variant.endswith(suffix) and form.startswith("attn_fwd16_p5_tr") and ("folded" in form) == low_mid, (k.variant, form)
         monkeypatch.setenv("MFA_FWD16_P5_TR", "0")
         assert k.launchForm(run.buffers, row=R, column=C, causal=causal).startswith("attn_fwd16v3")
         monkeypatch.delenv("MFA_FWD16_P5_TR")

@@ -316,12 +316,15 @@ def test_developer_library_routes_transposed_launches_to_the_in_place_streams():
             for t, name, want in ((T.backwardQuery, "attn_dq16_p4_tr", fq), (T.backwardKeyValue, "attn_dkv16_p4_tr", fkv)):
                 form = AttentionKernel(d.kernelDescriptor(t)).launchForm(b, row=R, column=C)
                 assert form.startswith(name) == want, (in_type, R, C, t, form)
-    # one operand transposed: no stream at these buckets yet
-    d = _desc(dims=(N, N, 256), low_in=True, in_type=P.BF16, tr=(False, True, False, False))
-    k = AttentionKernel(d.kernelDescriptor(T.forward))
-    b = {Op.Q: torch.zeros((N, 256), dtype=torch.bfloat16), Op.K: torch.zeros((256, N), dtype=torch.bfloat16),
-         Op.V: torch.zeros((N, 256), dtype=torch.bfloat16), Op.O: torch.zeros((N, 256)), Op.L: torch.zeros(N)}
-    assert k.launchForm(b, row=N, column=N).startswith("attn_fwd16v3")
+    # one operand transposed: the stream family of that pattern (generated at build time, model-verified)
+    for (tk, tv), which in (((True, False), "transposed K"), ((False, True), "transposed V")):
+        d = _desc(dims=(N, N, 256), low_in=True, in_type=P.BF16, tr=(False, tk, tv, False))
+        k = AttentionKernel(d.kernelDescriptor(T.forward))
+        b = {Op.Q: torch.zeros((N, 256), dtype=torch.bfloat16), Op.K: torch.zeros((256, N) if tk else (N, 256), dtype=torch.bfloat16),
+             Op.V: torch.zeros((256, N) if tv else (N, 256), dtype=torch.bfloat16), Op.O: torch.zeros((N, 256)), Op.L: torch.zeros(N)}
+        form = k.launchForm(b, row=N, column=N)
+        assert form.startswith("attn_fwd16_p5_tr") and which in form and "K / V" not in form, form
+        assert k.launchForm(b, row=N, column=N, causal=True).startswith("attn_fwd16_p5_tr")
 
 
 def test_low_precision_intermediates_select_the_folded_scale_stream():

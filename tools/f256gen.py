@@ -564,6 +564,28 @@ def write_inc(path):
         f.write("\n".join(lines))
 
 
+def write_one_operand_inc(path):
+    """the K^T-only / V^T-only streams (MODEL_ONLY_VARIANTS) for the DEVELOPER build: generated at build time by `make DEV=1`
+    (csrc/attn_fwd16_p5_tr1_stream.inc, git-ignored: ~150 KB of text per stream), included by attn_fwd16_p5_tr.h only"""
+    lines = ["// GENERATED by tools/f256gen.py --one-operand at build time (make DEV=1) -- not tracked.  Streams of attn_fwd16_p5_tr for",
+             "// ONE transposed operand: X(name, folds, head-dimension bucket, pattern: 1 = K^T, 2 = V^T)", "#pragma once", ""]
+    lines.append("#define MFA_P5_TR1_STREAM_LIST(X) \\")
+    for name, cfg in MODEL_ONLY_VARIANTS.items():
+        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.fold, cfg.D, cfg.tr))
+    lines.append("")
+    lines.append("")
+    for name, cfg in MODEL_ONLY_VARIANTS.items():
+        txt = render(Stream(cfg).build())
+        lines.append("// %s: dtype=%s fold=%d pattern=%d -- %d instructions" % (name, cfg.dtype, cfg.fold, cfg.tr, len(txt)))
+        lines.append("#define MFA_P5_STREAM_%s \\" % name)
+        for t in txt:
+            lines.append('  "%s\\n\\t" \\' % t)
+        lines.append('  ""')
+        lines.append("")
+    with open(path, "w") as f:
+        f.write("\n".join(lines))
+
+
 VARIANTS = {
     "BF16_THR8": Cfg("bf16"),
     "F16_THR8": Cfg("f16"),
@@ -593,6 +615,10 @@ for _d in (256, 192, 160):
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
+    if len(sys.argv) > 2 and sys.argv[1] == "--one-operand":
+        write_one_operand_inc(sys.argv[2])
+        print("wrote", os.path.normpath(sys.argv[2]), "-", len(MODEL_ONLY_VARIANTS), "streams")
+        sys.exit(0)
     out = os.path.join(here, "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p5_stream.inc")
     write_inc(out)
     ins = Stream(VARIANTS["BF16_THR8"]).build()

@@ -79,7 +79,7 @@ def test_transposed_key_value_streams(name):
 def test_streams_with_one_transposed_operand(name):
     """K^T alone or V^T alone (Cfg.tr is a bit mask like tools/p4gen.py's): the halves of a step's fragment list are independent --
     the transposed operand takes the exchanged read recipe (and, for V^T, four addresses), the other keeps the row-major one.
-    Model-only streams (f256gen.MODEL_ONLY_VARIANTS: not in the generated file until a kernel uses them)."""
+    Streams of f256gen.MODEL_ONLY_VARIANTS: not in the tracked generated file, `make DEV=1` generates them for the developer kernel."""
     cfg = f256gen.MODEL_ONLY_VARIANTS[name]
     for R, C, rblk, causal, mode in ((256, 32, 0, False, "late"), (256, 288, 0, False, "early"), (200, 160, 0, False, "late"),
                                      (512, 512, 1, True, "early")):

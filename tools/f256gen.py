@@ -604,8 +604,8 @@ for _d in (256, 192, 160):
     for _t in ("bf16", "f16"):
         TR_VARIANTS["D%d_%s_THR8_TR" % (_d, _t.upper())] = Cfg(_t, D=_d, tr=3)
         TR_VARIANTS["D%d_%s_FOLD_TR" % (_d, _t.upper())] = Cfg(_t, fold=1, D=_d, tr=3)
-# one operand transposed: verified on the model (tests/test_f256_stream.py), NOT written to the generated file until a kernel
-# uses them (~150 KB of text per stream)
+# one operand transposed: verified on the model (tests/test_f256_stream.py); not in the tracked generated file (~150 KB of text per
+# stream) -- `make DEV=1` writes them to csrc/attn_fwd16_p5_tr1_stream.inc for the developer kernel (write_one_operand_inc)
 MODEL_ONLY_VARIANTS = {}
 for _d in (256, 192, 160):
     for _t in ("bf16", "f16"):

@@ -18,12 +18,12 @@
 #include "attn_fwd16_v2.h"
 #include <type_traits>
 
-// Developer build only, until measured: at D > 128 hipcc leaves the transposed code objects' tile loads
+// Builds with MFA_TR_STREAMS only (developer library, `make TR_STREAMS=1` candidate), until measured: at D > 128 hipcc leaves the transposed code objects' tile loads
 // (issue_loads below: NCH pieces x two operands x a gathered and a 16-byte form) as a real FUNCTION called from four sites, its
 // closure in scratch memory (.private_segment_fixed_size 400-512, s_swappc_b64 in the loop) -- the reason those code objects run at
 // ~0.1 PFLOP/s (profiles/r03_dev_transposed_streams.txt).  Forcing the lambda inline removes call and scratch; the product
 // library keeps the code objects its evidence was taken with.
-#ifdef MFA_DEV_VARIANTS
+#ifdef MFA_TR_STREAMS
 #define MFA_V3_INLINE_LOADS __attribute__((always_inline))
 #else
 #define MFA_V3_INLINE_LOADS

@@ -142,7 +142,7 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           add(have, v);
           break;
         }
-#ifdef MFA_DEV_VARIANTS   // (developer library until the product library's evidence is re-taken with it)
+#ifdef MFA_TR_STREAMS   // (staged: developer library / TR_STREAMS=1 candidate until the product library's evidence is re-taken)
         default: {
           bool have = b16 == 160 ? fwd16_v3_tr_variant_d160(pq, b16, pattern, &v)
                     : b16 == 192 ? fwd16_v3_tr_variant_d192(pq, b16, pattern, &v) : fwd16_v3_tr_variant_d256(pq, b16, pattern, &v);
@@ -671,12 +671,14 @@ static auto split_launcher(const LaunchPlan &plan) -> decltype(plan.variant->lau
   return (plan.args.causal && plan.variant->launchSplitCausal) ? plan.variant->launchSplitCausal : plan.variant->launchSplit;
 }
 
-#ifdef MFA_DEV_VARIANTS
-// developer library: does this launch go to the in-place backward kernels?  (MFA_BWD16_TR=0: never -- A/B runs against the general kernel)
+#ifdef MFA_TR_STREAMS
+// staged (developer library, TR_STREAMS=1 candidate): does this launch go to the in-place backward kernels?
 static bool dev_in_place_backward(const mfa_attention_kernel *kernel, const LaunchPlan &plan) {
   if (!plan.useFallback || !kernel->relayout || kernel->desc.type == MFA_FORWARD) return false;
-  const char *knob = std::getenv("MFA_BWD16_TR");
+#ifdef MFA_DEV_VARIANTS
+  const char *knob = std::getenv("MFA_BWD16_TR");   // developer library: MFA_BWD16_TR=0 -- never (A/B runs against the general kernel)
   if (knob && std::strcmp(knob, "0") == 0) return false;
+#endif
   return bwd16_p4_tr_form(kernel->desc.type, plan.args) != nullptr;
 }
 #endif
@@ -710,15 +712,17 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   LaunchPlan plan;
   mfa_status st = prepare_launch(kernel, buffers, params, &plan);
   if (st != MFA_OK) return st;
-#ifdef MFA_DEV_VARIANTS
+#ifdef MFA_TR_STREAMS
   // developer library (until the product library's evidence is re-taken with them): a transposed backward
   // launch without a workspace goes to the kernels that read the operands in place when they take it (attn_bwd16_p4_tr.hip)
   if (dev_in_place_backward(kernel, plan)) {
     bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, (hipStream_t)stream, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32);
     hipError_t derr = hipGetLastError();
+#ifdef MFA_DEV_VARIANTS
     const char *knob = std::getenv("MFA_BWD16_TR");
     if (knob && std::strcmp(knob, "verbose") == 0)
       std::fprintf(stderr, "mfa: %s on transposed operands in place\n", kernel->desc.type == MFA_BACKWARD_QUERY ? "attn_dq16_p4_tr" : "attn_dkv16_p4_tr");
+#endif
     return derr == hipSuccess ? MFA_OK : hip_fail(derr, "attn_bwd16_p4_tr");
   }
 #endif
@@ -745,7 +749,7 @@ mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, 
   if (st != MFA_OK) return st;
   std::string text;
   if (plan.nRelayouts) text += "attn_relayout x" + std::to_string(plan.nRelayouts) + " + ";
-#ifdef MFA_DEV_VARIANTS
+#ifdef MFA_TR_STREAMS
   if (dev_in_place_backward(kernel, plan)) {
     std::snprintf(out, capacity, "%s", bwd16_p4_tr_form(kernel->desc.type, plan.args));
     return MFA_OK;
@@ -806,7 +810,7 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   err = hipEventCreate(&stop);
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
   auto go = [&]() {
-#ifdef MFA_DEV_VARIANTS
+#ifdef MFA_TR_STREAMS
     if (dev_in_place_backward(kernel, plan)) {
       bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, s, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32);
       return;

@@ -36,6 +36,10 @@ from metal_flash_attention_amd import _abi
 DEV_LIBRARY = "libmfa_hip_dev" in os.path.basename(_abi.library_path()) if hasattr(_abi, "library_path") else False
 needs_dev_library = pytest.mark.skipif(
     not DEV_LIBRARY, reason="developer schedule: run with MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_dev.so (make DEV=1)")
+# kernels staged for the product library (make TR_STREAMS=1 -> libmfa_hip_tr.so; the developer library has them too, with A/B knobs)
+STAGED_KERNELS = DEV_LIBRARY or ("libmfa_hip_tr" in os.path.basename(_abi.library_path()) if hasattr(_abi, "library_path") else False)
+needs_staged_kernels = pytest.mark.skipif(
+    not STAGED_KERNELS, reason="staged kernels: run with MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_tr.so (make TR_STREAMS=1) or the developer library")
 
 
 @contextlib.contextmanager
@@ -820,7 +824,7 @@ def test_hand_placed_stream_with_one_transposed_operand(kv, low_mid, in_type):
         assert all(run.tails_ok.values())
 
 
-@needs_dev_library
+@needs_staged_kernels
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
@@ -841,7 +845,7 @@ def test_developer_backward_kernels_read_transposed_operands_in_place(causal, lo
             assert run.kernels[t].launchForm(run.buffers, row=R, column=C, causal=causal).startswith(name)
         got = run.execute()                      # no workspace
         err = capfd.readouterr().err
-        assert "attn_dq16_p4_tr" in err and "attn_dkv16_p4_tr" in err, err
+        assert not DEV_LIBRARY or ("attn_dq16_p4_tr" in err and "attn_dkv16_p4_tr" in err), err   # (MFA_BWD16_TR=verbose: developer library)
         round_inputs(net, desc)
         ref = net.run(causal=causal)
         failures, report = harness.compare(ref, got, TOL_MIXED)
@@ -849,7 +853,7 @@ def test_developer_backward_kernels_read_transposed_operands_in_place(causal, lo
         assert all(run.tails_ok.values()), run.tails_ok
 
 
-@needs_dev_library
+@needs_staged_kernels
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
 def test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions(causal, low_mid, monkeypatch, capfd):
@@ -870,9 +874,10 @@ def test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head
         form = k.launchForm(run.buffers, row=R, column=C, causal=causal)
         suffix = {(True, True): "_tr_kv", (True, False): "_tr_k", (False, True): "_tr_v"}[(tr[1], tr[2])]
         assert k.variant.endswith(suffix) and form.startswith("attn_fwd16_p5_tr") and ("folded" in form) == low_mid, (k.variant, form)
-        monkeypatch.setenv("MFA_FWD16_P5_TR", "0")
-        assert k.launchForm(run.buffers, row=R, column=C, causal=causal).startswith("attn_fwd16v3")
-        monkeypatch.delenv("MFA_FWD16_P5_TR")
+        if DEV_LIBRARY:     # (the A/B knob exists in the developer library only)
+            monkeypatch.setenv("MFA_FWD16_P5_TR", "0")
+            assert k.launchForm(run.buffers, row=R, column=C, causal=causal).startswith("attn_fwd16v3")
+            monkeypatch.delenv("MFA_FWD16_P5_TR")
         got = run.execute()
         round_inputs(net, desc)
         ref = net.run(backward=False, causal=causal)

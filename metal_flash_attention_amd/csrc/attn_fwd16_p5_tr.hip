@@ -86,16 +86,21 @@ bool fwd16_p5_tr_variant(int precision, int bucket, int pattern, bool fold, Vari
     case 256: MFA_P5TR_ATTACH1(T, TN, 256, SFX)    \
     default: return false;                         \
   }
+#ifdef MFA_P5_TR1_STREAMS   // (the one-operand streams are generated at build time, attn_fwd16_p5_tr.h)
+#define MFA_P5TR_ONE_OPERAND(T, TN) case 1: MFA_P5TR_ATTACH(T, TN, TRK) case 2: MFA_P5TR_ATTACH(T, TN, TRV)
+#else
+#define MFA_P5TR_ONE_OPERAND(T, TN)
+#endif
 #define MFA_P5TR_PATTERNS(T, TN)                   \
   switch (pattern) {                               \
-    case 1: MFA_P5TR_ATTACH(T, TN, TRK)            \
-    case 2: MFA_P5TR_ATTACH(T, TN, TRV)            \
+    MFA_P5TR_ONE_OPERAND(T, TN)                    \
     case 3: MFA_P5TR_ATTACH(T, TN, TR)             \
     default: return false;                         \
   }
   if (precision == PREC_BF16) { MFA_P5TR_PATTERNS(__bf16, BF16) }
   if (precision == PREC_FP16) { MFA_P5TR_PATTERNS(_Float16, F16) }
 #undef MFA_P5TR_PATTERNS
+#undef MFA_P5TR_ONE_OPERAND
 #undef MFA_P5TR_ATTACH
 #undef MFA_P5TR_ATTACH1
   return false;

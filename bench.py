@@ -127,6 +127,9 @@ def main():
                     help="untimed run of the same step before the W warmup steps, until the power management has settled "
                          "(the first ~10 launches after an idle period run ~9 %% slower: profiles/r02_bench_spinup.txt)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle sample")
+    ap.add_argument("--fill", default="normal", choices=("normal", "zero"),
+                    help="zero: all-zero Q/K/V/dO -- NOT a valid measurement, only the clock experiment of tools/zero_vs_random.sh "
+                         "(MI355X_MICROARCH.md DVFS note: operand toggling sets the power-limited clock); the line says so in `data`")
     args = ap.parse_args()
 
     if args.workload == "c1_cpu":
@@ -193,11 +196,16 @@ def main():
     tprec = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
     bufs[Op.O] = torch.empty(shape, device="cuda", dtype=tprec[mem[Op.O]])
     bufs[Op.L] = torch.empty((B, H, N), device="cuda", dtype=tprec[mem[Op.L]])
+    if args.fill == "zero":
+        for op in (Op.Q, Op.K, Op.V):
+            bufs[op].zero_()
     backward = len(types) > 1
     if backward:
         # the reference stores dO as BF16 in low-precision mode (+Precisions.swift:17)
         bufs[Op.dO] = torch.randn(shape, generator=gen, device="cuda", dtype=torch.float32).to(
             torch.bfloat16 if low else torch.float32)
+        if args.fill == "zero":
+            bufs[Op.dO].zero_()
         bufs[Op.D] = torch.empty((B, H, N), device="cuda", dtype=tprec[mem[Op.D]])
         for op in (Op.dQ, Op.dK, Op.dV):
             bufs[op] = torch.empty(shape, device="cuda", dtype=torch.float32)
@@ -331,7 +339,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": w["dtype"],
-        "data": "synthetic",
+        "data": "synthetic" if args.fill == "normal" else "all-zero operands: clock experiment only, not a measurement of the metric",
         "config": {"workload": f"attention {'+'.join(w.get('timed', w['types']))} N={N} D={D} {w['dtype']} Q/K/V, fp32 O, {mem[Op.L].name} L; "
                                f"B={B} H={H} heads per GPU, batch x head sharded across GPUs, no collectives",
                    "precision_mode": ("mixed: lowPrecisionInputs + lowPrecisionIntermediates (the reference's mixed-precision "

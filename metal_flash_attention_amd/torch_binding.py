@@ -146,7 +146,10 @@ def _run_backward(q, k, v, o, l, grad_out, causal, lengths, mask_kw, fast_scale)
     lds = {}
     # saved as the (possibly strided) views the forward used; a strided grad_out (e.g. the gradient of a permuted view)
     # is passed with its own leading dimension / head / batch strides instead of being copied
-    bufs[Op.dO] = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v, dO=do)["dO"]
+    # every operand is the tensor its strides describe: an input that had to be made contiguous (torch.library path: the raw inputs
+    # are what was saved) must be passed as that copy, not as the original pointer
+    views = _apply_layouts(hs, bs, lds, Q=q, K=k, V=v, dO=do)
+    bufs[Op.Q], bufs[Op.K], bufs[Op.V], bufs[Op.dO] = views["Q"], views["K"], views["V"], views["dO"]
     with torch.cuda.device(q.device):
         stream = torch.cuda.current_stream(q.device).cuda_stream
         for kind in (AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):   # dQ writes D first
@@ -177,52 +180,70 @@ class _FlashAttention(torch.autograd.Function):
 # ---- the same two steps as torch.library custom ops: opaque to the tracer but with shape functions and an autograd formula, so a
 # function that calls flash_attention_op compiles with torch.compile(fullgraph=True) (the autograd.Function above is a graph break).
 # Dense / causal only; per-batch lengths and block masks stay on flash_attention().
-@torch.library.custom_op("mfa::attention_forward", mutates_args=(), device_types="cuda")
-def _op_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, fast_scale: bool) -> Tuple[torch.Tensor, torch.Tensor]:
-    o, l, _views, _lengths, _mask, _fast = _run_forward(q, k, v, causal, None, None, None, fast_scale)
-    return o, l
+def _register_ops():
+    """defines mfa::attention_forward / mfa::attention_backward once per process (a module reload finds them already defined);
+    torch < 2.4 has no torch.library.custom_op: flash_attention() keeps working there, flash_attention_op() raises."""
+    if not hasattr(torch.library, "custom_op"):
+        return False
+    try:
+        torch.ops.mfa.attention_forward  # noqa: B018 -- AttributeError when the op is not defined yet
+        torch.ops.mfa.attention_backward  # noqa: B018
+        return True
+    except (AttributeError, RuntimeError):
+        pass
+
+    @torch.library.custom_op("mfa::attention_forward", mutates_args=(), device_types="cuda")
+    def _op_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, fast_scale: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+        o, l, _views, _lengths, _mask, _fast = _run_forward(q, k, v, causal, None, None, None, fast_scale)
+        return o, l
 
 
-@_op_forward.register_fake
-def _op_forward_fake(q, k, v, causal, fast_scale):
-    B, H, R, D = q.shape
-    fast = bool(fast_scale) and q.dtype != torch.float32
-    return q.new_empty((B, H, R, D)), q.new_empty((B, H, R), dtype=torch.float16 if fast else torch.float32)
+    @_op_forward.register_fake
+    def _op_forward_fake(q, k, v, causal, fast_scale):
+        B, H, R, D = q.shape
+        fast = bool(fast_scale) and q.dtype != torch.float32
+        return q.new_empty((B, H, R, D)), q.new_empty((B, H, R), dtype=torch.float16 if fast else torch.float32)
 
 
-@torch.library.custom_op("mfa::attention_backward", mutates_args=(), device_types="cuda")
-def _op_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, l: torch.Tensor, grad_out: torch.Tensor,
-                 causal: bool, fast_scale: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    _check(q, k, v)
-    fast = bool(fast_scale) and q.dtype != torch.float32
-    return _run_backward(q, k, v, o, l, grad_out, causal, (None, None), {}, fast)
+    @torch.library.custom_op("mfa::attention_backward", mutates_args=(), device_types="cuda")
+    def _op_backward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, l: torch.Tensor, grad_out: torch.Tensor,
+                     causal: bool, fast_scale: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        _check(q, k, v)
+        fast = bool(fast_scale) and q.dtype != torch.float32
+        return _run_backward(q, k, v, o, l, grad_out, causal, (None, None), {}, fast)
 
 
-@_op_backward.register_fake
-def _op_backward_fake(q, k, v, o, l, grad_out, causal, fast_scale):
-    return torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty_like(k, memory_format=torch.contiguous_format), \
-        torch.empty_like(v, memory_format=torch.contiguous_format)
+    @_op_backward.register_fake
+    def _op_backward_fake(q, k, v, o, l, grad_out, causal, fast_scale):
+        return torch.empty_like(q, memory_format=torch.contiguous_format), torch.empty_like(k, memory_format=torch.contiguous_format), \
+            torch.empty_like(v, memory_format=torch.contiguous_format)
 
 
-def _op_setup_context(ctx, inputs, output):
-    q, k, v, causal, fast_scale = inputs
-    o, l = output
-    ctx.save_for_backward(q, k, v, o, l)
-    ctx.causal, ctx.fast_scale = causal, fast_scale
+    def _op_setup_context(ctx, inputs, output):
+        q, k, v, causal, fast_scale = inputs
+        o, l = output
+        ctx.save_for_backward(q, k, v, o, l)
+        ctx.causal, ctx.fast_scale = causal, fast_scale
 
 
-def _op_autograd(ctx, grad_o, grad_l):
-    q, k, v, o, l = ctx.saved_tensors
-    dq, dk, dv = torch.ops.mfa.attention_backward(q, k, v, o, l, grad_o, ctx.causal, ctx.fast_scale)
-    return dq, dk, dv, None, None
+    def _op_autograd(ctx, grad_o, grad_l):
+        q, k, v, o, l = ctx.saved_tensors
+        dq, dk, dv = torch.ops.mfa.attention_backward(q, k, v, o, l, grad_o, ctx.causal, ctx.fast_scale)
+        return dq, dk, dv, None, None
 
 
-_op_forward.register_autograd(_op_autograd, setup_context=_op_setup_context)
+    _op_forward.register_autograd(_op_autograd, setup_context=_op_setup_context)
+    return True
+
+
+_HAVE_OPS = _register_ops()
 
 
 def flash_attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool = False, fast_scale: bool = False) -> torch.Tensor:
     """flash_attention(q, k, v, causal, fast_scale=...) through the torch.library ops `mfa::attention_forward` /
     `mfa::attention_backward`: traceable by torch.compile (fullgraph) and torch.export; dense or causal."""
+    if not _HAVE_OPS:
+        raise RuntimeError("flash_attention_op needs torch.library.custom_op (torch >= 2.4); use flash_attention() on this torch")
     return torch.ops.mfa.attention_forward(q, k, v, causal, fast_scale)[0]
 
 

@@ -66,6 +66,27 @@ def test_library_op_compiles_fullgraph_and_matches(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_library_op_backward_uses_the_laid_out_copies_of_non_contiguous_inputs(dtype):
+    """inputs whose LAST dimension is not contiguous (x.transpose(-1, -2)) have to be copied; the torch.library path saves the raw
+    inputs, so the backward op must hand the kernels the copy its strides describe, not the original pointer"""
+    from metal_flash_attention_amd import torch_binding as tb
+    B, H, R, C, D = 1, 2, 136, 200, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    qt, kt, vt = (torch.randn(B, H, D, n, generator=g, device="cuda").to(dtype).requires_grad_(True) for n in (R, C, C))
+
+    def f(qt, kt, vt):
+        return tb.flash_attention_op(qt.transpose(-1, -2), kt.transpose(-1, -2), vt.transpose(-1, -2), causal=False).float().square().sum()
+
+    loss = torch.compile(f, backend="aot_eager", fullgraph=True)(qt, kt, vt)
+    loss.backward()
+    qr, kr, vr, orf = reference(qt.transpose(-1, -2), kt.transpose(-1, -2), vt.transpose(-1, -2), False)
+    orf.square().sum().backward()
+    for got, ref, name in ((qt.grad, qr.grad, "dQ"), (kt.grad, kr.grad, "dK"), (vt.grad, vr.grad, "dV")):
+        assert (got.float().transpose(-1, -2) - ref).abs().max().item() < (5e-4 if dtype == torch.float32 else 8e-2), name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("shape", [(2, 3, 200, 200, 64), (1, 2, 129, 300, 128), (1, 1, 64, 64, 40)])

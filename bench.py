@@ -97,13 +97,15 @@ WORKLOADS = {
     # transposed code object (round 3; round 2: re-layout passes through a workspace)
     "fwd_bf16_d128_transposed": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), low_mid=True,
                                      tr=(True, True, True, True)),
-    # BASELINE config 4's shape with Q, K, V, O transposed: the 8 x 32 kernel's transposed code object in the product library (slow at
-    # D > 128: DESIGN.md 10 item 4), the hand-placed stream attn_fwd16_p5_tr in the developer library; and the backward kernels on
-    # transposed operands (through the workspace in the product library)
+    # BASELINE config 4's shape with Q, K, V, O transposed (the hand-placed stream attn_fwd16_p5_tr reads K^T / V^T in place); and
+    # all three kernels on transposed operands WITHOUT a workspace (round 4: the in-place backward kernels attn_dq16_p4_tr /
+    # attn_dkv16_p4_tr); `_ws` = the same with a caller workspace, i.e. the re-layout path of round 2
     "fwd_bf16_d256_transposed": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",), low_mid=True,
                                      tr=(True, True, True, True)),
     "fwdbwd_bf16_d128_transposed": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, tr=(True, True, True, True),
                                         types=("forward", "backwardQuery", "backwardKeyValue")),
+    "fwdbwd_bf16_d128_transposed_ws": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, low_mid=True, tr=(True, True, True, True),
+                                           relayout_workspace=True, types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),
     "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
                                     types=("forward", "backwardQuery", "backwardKeyValue")),
@@ -159,8 +161,10 @@ def main():
         try:
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=120))
         except Exception as exc:   # noqa: BLE001 -- the rendezvous port was taken between spawn_ranks' probe and rank 0's listen
-            if os.environ.get("MFA_BENCH_SPAWNED") and ("EADDRINUSE" in str(exc) or "address already in use" in str(exc).lower()
-                                                        or rank != 0):
+            # only an address-in-use condition asks spawn_ranks for a new port (it looks at rank 0's exit code); timeouts and
+            # real gloo errors keep their own exception and exit code on every rank
+            msg = str(exc).lower()
+            if os.environ.get("MFA_BENCH_SPAWNED") and ("eaddrinuse" in msg or "address already in use" in msg):
                 raise SystemExit(EADDRINUSE_EXIT)
             raise
 
@@ -213,7 +217,7 @@ def main():
     bs = {op: v * H for op, v in hs.items()}
     stream = torch.cuda.current_stream().cuda_stream
     # caller-owned scratch: lets a launch with too few row blocks (single head) run column-parallel
-    relayout = any(w.get("tr", ()))      # transposed operands: every kernel type gets its re-layout scratch
+    relayout = bool(w.get("relayout_workspace"))   # transposed operands through the re-layout scratch instead of in place
     ws_bytes = max(kernels[t].workspaceSize(row=N, column=N, heads=H, batches=B) if (t.name == "forward" or relayout) else 0
                    for t in types)
     workspace = torch.empty(ws_bytes, dtype=torch.uint8, device="cuda") if ws_bytes else None
@@ -358,7 +362,8 @@ def main():
                      "frac_of_sustained": (round(achieved_tflops / SUSTAINED_TFLOPS_RANDOM[w["dtype"]], 4)
                                            if w["dtype"] in SUSTAINED_TFLOPS_RANDOM else None),
                      "traffic": traffic_bytes, "traffic_unit": "bytes/launch (HBM, PMC)", "traffic_source": traffic_source,
-                     "algorithmic_bytes": (3 * N * D * (2 if low else 4) + N * D * 4 + N * 4) * B * H if not backward else None,
+                     "algorithmic_bytes": (3 * N * D * (2 if low else 4) + N * D * bufs[Op.O].element_size()
+                                           + N * bufs[Op.L].element_size()) * B * H if not backward else None,
                      "kernel": "+".join(kernels[t].variant for t in types), "launch_ms": round(launch_ms, 4),
                      # what the timed launches ran (mfa_attention_kernel_launch_form): e.g. the persistent form attn_fwd16_p4p of the
                      # D <= 128 forward object -- the kernel name rocprofv3 reports for this command
@@ -397,7 +402,7 @@ def spawn_ranks(n):
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
         codes = [p.wait() for p in procs]
         code = max(abs(c) for c in codes)
-        if EADDRINUSE_EXIT not in codes:
+        if codes[0] != EADDRINUSE_EXIT:   # rank 0 owns the listening socket: only its address-in-use exit means "try another port"
             break
     return code
 

@@ -233,8 +233,10 @@ typedef struct mfa_launch_params {
   /* Variable sequence lengths (extension): device arrays of `batches` uint32
    * entries, or NULL.  Batch entry b uses the first rowLengths[b] rows and columnLengths[b] columns of its
    * row x column problem (entries are clamped to row / column); the rest of its buffers is padding that is
-   * neither read into the result nor written.  With `causal`, columnLengths[b] >= rowLengths[b] is the
-   * caller's responsibility.  All three kernel types; launches with lengths are never column-split. */
+   * neither read into the result nor written.  With `causal` the diagonal of entry b is placed by ITS lengths: row r
+   * sees column c iff c <= r + max(columnLengths[b] - rowLengths[b], 0) -- an entry with fewer columns than rows (which the
+   * host cannot see: the arrays live on the device) gets offset 0, so every row keeps at least one visible key.
+   * All three kernel types; launches with lengths are never column-split. */
   const uint32_t *rowLengths;
   const uint32_t *columnLengths;
   /* Block-sparse mask (extension; the reference names block sparsity next to masks, README.md:7, :210):

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
 
   // CAUSAL (extension): keys past the last row's limit are never visited; blocks crossing the diagonal
   // get P = 0 element-wise (hence dS = 0)
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   int ntiles = (C + BC - 1) / BC;
   if constexpr (CAUSAL) {
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * 32)) - 1;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv16(const KernelArgs a, const 
 
   // CAUSAL (extension): rows r with r + (C - R) < (first key of the workgroup) see none of its keys: the
   // traversal starts at the first row block that can; blocks crossing the diagonal get P = 0 element-wise
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * (NW * 32) - coff) / 32) : 0;
 
   // ---- Q / dO staging (two images each) + the L, D slices along the traversal dimension

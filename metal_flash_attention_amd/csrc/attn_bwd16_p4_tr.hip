@@ -1,7 +1,7 @@
-// attn_bwd16_p4_tr.hip -- DEVELOPER BUILD ONLY: launchers of the backward kernels that read transposed operands in place
-// (attn_dq16_p4_tr.h: K^T / V^T; attn_dkv16_p4_tr.h: Q^T / dO^T).  Reached from mfa_attention_kernel_launch / _time / _launch_form of
-// the developer library when a transposed backward launch carries no workspace (the product library takes the general kernel
-// there); MFA_BWD16_TR=0 is the developer library's A/B knob; false / nullptr = the launch is not one these kernels take.
+// attn_bwd16_p4_tr.hip -- launchers of the backward kernels that read transposed operands in place (attn_dq16_p4_tr.h: K^T / V^T;
+// attn_dkv16_p4_tr.h: Q^T / dO^T).  Reached from mfa_attention_kernel_launch / _time / _launch_form when a transposed backward
+// launch carries no workspace (with one, the re-layout path runs: the caller chose it); MFA_BWD16_TR=0 is the developer
+// library's A/B knob; false / nullptr = the launch is not one these kernels take (the general kernel serves it).
 #include <mutex>
 #include <set>
 #include <utility>

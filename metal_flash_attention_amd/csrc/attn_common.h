@@ -94,6 +94,11 @@ __device__ __forceinline__ void batch_lengths(const KernelArgs &a, uint32_t batc
   if (a.colLen) C = min(C, (int)a.colLen[batch]);
 }
 
+// causal launches: row r sees column c iff c <= r + causal_offset(R, C).  The host validates column >= row; per-batch lengths
+// (device arrays, resolved by batch_lengths above) can still make an entry's C smaller than its R -- the offset is clamped at 0
+// there (row r then sees columns <= min(r, C - 1)), so that no row is left without a visible key (include/mfa.h, rowLengths).
+__device__ __forceinline__ int causal_offset(int R, int C) { return max(C - R, 0); }
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // mask value for padded attention-matrix columns, AttentionKernel+Softmax.swift:242-243:

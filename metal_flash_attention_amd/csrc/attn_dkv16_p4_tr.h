@@ -1,4 +1,4 @@
-// attn_dkv16_p4_tr.h -- DEVELOPER BUILD ONLY (make DEV=1; MFA_DEV_VARIANTS): backwardKeyValue on the hand-placed stream with Q and
+// attn_dkv16_p4_tr.h -- backwardKeyValue on the hand-placed stream with Q and
 // dO stored TRANSPOSED ([D][rows]), read where they lie; K, V, dK, dV either way (run-time flags, outside the statement).
 //
 // The streams (tools/dkv4gen.py Cfg.tr, MFA_DKV4_TR_STREAM_LIST) are verified on the lane-exact model
@@ -7,8 +7,8 @@
 // come from transposing reads -- the contraction index in the order of an accumulator block's registers (4 hi + {0..3, 8..11}), so
 // the K' and V fragments are parked in that order -- and the dO^T / Q^T fragments are two 8-byte reads each (addresses ta0..ta3).
 // Whole steps only (R % 32 == 0), 16-byte aligned rows of Q^T / dO^T, no per-batch lengths, no block mask, dO in the type of
-// Q / K / V, L and D in the stream's storage types: the launcher (attn_bwd16_p4_tr.hip) checks.  Not in the product library until
-// it has been measured.
+// Q / K / V, L and D in the stream's storage types: the launcher (attn_bwd16_p4_tr.hip) checks.  Product library since round 4
+// (GPU evidence: profiles/r04_candidate/).
 #pragma once
 #include "attn_dkv16_p4.h"
 
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void attn_dkv16_p4_tr(const KernelArgs a, cons
   }
 
   // ---- traversal range: whole 32-row steps from the first row block that sees the workgroup's first key (CAUSAL) to the end
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const int row_first = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * GKEYS - coff) / BR) * BR : 0;
   const int nsteps = max(1, (R - row_first) / BR);
   int maskuntil = 0;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(dkv16rs_pairs<D>() * 128) void attn_dkv16_rs(const 
   }
 
   // CAUSAL (extension): the traversal starts at the first row block that sees the workgroup's first key
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   int block0 = CAUSAL ? (int)(max((int64_t)0, (int64_t)cblk * WGCOLS - coff) / 32) : 0;   // (SPARSE: first row block of the current run)
   int block_end = (R + 31) / 32;
   if constexpr (SPLIT) {   // this workgroup's piece of the row blocks [block0, block_end)

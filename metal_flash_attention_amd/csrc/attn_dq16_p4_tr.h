@@ -1,4 +1,4 @@
-// attn_dq16_p4_tr.h -- DEVELOPER BUILD ONLY (make DEV=1; MFA_DEV_VARIANTS): backwardQuery on the hand-placed stream with K and V
+// attn_dq16_p4_tr.h -- backwardQuery on the hand-placed stream with K and V
 // stored TRANSPOSED ([D][keys]), read where they lie; Q, dO, O, dQ either way (run-time flags, outside the statement).
 //
 // The streams (tools/dq4gen.py Cfg.tr, MFA_DQ4_TR_STREAM_LIST) are verified on the lane-exact model
@@ -7,8 +7,8 @@
 // row fragments come from transposing reads -- which return the contraction index in the order of an accumulator block's registers
 // (4 hi + {0..3, 8..11}), so Q' and dO go into the accumulator registers in that order -- and the K^T fragments of the dQ update
 // are two 8-byte reads per fragment (addresses ta0..ta3).  Whole tiles only (C % 64 == 0), 16-byte aligned rows of K^T / V^T,
-// no per-batch lengths, no block mask, dO in the type of Q / K / V: the launcher (attn_bwd16_p4_tr.hip) checks.  Not in the
-// product library until it has been measured.
+// no per-batch lengths, no block mask, dO in the type of Q / K / V: the launcher (attn_bwd16_p4_tr.hip) checks.  Product
+// library since round 4 (GPU evidence: profiles/r04_candidate/).
 #pragma once
 #include "attn_dq16_p4.h"
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void attn_dq16_p4_tr(const KernelArgs a, const
 
   // ---- traversal range (whole tiles)
   const int tiles_total = C / BC;
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   int nt = tiles_total;
   if constexpr (CAUSAL) {
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * GROWS) - 1;

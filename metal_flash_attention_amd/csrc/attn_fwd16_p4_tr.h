@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4_tr(const KernelArgs a, cons
 
   // ---- traversal range
   const int tiles_total = (C + BC - 1) / BC;
-  const int coff = C - R;   // CAUSAL (extension): row r sees key c iff c <= r + (C - R)
+  const int coff = causal_offset(R, C);   // CAUSAL (extension): row r sees key c iff c <= r + (C - R)
   int nt = tiles_total;
   if constexpr (CAUSAL) {
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * GROWS) - 1;

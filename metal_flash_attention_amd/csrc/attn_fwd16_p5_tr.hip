@@ -1,11 +1,8 @@
-// attn_fwd16_p5_tr.hip -- DEVELOPER BUILD ONLY (DEV_ONLY_HIP in the Makefile) until the product library's evidence is re-taken
-// with it: instantiations of the hand-placed forward kernel for transposed K and V at the head-dimension
+// attn_fwd16_p5_tr.hip -- instantiations of the hand-placed forward kernel for transposed K and / or V at the head-dimension
 // buckets 160 / 192 / 256 (attn_fwd16_p5_tr.h) and the launcher that prefers it over the 8 x 32 kernel's transposed code object
 // when the launch is whole 32-key steps of aligned rows -- the same arrangement as attn_fwd16_p4_tr.hip at D <= 128.
-// GPU status (end of round 3): the K^T + V^T kernels passed their parity test and were timed (profiles/r03_dev_transposed_streams.txt)
-// BEFORE attn_fwd16_p5_tr.h learned the one-operand patterns -- hipcc compiles them a few instructions differently since (same
-// statement, same lane constants); the K^T-only / V^T-only kernels have not run on a GPU yet.  First call of the next round:
-// tests/test_attention_gpu.py::test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions.
+// GPU evidence (round 4, all patterns): tests/test_attention_gpu.py::test_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions,
+// profiles/r04_candidate/time_p5_tr_32heads.txt.
 #include <cstdlib>
 #include <cstring>
 #include "attn_fwd16_p5_tr.h"

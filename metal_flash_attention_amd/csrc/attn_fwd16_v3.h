@@ -18,16 +18,12 @@
 #include "attn_fwd16_v2.h"
 #include <type_traits>
 
-// Builds with MFA_TR_STREAMS only (developer library, `make TR_STREAMS=1` candidate), until measured: at D > 128 hipcc leaves the transposed code objects' tile loads
-// (issue_loads below: NCH pieces x two operands x a gathered and a 16-byte form) as a real FUNCTION called from four sites, its
-// closure in scratch memory (.private_segment_fixed_size 400-512, s_swappc_b64 in the loop) -- the reason those code objects run at
-// ~0.1 PFLOP/s (profiles/r03_dev_transposed_streams.txt).  Forcing the lambda inline removes call and scratch; the product
-// library keeps the code objects its evidence was taken with.
-#ifdef MFA_TR_STREAMS
+// Tile loads forced inline: at D > 128 hipcc otherwise leaves the transposed code objects' tile loads (issue_loads below: NCH
+// pieces x two operands x a gathered and a 16-byte form) as a real FUNCTION called from four sites, its closure in scratch memory
+// (.private_segment_fixed_size 400-512, s_swappc_b64 in the loop) -- those code objects ran at ~0.1 PFLOP/s
+// (profiles/r03_dev_transposed_streams.txt; with the lambda inline 0.48-0.62, profiles/r04_candidate/time_p5_tr_32heads.txt).
+// tools/audit_code_objects.py fails the build check on any s_swappc_b64 or scratch in these objects.
 #define MFA_V3_INLINE_LOADS __attribute__((always_inline))
-#else
-#define MFA_V3_INLINE_LOADS
-#endif
 
 namespace mfa {
 
@@ -189,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;   // (SPARSE: first tile of the current run)
   // CAUSAL (extension): row r sees key c iff c <= r + (C - R); the workgroup stops at the tile that holds
   // the last key its last row may see, tiles that cross the diagonal are masked element-wise.
-  const int coff = (TR != 0 && !a.causal) ? 0x3FFFFFFF : C - R;   // TR kernels: the mask is a run-time flag (never reached without it)
+  const int coff = (TR != 0 && !a.causal) ? 0x3FFFFFFF : causal_offset(R, C);   // TR kernels: the mask is a run-time flag (never reached without it)
   int tiles_visible = tiles_total;
   if constexpr (CAUSAL) {
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * RB * 32)) - 1;

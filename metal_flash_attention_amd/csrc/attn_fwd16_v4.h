@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v4(const KernelArgs a, con
   // ---- key range (as v3)
   const int tiles_total = (C + BC - 1) / BC;
   const int tile0 = SPLIT ? (int)((uint64_t)split * tiles_total / grid.splits) : 0;
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   int tiles_visible = tiles_total;
   if constexpr (CAUSAL) {
     const int64_t last_row = min((int64_t)R, ((int64_t)rblk + 1) * (NW * 32)) - 1;

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NW * 64, (DP <= 128 ? 2 : 1)) void attn_generic_fwd
   // before the arithmetic of this tile and land in registers; other layouts stage synchronously.
   // causal extension: row r sees column c iff c <= r + coff; columns past the last row's limit are
   // never visited by this workgroup, the tiles on the diagonal are masked element-wise below
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
   const uint32_t *mrow = MASKED ? mask_base(a, head, batch) : nullptr;   // MASKED: separate code objects, the dense ones carry no mask code
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dq(const KernelArgs a) {
   // before the arithmetic of this tile and land in registers; other layouts stage synchronously.
   // causal extension: row r sees column c iff c <= r + coff; columns past the last row's limit are
   // never visited by this workgroup, the tiles on the diagonal are masked element-wise below
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const int Cend = a.causal ? (int)min((int64_t)C, min((int64_t)R, r0 + BR) + coff) : C;
   constexpr bool CAN_PREFETCH = (DP <= 128);   // 2 x (32 x DP / 4 / NT) float4 of staging registers
   const uint32_t *mrow = MASKED ? mask_base(a, head, batch) : nullptr;   // MASKED: separate code objects, the dense ones carry no mask code
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(NW * 64) void attn_generic_dkv(const KernelArgs a) 
   const char *lbase = operand_base(a.op[SLOT_L], head, batch);
   const char *dbase = operand_base(a.op[SLOT_D], head, batch);
   // causal extension: rows above the workgroup's first column minus the offset see none of its columns
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const int rstart = a.causal ? (int)(max((int64_t)0, c0 - coff) / BRW) * BRW : 0;
   constexpr bool CAN_PREFETCH = (DP <= 128) && !SEQ;
   const uint32_t *mbase = MASKED ? mask_base(a, head, batch) : nullptr;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void attn_paged_fwd(const KernelArgs a, const 
   float *ob = reinterpret_cast<float *>(operand_base(a.op[SLOT_O], head, batch));
   const OperandView &ov = a.op[SLOT_O];
   const uint32_t *mk = mask_base(a, head, batch);
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const bool causal = a.causal != 0;
   float m = -3.402823466e+38f, l = 0.f;   // +Caching.swift:310-311
   bool first = true;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void attn_paged_dq(const KernelArgs a, const p
   float *qg = reinterpret_cast<float *>(operand_base(a.op[SLOT_dQ], head, batch));
   const OperandView &qgv = a.op[SLOT_dQ], &gv = a.op[SLOT_dO], &ovw = a.op[SLOT_O];
   const uint32_t *mk = mask_base(a, head, batch);
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const bool causal = a.causal != 0;
   // D_row = sum_d dO O (1 / sqrt D)
   float dpart = 0.f;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_paged_dkv(const KernelArgs a, const 
   float *vg = reinterpret_cast<float *>(operand_base(a.op[SLOT_dV], head, batch)), *kg = reinterpret_cast<float *>(operand_base(a.op[SLOT_dK], head, batch));
   const OperandView &vgv = a.op[SLOT_dV], &kgv = a.op[SLOT_dK];
   const uint32_t *mk = mask_base(a, head, batch);
-  const int coff = C - R;
+  const int coff = causal_offset(R, C);
   const bool causal = a.causal != 0;
   bool first = true;
   int64_t rstart = 0;

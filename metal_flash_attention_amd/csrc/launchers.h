@@ -98,13 +98,11 @@ bool dkv16_rs_variant_d96(int precision, int gprecision, VariantInfo *out);
 bool dkv16_rs_variant_d160(int precision, int gprecision, VariantInfo *out);
 bool dkv16_rs_variant_d192(int precision, int gprecision, VariantInfo *out);
 
-#ifdef MFA_TR_STREAMS
-// staged kernels (developer library, TR_STREAMS=1 candidate): backward kernels that read transposed operands in place (attn_bwd16_p4_tr.hip); false = not such a launch
+// backward kernels that read transposed operands in place (attn_bwd16_p4_tr.hip); false = not such a launch
 bool bwd16_p4_tr_launch(int type, const KernelArgs &args, uint32_t heads, uint32_t batches, hipStream_t stream, bool fold);
 const char *bwd16_p4_tr_form(int type, const KernelArgs &args);
-// developer build: launches with K^T and / or V^T at the buckets 160 / 192 / 256 that are whole 32-key steps of aligned rows go
+// launches with K^T and / or V^T at the buckets 160 / 192 / 256 that are whole 32-key steps of aligned rows go
 // to the hand-placed stream (attn_fwd16_p5_tr.h); `out` arrives filled by fwd16_v3_tr_variant_dNN, whose kernel keeps the others
 bool fwd16_p5_tr_variant(int precision, int bucket, int pattern, bool fold, VariantInfo *out);
-#endif
 
 } // namespace mfa

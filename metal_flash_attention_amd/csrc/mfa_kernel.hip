@@ -142,7 +142,6 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           add(have, v);
           break;
         }
-#ifdef MFA_TR_STREAMS   // (staged: developer library / TR_STREAMS=1 candidate until the product library's evidence is re-taken)
         default: {
           bool have = b16 == 160 ? fwd16_v3_tr_variant_d160(pq, b16, pattern, &v)
                     : b16 == 192 ? fwd16_v3_tr_variant_d192(pq, b16, pattern, &v) : fwd16_v3_tr_variant_d256(pq, b16, pattern, &v);
@@ -150,11 +149,6 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           add(have, v);
           break;
         }
-#else
-        case 160: add(fwd16_v3_tr_variant_d160(pq, b16, pattern, &v), v); break;
-        case 192: add(fwd16_v3_tr_variant_d192(pq, b16, pattern, &v), v); break;
-        default: add(fwd16_v3_tr_variant_d256(pq, b16, pattern, &v), v); break;
-#endif
       }
     } else if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && b16 > 0) {
       VariantInfo v3;
@@ -284,7 +278,9 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     if (c.traversal != kdesc->traversal) d += 2;
     if (c.cacheLeft != (kdesc->cacheState[firstLeft] != 0)) d += 1;
     if (type != MFA_FORWARD && c.cacheSecond != (kdesc->cacheState[secondLeft] != 0)) d += 1;
-    if (!accumulators_cached_requested()) d += 1;   // accumulators never leave the registers on gfx950 (D <= 256)
+    // accumulators stay in registers in every code object except the paged one (D > 384: paged through the output buffers,
+    // +Accumulate.swift:403-469): a row that asks for what the candidate does is an exact match either way
+    if (accumulators_cached_requested() == c.pagedAccumulators) d += 1;
     return d;
   };
   size_t best = 0;
@@ -671,8 +667,7 @@ static auto split_launcher(const LaunchPlan &plan) -> decltype(plan.variant->lau
   return (plan.args.causal && plan.variant->launchSplitCausal) ? plan.variant->launchSplitCausal : plan.variant->launchSplit;
 }
 
-#ifdef MFA_TR_STREAMS
-// staged (developer library, TR_STREAMS=1 candidate): does this launch go to the in-place backward kernels?
+// does this launch go to the in-place backward kernels? (transposed operands, no workspace)
 static bool dev_in_place_backward(const mfa_attention_kernel *kernel, const LaunchPlan &plan) {
   if (!plan.useFallback || !kernel->relayout || kernel->desc.type == MFA_FORWARD) return false;
 #ifdef MFA_DEV_VARIANTS
@@ -681,7 +676,6 @@ static bool dev_in_place_backward(const mfa_attention_kernel *kernel, const Laun
 #endif
   return bwd16_p4_tr_form(kernel->desc.type, plan.args) != nullptr;
 }
-#endif
 
 static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const LaunchPlan &plan) {
   if (plan.variant->ldsBytes <= 64 * 1024) return MFA_OK;
@@ -712,9 +706,8 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
   LaunchPlan plan;
   mfa_status st = prepare_launch(kernel, buffers, params, &plan);
   if (st != MFA_OK) return st;
-#ifdef MFA_TR_STREAMS
-  // developer library (until the product library's evidence is re-taken with them): a transposed backward
-  // launch without a workspace goes to the kernels that read the operands in place when they take it (attn_bwd16_p4_tr.hip)
+  // a transposed backward launch without a workspace goes to the kernels that read the operands in place when they take it
+  // (attn_bwd16_p4_tr.hip; AttentionKernel.swift:189-204: the reference reads transposed operands in place in every kernel)
   if (dev_in_place_backward(kernel, plan)) {
     bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, (hipStream_t)stream, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32);
     hipError_t derr = hipGetLastError();
@@ -725,7 +718,6 @@ mfa_status mfa_attention_kernel_launch(const mfa_attention_kernel *kernel, void 
 #endif
     return derr == hipSuccess ? MFA_OK : hip_fail(derr, "attn_bwd16_p4_tr");
   }
-#endif
   st = ensure_lds_attribute(const_cast<mfa_attention_kernel *>(kernel), plan);
   if (st != MFA_OK) return st;
   for (int i = 0; i < plan.nRelayouts; ++i)
@@ -749,12 +741,10 @@ mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, 
   if (st != MFA_OK) return st;
   std::string text;
   if (plan.nRelayouts) text += "attn_relayout x" + std::to_string(plan.nRelayouts) + " + ";
-#ifdef MFA_TR_STREAMS
   if (dev_in_place_backward(kernel, plan)) {
     std::snprintf(out, capacity, "%s", bwd16_p4_tr_form(kernel->desc.type, plan.args));
     return MFA_OK;
   }
-#endif
   if (plan.useFallback) {
     text += std::string(plan.variant->name) + " (general kernel: the launch does not meet the requirements of " + kernel->variant.name + ")";
   } else if (plan.splits > 1) {
@@ -810,12 +800,10 @@ mfa_status mfa_attention_kernel_time(const mfa_attention_kernel *kernel, void *c
   err = hipEventCreate(&stop);
   if (err != hipSuccess) { (void)hipEventDestroy(start); return hip_fail(err, "hipEventCreate"); }
   auto go = [&]() {
-#ifdef MFA_TR_STREAMS
     if (dev_in_place_backward(kernel, plan)) {
       bwd16_p4_tr_launch(kernel->desc.type, plan.args, plan.heads, plan.batches, s, kernel->desc.registerPrecisions[MFA_P] > MFA_FP32);
       return;
     }
-#endif
     for (int i = 0; i < plan.nRelayouts; ++i)
       if (!plan.relayouts[i].output) launch_relayout(plan, plan.relayouts[i], s);
     if (plan.splits > 1) split_launcher(plan)(plan.grid, plan.splits, plan.wsO, plan.wsML, s, plan.args);

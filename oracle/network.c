@@ -158,7 +158,7 @@ void oracle_round_trip(float *x, size_t n, int precision) {
 #define ROW_CHUNK 128
 
 /* `causal` is this project's extension (the reference is unmasked, README.md:7 names masks as the first
-   extension): row r may attend column c iff c <= r + (C - R).  Masked columns are simply left out of
+   extension): row r may attend column c iff c <= r + max(C - R, 0).  Masked columns are simply left out of
    every sum (maximum, exp-sum, P V, dS), which is what P = 0 there means.  causal = 0 reproduces
    Network.swift exactly. */
 int oracle_network_run_masked(int R, int C, int D,
@@ -211,9 +211,10 @@ int oracle_network_run_masked(int R, int C, int D,
       for (int rr = 0; rr < rows; ++rr) {
         const int rowID = r0 + rr;
         float *p = Pc + (size_t)rr * C;
-        /* number of visible columns of this row: all of them, or c <= rowID + (C - R) */
+        /* number of visible columns of this row: all of them, or c <= rowID + max(C - R, 0) (the offset is clamped at 0 when
+           C < R -- only per-batch lengths can produce that, include/mfa.h rowLengths -- so every row sees at least one column) */
         int CV = C;
-        if (causal) { CV = rowID + (C - R) + 1; if (CV < 0) CV = 0; if (CV > C) CV = C; }
+        if (causal) { CV = rowID + (C > R ? C - R : 0) + 1; if (CV > C) CV = C; }
         /* createMatrixSRow, Network.swift:134-149 : dot over d, sequential */
         for (int c = 0; c < C; ++c) p[c] = 0.0f;
         for (int d = 0; d < D; ++d) {

@@ -17,9 +17,9 @@ def attention_f64(Q, K, V, dO=None, causal=False, mask=None):
     D = Q.shape[-1]
     scale = 1.0 / np.sqrt(np.float64(D))
     S = (Q @ K.T) * scale                                   # Network.swift:134-149, :153
-    if causal:  # extension: row r sees column c iff c <= r + (C - R)
+    if causal:  # extension: row r sees column c iff c <= r + max(C - R, 0)
         R_, C_ = S.shape
-        S = np.where(np.arange(C_)[None, :] <= np.arange(R_)[:, None] + (C_ - R_), S, -np.inf)
+        S = np.where(np.arange(C_)[None, :] <= np.arange(R_)[:, None] + max(C_ - R_, 0), S, -np.inf)
     if mask is not None:
         S = np.where(mask, S, -np.inf)
     empty = ~np.isfinite(S).any(axis=1, keepdims=True)

@@ -19,3 +19,63 @@ def built_library():
 
     entry.build()
     return True
+
+
+# ---- which code objects do the GPU tests launch?  (-m gpu sessions on a GPU box only) -----------------------------------------
+# Every AttentionKernel.dispatch / .time of the session is recorded as variant name -> the test ids that launched it, written to
+# gpurun_out/variant_coverage.json at session end; a copy of a full `-m gpu` run is committed as tests/golden/variant_coverage.json
+# and tests/test_variant_coverage.py (CPU) holds the library's variant names against it.
+_COVERAGE = {"variants": {}, "forms": {}}
+_CURRENT = {"id": None}
+
+
+def _gpu_session():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        return False
+
+
+@pytest.fixture(autouse=True)
+def _current_test_id(request):
+    _CURRENT["id"] = request.node.nodeid
+    yield
+    _CURRENT["id"] = None
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _record_launched_variants():
+    if not _gpu_session():
+        yield
+        return
+    import json
+    from metal_flash_attention_amd import AttentionKernel
+    real = {name: getattr(AttentionKernel, name) for name in ("dispatch", "time")}
+
+    def wrap(name):
+        def method(self, buffers, **kw):
+            tests = _COVERAGE["variants"].setdefault(self.variant, [])
+            tid = _CURRENT["id"] or "?"
+            if tid not in tests and len(tests) < 4:
+                tests.append(tid)
+            try:   # the launch form names the kernel family that really runs (persistent form, split pieces, re-layout, fallback)
+                form_kw = {k: v for k, v in kw.items() if k not in ("stream", "warmup", "iterations")}
+                form = self.launchForm(buffers, **form_kw).split(" ")[0]
+                _COVERAGE["forms"][form] = _COVERAGE["forms"].get(form, 0) + 1
+            except Exception:  # noqa: BLE001 -- a launch that is about to fail validation: let the real call report it
+                pass
+            return real[name](self, buffers, **kw)
+        return method
+
+    for name in real:
+        setattr(AttentionKernel, name, wrap(name))
+    yield
+    for name, fn in real.items():
+        setattr(AttentionKernel, name, fn)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    from metal_flash_attention_amd import _abi
+    with open(os.path.join(out, "variant_coverage.json"), "w") as f:
+        json.dump({"library": os.path.basename(_abi.library_path()), "variants": dict(sorted(_COVERAGE["variants"].items())),
+                   "forms": dict(sorted(_COVERAGE["forms"].items()))}, f, indent=1)

@@ -36,10 +36,6 @@ from metal_flash_attention_amd import _abi
 DEV_LIBRARY = "libmfa_hip_dev" in os.path.basename(_abi.library_path()) if hasattr(_abi, "library_path") else False
 needs_dev_library = pytest.mark.skipif(
     not DEV_LIBRARY, reason="developer schedule: run with MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_dev.so (make DEV=1)")
-# kernels staged for the product library (make TR_STREAMS=1 -> libmfa_hip_tr.so; the developer library has them too, with A/B knobs)
-STAGED_KERNELS = DEV_LIBRARY or ("libmfa_hip_tr" in os.path.basename(_abi.library_path()) if hasattr(_abi, "library_path") else False)
-needs_staged_kernels = pytest.mark.skipif(
-    not STAGED_KERNELS, reason="staged kernels: run with MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_tr.so (make TR_STREAMS=1) or the developer library")
 
 
 @contextlib.contextmanager
@@ -824,15 +820,13 @@ def test_hand_placed_stream_with_one_transposed_operand(kv, low_mid, in_type):
         assert all(run.tails_ok.values())
 
 
-@needs_staged_kernels
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
-def test_developer_backward_kernels_read_transposed_operands_in_place(causal, low_mid, in_type, monkeypatch, capfd):
-    """Developer library: the backward streams on transposed operands (K^T / V^T in backwardQuery, Q^T / dO^T in
-    backwardKeyValue; whole tiles, aligned rows) without a workspace -- model-verified streams behind developer-only kernels
-    (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h), the developer library's choice for such launches (launch form; MFA_BWD16_TR=0 keeps
-    the general kernel), not in the product library until its evidence is re-taken.  Every operand transposed; results
+def test_backward_kernels_read_transposed_operands_in_place(causal, low_mid, in_type, monkeypatch, capfd):
+    """The backward streams on transposed operands (K^T / V^T in backwardQuery, Q^T / dO^T in backwardKeyValue; whole tiles,
+    aligned rows) without a workspace (attn_dq16_p4_tr.h, attn_dkv16_p4_tr.h: transposed operands read where they lie,
+    AttentionKernel.swift:189-204; MFA_BWD16_TR=0 is the developer library's A/B knob).  Every operand transposed; results
     against the oracle at the reference's mixed tolerances.  With FP16 inputs the reference's descriptors store dO in BF16
     (+Precisions.swift:13-17): backwardQuery converts the fragments when it loads them, backwardKeyValue runs the two products
     that read dO^T in BF16 (streams F16_DOBF16_*_TR)."""
@@ -853,18 +847,16 @@ def test_developer_backward_kernels_read_transposed_operands_in_place(causal, lo
         assert all(run.tails_ok.values()), run.tails_ok
 
 
-@needs_staged_kernels
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("causal", [False, True])
-def test_developer_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions(causal, low_mid, monkeypatch, capfd):
-    """Developer library: the hand-placed forward stream of the 160 / 192 / 256 buckets on K^T / V^T in place (attn_fwd16_p5_tr.h;
-    whole 32-key steps, aligned rows), attached to the transposed variants the way attn_fwd16_p4_tr is at D <= 128 -- the product
-    library keeps the 8 x 32 kernel's transposed code object there until its evidence is re-taken.  Q / O
+def test_forward_stream_reads_transposed_keys_and_values_at_large_head_dimensions(causal, low_mid, monkeypatch, capfd):
+    """The hand-placed forward stream of the 160 / 192 / 256 buckets on K^T / V^T in place (attn_fwd16_p5_tr.h; whole 32-key
+    steps, aligned rows), attached to the transposed variants the way attn_fwd16_p4_tr is at D <= 128.  Q / O
     row-major and transposed, a head dimension inside each bucket and on its edge; against the oracle at the product tolerances of
     that path; MFA_FWD16_P5_TR=0 (A/B knob of the developer library) and a launch that is not whole steps keep the 8 x 32 object."""
     for (R, C, D), in_type, tr in (((320, 448, 256), P.BF16, (True, True, True, True)), ((300, 352, 152), P.BF16, (False, True, True, False)),
                                    ((256, 288, 192), P.FP16, (False, True, True, True)), ((264, 320, 232), P.FP16, (True, True, True, False)),
-                                   # one operand transposed (streams generated at build time; written after the round's last GPU call)
+                                   # one operand transposed
                                    ((320, 448, 256), P.BF16, (False, True, False, False)), ((300, 352, 152), P.FP16, (True, False, True, True)),
                                    ((256, 288, 192), P.BF16, (True, True, False, True)), ((264, 320, 232), P.FP16, (False, False, True, False))):
         net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
@@ -1247,9 +1239,10 @@ def test_variable_sequence_lengths(low, causal, D):
     oracle run on its own (rows, columns) slice, and nothing beyond an entry's length may be written.  D = 128 / 200 / 256:
     the hand-placed streams (their workgroups cover 256 rows / keys: entries shorter than a workgroup, empty workgroups)."""
     import torch
-    B, H, Rmax, Cmax = 4, 2, 200, 333
-    rlen = [200, 77, 1, 130]
-    clen = [333, 100, 64, 130]
+    # (last entry: fewer columns than rows -- with `causal` its diagonal offset is clamped at 0, include/mfa.h rowLengths)
+    B, H, Rmax, Cmax = 5, 2, 200, 333
+    rlen = [200, 77, 1, 130, 150]
+    clen = [333, 100, 64, 130, 90]
     in_type = P.BF16
     desc = make_desc(Rmax, Cmax, D, low_in=low, in_type=in_type)
     kernels = {t: AttentionKernel(desc.kernelDescriptor(t)) for t in AttentionKernelType}

@@ -57,12 +57,10 @@ def test_scratch_stays_out_of_the_way(obj):
         assert n <= 40, (name, n)
 
 
-# translation units whose kernels are known to CALL a device function hipcc did not inline (by-reference captures in scratch):
-# the transposed 8 x 32 code objects at D > 128 -- tile-load lambda of attn_fwd16_v3.h, found at the end of round 3 when these
-# code objects were first timed at D = 256 (profiles/r03_dev_transposed_streams.txt: ~0.1 PFLOP/s).  The developer build forces the
-# lambda inline (MFA_V3_INLINE_LOADS; so does `make TR_STREAMS=1`); the product library keeps the objects its evidence was taken with until that is timed
-# (DESIGN.md 10 item 4).  Empty this set when the fix ships.
-KNOWN_CALLERS = {"attn_fwd16_v3_tr_d160", "attn_fwd16_v3_tr_d192", "attn_fwd16_v3_tr_d256"}
+# translation units whose kernels are allowed to CALL a device function hipcc did not inline (by-reference captures in scratch): none.
+# (Round 3 found the transposed 8 x 32 code objects at D > 128 calling the tile-load lambda of attn_fwd16_v3.h -- ~0.1 PFLOP/s,
+# profiles/r03_dev_transposed_streams.txt; MFA_V3_INLINE_LOADS forces it inline in every build since round 4.)
+KNOWN_CALLERS = set()
 
 
 def _audit(build):
@@ -88,10 +86,9 @@ def test_no_kernel_calls_a_function():
         assert all(f.startswith("_ZZN3mfa13attn_fwd16_v3I") and f.endswith("ENKUlvE_clEv") for f in report[tu]["functions"]), report[tu]["functions"]
 
 
-@pytest.mark.parametrize("build", ["build_dev", "build_tr"])
-def test_builds_with_the_staged_kernels_have_the_tile_loads_inline(build):
-    """developer library (make DEV=1) and the candidate product library (make TR_STREAMS=1): MFA_V3_INLINE_LOADS -- no translation
-    unit calls a function, and the transposed code objects at 160 / 192 lose their stack"""
+@pytest.mark.parametrize("build", ["build", "build_dev"])
+def test_transposed_code_objects_have_the_tile_loads_inline(build):
+    """MFA_V3_INLINE_LOADS: no translation unit calls a function, and the transposed code objects at 160 / 192 have no stack"""
     report = _audit(build)
     assert not {tu for tu, r in report.items() if r["functions"]}
     for tu in ("attn_fwd16_v3_tr_d160", "attn_fwd16_v3_tr_d192"):

@@ -76,7 +76,7 @@ def test_transposed_query_gradient_streams(name, dma_mode, order):
     assert wg.waves[0].count.get("ds_read_b128", 0) == 32 and wg.waves[0].count["ds_read_b64"] > 0   # (b128: the K' / V hand-over only)
 
 
-def test_stream_file_is_current():
+def test_stream_file_is_current(built_library):
     """csrc/attn_dkv16_p4_stream.inc is what tools/dkv4gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_dkv16_p4_stream.inc")
     with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:

@@ -103,7 +103,7 @@ def test_transposed_streams_survive_a_ragged_last_step_on_dense_rows(name):
         _check(R, C, causal=causal, cfg=cfg, seed=18, tol_o=8e-3)   # (40 keys do not average BF16's roundings out: 4.7e-3 in the folded stream)
 
 
-def test_stream_file_is_current():
+def test_stream_file_is_current(built_library):
     """csrc/attn_fwd16_p5_stream.inc is what tools/f256gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p5_stream.inc")
     with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:

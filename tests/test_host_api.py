@@ -282,15 +282,10 @@ def test_transposed_descriptors_select_the_in_place_forward_code_objects():
     assert k.variant.startswith("attn_generic")
 
 
-def test_developer_library_routes_transposed_launches_to_the_in_place_streams():
-    """Libraries with the staged kernels only (MFA_LIBRARY=.../libmfa_hip_dev.so or .../libmfa_hip_tr.so; skipped on the product
-    library, which keeps the 8 x 32 kernel's transposed code object at these buckets until its evidence is re-taken, DESIGN.md 10
-    item 4): K^T + V^T at the buckets
-    160 / 192 / 256 keep their variant, and a launch of whole 32-key steps of aligned rows is handed to attn_fwd16_p5_tr -- planned
-    without a GPU (host pointers only decide the alignment)."""
-    from metal_flash_attention_amd import _abi
-    if not any(tag in os.path.basename(_abi.library_path()) for tag in ("libmfa_hip_dev", "libmfa_hip_tr")):
-        pytest.skip("developer library (make DEV=1) or the candidate product library with the staged kernels (make TR_STREAMS=1)")
+def test_transposed_launches_are_routed_to_the_in_place_streams():
+    """K^T + V^T at the buckets 160 / 192 / 256 keep their variant, and a launch of whole 32-key steps of aligned rows is handed
+    to attn_fwd16_p5_tr (transposed operands read where they lie, AttentionKernel.swift:189-204) -- planned without a GPU (host
+    pointers only decide the alignment)."""
     torch = pytest.importorskip("torch")
     N = 512
     for D, bucket in ((136, 160), (192, 192), (200, 256), (256, 256)):

@@ -153,7 +153,7 @@ def test_rendered_memory_instructions_keep_their_offsets():
                 assert ("offset:%d" % ins.mod["offset"]) in p4gen.render_one(ins), p4gen.render_one(ins)
 
 
-def test_stream_file_is_current():
+def test_stream_file_is_current(built_library):
     """csrc/attn_fwd16_p4_stream.inc is what tools/p4gen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4_stream.inc")
     import tempfile

@@ -155,7 +155,7 @@ def test_fused_tail_experiment(C):
     _check(2, 300, C, cfg=p4pgen.VARIANTS["BF16_FOLD_L16_FUSE"], seed=16, dma_mode="early", stores="early", order=(3, 2, 1, 0))
 
 
-def test_stream_file_is_current():
+def test_stream_file_is_current(built_library):
     """csrc/attn_fwd16_p4p_stream.inc is what tools/p4pgen.py generates"""
     path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_fwd16_p4p_stream.inc")
     import tempfile

@@ -24,6 +24,7 @@ static void launch_dkv_p4_split(dim3 grid, uint32_t splits, float *ws, float *, 
 // `v` arrives filled by dkv16_rs_variant: block-sparse launches and causal row-parallel ones keep the role-split kernel's code objects
 template <typename T, int STREAM> static void fill_dkv_p4(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dkv16_p4<T, STREAM, false>);
+  if (v->name && v->name[0]) v->siblingName = v->name;   // (arrives filled by the kernel whose split / sparse launches it keeps)
   v->name = name;
   v->siblingParallelization = v->parallelization;   // split / block-sparse launches: the role-split kernel's workgroups
   v->parallelization = 256;   // key columns per workgroup: four waves x 64

@@ -24,6 +24,7 @@ static void launch_dq_p4_split(dim3 grid, uint32_t splits, float *ws, float *, h
 // causal column-parallel ones keep that kernel's code objects
 template <typename T, int STREAM, typename TG = T> static void fill_dq_p4(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_dq16_p4<T, STREAM, false, TG>);
+  if (v->name && v->name[0]) v->siblingName = v->name;   // (arrives filled by the kernel whose split / sparse launches it keeps)
   v->name = name;
   v->parallelization = 256;
   v->traversal = 64;

@@ -29,6 +29,7 @@ static void launch_p4_split(dim3 grid, uint32_t splits, float *wsO, float *wsML,
 
 template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false>);
+  if (v->name && v->name[0]) v->siblingName = v->name;   // (arrives filled by the kernel whose split / sparse launches it keeps)
   v->name = name;
   v->parallelization = 256;
   v->traversal = 64;
@@ -70,7 +71,9 @@ bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out) {
   if (D != 128) return false;
   if (precision == PREC_BF16) {
     if (impl == 0) { fill_p4<__bf16, p4::S_BF16_THR8>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8"); return true; }
+#ifdef MFA_DEV_VARIANTS   // (no descriptor selects the THR = 0 stream: developer library only, MFA_FWD16_IMPL=p4:1)
     if (impl == 1) { fill_p4<__bf16, p4::S_BF16_THR0>(out, "attn_fwd16p4_bf16_d128_w4x64_thr0"); return true; }
+#endif
     if (impl == 10) { fill_p4<__bf16, p4::S_BF16_FOLD>(out, "attn_fwd16p4_bf16_d128_w4x64_thr8_fold"); return true; }
 #ifdef MFA_DEV_VARIANTS
 #define MFA_P4_DEV(name) if (impl == 1000 + p4::S_##name) { fill_p4_dev<__bf16, p4::S_##name>(out, "attn_fwd16p4_DEV_" #name); return true; }

@@ -23,6 +23,7 @@ static void launch_p5_split(dim3 grid, uint32_t splits, float *wsO, float *wsML,
 // `v` arrives filled by fwd16_v3_variant (D = 256: four waves x 32 rows): block-sparse launches keep its code objects
 template <typename T, int STREAM> static void fill_p5(VariantInfo *v, const char *name) {
   v->func = reinterpret_cast<const void *>(&attn_fwd16_p5<T, STREAM, false>);
+  if (v->name && v->name[0]) v->siblingName = v->name;   // (arrives filled by the kernel whose split / sparse launches it keeps)
   v->name = name;
   v->siblingParallelization = v->parallelization;
   v->parallelization = 256;

@@ -7,6 +7,9 @@ namespace mfa {
 struct VariantInfo {
   const void *func = nullptr;   // __global__ function address (for hipFuncSetAttribute)
   const char *name = "";
+  // the variant whose launchSplit / launchSplitCausal / launchSparse this one inherited (a hand-placed stream laid over the 8 x 32 /
+  // role-split kernel of the same block dimensions): named in the launch form of such launches; nullptr = they are its own
+  const char *siblingName = nullptr;
   uint16_t parallelization = 0; // rows (fwd, dQ) or columns (dK/dV) per workgroup
   uint16_t siblingParallelization = 0;   // the same for launchSparse / launchSplit when they belong to another kernel (0: equal)
   uint16_t splitTarget = 0;     // workgroups a traversal-parallel launch aims at (0: 512 = two per compute unit)

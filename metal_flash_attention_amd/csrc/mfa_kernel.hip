@@ -749,12 +749,13 @@ mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, 
     text += std::string(plan.variant->name) + " (general kernel: the launch does not meet the requirements of " + kernel->variant.name + ")";
   } else if (plan.splits > 1) {
     text += std::string(plan.variant->name) + " column-parallel x" + std::to_string(plan.splits) + " + combine";
-    if (plan.args.causal && plan.variant->launchSplitCausal) text += " (pieces by the sibling kernel)";
+    const bool own = plan.variant->splitParallelization && !(plan.args.causal && plan.variant->launchSplitCausal);
+    if (!own && plan.variant->siblingName) text += std::string(" (pieces by the sibling kernel ") + plan.variant->siblingName + ")";
   } else {
     const bool sparse = plan.args.mask && plan.variant->launchSparse;
     const char *form = (!sparse && plan.variant->launchForm) ? plan.variant->launchForm(plan.args) : nullptr;
     text += form ? form : plan.variant->name;
-    if (sparse) text += " (block-sparse sibling)";
+    if (sparse) text += plan.variant->siblingName ? std::string(" (block-sparse sibling ") + plan.variant->siblingName + ")" : std::string(" (block-sparse code object)");
   }
   std::snprintf(out, capacity, "%s", text.c_str());
   return MFA_OK;

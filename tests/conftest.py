@@ -61,8 +61,9 @@ def _record_launched_variants():
                 tests.append(tid)
             try:   # the launch form names the kernel family that really runs (persistent form, split pieces, re-layout, fallback)
                 form_kw = {k: v for k, v in kw.items() if k not in ("stream", "warmup", "iterations")}
-                form = self.launchForm(buffers, **form_kw).split(" ")[0]
-                _COVERAGE["forms"][form] = _COVERAGE["forms"].get(form, 0) + 1
+                import re
+                for form in set(re.findall(r"attn_[A-Za-z0-9_]+", self.launchForm(buffers, **form_kw))):   # (incl. a named sibling)
+                    _COVERAGE["forms"][form] = _COVERAGE["forms"].get(form, 0) + 1
             except Exception:  # noqa: BLE001 -- a launch that is about to fail validation: let the real call report it
                 pass
             return real[name](self, buffers, **kw)

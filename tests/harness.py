@@ -93,7 +93,10 @@ class DeviceRun:
     """One forward+backward pass of the three kernels for a single (R, C, D) problem."""
 
     def __init__(self, desc: AttentionDescriptor, network, seed: int = 1234, heads: int = 1,
-                 run_backward: bool = True, causal: bool = False):
+                 run_backward: bool = True, causal: bool = False, memory_overrides=None):
+        """memory_overrides: {operand: precision} written into every kernel descriptor after the table lookup (the Swift struct
+        lets a caller do the same, AttentionKernelDescriptor.swift:8-49) -- e.g. dO stored in FP16 next to FP16 Q / K / V instead
+        of the BF16 the reference's descriptor picks (+Precisions.swift:13-17)"""
         import torch
 
         self.torch = torch
@@ -103,7 +106,8 @@ class DeviceRun:
         R, C, D = desc.matrixDimensions
         self.R, self.C, self.D = R, C, D
         self.heads = heads
-        self.precisions = desc.memoryPrecisions
+        self.precisions = dict(desc.memoryPrecisions)
+        self.precisions.update(memory_overrides or {})
         tQ, tK, tV, tO = desc.transposeState
         self.transposed = {
             AttentionOperand.Q: tQ, AttentionOperand.K: tK, AttentionOperand.V: tV, AttentionOperand.O: tO,
@@ -138,7 +142,11 @@ class DeviceRun:
         if run_backward:
             types += [AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue]
         for t in types:
-            self.kernels[t] = AttentionKernel(desc.kernelDescriptor(t))
+            kdesc = desc.kernelDescriptor(t)
+            for op, prec in (memory_overrides or {}).items():
+                if op in kdesc.memoryPrecisions:
+                    kdesc.memoryPrecisions[op] = prec
+            self.kernels[t] = AttentionKernel(kdesc)
 
     def execute(self, with_workspace: bool = False):
         """with_workspace: give every launch the scratch it asks for (workspaceSize): split launches, and the row-major

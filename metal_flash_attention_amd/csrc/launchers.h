@@ -69,6 +69,9 @@ bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out);
 // backwardKeyValue counterpart: four waves x 64 keys (attn_dkv16_p4.h); `out` arrives filled by dkv16_rs_variant, whose
 // split / block-sparse launchers it keeps.  lprec / dprec: storage types of L and D (fixed per instruction stream)
 bool dkv16_p4_variant(int precision, int gprecision, int lprec, int dprec, int D, int impl, VariantInfo *out);
+// buckets 160 / 192 / 256: role-split wave pairs x 64 keys, hand-placed stream (attn_dkv16_p5.h); `out` arrives filled by the 32-key
+// role-split kernel of the bucket (attn_dkv16_rs.h), which keeps the block-sparse and row-parallel launches
+bool dkv16_p5_variant(int precision, int gprecision, int lprec, int dprec, int D, VariantInfo *out);
 // backwardQuery counterpart: four waves x 64 rows (attn_dq16_p4.h); `out` arrives filled by dq16_variant
 bool dq16_p4_variant(int precision, int gprecision, int D, int impl, VariantInfo *out);
 // 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)

@@ -81,13 +81,13 @@ static const char *kDefaultTables[3][2] = {
      "| 256 | 128 | 32 | 256 | K, V, dV, dK |\n"
      "| 384 | 32  | 32 | 384 | dV, dK       |\n",
      // backwardKeyValue, mixed: D <= 128 -> 4 waves x 64 keys (attn_dkv16_p4.h); | 128 | 128 | 32 | 128 | selects the role-split wave pairs
-     // (attn_dkv16_rs.h), which also serve the other buckets (a 96-wide object too: | 96 | 128 | 32 | 96 |); | 128 | 128 | 64 | 128 | the
-     // one-wave-per-key-block kernel (attn_bwd16.h)
+     // (attn_dkv16_rs.h; a 96-wide object too: | 96 | 128 | 32 | 96 |); | 128 | 128 | 64 | 128 | the one-wave-per-key-block kernel
+     // (attn_bwd16.h); D > 128 -> two role-split pairs x 64 keys (attn_dkv16_p5.h, round 4), | D | 64 | 32 | D | the 32-key pairs
      "| 64  | 256 | 32 | 64  | K, V, dV, dK |\n"
      "| 128 | 256 | 32 | 128 | K, V, dV, dK |\n"
-     "| 160 | 64  | 32 | 160 | K, V, dV, dK |\n"
-     "| 192 | 64  | 32 | 192 | K, V, dV, dK |\n"
-     "| 256 | 64  | 32 | 256 | K, V, dV, dK |\n"
+     "| 160 | 128 | 32 | 160 | K, V, dV, dK |\n"
+     "| 192 | 128 | 32 | 192 | K, V, dV, dK |\n"
+     "| 256 | 128 | 32 | 256 | K, V, dV, dK |\n"
      "| 384 | 32  | 32 | 384 | dV, dK       |\n"}};
 
 static std::mutex g_table_mutex;

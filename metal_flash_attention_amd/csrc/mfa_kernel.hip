@@ -198,8 +198,18 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
       }
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&
           kdesc->memoryPrecisions[MFA_dK] == kdesc->memoryPrecisions[MFA_dV]) {
+        // buckets 160, 192, 256: two wave pairs x 64 keys, hand-placed role-split stream (attn_dkv16_p5.h), in front of the
+        // 32-key pairs of the same bucket (| D | 64 | 32 | D | selects those)
+        auto add_p5 = [&](bool rs, int b) {
+          if (rs) {
+            VariantInfo v5 = v;
+            add(dkv16_p5_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], b, &v5), v5);
+          }
+          add(rs, v);
+        };
         auto add_bucket = [&](int b) {   // buckets 64, 128, 256
           const bool rs = dkv16_rs_variant(pq, pg, b, 0, &v);
+          if (b == 256) { add_p5(rs, 256); return; }
           if (rs && (b == 128 || b == 64)) {   // four waves x 64 keys, hand-placed stream (attn_dkv16_p4.h)
             VariantInfo v4 = v;
             add(dkv16_p4_variant(pq, pg, kdesc->memoryPrecisions[MFA_L], kdesc->memoryPrecisions[MFA_D], b, 0, &v4), v4);
@@ -210,8 +220,8 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
           // 64 < D <= 96: the 128 bucket's stream is 1.4 x faster than the 96-wide role-split pairs
           // (profiles/r02_bucket96_dkv.txt) and is what the default table row asks for; a | 96 | 128 | 32 | 96 | row selects these
           case 96: add(dkv16_rs_variant_d96(pq, pg, &v), v); add_bucket(128); break;
-          case 160: add(dkv16_rs_variant_d160(pq, pg, &v), v); break;
-          case 192: add(dkv16_rs_variant_d192(pq, pg, &v), v); break;
+          case 160: add_p5(dkv16_rs_variant_d160(pq, pg, &v), 160); break;
+          case 192: add_p5(dkv16_rs_variant_d192(pq, pg, &v), 192); break;
           default: add_bucket(b16); break;
         }
         add(dkv16_variant(pq, pg, b16 == 96 ? 128 : b16, &v), v);   // one wave per key block (attn_bwd16.h; D = 64, 128 only)

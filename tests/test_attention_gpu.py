@@ -666,9 +666,9 @@ BWD16_SHAPES = [(256, 256, 128), (300, 200, 128), (64, 64, 64), (255, 257, 64), 
 @pytest.mark.parametrize("dkv_impl", ["w4", "rs", "p4"])
 @pytest.mark.parametrize("shape", BWD16_SHAPES)
 def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
-    """dkv_impl: one wave per key block / role-split wave pairs (attn_dkv16_rs.h) / four waves x 64 keys, hand-placed
-    (attn_dkv16_p4.h: the default row for D in (96, 128]; low_mid selects its stream with K pre-multiplied by the softmax
-    scale, FP16 L, BF16 D).
+    """dkv_impl: one wave per key block / role-split wave pairs x 32 keys (attn_dkv16_rs.h) / the default rows: four waves x 64
+    keys, hand-placed (attn_dkv16_p4.h) for D <= 128, two role-split pairs x 64 keys, hand-placed (attn_dkv16_p5.h) above; low_mid
+    selects the streams with K pre-multiplied by the softmax scale, FP16 L, BF16 D.
     All three kernels on the BF16 matrix cores (Q, K, V, dO BF16): within the reference's mixed
     tolerances of the oracle fed with the rounded inputs, and within a tighter bound (2e-2 absolute on
     the gradients, whose dS is rounded to BF16 like the reference's register precision for dS,
@@ -676,8 +676,6 @@ def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
     R, C, D = shape
     if dkv_impl == "w4" and (D > 128 or 64 < D <= 96):
         pytest.skip("the one-wave-per-key-block kernel exists for the 64 and 128 buckets only")
-    if dkv_impl == "p4" and D > 128:
-        pytest.skip("the four-wave kernel exists for the 64 and 128 buckets only (64 < D <= 96 runs in the 128 bucket)")
     if low_mid and dkv_impl == "w4":
         pytest.skip("covered with FP32 intermediates")
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
@@ -687,7 +685,9 @@ def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
     variants = {t.name: k.variant for t, k in run.kernels.items()}
     assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
     assert ("attn_dkv16rs" in variants["backwardKeyValue"]) == (dkv_impl == "rs"), variants
-    assert ("attn_dkv16p4" in variants["backwardKeyValue"]) == (dkv_impl == "p4"), variants
+    # default rows ("p4"): four waves x 64 keys up to D = 128 (attn_dkv16_p4.h), two role-split pairs x 64 keys above (attn_dkv16_p5.h)
+    assert ("attn_dkv16p4" in variants["backwardKeyValue"]) == (dkv_impl == "p4" and D <= 128), variants
+    assert ("attn_dkv16p5" in variants["backwardKeyValue"]) == (dkv_impl == "p4" and D > 128), variants
     assert ("attn_dq16p4" in variants["backwardQuery"]) == (D <= 128), variants   # attn_dq16_p4.h: buckets 64 and 128 (D in (64, 128])
     got = run.execute()
     round_inputs(net, desc)

@@ -1,0 +1,96 @@
+"""CPU checks of the hand-placed ROLE-SPLIT instruction stream of attn_dkv16_p5 (tools/dkv5gen.py: backwardKeyValue at the
+head-dimension buckets 160 / 192 / 256) on the lane-exact model in tools/p4sim.py: the stream that is compiled into libmfa_hip.so
+is executed instruction by instruction for one 128-key workgroup (two V-role waves, two K-role waves exchanging P through LDS) over
+all its row blocks and compared with a float64 backward pass (the formulas of the reference's Network.swift:202-330 in matrix
+form).  No GPU, no oracle library needed."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+import dkv5gen  # noqa: E402
+import dkv5sim  # noqa: E402
+
+V = dkv5gen.VARIANTS
+
+
+def _check(R, C, cblk=0, causal=False, cfg=None, seed=0, **kw):
+    cfg = cfg or V["D256_BF16_MIXED"]
+    ev, ek, mv, mk, wg = dkv5sim.check(R=R, C=C, cblk=cblk, causal=causal, cfg=cfg, seed=seed, **kw)
+    # P and dS enter the second products in the 16-bit type (8 / 11 bits of mantissa); dS' is formed from the ROUNDED P (the
+    # exchange carries the packed fragments -- the reference's register precision of P, +Precisions.swift:149-215)
+    rel = 3e-3 if (cfg.dtype == "f16" and not cfg.mix) else 1.5e-2    # mix streams: P and V enter the dO products as BF16
+    assert ev < rel * max(1.0, mv) and ek < rel * max(1.0, mk), (ev, mv, ek, mk)
+    return wg
+
+
+@pytest.mark.parametrize("D", [160, 192, 256])
+@pytest.mark.parametrize("R", [32, 64, 96, 128, 160, 320])   # one block (no loop), two, odd / even counts, two wraps of the four-stage ring
+def test_row_blocks(R, D):
+    _check(R, 128, cfg=V["D%d_BF16_MIXED" % D])
+
+
+@pytest.mark.parametrize("R,C,cblk", [(77, 100, 0), (50, 200, 1), (1, 128, 0), (100, 129, 1), (33, 64, 0)])
+def test_ragged(R, C, cblk):
+    _check(R, C, cblk=cblk, seed=1)
+    _check(R, C, cblk=cblk, seed=1, cfg=V["D192_BF16_F32"])
+
+
+@pytest.mark.parametrize("D", [160, 256])
+@pytest.mark.parametrize("R,C,cblk", [(128, 128, 0), (300, 392, 1), (200, 256, 1), (256, 256, 1), (96, 256, 0)])
+def test_causal(R, C, cblk, D):
+    _check(R, C, cblk=cblk, causal=True, seed=2, cfg=V["D%d_BF16_MIXED" % D])
+
+
+@pytest.mark.parametrize("dma_mode", ["early", "late"])
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 2, 1, 0), (2, 0, 3, 1)])
+def test_ring_and_exchange_discipline(dma_mode, order):
+    # DMA data landing as early / as late as the waits allow, the exchange writes landing as late as the waits allow, waves of
+    # either role running ahead of / behind each other between barriers
+    _check(224, 128, dma_mode=dma_mode, order=order, seed=3)
+    _check(160, 256, cblk=1, dma_mode=dma_mode, order=order, seed=3, cfg=V["D160_F16_MIXED"], causal=True)
+
+
+@pytest.mark.parametrize("name", list(V))
+def test_every_compiled_variant(name):
+    _check(96, 128, cfg=V[name], seed=4)
+    _check(160, 200, cfg=V[name], causal=True, seed=5, cblk=1)
+
+
+@pytest.mark.parametrize("D,Dr", [(160, 136), (160, 152), (192, 176), (256, 200), (256, 232), (256, 248)])
+def test_head_dimensions_inside_a_bucket(D, Dr):
+    """chunks beyond the head dimension are zero-filled (LDS-DMA offsets out of range, cached fragments zeroed by the kernel)"""
+    _check(100, 128, cfg=V["D%d_BF16_MIXED" % D], Dr=Dr, seed=6)
+    _check(64, 100, cfg=V["D%d_F16_F32" % D], Dr=Dr, seed=7)
+
+
+def test_exact_stream_is_closer():
+    """the exact streams keep K as stored and scale in fp32: with FP16 inputs and FP32 L, D the dK result is closer to float64
+    than with K pre-multiplied in the 16-bit type"""
+    e_fold = dkv5sim.check(R=96, C=128, cfg=V["D192_F16_MIXED"], seed=6)
+    e_exact = dkv5sim.check(R=96, C=128, cfg=V["D192_F16_F32"], seed=6)
+    assert e_exact[1] < 0.7 * e_fold[1]
+
+
+def test_instruction_budget():
+    """a full iteration is 2 + 4 nks matrix instructions per wave; every LDS fragment feeds two of them"""
+    for name in ("D160_BF16_MIXED", "D192_BF16_MIXED", "D256_BF16_MIXED"):
+        cfg = V[name]
+        wg = _check(32 * 9, 128, cfg=cfg, seed=8)          # 9 blocks: iteration 0, 8 full ones, the last
+        for w in wg.waves:
+            mfma = sum(n for op, n in w.count.items() if op.startswith("v_mfma"))
+            assert mfma == 9 * cfg.NM, (name, w.id, mfma)
+            frag_reads = w.count["ds_read_b128"] - 2 * cfg.nks - (0 if w.id < 2 else 9 * 4)     # minus the hand-over, the P pick-ups
+            assert frag_reads == 9 * cfg.nks and w.count["ds_read_b64_tr_b16"] == 9 * 2 * cfg.nks
+            assert w.count.get("ds_write_b128", 0) == (9 * 4 if w.id < 2 else 0)
+
+
+def test_stream_file_is_current(built_library):
+    """csrc/attn_dkv16_p5_stream.inc is what tools/dkv5gen.py generates"""
+    path = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc", "attn_dkv16_p5_stream.inc")
+    with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:
+        dkv5gen.write_inc(tmp.name)
+        assert open(path).read() == open(tmp.name).read(), "run python tools/dkv5gen.py"

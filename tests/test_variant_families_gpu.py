@@ -30,8 +30,6 @@ def test_fp16_inputs_with_either_gradient_type(D, rows, low_mid, grad):
     """FP16 Q / K / V with dO stored in FP16 (descriptor override) or BF16 (the reference's mix), every backward code-object family"""
     if rows == "w4" and (D not in (64, 128) or low_mid):
         pytest.skip("the one-wave-per-key-block kernel exists for the 64 and 128 buckets, FP32 intermediates")
-    if rows == "rs" and D > 128:
-        pytest.skip("the default rows already select the role-split pairs there")
     R, C = 200, 328
     net = Network(NetworkDescriptor(R, C, D), seed=3 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.FP16)

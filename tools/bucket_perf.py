@@ -20,12 +20,17 @@ ap.add_argument("--mixed", action="store_true")
 ap.add_argument("--transposed", action="store_true")
 ap.add_argument("--causal", action="store_true")
 ap.add_argument("--fill", default="normal", choices=("normal", "zero"))
+ap.add_argument("--dkv32", action="store_true", help="A/B: the 32-key role-split pairs (attn_dkv16_rs.h) at D > 128 instead of attn_dkv16_p5")
 ap.add_argument("--heads", type=int, default=64)
 ap.add_argument("--n", type=int, default=4096)
 args = ap.parse_args()
 if os.environ.get("MIXED", "0") == "1":   # (the round-2/3 spelling)
     args.mixed = True
 N, H = args.n, args.heads
+if args.dkv32:
+    import metal_flash_attention_amd as mfa
+    mfa.setParameterFile(T.backwardKeyValue, True, "| 64 | 256 | 32 | 64 | K, V, dV, dK |\n| 128 | 256 | 32 | 128 | K, V, dV, dK |\n| 160 | 64 | 32 | 160 | K, V, dV, dK |\n"
+                         "| 192 | 64 | 32 | 192 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
 print(f"# tools/bucket_perf.py: N={N} heads={H} bf16 mixed={int(args.mixed)} transposed={int(args.transposed)} causal={int(args.causal)} fill={args.fill}")
 for D in args.dims or [64, 128, 160, 192, 256]:
     desc = AttentionDescriptor()

@@ -117,6 +117,9 @@ class Wave:
     def retire_lds(self, keep):
         while len(self.lds_q) > keep:
             dests, data = self.lds_q.pop(0)
+            if isinstance(dests, tuple) and dests and dests[0] == "write":     # ds_write: the data reach LDS as late as the waits allow
+                self.wg.lds_write16(dests[1], data)
+                continue
             for (kind, idx), row in zip(dests, data):
                 (self.v if kind == "v" else self.a)[idx] = row
                 self.poison.discard((kind, idx))
@@ -239,6 +242,19 @@ class Workgroup:
             for t in dests:
                 w.poison.add(t)
             w.lds_q.append((dests, data.T.copy()))
+        elif op == "ds_write_b128":
+            # s = (address register, four data registers); in the wave's in-order LDS queue (lgkmcnt) like a read.  The data are read
+            # at issue and land when a wait retires the entry ("late": a barrier without the wait leaves other waves the old bytes)
+            addr = (w.rd(s[0]).astype(np.int64) + int(m.get("offset", 0)))
+            words = w.rd_multi(s[1]).astype(np.uint32)                 # [4][64]
+            data = np.ascontiguousarray(words.T).view(np.uint8).reshape(64, 16).copy()
+            if getattr(self, "lds_write_mode", "late") == "early":
+                self.lds_write16(addr, data)
+                w.lds_q.append(([], np.zeros((0, 64), np.uint32)))
+            else:
+                w.lds_q.append((("write", addr, None), data))
+        elif op == "v_lshrrev_b32":
+            w.wr(d, w.rd(s[1]) >> np.uint32(int(s[0][1])))
         elif op == "ds_read_b64":
             addr = w.rd(s[0]) + m["offset"]
             data = self.lds_read(addr, 8).copy().view(np.uint32)      # [64][2]

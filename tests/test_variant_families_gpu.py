@@ -88,17 +88,18 @@ def test_forward_32_row_wave_objects_at_every_bucket(D, in_type):
     assert not failures, (failures, k.variant)
 
 
+@pytest.mark.parametrize("in_type,grad", [(P.BF16, None), (P.FP16, None), (P.FP16, P.FP16)])
 @pytest.mark.parametrize("kind", ["split", "sparse"])
 @pytest.mark.parametrize("D", [64, 128, 160, 256])
-def test_launch_form_names_the_sibling_code_object(D, kind):
+def test_launch_form_names_the_sibling_code_object(D, kind, in_type, grad):
     """column-parallel and block-sparse launches of a hand-placed variant run the sibling kernel's code objects: the launch form says
     which (mfa_attention_kernel_launch_form), and the results are the oracle's"""
     import torch
     from metal_flash_attention_amd.torch_binding import pack_block_mask
     R = C = 1024
     net = Network(NetworkDescriptor(R, C, D), seed=D + 11)
-    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16)
-    run = harness.DeviceRun(desc, net)
+    desc = make_desc(R, C, D, low_in=True, in_type=in_type)
+    run = harness.DeviceRun(desc, net, memory_overrides=({Op.dO: grad} if grad is not None else None))
     _rounded(net, run.precisions)
     stream = torch.cuda.current_stream().cuda_stream
     forms = {}

@@ -72,6 +72,9 @@ bool dkv16_p4_variant(int precision, int gprecision, int lprec, int dprec, int D
 // buckets 160 / 192 / 256: role-split wave pairs x 64 keys, hand-placed stream (attn_dkv16_p5.h); `out` arrives filled by the 32-key
 // role-split kernel of the bucket (attn_dkv16_rs.h), which keeps the block-sparse and row-parallel launches
 bool dkv16_p5_variant(int precision, int gprecision, int lprec, int dprec, int D, VariantInfo *out);
+// buckets 160 / 192 / 256: role-split wave pairs x 64 rows, hand-placed stream (attn_dq16_p5.h); `out` arrives filled by the 32-row-wave
+// kernel of the bucket (attn_bwd16.h attn_dq16), which keeps the block-sparse and column-parallel launches
+bool dq16_p5_variant(int precision, int gprecision, int D, int impl, VariantInfo *out);
 // backwardQuery counterpart: four waves x 64 rows (attn_dq16_p4.h); `out` arrives filled by dq16_variant
 bool dq16_p4_variant(int precision, int gprecision, int D, int impl, VariantInfo *out);
 // 8 waves x 32 rows, SIMD partners alternate matrix / vector segments (see attn_fwd16_v4.h)

@@ -67,12 +67,13 @@ static const char *kDefaultTables[3][2] = {
      "| 128 | 128 | 32 | 128 | Q, dO, dQ |\n"
      "| 256 | 128 | 32 | 256 | Q, dO, dQ |\n"
      "| 384 | 32  | 32 | 384 | Q, dQ     |\n",
-     // backwardQuery, mixed
+     // backwardQuery, mixed: D <= 128 -> 4 waves x 64 rows, 64-key tiles (attn_dq16_p4.h); D > 128 -> two role-split pairs x 64 rows,
+     // 32-key blocks (attn_dq16_p5.h, round 4); | D | 128 | 64 | D | selects the four 32-row waves of attn_bwd16.h there
      "| 64  | 256 | 64 | 64  | Q, dO, dQ |\n"
      "| 128 | 256 | 64 | 128 | Q, dO, dQ |\n"
-     "| 160 | 128 | 64 | 160 | Q, dO, dQ |\n"
-     "| 192 | 128 | 64 | 192 | Q, dO, dQ |\n"
-     "| 256 | 128 | 64 | 256 | Q, dO, dQ |\n"
+     "| 160 | 128 | 32 | 160 | Q, dO, dQ |\n"
+     "| 192 | 128 | 32 | 192 | Q, dO, dQ |\n"
+     "| 256 | 128 | 32 | 256 | Q, dO, dQ |\n"
      "| 384 | 32  | 32 | 384 | Q, dQ     |\n"},
     {// backwardKeyValue, FP32
      "| 32  | 128 | 32 | 32  | K, V, dV, dK |\n"

@@ -182,9 +182,19 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     const int b16 = bucket16(D, type == MFA_BACKWARD_QUERY ? B16_DQ : B16_DKV);
     if (same16 && pg != MFA_FP32 && (D % 8) == 0 && b16 > 0) {
       if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ)) {
+        // buckets 160, 192, 256: two wave pairs x 64 rows, hand-placed role-split stream (attn_dq16_p5.h), in front of the four
+        // 32-row waves of the same bucket (| D | 128 | 64 | D | selects those)
+        auto add_dq5 = [&](bool w4, int b) {
+          if (w4) {
+            VariantInfo v5 = v;
+            add(dq16_p5_variant(pq, pg, b, kdesc->registerPrecisions[MFA_P] > MFA_FP32 ? 10 : 0, &v5), v5);
+          }
+          add(w4, v);
+        };
         switch (b16) {
-          case 160: add(dq16_variant_d160(pq, pg, &v), v); break;
-          case 192: add(dq16_variant_d192(pq, pg, &v), v); break;
+          case 160: add_dq5(dq16_variant_d160(pq, pg, &v), 160); break;
+          case 192: add_dq5(dq16_variant_d192(pq, pg, &v), 192); break;
+          case 256: add_dq5(dq16_variant(pq, pg, 256, &v), 256); break;
           default: {
             const bool w8 = dq16_variant(pq, pg, b16, &v);
             if (w8 && (b16 == 128 || b16 == 64)) {   // four waves x 64 rows, hand-placed stream (attn_dq16_p4.h): the same block

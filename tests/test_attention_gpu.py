@@ -53,6 +53,9 @@ def parameter_rows(*rows):
 FWD_8x32 = (AttentionKernelType.forward, True, "| 32 | 128 | 32 | 32 | Q, O |\n| 64 | 256 | 32 | 64 | Q, O |\n| 128 | 256 | 32 | 128 | Q, O |\n| 256 | 128 | 32 | 256 | Q, O |\n")
 DKV_RS = (AttentionKernelType.backwardKeyValue, True, "| 64 | 128 | 32 | 64 | K, V, dV, dK |\n| 96 | 128 | 32 | 96 | K, V, dV, dK |\n| 128 | 128 | 32 | 128 | K, V, dV, dK |\n"
           "| 160 | 64 | 32 | 160 | K, V, dV, dK |\n| 192 | 64 | 32 | 192 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
+# backwardQuery: the four 32-row waves of attn_bwd16.h at D > 128 (the default rows select the role-split pairs of attn_dq16_p5.h)
+DQ_W4 = (AttentionKernelType.backwardQuery, True, "| 64 | 256 | 64 | 64 | Q, dO, dQ |\n| 128 | 256 | 64 | 128 | Q, dO, dQ |\n| 160 | 128 | 64 | 160 | Q, dO, dQ |\n"
+         "| 192 | 128 | 64 | 192 | Q, dO, dQ |\n| 256 | 128 | 64 | 256 | Q, dO, dQ |\n")
 DKV_W4 = (AttentionKernelType.backwardKeyValue, True, "| 64 | 128 | 64 | 64 | K, V, dV, dK |\n| 128 | 128 | 64 | 128 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
 
 
@@ -680,9 +683,10 @@ def test_backward_16bit_mfma(shape, dkv_impl, low_mid, monkeypatch):
         pytest.skip("covered with FP32 intermediates")
     net = Network(NetworkDescriptor(R, C, D), seed=7 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, in_type=P.BF16, low_mid=low_mid)
-    with parameter_rows(*({"w4": [DKV_W4], "rs": [DKV_RS], "p4": []}[dkv_impl])):
+    with parameter_rows(*({"w4": [DKV_W4], "rs": [DKV_RS, DQ_W4], "p4": []}[dkv_impl])):
         run = harness.DeviceRun(desc, net)
     variants = {t.name: k.variant for t, k in run.kernels.items()}
+    assert ("attn_dq16p5" in variants["backwardQuery"]) == (D > 128 and dkv_impl != "rs"), variants   # attn_dq16_p5.h: buckets 160 / 192 / 256
     assert variants["backwardQuery"].startswith("attn_dq16") and variants["backwardKeyValue"].startswith("attn_dkv16"), variants
     assert ("attn_dkv16rs" in variants["backwardKeyValue"]) == (dkv_impl == "rs"), variants
     # default rows ("p4"): four waves x 64 keys up to D = 128 (attn_dkv16_p4.h), two role-split pairs x 64 keys above (attn_dkv16_p5.h)

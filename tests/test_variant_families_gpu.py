@@ -10,7 +10,7 @@ import harness
 from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType, AttentionOperand as Op,
                                        GEMMOperandPrecision as P)
 from oracle import Network, NetworkDescriptor, round_trip
-from test_attention_gpu import DKV_RS, DKV_W4, FWD_8x32, TOL_MIXED, make_desc, parameter_rows
+from test_attention_gpu import DKV_RS, DKV_W4, DQ_W4, FWD_8x32, TOL_MIXED, make_desc, parameter_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def test_fp16_inputs_with_either_gradient_type(D, rows, low_mid, grad):
     R, C = 200, 328
     net = Network(NetworkDescriptor(R, C, D), seed=3 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.FP16)
-    with parameter_rows(*({"default": [], "rs": [DKV_RS], "w4": [DKV_W4]}[rows])):
+    with parameter_rows(*({"default": [], "rs": [DKV_RS, DQ_W4], "w4": [DKV_W4]}[rows])):
         run = harness.DeviceRun(desc, net, memory_overrides={Op.dO: grad})
     names = {t.name: k.variant for t, k in run.kernels.items()}
     tag = "_f16_d" if grad == P.FP16 else "_f16_dObf16_d"

@@ -1426,8 +1426,8 @@ def test_backward_split_matches_unsplit_and_oracle(shape, causal):
         form = k.launchForm(run.buffers, row=R, column=C, causal=causal, workspace=ws)
         assert "column-parallel x" in form, form
         # the hand-placed kernels of D <= 128 cut dense launches into pieces themselves, causal ones belong to their siblings;
-        # attn_dkv16_p5 (D > 128) leaves every row-parallel launch to the 32-key role-split pairs
-        assert ("sibling" in form) == ((causal and "p4" in k.variant) or "dkv16p5" in k.variant), form
+        # attn_dq16_p5 / attn_dkv16_p5 (D > 128) leave every traversal-parallel launch to the 32-row waves / 32-key role-split pairs
+        assert ("sibling" in form) == ((causal and "p4" in k.variant) or "16p5" in k.variant), form
     torch.cuda.synchronize()
     got = run.results()
     # the unsplit launch of the 128 bucket is the four-wave hand-placed kernel, the split one its 8 x 32 / role-split sibling:

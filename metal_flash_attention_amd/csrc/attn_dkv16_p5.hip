@@ -2,6 +2,7 @@
 // 160 / 192 / 256 (attn_dkv16_p5.h).
 #include "attn_dkv16_p5.h"
 #include "launchers.h"
+#include <cstdlib>
 
 namespace mfa {
 
@@ -37,6 +38,12 @@ template <typename T, int STREAM> static void fill_dkv_p5(VariantInfo *v, const 
 bool dkv16_p5_variant(int precision, int gprecision, int lprec, int dprec, int D, VariantInfo *out) {
   const bool mixed = lprec == PREC_FP16 && dprec == PREC_BF16, f32 = lprec == PREC_FP32 && dprec == PREC_FP32;
   if (!mixed && !f32) return false;
+#ifdef MFA_DEV_VARIANTS   // developer library: MFA_BWD5_PROF=1 -> the clock-stamping streams (tools/bwd5_prof.py)
+  if (std::getenv("MFA_BWD5_PROF") && mixed && precision == PREC_BF16 && gprecision == PREC_BF16) {
+    if (D == 256) { fill_dkv_p5<__bf16, dkv5::S_D256_BF16_MIXED_PROF>(out, "attn_dkv16p5_DEV_D256_BF16_MIXED_PROF"); return true; }
+    if (D == 160) { fill_dkv_p5<__bf16, dkv5::S_D160_BF16_MIXED_PROF>(out, "attn_dkv16p5_DEV_D160_BF16_MIXED_PROF"); return true; }
+  }
+#endif
 #define MFA_DKV5_PICK(DD)                                                                                                                      \
   if (D == DD) {                                                                                                                               \
     if (precision == PREC_FP16 && gprecision == PREC_BF16) {                                                                                   \

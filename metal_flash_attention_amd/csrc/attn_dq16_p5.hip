@@ -2,6 +2,7 @@
 // 160 / 192 / 256 (attn_dq16_p5.h).
 #include "attn_dq16_p5.h"
 #include "launchers.h"
+#include <cstdlib>
 
 namespace mfa {
 
@@ -35,6 +36,12 @@ template <typename T, int STREAM, typename TG = T> static void fill_dq_p5(Varian
 // impl 0: Q as stored, softmax scale in fp32 (descriptors that keep the attention matrix in FP32 registers); impl 10: Q
 // pre-multiplied by the scale in the 16-bit type (lowPrecisionIntermediates)
 bool dq16_p5_variant(int precision, int gprecision, int D, int impl, VariantInfo *out) {
+#ifdef MFA_DEV_VARIANTS   // developer library: MFA_BWD5_PROF=1 -> the clock-stamping streams (tools/bwd5_prof.py)
+  if (std::getenv("MFA_BWD5_PROF") && impl == 10 && precision == PREC_BF16 && gprecision == PREC_BF16) {
+    if (D == 256) { fill_dq_p5<__bf16, dq5::S_D256_BF16_FOLD_PROF>(out, "attn_dq16p5_DEV_D256_BF16_FOLD_PROF"); return true; }
+    if (D == 160) { fill_dq_p5<__bf16, dq5::S_D160_BF16_FOLD_PROF>(out, "attn_dq16p5_DEV_D160_BF16_FOLD_PROF"); return true; }
+  }
+#endif
   if (impl != 0 && impl != 10) return false;
   const bool fold = impl == 10;
 #define MFA_DQ5_PICK(DD)                                                                                                                       \

@@ -58,13 +58,14 @@ XPAR = 4096                 # bytes of one parity of a pair's exchange buffer: 4
 
 # named operands of the asm statement (attn_dkv16_p5.h); order = operand order
 INOUT_V = ["qoff0", "qoff1", "qoff2", "qoff3", "goff0", "goff1", "goff2", "goff3", "ldoff", "ra0", "ra1", "ta0", "ta1"]
-TMP_S = ["j", "stg", "delta", "deltat", "wr", "t0", "t1"]
+TMP_S = ["j", "stg", "delta", "deltat", "wr", "t0", "t1", "pa", "pb", "pc", "pd", "plast"]   # p*: PROF streams
+TMP_S64 = ["ptime"]
 IN_V = ["onesw", "tk", "kvback", "xaddr"]
 IN_S = ["qres", "gres", "ldres", "nsteps", "rscale", "rscale2", "qinc", "ginc", "ldinc", "wr0", "ringend", "maskuntil", "scale2x2", "role"]
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", exact=0, gdtype=None, D=256, abl=()):
+    def __init__(self, dtype="bf16", lprec="f32", dprec="f32", exact=0, gdtype=None, D=256, abl=(), prof=0):
         """dtype: type of Q, K, V (and of the packed dS'); gdtype: storage type of dO (the reference's own mix: FP16 Q, K, V with
         BF16 dO, +Precisions.swift:13-17): the two products that read dO -- dP' and dV^T -- run in it (V converted once by the
         kernel, P packed to it).  lprec / dprec: storage types of L and D.  exact: K stays as stored, the softmax scale is applied
@@ -80,8 +81,8 @@ class Cfg:
         self.NPW = self.DI // 64                    # 1 KiB LDS-DMA pieces per wave and operand tile
         self.F = 2 * self.nks                       # fragments of a full iteration: nks row fragments, 2 ndb transposed ones
         self.NM = 2 + 2 * self.F                    # matrix instructions of a full iteration
-        self.prof = 0
-        self.abl = frozenset(abl)
+        self.prof = prof      # developer streams: shader-clock sums per wave -- pa: behind the barrier .. end of phase A, pb: phase B up to
+        self.abl = frozenset(abl)   # the seam, pc: the seam's waits + barrier (full iterations only; every stamp costs an lgkmcnt(0))
 
 
 def af(k):
@@ -120,6 +121,16 @@ class Stream(_P4Stream):
     def lds_write(self, addr, data, offset):
         self.emit("ds_write_b128", None, [addr, data], offset=offset)
         self.lds_issued += 1
+
+    def stamp0(self):
+        """PROF streams: start the clock (no accumulation)"""
+        if not self.cfg.prof:
+            return
+        self.emit("s_memtime", SN("ptime", 2))
+        self.emit("s_waitcnt", None, [], lgkmcnt=0)
+        self.lds_done = self.lds_issued
+        self.emit("s_mov_b64", VCC, [SN("ptime", 2)])
+        self.emit("s_mov_b32", SN("plast"), [("vcc_lo",)])
 
     # ---------------------------------------------------------------- LDS fragment reads
     def frag_read(self, role, k):
@@ -386,15 +397,21 @@ class Stream(_P4Stream):
         # ---- the seam to the next iteration
         if alt_label is not None:
             def seam():
+                if full:
+                    self.stamp("pb")
                 self.emit("s_waitcnt", None, [], vmcnt=2 * NPW if "dma" not in cfg.abl else 0, lgkmcnt=0)
                 self.lds_done = self.lds_issued
                 self.emit("s_barrier")
+                if full:
+                    self.stamp("pc")
                 self.addr_advance(["ta0", "ta1"], "deltat")
                 self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
                 self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nsteps")])
                 self.emit("s_cbranch_scc1", None, [], target=alt_label)
                 self.alt_capture = (self.lds_issued, self.lds_done, dict(self.frag_rid))
             at(seam_g, seam)
+            if full:
+                at(nA - 1, lambda: self.stamp("pa"))
             conv = self.ld_convert_ops(role)
             for n, fn in enumerate(conv):
                 at(seam_g + 1 + (n * 2) // len(conv), fn)
@@ -474,9 +491,12 @@ class Stream(_P4Stream):
         self.emit("s_mov_b32", SN("j"), [I(0)])
         self.emit("s_mov_b32", SN("stg"), [I(0)])
         self.emit("s_mov_b32", SN("delta"), [I(cfg.STAGE)])
+        for d in ("pa", "pb", "pc", "pd"):
+            self.emit("s_mov_b32", SN(d), [I(0)])
         lbl = {n: self.newlabel(tag + n) for n in ("LOOP", "ALT0", "ALT1", "ALTP", "EPI0", "EPI1", "END")}
         # ---- iteration 0 (parity 0): phase A only
         st = self.iteration(role, 0, True, False, lbl["ALTP"])
+        self.stamp0()
         self.enter_full()
         # ---- the loop: iterations 1, 3, ... (parity 1) and 2, 4, ... (parity 0)
         self.label(lbl["LOOP"])
@@ -521,10 +541,10 @@ def write_inc(path):
              "// header for the register map and the iteration table).", "#pragma once", ""]
     lines.append("#define MFA_DKV5_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256)))
     lines.append("")
-    lines.append("// X(name, applies the softmax scale in fp32, dO is BF16 next to FP16 Q / K / V, head-dimension bucket)")
+    lines.append("// X(name, applies the softmax scale in fp32, dO is BF16 next to FP16 Q / K / V, head-dimension bucket, stamps the shader clock)")
     lines.append("#define MFA_DKV5_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.exact, int(cfg.mix), cfg.D))
+        lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.exact, int(cfg.mix), cfg.D, cfg.prof))
     lines.append("")
     lines.append("")
     for name, cfg in VARIANTS.items():
@@ -550,6 +570,8 @@ def _variants():
             out["D%d_%s_F32" % (D, T)] = Cfg(dt, "f32", "f32", exact=1, D=D)       # lowPrecisionInputs alone: FP32 L, D, scale in fp32
         out["D%d_F16_DOBF16_MIXED" % D] = Cfg("f16", "f16", "bf16", gdtype="bf16", D=D)   # the reference's default low-precision mix
         out["D%d_F16_DOBF16_F32" % D] = Cfg("f16", "f32", "f32", exact=1, gdtype="bf16", D=D)
+    out["D256_BF16_MIXED_PROF"] = Cfg("bf16", "f16", "bf16", D=256, prof=1)       # developer library only (tools/bwd5_prof.py)
+    out["D160_BF16_MIXED_PROF"] = Cfg("bf16", "f16", "bf16", D=160, prof=1)
     return out
 
 

@@ -58,13 +58,14 @@ KRING, VRING = 5, 3
 XPAR = 4096
 
 INOUT_V = ["koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3", "ra0", "ra1", "ta0", "ta1"]
-TMP_S = ["j", "sk", "sv", "kd0", "kd1", "kd2", "vd0", "wrk", "wrv", "t0", "t1"]
+TMP_S = ["j", "sk", "sv", "kd0", "kd1", "kd2", "vd0", "wrk", "wrv", "t0", "t1", "pa", "pb", "pc", "pd", "plast"]   # p*: PROF streams
+TMP_S64 = ["ptime"]
 IN_V = ["negt0", "negt1", "lim0", "lim1", "xp", "xs"]
 IN_S = ["kres", "vres", "nt", "kinc", "vinc", "wrk0", "wrv0", "kend", "vend", "maskfrom", "scale2x2", "role"]
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", exact=0, D=256, abl=()):
+    def __init__(self, dtype="bf16", exact=0, D=256, abl=(), prof=0):
         """exact: Q stays as stored, -L arrives divided by log2(e)/sqrt(D) and the scale is applied in fp32 before the exp2 (one
         packed multiply per two scores); otherwise Q arrives pre-multiplied, rounded to the 16-bit type.  dO arrives in dtype (the
         kernel converts BF16 gradients next to FP16 operands while it loads the fragments, as attn_dq16_p4.h)."""
@@ -79,8 +80,8 @@ class Cfg:
         self.XP0 = (KRING + VRING) * self.TI
         self.XS0 = self.XP0 + 4 * XPAR
         self.LDS = self.XS0 + 4 * XPAR
-        self.prof = 0
-        self.abl = frozenset(abl)
+        self.prof = prof      # developer streams: shader-clock sums per wave -- pa: behind the barrier .. end of phase A, pb: phase B up to
+        self.abl = frozenset(abl)   # the seam, pc: the seam's waits + barrier (full iterations only; every stamp costs an lgkmcnt(0))
 
     def share(self, role):
         return self.ndbs if role == 0 else self.ndb - self.ndbs
@@ -122,6 +123,16 @@ class Stream(_P4Stream):
     def lds_write(self, addr, data, offset):
         self.emit("ds_write_b128", None, [addr, data], offset=offset)
         self.lds_issued += 1
+
+    def stamp0(self):
+        """PROF streams: start the clock (no accumulation)"""
+        if not self.cfg.prof:
+            return
+        self.emit("s_memtime", SN("ptime", 2))
+        self.emit("s_waitcnt", None, [], lgkmcnt=0)
+        self.lds_done = self.lds_issued
+        self.emit("s_mov_b64", VCC, [SN("ptime", 2)])
+        self.emit("s_mov_b32", SN("plast"), [("vcc_lo",)])
 
     # ---------------------------------------------------------------- LDS reads
     def row_read(self, dst, ks, key):
@@ -167,12 +178,16 @@ class Stream(_P4Stream):
             self.emit("s_cselect_b32", SN(cnt), [I(0), SN(cnt)])
             self.emit("s_sub_u32", SN(dst), [I(ti), SN("t1")])
 
-    def seam(self, role, pieces, target=None, cond=None):
+    def seam(self, role, pieces, target=None, prof=False):
         """end of an iteration: own LDS-DMA pieces of the next block have landed, the exchange writes are out; barrier; the read
         addresses move on; then the exit test (cond = 'ge': branch to `target` when the next iteration index >= n)"""
+        if prof:
+            self.stamp("pb")
         self.emit("s_waitcnt", None, [], vmcnt=pieces, lgkmcnt=0)
         self.lds_done = self.lds_issued
         self.emit("s_barrier")
+        if prof:
+            self.stamp("pc")
         self.deltas()
         for n in ("ra0", "ra1"):
             self.emit("v_add_u32", VN(n), [SN("kd0" if role == 0 else "vd0"), VN(n)])
@@ -291,7 +306,9 @@ class Stream(_P4Stream):
         seam_g = None
         if not last:
             seam_g = NM - 4 if (phase_a and phase_b) else NM - 1
-            at(seam_g, lambda: self.seam(0, 2 * cfg.NPW if (phase_a and "dma" not in cfg.abl) else 0, seam_target))
+            at(seam_g, lambda: self.seam(0, 2 * cfg.NPW if (phase_a and "dma" not in cfg.abl) else 0, seam_target, prof=phase_a and phase_b))
+            if phase_a and phase_b:
+                at(nA - 1, lambda: self.stamp("pa"))
 
             def capture():
                 self.alt_capture = (self.lds_issued, self.lds_done, dict(self.rid))
@@ -404,7 +421,9 @@ class Stream(_P4Stream):
             for n, fn in enumerate(valu):
                 at(lo + (n * (hi - lo + 1)) // len(valu), fn)
         seam_g = NM - 4 if (phase_a and phase_b) else NM - 1
-        at(seam_g, lambda: self.seam(1, 2 * cfg.NPW if (phase_a and "dma" not in cfg.abl) else 0, seam_target))
+        at(seam_g, lambda: self.seam(1, 2 * cfg.NPW if (phase_a and "dma" not in cfg.abl) else 0, seam_target, prof=phase_a and phase_b))
+        if phase_a and phase_b:
+            at(nA - 1, lambda: self.stamp("pa"))
 
         def capture():
             self.alt_capture = (self.lds_issued, self.lds_done, dict(self.rid))
@@ -472,6 +491,8 @@ class Stream(_P4Stream):
         self.emit("s_mov_b32", SN("sv"), [I(0)])
         for d in ("kd0", "kd1", "kd2", "vd0"):
             self.emit("s_mov_b32", SN(d), [I(cfg.TI)])
+        for d in ("pa", "pb", "pc", "pd"):
+            self.emit("s_mov_b32", SN(d), [I(0)])
 
     def role_stream(self, role):
         cfg = self.cfg
@@ -485,6 +506,7 @@ class Stream(_P4Stream):
             st_a = self.s_iteration(0, True, False, L["ALTA"])                 # i = 0
             self.enter(6, keys)
             st_b = self.s_iteration(1, True, False, L["ALTB"])                 # i = 1 (n >= 2)
+            self.stamp0()
             self.enter(6, keys)
             self.label(L["LOOP"])
             st0 = self.s_iteration(0, True, True, L["ALT0"])                   # i even
@@ -518,6 +540,7 @@ class Stream(_P4Stream):
             for k in range(2):
                 self.row_read(af(k), k, ("f", k))
             st_a = self.p_iteration(0, True, False, L["ALTA"])                 # i = 0
+            self.stamp0()
             self.enter(2, keys)
             self.label(L["LOOP"])
             st1 = self.p_iteration(1, True, True, L["ALT1"])                   # i odd
@@ -561,10 +584,10 @@ def write_inc(path):
              "// header for the register map and the iteration table).", "#pragma once", ""]
     lines.append("#define MFA_DQ5_OWNED_VGPRS " + ", ".join('"v%d"' % i for i in range(FIRST_OWNED_VGPR, 256)))
     lines.append("")
-    lines.append("// X(name, applies the softmax scale in fp32, head-dimension bucket)")
+    lines.append("// X(name, applies the softmax scale in fp32, head-dimension bucket, stamps the shader clock)")
     lines.append("#define MFA_DQ5_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
-        lines.append("  X(%s, %d, %d) \\" % (name, cfg.exact, cfg.D))
+        lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.exact, cfg.D, cfg.prof))
     lines.append("")
     lines.append("")
     for name, cfg in VARIANTS.items():
@@ -586,6 +609,8 @@ def _variants():
         for dt in ("bf16", "f16"):
             out["D%d_%s_FOLD" % (D, dt.upper())] = Cfg(dt, D=D)
             out["D%d_%s_EXACT" % (D, dt.upper())] = Cfg(dt, exact=1, D=D)
+    out["D256_BF16_FOLD_PROF"] = Cfg("bf16", D=256, prof=1)       # developer library only (tools/bwd5_prof.py)
+    out["D160_BF16_FOLD_PROF"] = Cfg("bf16", D=160, prof=1)
     return out
 
 

@@ -109,6 +109,13 @@ WORKLOADS = {
     "fwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",), causal=True),
     "fwdbwd_bf16_d128_causal": dict(N=4096, D=128, dtype="bf16", batch=4, heads=16, causal=True,
                                     types=("forward", "backwardQuery", "backwardKeyValue")),
+    # BASELINE config 4's head dimension, all three kernels (round 4: the role-split backward streams attn_dq16_p5 / attn_dkv16_p5)
+    "fwdbwd_bf16_d256_mixed": dict(N=4096, D=256, dtype="bf16", batch=4, heads=16, low_mid=True,
+                                   types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dq_bf16_d256": dict(N=4096, D=256, dtype="bf16", batch=4, heads=16, low_mid=True, timed=("backwardQuery",),
+                         types=("forward", "backwardQuery", "backwardKeyValue")),
+    "dkv_bf16_d256": dict(N=4096, D=256, dtype="bf16", batch=4, heads=16, low_mid=True, timed=("backwardKeyValue",),
+                          types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_n16k": dict(N=16384, D=128, dtype="bf16", batch=1, heads=32, types=("forward",)),  # config 5 shard
     "c1_cpu": dict(N=128, D=64, dtype="f32", batch=1, heads=1, types=("forward",)),                   # config 1, CPU only
 }

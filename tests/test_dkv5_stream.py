@@ -22,7 +22,10 @@ def _check(R, C, cblk=0, causal=False, cfg=None, seed=0, **kw):
     ev, ek, mv, mk, wg = dkv5sim.check(R=R, C=C, cblk=cblk, causal=causal, cfg=cfg, seed=seed, **kw)
     # P and dS enter the second products in the 16-bit type (8 / 11 bits of mantissa); dS' is formed from the ROUNDED P (the
     # exchange carries the packed fragments -- the reference's register precision of P, +Precisions.swift:149-215)
-    rel = 3e-3 if (cfg.dtype == "f16" and not cfg.mix) else 1.5e-2    # mix streams: P and V enter the dO products as BF16
+    # FP16 streams get the tight bound only with FP32 L, D: in the reference's mixed storage D is BF16, and its 8 bits of mantissa
+    # enter dS' = P (dP - D) whatever the operand type (short causal rows do not average it out: tools/fuzz_stream_models.py,
+    # family dkv5, seed 4 cases 50 and 149 -- the same finding as for attn_dkv16_p4)
+    rel = 3e-3 if (cfg.dtype == "f16" and not cfg.mix and cfg.dprec == "f32") else 1.5e-2    # mix streams: P and V enter the dO products as BF16
     assert ev < rel * max(1.0, mv) and ek < rel * max(1.0, mk), (ev, mv, ek, mk)
     return wg
 

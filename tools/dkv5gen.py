@@ -55,6 +55,7 @@ ONES, PAIR, AF, PR, X1, SB, CF = 32, 36, 40, 56, 64, 96, 128
 FIRST_OWNED_VGPR = 28
 RING = 4
 XPAR = 4096                 # bytes of one parity of a pair's exchange buffer: 4 fragments x 64 lanes x 16 bytes
+WAIT_AHEAD = int(os.environ.get("MFA_GEN_WAIT_AHEAD", "3"))      # matrix instructions whose fragments one s_waitcnt may cover (0: exact waits)
 
 # named operands of the asm statement (attn_dkv16_p5.h); order = operand order
 INOUT_V = ["qoff0", "qoff1", "qoff2", "qoff3", "goff0", "goff1", "goff2", "goff3", "ldoff", "ra0", "ra1", "ta0", "ta1"]
@@ -131,6 +132,15 @@ class Stream(_P4Stream):
         self.lds_done = self.lds_issued
         self.emit("s_mov_b64", VCC, [SN("ptime", 2)])
         self.emit("s_mov_b32", SN("plast"), [("vcc_lo",)])
+
+    def need(self, frags, ahead=()):
+        """the reads of fragments `frags` have returned; when that takes a wait, the same wait also covers the fragments of the
+        next matrix instructions that are already in flight: an s_waitcnt costs an issue slot of the only wave of the SIMD"""
+        now = max(self.frag_rid[k] for k in frags)
+        if now <= self.lds_done:
+            return
+        more = [self.frag_rid[k] for k in ahead if k in self.frag_rid and self.lds_done < self.frag_rid[k] <= self.lds_issued]
+        self.lds_need(max([now] + more))
 
     # ---------------------------------------------------------------- LDS fragment reads
     def frag_read(self, role, k):
@@ -266,12 +276,15 @@ class Stream(_P4Stream):
         out = []
         base = sset(q)
         rid = {}
+        packs = {0: [], 1: []}
         for u in range(2):
             for kb in range(2):
                 def rd(kb=kb, u=u):
                     rid[(kb, u)] = self.lds_read("ds_read_b128", V(PR + 4 * kb, 4), VN("xaddr"), par_prev * XPAR + (2 * kb + u) * 1024,
                                                  note="P kb%d u%d" % (kb, u))
                 out.append(("read", rd))
+            if u == 1:          # the packs of the first half cover the flight of the second half's P words
+                out += packs[0]
             for kb in range(2):
                 for w in range(4):
                     word = V(PR + 4 * kb + w)
@@ -298,9 +311,9 @@ class Stream(_P4Stream):
             for kb in range(2):
                 for w in range(4):
                     r = 8 * u + 2 * w
-                    out.append(("valu", lambda kb=kb, u=u, w=w, r=r: self.emit(
+                    packs[u].append(("valu", lambda kb=kb, u=u, w=w, r=r: self.emit(
                         "v_cvt_pk_%s_f32" % cfg.dtype, V(base + 16 * kb + 4 * u + w), [V(base + 16 * kb + r), V(base + 16 * kb + r + 1)])))
-        return out
+        return out + packs[1]
 
     # ---------------------------------------------------------------- one iteration
     def iteration(self, role, par, phase_a, phase_b, alt_label):
@@ -355,11 +368,19 @@ class Stream(_P4Stream):
         seam_g = None if alt_label is None else (NM - 4 if full else NM - 1)
         if phase_a:
             # ---- LDS-DMA of block i + 2 (stage wr): one piece per even gap; the offsets advance in the following even gaps
-            if "dma" not in cfg.abl:
+            # (the K-role wave, whose phase A carries the dS' arithmetic -- 4.5 instructions per matrix-instruction gap with the
+            # LDS-DMA work --, issues its pieces in phase B instead, which has nothing but fragment reads)
+            if "dma" not in cfg.abl and not (role == 1 and phase_b):
                 for n in range(2 * NPW):
                     at(2 + 2 * n, lambda n=n: self.dma_piece(n))
                     at(2 + 4 * NPW + 2 * n, lambda n=n: self.dma_advance(n))
                 at(2 + 8 * NPW, lambda: self.wr_advance())
+            elif "dma" not in cfg.abl:
+                ops = [lambda n=n: self.dma_piece(n) for n in range(2 * NPW)] + [lambda n=n: self.dma_advance(n) for n in range(2 * NPW)] + \
+                      [lambda: self.wr_advance()]
+                lo, hi = nA + 1, NM - 5
+                for n, fn in enumerate(ops):
+                    at(lo + (n * (hi - lo + 1)) // len(ops), fn)
             at(0, lambda: self.stage_delta())
             # row-read addresses move to the next stage once the last row fragment is requested
             at(first_g[frags[nks - 5]] + 2 if nks >= 5 else 2, lambda: self.addr_advance(["ra0", "ra1"], "delta"))
@@ -387,16 +408,21 @@ class Stream(_P4Stream):
                     at(NM - 1, fn)
         if role == 1 and phase_b:
             ops = self.k_ops(q_prev, q_prev)
-            if phase_a:
-                g0, g1 = 2, nA - 2
+            if phase_a:      # the first two P fragments are requested at once, the arithmetic starts three gaps later
+                for n, (kind, fn) in enumerate(ops[:2]):
+                    at(0, fn)
+                g0, g1 = 3, nA - 2
                 span = g1 - g0 + 1
-                for n, (kind, fn) in enumerate(ops):
-                    at(g0 + (n * span) // len(ops), fn)
+                for n, (kind, fn) in enumerate(ops[2:]):
+                    at(g0 + (n * span) // len(ops[2:]), fn)
             else:
                 pre_ops = ops
         # ---- the seam to the next iteration
         if alt_label is not None:
             def seam():
+                # (address arithmetic in front of the barrier: the last transposing read of the iteration is issued)
+                self.addr_advance(["ta0", "ta1"], "deltat")
+                self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
                 if full:
                     self.stamp("pb")
                 self.emit("s_waitcnt", None, [], vmcnt=2 * NPW if "dma" not in cfg.abl else 0, lgkmcnt=0)
@@ -404,8 +430,6 @@ class Stream(_P4Stream):
                 self.emit("s_barrier")
                 if full:
                     self.stamp("pc")
-                self.addr_advance(["ta0", "ta1"], "deltat")
-                self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
                 self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nsteps")])
                 self.emit("s_cbranch_scc1", None, [], target=alt_label)
                 self.alt_capture = (self.lds_issued, self.lds_done, dict(self.frag_rid))
@@ -427,7 +451,7 @@ class Stream(_P4Stream):
         alt_state = None
         for g, (d, a_, b_, c_, fr, typ) in enumerate(mm):
             if fr is not None:
-                self.lds_need(self.frag_rid[fr])
+                self.need([fr], [m[4] for m in mm[g + 1:g + 1 + WAIT_AHEAD] if m[4] is not None])
             self.emit("v_mfma_f32_32x32x16_" + typ, d, [a_, b_, c_])
             for fn in fill[g]:
                 fn()

@@ -56,6 +56,7 @@ T_TL, T_MASKV, T_T0, T_T1 = 240, 242, 243, 244
 FIRST_OWNED_VGPR = 64
 KRING, VRING = 5, 3
 XPAR = 4096
+WAIT_AHEAD = int(os.environ.get("MFA_GEN_WAIT_AHEAD", "2"))      # matrix instructions whose fragments one s_waitcnt may cover (0: exact waits)
 
 INOUT_V = ["koff0", "koff1", "koff2", "koff3", "voff0", "voff1", "voff2", "voff3", "ra0", "ra1", "ta0", "ta1"]
 TMP_S = ["j", "sk", "sv", "kd0", "kd1", "kd2", "vd0", "wrk", "wrv", "t0", "t1", "pa", "pb", "pc", "pd", "plast"]   # p*: PROF streams
@@ -134,6 +135,16 @@ class Stream(_P4Stream):
         self.emit("s_mov_b64", VCC, [SN("ptime", 2)])
         self.emit("s_mov_b32", SN("plast"), [("vcc_lo",)])
 
+    def need(self, keys, ahead=()):
+        """the reads behind `keys` have returned; when that takes a wait, one wait also covers the reads of the next matrix
+        instructions that are already in flight (`ahead`): an s_waitcnt costs an issue slot of the only wave of the SIMD -- the
+        PROF streams, whose stamps flush the queue twice per iteration, ran 3.5 % FASTER than one exact wait per fragment)"""
+        now = max(self.rid[k] for k in keys)
+        if now <= self.lds_done:
+            return
+        more = [self.rid[k] for k in ahead if k in self.rid and self.lds_done < self.rid[k] <= self.lds_issued]
+        self.lds_need(max([now] + more))
+
     # ---------------------------------------------------------------- LDS reads
     def row_read(self, dst, ks, key):
         """row fragment ks of the tile the row-read addresses point at (S-role: K block i; P-role: V block i)"""
@@ -181,6 +192,14 @@ class Stream(_P4Stream):
     def seam(self, role, pieces, target=None, prof=False):
         """end of an iteration: own LDS-DMA pieces of the next block have landed, the exchange writes are out; barrier; the read
         addresses move on; then the exit test (cond = 'ge': branch to `target` when the next iteration index >= n)"""
+        # (the address arithmetic in front of the barrier: every read of this iteration is issued, and a wave that arrives early
+        # does it while it would wait)
+        self.deltas()
+        for n in ("ra0", "ra1"):
+            self.emit("v_add_u32", VN(n), [SN("kd0" if role == 0 else "vd0"), VN(n)])
+        for n in ("ta0", "ta1"):
+            self.emit("v_add_u32", VN(n), [SN("kd2" if role == 0 else "kd1"), VN(n)])
+        self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         if prof:
             self.stamp("pb")
         self.emit("s_waitcnt", None, [], vmcnt=pieces, lgkmcnt=0)
@@ -188,24 +207,29 @@ class Stream(_P4Stream):
         self.emit("s_barrier")
         if prof:
             self.stamp("pc")
-        self.deltas()
-        for n in ("ra0", "ra1"):
-            self.emit("v_add_u32", VN(n), [SN("kd0" if role == 0 else "vd0"), VN(n)])
-        for n in ("ta0", "ta1"):
-            self.emit("v_add_u32", VN(n), [SN("kd2" if role == 0 else "kd1"), VN(n)])
-        self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
         if target is not None:
             self.emit("s_cmp_ge_i32", None, [SN("j"), SN("nt")])
             self.emit("s_cbranch_scc1", None, [], target=target)
 
-    def dma_fill(self, at, NM):
+    def dma_fill(self, at, NM, window=None):
+        """the wave's LDS-DMA pieces of block i + 2, their offset advances and the write pointers' advance.  window = None: one
+        piece per odd gap from the start of the iteration (the role whose phase A is light); (lo, hi): dealt out over those gaps
+        (the P-role wave: behind its phase-A arithmetic -- phase A carried 4.9 instructions per matrix-instruction gap with them,
+        profiles/r04_call6)"""
         npw = self.cfg.NPW
         if "dma" in self.cfg.abl:
             return
-        for n in range(2 * npw):
-            at(1 + 2 * n, lambda n=n: self.dma_piece(n))
-            at(1 + 4 * npw + 2 * n, lambda n=n: self.dma_advance(n))
-        at(2 + 8 * npw, lambda: self.wr_advance())
+        if window is None:
+            for n in range(2 * npw):
+                at(1 + 2 * n, lambda n=n: self.dma_piece(n))
+                at(1 + 4 * npw + 2 * n, lambda n=n: self.dma_advance(n))
+            at(2 + 8 * npw, lambda: self.wr_advance())
+            return
+        lo, hi = window
+        ops = [lambda n=n: self.dma_piece(n) for n in range(2 * npw)] + [lambda n=n: self.dma_advance(n) for n in range(2 * npw)] + \
+              [lambda: self.wr_advance()]
+        for n, fn in enumerate(ops):
+            at(lo + (n * (hi - lo + 1)) // len(ops), fn)
 
     # ---------------------------------------------------------------- S-role
     def s_valu(self, rb):
@@ -320,8 +344,7 @@ class Stream(_P4Stream):
             fn()
         state = None
         for g, (d, a_, b_, c_, keys) in enumerate(mm):
-            for key in keys:
-                self.lds_need(self.rid[key])
+            self.need(keys, [k for m in mm[g + 1:g + 1 + WAIT_AHEAD] for k in m[4]])
             self.emit("v_mfma_f32_32x32x16_" + cfg.dtype, d, [a_, b_, c_])
             for fn in fill[g]:
                 fn()
@@ -410,16 +433,18 @@ class Stream(_P4Stream):
         if phase_a:
             at(0, lambda: fread(frags[2]))
             at(1, lambda: fread(frags[3]))
-            self.dma_fill(at, NM)
+            self.dma_fill(at, NM, (nA - 2, NM - 5) if phase_b else None)
         else:
             pre = [lambda k=k: fread(k) for k in frags[:4]]
         for n in range(len(frags) - 4):
             at(first_g[frags[n]] + 1, lambda n=n: fread(frags[n + 4]))
         valu = self.p_valu(q_prev, q_prev) if phase_b else []
-        if phase_b and phase_a:
-            lo, hi = 2, nA - 3
-            for n, fn in enumerate(valu):
-                at(lo + (n * (hi - lo + 1)) // len(valu), fn)
+        if phase_b and phase_a:      # the partner's four P fragments are requested at once, the arithmetic starts four gaps later
+            for n, fn in enumerate(valu[:4]):
+                at(n // 2, fn)
+            lo, hi = 4, nA - 3
+            for n, fn in enumerate(valu[4:]):
+                at(lo + (n * (hi - lo + 1)) // len(valu[4:]), fn)
         seam_g = NM - 4 if (phase_a and phase_b) else NM - 1
         at(seam_g, lambda: self.seam(1, 2 * cfg.NPW if (phase_a and "dma" not in cfg.abl) else 0, seam_target, prof=phase_a and phase_b))
         if phase_a and phase_b:
@@ -438,8 +463,7 @@ class Stream(_P4Stream):
             fn()
         state = None
         for g, (d, a_, b_, c_, keys) in enumerate(mm):
-            for key in keys:
-                self.lds_need(self.rid[key])
+            self.need(keys, [k for m in mm[g + 1:g + 1 + WAIT_AHEAD] for k in m[4]])
             self.emit("v_mfma_f32_32x32x16_" + cfg.dtype, d, [a_, b_, c_])
             for fn in fill[g]:
                 fn()

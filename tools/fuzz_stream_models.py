@@ -2,7 +2,7 @@
 """Random problems for the lane-exact CPU models of the hand-placed instruction streams (no GPU): every compiled stream family --
 forward D <= 128 (tools/p4gen.py, with the transposed families), the persistent forward stream (p4pgen), forward 128 < D <= 256
 (f256gen, with the transposed and the model-only one-operand streams), backwardQuery (dq4gen) and backwardKeyValue (dkv4gen), with
-their transposed streams -- on random shapes, row / column blocks, causal or dense, LDS-DMA landing as early or as late as the
+their transposed streams, and the role-split backward streams of the 160 / 192 / 256 buckets (dq5gen, dkv5gen) -- on random shapes, row / column blocks, causal or dense, LDS-DMA landing as early or as late as the
 waits allow, waves in a random order.  Each case goes through the `_check` helper of that family's test file (same float64
 reference, same tolerances as tests/test_*_stream.py); the seeded test matrices pin chosen corners, this walks between them.
 
@@ -118,7 +118,38 @@ def fuzz_dkv4(rng):
     return name, R, C, cblk, causal
 
 
-FAMILIES = {"p4": fuzz_p4, "p4p": fuzz_p4p, "p5": fuzz_p5, "dq4": fuzz_dq4, "dkv4": fuzz_dkv4}
+def fuzz_dq5(rng):
+    """role-split backwardQuery streams (buckets 160 / 192 / 256): every loop exit (1 .. 14 key blocks), row blocks, head dimensions
+    inside the bucket"""
+    import dq5gen
+    import test_dq5_stream as t
+    pool = {n: c for n, c in dq5gen.VARIANTS.items() if not c.prof}
+    name = str(rng.choice(sorted(pool)))
+    cfg = pool[name]
+    causal = bool(rng.integers(2))
+    R, C = shape(rng, 400, 448, causal=causal)
+    rblk = int(rng.integers((R + 127) // 128))
+    Dr = int(rng.choice([cfg.D, cfg.D, cfg.D - 8, cfg.D - 24]))
+    t._check(R, C, rblk=rblk, causal=causal, cfg=cfg, seed=int(rng.integers(1 << 30)), Dr=Dr, **modes(rng))
+    return name, R, C, rblk, causal, Dr
+
+
+def fuzz_dkv5(rng):
+    """role-split backwardKeyValue streams (buckets 160 / 192 / 256)"""
+    import dkv5gen
+    import test_dkv5_stream as t
+    pool = {n: c for n, c in dkv5gen.VARIANTS.items() if not c.prof}
+    name = str(rng.choice(sorted(pool)))
+    cfg = pool[name]
+    causal = bool(rng.integers(2))
+    R, C = shape(rng, 448, 400, causal=causal)
+    cblk = int(rng.integers((C + 127) // 128))
+    Dr = int(rng.choice([cfg.D, cfg.D, cfg.D - 8, cfg.D - 24]))
+    t._check(R, C, cblk=cblk, causal=causal, cfg=cfg, seed=int(rng.integers(1 << 30)), Dr=Dr, **modes(rng))
+    return name, R, C, cblk, causal, Dr
+
+
+FAMILIES = {"p4": fuzz_p4, "p4p": fuzz_p4p, "p5": fuzz_p5, "dq4": fuzz_dq4, "dkv4": fuzz_dkv4, "dq5": fuzz_dq5, "dkv5": fuzz_dkv5}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -20,7 +20,7 @@ ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof" --steps 20 --warm
 if [ -z "$FAST" ]; then
   for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_1head \
            fwd_bf16_d256 fwd_bf16_d256_mixed fwdbwd_bf16_d128 fwdbwd_bf16_d128_mixed fwdbwd_bf16_d128_causal fwdbwd_bf16_d128_transposed \
-           fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128; do
+           fwdbwd_bf16_d128_transposed_ws fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128 fwdbwd_bf16_d256_mixed dq_bf16_d256 dkv_bf16_d256; do
     timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_$w.json"
   done
   timeout 200 python bench.py --workload c1_cpu 2>/dev/null | tail -1 > "$OUT/bench_c1_cpu.json"
@@ -33,8 +33,15 @@ for f in sorted(glob.glob("$OUT/bench_*.json")):
     except Exception as e:
         print(f, "unreadable", e)
 PY
-  timeout 200 python tools/bucket_perf.py --mixed 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed.txt"
+  timeout 200 python tools/bucket_perf.py --mixed 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed.txt"; cat "$OUT/bucket_perf_mixed.txt"
   timeout 200 python tools/bucket_perf.py 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_fp32mid.txt"
+  timeout 200 python tools/bucket_perf.py --mixed --fill zero 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_fill_zero.txt"; cat "$OUT/bucket_perf_mixed_fill_zero.txt"
+  timeout 200 python tools/bucket_perf.py --mixed --causal 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_causal.txt"
+  timeout 200 python tools/bucket_perf.py --mixed --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_transposed_no_workspace.txt"
+  timeout 300 bash tools/zero_vs_random.sh "$OUT/zero_vs_random" > /dev/null 2>&1; cp "$OUT/zero_vs_random/zero_vs_random.txt" "$OUT/headline_zero_vs_random.txt"; rm -rf "$OUT/zero_vs_random"
+  if [ -f metal_flash_attention_amd/libmfa_hip_dev.so ]; then
+    for D in 256 160; do timeout 200 python tools/bwd5_prof.py --D $D 2>&1 | grep -v amdgpu.ids > "$OUT/bwd5_prof_d$D.txt"; done
+  fi
   timeout 200 python tools/time_single_head.py 2>&1 | grep -v amdgpu.ids > "$OUT/single_head.txt"
   timeout 300 python tools/fuzz_shapes.py 120 1 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_120_seed1.txt"; grep "random problems" "$OUT/fuzz_120_seed1.txt"
   timeout 300 python tools/fuzz_shapes.py 120 2 --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_120_seed2.txt"; grep "random problems" "$OUT/fuzz_transposed_120_seed2.txt"

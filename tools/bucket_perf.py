@@ -21,6 +21,7 @@ ap.add_argument("--transposed", action="store_true")
 ap.add_argument("--causal", action="store_true")
 ap.add_argument("--fill", default="normal", choices=("normal", "zero"))
 ap.add_argument("--dkv32", action="store_true", help="A/B: the 32-key role-split pairs (attn_dkv16_rs.h) at D > 128 instead of attn_dkv16_p5")
+ap.add_argument("--f16", action="store_true", help="FP16 Q / K / V (the reference's own low-precision type; dO stays BF16 as its descriptors say)")
 ap.add_argument("--heads", type=int, default=64)
 ap.add_argument("--n", type=int, default=4096)
 args = ap.parse_args()
@@ -31,17 +32,18 @@ if args.dkv32:
     import metal_flash_attention_amd as mfa
     mfa.setParameterFile(T.backwardKeyValue, True, "| 64 | 256 | 32 | 64 | K, V, dV, dK |\n| 128 | 256 | 32 | 128 | K, V, dV, dK |\n| 160 | 64 | 32 | 160 | K, V, dV, dK |\n"
                          "| 192 | 64 | 32 | 192 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
-print(f"# tools/bucket_perf.py: N={N} heads={H} bf16 mixed={int(args.mixed)} transposed={int(args.transposed)} causal={int(args.causal)} fill={args.fill}")
+print(f"# tools/bucket_perf.py: N={N} heads={H} {'f16 (dO bf16)' if args.f16 else 'bf16'} mixed={int(args.mixed)} transposed={int(args.transposed)} causal={int(args.causal)} fill={args.fill}")
 for D in args.dims or [64, 128, 160, 192, 256]:
     desc = AttentionDescriptor()
     desc.lowPrecisionInputs = True
     desc.lowPrecisionIntermediates = args.mixed
-    desc.lowPrecisionInputType = P.BF16
+    desc.lowPrecisionInputType = P.FP16 if args.f16 else P.BF16
     desc.matrixDimensions = (N, N, D)
     desc.transposeState = (args.transposed,) * 4
     g = torch.Generator(device="cuda")
     g.manual_seed(0)
-    bufs = {op: torch.randn((H, N, D), generator=g, device="cuda").to(torch.bfloat16) for op in (Op.Q, Op.K, Op.V, Op.dO)}
+    tin = torch.float16 if args.f16 else torch.bfloat16
+    bufs = {op: torch.randn((H, N, D), generator=g, device="cuda").to(torch.bfloat16 if op == Op.dO else tin) for op in (Op.Q, Op.K, Op.V, Op.dO)}
     if args.fill == "zero":
         for t in bufs.values():
             t.zero_()

@@ -293,18 +293,17 @@ class Stream(_P4Stream):
 
                     def first(kb=kb, u=u, word=word, lo=lo):
                         self.lds_need(rid[(kb, u)])
-                        if g16:
-                            self.emit("v_cvt_f32_f16", V(T_T0), [word])
-                        else:
-                            self.emit("v_lshlrev_b32", V(T_T0), [I(16), word])
+                        if g16:       # FP16 half x FP32 in one instruction (v_cvt + v_mul: two)
+                            self.emit("v_fma_mix_f32", lo, [word, lo, I(0)], op_sel=(0, 0, 0), op_sel_hi=(1, 0, 0))
+                            return
+                        self.emit("v_lshlrev_b32", V(T_T0), [I(16), word])
                         self.emit("v_mul_f32", lo, [V(T_T0), lo])
 
                     def second(word=word, hi=hi):
                         if g16:
-                            self.emit("v_lshrrev_b32", V(T_T1), [I(16), word])
-                            self.emit("v_cvt_f32_f16", V(T_T1), [V(T_T1)])
-                        else:
-                            self.emit("v_and_b32", V(T_T1), [I(0xFFFF0000), word])
+                            self.emit("v_fma_mix_f32", hi, [word, hi, I(0)], op_sel=(1, 0, 0), op_sel_hi=(1, 0, 0))
+                            return
+                        self.emit("v_and_b32", V(T_T1), [I(0xFFFF0000), word])
                         self.emit("v_mul_f32", hi, [V(T_T1), hi])
                     out.append(("valu", first))
                     out.append(("valu", second))

@@ -763,6 +763,9 @@ def render_one(ins, suffix="%="):
         return "%s %s, %s, %s, 0 offen" % (op, fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
     if op == "buffer_store_dwordx4":     # s = (four data registers, per-lane byte offset, buffer resource)
         return "buffer_store_dwordx4 %s, %s, %s, 0 offen" % (fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
+    if op == "v_fma_mix_f32":
+        return "v_fma_mix_f32 %s, %s, %s, %s op_sel:[%d,%d,%d] op_sel_hi:[%d,%d,%d]" % (
+            (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2])) + tuple(m["op_sel"]) + tuple(m["op_sel_hi"]))
     if op == "ds_write_b128":           # s = (address register, four data registers)
         return "ds_write_b128 %s, %s offset:%d" % (fmt(ins.s[0]), fmt(ins.s[1]), m["offset"])
     if op in ("ds_read_b128", "ds_read_b64", "ds_read_b64_tr_b16"):

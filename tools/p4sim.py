@@ -253,6 +253,18 @@ class Workgroup:
                 w.lds_q.append(([], np.zeros((0, 64), np.uint32)))
             else:
                 w.lds_q.append((("write", addr, None), data))
+        elif op == "v_fma_mix_f32":
+            # d = s0 * s1 + s2 in fp32; source i is an FP16 half of its register when op_sel_hi[i] (the high half when op_sel[i]), else FP32
+            vals = []
+            for i in range(3):
+                raw = w.rd(s[i])
+                if m["op_sel_hi"][i]:
+                    half = (raw >> 16) if m["op_sel"][i] else (raw & 0xFFFF)
+                    vals.append(h16_to_f32(half & 0xFFFF, True).astype(np.float64))
+                else:
+                    vals.append(raw.view(np.float32).astype(np.float64))
+            with np.errstate(over="ignore", invalid="ignore"):
+                w.wr(d, (vals[0] * vals[1] + vals[2]).astype(np.float32))
         elif op == "v_lshrrev_b32":
             w.wr(d, w.rd(s[1]) >> np.uint32(int(s[0][1])))
         elif op == "ds_read_b64":

@@ -35,8 +35,10 @@
  *     read dO run in BF16 -- V is rounded to BF16 once per workgroup and P is packed to BF16 for dV -- while S and dK stay
  *     FP16; the other kernels convert dO to FP16 instead (exact in FP16's range).
  *   - Transposed operands (transposeState): the forward kernel reads and writes them in place on the 16-bit matrix cores
- *     (any leading dimension); the backward kernels run on the matrix cores only when the launch is given a workspace
- *     (mfa_attention_kernel_needs_workspace_for_fast_path), without one the fp32-arithmetic kernels serve them.
+ *     (any leading dimension).  The backward kernels of the 128 bucket (64 < D <= 128) read them in place too when the launch
+ *     is whole tiles of 16-byte aligned rows and carries no workspace (attn_dq16_p4_tr / attn_dkv16_p4_tr); every other
+ *     transposed backward launch runs on the matrix cores when it is given a workspace
+ *     (mfa_attention_kernel_needs_workspace_for_fast_path: re-layout pass), and on the fp32-arithmetic kernels without one.
  *   - Head dimensions: any.  16-bit matrix-core code objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic
  *     kernels whatever the storage type, accumulators in registers; D > 384 (beyond the reference's tables, which fall through
  *     to their last row, +Parameters.swift:60-65) runs D-blocked kernels that page the accumulators through the output
@@ -192,8 +194,8 @@ const char *mfa_attention_kernel_fallback_variant(const mfa_attention_kernel *ke
  * leading dimension) are gathered element-wise -- slower, never the fp32-arithmetic kernel.  This function returns 0.
  * BACKWARD (dQ, dK/dV): those kernels read row-major tiles, so a launch with `workspace` first re-lays every transposed
  * operand out into the workspace (one HBM-bound pass per operand, 2 x sequence x D x size bytes; transposed outputs are written
- * back the same way) and then runs the matrix-core code object; without a workspace the general kernel reads the transposed
- * operands in place.  Non-zero = this kernel is in that situation (size the workspace with mfa_attention_kernel_workspace_size). */
+ * back the same way) and then runs the matrix-core code object; without a workspace the in-place backward kernels take the
+ * launches they can (128 bucket, whole aligned tiles) and the general kernel reads the transposed operands in place otherwise.  Non-zero = this kernel is in that situation (size the workspace with mfa_attention_kernel_workspace_size). */
 int mfa_attention_kernel_needs_workspace_for_fast_path(const mfa_attention_kernel *kernel);
 /* The descriptor as the selected code object really executes it: the Swift struct lets callers
  * request any block dimensions / cache state (AttentionKernelDescriptor.swift:9-13); a

@@ -105,17 +105,27 @@ struct Fwd16Grid {
   float *wsML;
 };
 
-__device__ __forceinline__ void fwd16_decode_block(const Fwd16Grid &g, uint32_t bid, uint32_t *rb,
-                                                   uint32_t *head, uint32_t *batch) {
+// (per-lane form: `bid` may differ from lane to lane -- the persistent forward kernel builds its block table with it)
+__device__ __forceinline__ void fwd16_decode_block_lane(const Fwd16Grid &g, uint32_t bid, uint32_t *rb,
+                                                        uint32_t *head, uint32_t *batch) {
   // Hardware places workgroup b on XCD b % 8 (observed; used for speed only).  All row blocks of
   // one (head, batch) share K and V, so we give each XCD whole heads: its private 4 MiB L2 then
   // holds the K/V of the few heads it is working on.
+  // Within an XCD the heads come in PAIRS whose blocks alternate: (block 0, head a), (block 0, head b), (block 1, head a), ...
+  // The L2 working set is the same two heads (32 compute units = two heads x 16 blocks of 256 rows at N = 4096), but a causal
+  // launch -- whose blocks shrink (or grow) along the block index -- is dealt out longest-first ACROSS the pair: with one head
+  // after the other, the in-order dispatcher left the compute units 15 % apart at the end (simulated: 331 against 287 units
+  // of time for 8 heads x 16 blocks on 32 units, profiles/r04_causal_dispatch_order.txt); dense launches do not care.
   const uint32_t nh = g.heads * g.batches;
   uint32_t hb, r;
   if ((nh & 7u) == 0) {
     const uint32_t xcd = bid & 7u, slot = bid >> 3;
-    hb = (slot / g.rowBlocks) * 8u + xcd;
-    r = slot % g.rowBlocks;
+    const uint32_t hpx = nh >> 3;                          // heads of this XCD
+    const uint32_t grp = slot / (2u * g.rowBlocks), t = slot % (2u * g.rowBlocks);
+    uint32_t hx;
+    if (2u * grp + 1u < hpx) { hx = 2u * grp + (t & 1u); r = t >> 1; }
+    else { hx = 2u * grp; r = t; }                         // (an odd head count leaves the last head on its own)
+    hb = hx * 8u + xcd;
   } else {
     hb = bid / g.rowBlocks;
     r = bid % g.rowBlocks;
@@ -123,6 +133,17 @@ __device__ __forceinline__ void fwd16_decode_block(const Fwd16Grid &g, uint32_t 
   *rb = r;
   *head = hb % g.heads;
   *batch = hb / g.heads;
+}
+
+// the block of a WORKGROUP (`bid` wave-uniform): the integer divisions run on the vector ALU, and hipcc does not move their
+// results back to scalar registers by itself when an asm statement asks for an "s" operand derived from them
+__device__ __forceinline__ void fwd16_decode_block(const Fwd16Grid &g, uint32_t bid, uint32_t *rb,
+                                                   uint32_t *head, uint32_t *batch) {
+  uint32_t r, h, b;
+  fwd16_decode_block_lane(g, bid, &r, &h, &b);
+  *rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+  *head = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+  *batch = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
 }
 
 template <typename T, int D, int NW, int RB>

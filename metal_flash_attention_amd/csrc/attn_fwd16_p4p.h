@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   if constexpr (TR.causal) dgrid.rowBlocks = (RB + 1) / 2;
   for (uint32_t n = tid; n < nunits; n += 256) {
     uint32_t r, head, batch;
-    fwd16_decode_block(dgrid, first + n * G, &r, &head, &batch);
+    fwd16_decode_block_lane(dgrid, first + n * G, &r, &head, &batch);
     const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
                               (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
                               (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
       if (RB & 1u) {
         for (uint32_t i = 0; i < n; ++i) {
           uint32_t ri, hi_, bi;
-          fwd16_decode_block(dgrid, first + i * G, &ri, &hi_, &bi);
+          fwd16_decode_block_lane(dgrid, first + i * G, &ri, &hi_, &bi);
           if (ri == RB - 1 - ri) --pos;
         }
       }

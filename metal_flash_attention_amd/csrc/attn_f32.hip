@@ -1,0 +1,71 @@
+// attn_f32.hip -- instantiations and launchers of the FP32 production kernels (attn_f32.h).  The general kernels' launchers
+// (attn_generic_{fwd,dq,dkv}.hip) hand a launch over when f32k::serves() says its operands qualify; the launch form names the
+// code object that ran (mfa_attention_kernel_launch_form).
+#include "attn_f32.h"
+#include "launchers.h"
+
+#include <cstdlib>
+#include <mutex>
+#include <set>
+#include <utility>
+
+namespace mfa {
+
+namespace {
+
+// the large-LDS attribute of a code object, once per (kernel, device): launches stay free of driver calls after the first one
+template <typename Kernel> bool raise_lds(Kernel kernel, int bytes) {
+  static std::mutex guard;
+  static std::set<std::pair<const void *, int>> done;
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return false;
+  const std::pair<const void *, int> key(reinterpret_cast<const void *>(kernel), device);
+  std::lock_guard<std::mutex> lock(guard);
+  if (done.count(key)) return true;
+  if (hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  done.insert(key);
+  return true;
+}
+
+template <int DP> bool launch(int type, dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z};
+  const dim3 flat(grid.x * grid.y * grid.z);
+  switch (type) {
+    case 0:
+      if (!raise_lds(&f32k::attn_f32_fwd<DP>, f32k::lds_bytes<DP>())) return false;
+      hipLaunchKernelGGL((f32k::attn_f32_fwd<DP>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g);
+      return true;
+    case 1:
+      if (!raise_lds(&f32k::attn_f32_dq<DP>, f32k::lds_bytes<DP>())) return false;
+      hipLaunchKernelGGL((f32k::attn_f32_dq<DP>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g);
+      return true;
+    default:
+      if (!raise_lds(&f32k::attn_f32_dkv<DP>, f32k::lds_bytes_dkv<DP>())) return false;
+      hipLaunchKernelGGL((f32k::attn_f32_dkv<DP>), flat, dim3(256), f32k::lds_bytes_dkv<DP>(), stream, args, g);
+      return true;
+  }
+}
+
+bool taken(int type, int DP, const KernelArgs &args) {
+#ifdef MFA_DEV_VARIANTS   // developer builds: MFA_F32_GENERAL=1 keeps the general kernels on these launches (A/B runs)
+  if (std::getenv("MFA_F32_GENERAL")) return false;
+#endif
+  return f32k::serves(type, DP, args);
+}
+
+}  // namespace
+
+bool f32_launch(int type, int DP, dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if (!taken(type, DP, args)) return false;
+  return DP == 64 ? launch<64>(type, grid, stream, args) : launch<128>(type, grid, stream, args);
+}
+
+const char *f32_form(int type, int DP, const KernelArgs &args) {
+  if (!taken(type, DP, args)) return nullptr;
+  static const char *const names[3][2] = {{"attn_f32_fwd_d64_w4x32", "attn_f32_fwd_d128_w4x32"},
+                                          {"attn_f32_dq_d64_w4x32", "attn_f32_dq_d128_w4x32"},
+                                          {"attn_f32_dkv_d64_w4x32", "attn_f32_dkv_d128_w4x32"}};
+  return names[type][DP == 128];
+}
+
+}  // namespace mfa

@@ -7,6 +7,8 @@ namespace mfa {
 
 template <int DP, int NW, bool CACHE, bool X = false>
 static void launch_dq(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if constexpr (NW == 4 && CACHE && (DP == 64 || DP == 128))   // the FP32 production case: attn_f32.h
+    if (f32_launch(1, DP, grid, stream, args)) return;
   constexpr uint32_t lds = generic_dq_lds_floats<DP, NW, CACHE, X>() * sizeof(float);
   hipLaunchKernelGGL((attn_generic_dq<DP, NW, CACHE, false, X>), grid, dim3(NW * 64), lds, stream, args);
 }
@@ -16,6 +18,8 @@ static void launch_dq_masked(dim3 grid, hipStream_t stream, const KernelArgs &ar
   constexpr uint32_t lds = generic_dq_lds_floats<DP, NW, CACHE, X>() * sizeof(float);
   hipLaunchKernelGGL((attn_generic_dq<DP, NW, CACHE, true, X>), grid, dim3(NW * 64), lds, stream, args);
 }
+
+template <int DP> static const char *f32_form_of(const KernelArgs &args) { return f32_form(1, DP, args); }
 
 template <int DP, int NW, bool CACHE, bool X = false>
 static void fill(VariantInfo *v, const char *name) {
@@ -32,6 +36,7 @@ static void fill(VariantInfo *v, const char *name) {
   v->launchSparse = &launch_dq_masked<DP, NW, CACHE, X>;   // block mask: own code objects
   v->funcSparse = reinterpret_cast<const void *>(&attn_generic_dq<DP, NW, CACHE, true, X>);
   v->launch = &launch_dq<DP, NW, CACHE, X>;
+  if constexpr (NW == 4 && CACHE && (DP == 64 || DP == 128)) v->launchForm = &f32_form_of<DP>;
 }
 
 bool generic_dq_variant(int DP, VariantInfo *out) {

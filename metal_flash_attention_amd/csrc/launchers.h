@@ -52,6 +52,11 @@ struct VariantInfo {
 bool paged_variant(int type, VariantInfo *out);
 
 // generic (fp32-MFMA) family: returns false if (DP) is not compiled
+// FP32 production kernels (attn_f32.h): the general kernels' launchers of the 64 / 128 head blocks hand over the launches whose
+// operands qualify (all FP32, row-major, 16-byte aligned rows, D % 4 == 0, no block mask).  type: 0 forward, 1 backwardQuery,
+// 2 backwardKeyValue; grid as the general kernel's (blocks of 128, heads, batches).  false / nullptr: not one of theirs
+bool f32_launch(int type, int DP, dim3 grid, hipStream_t stream, const KernelArgs &args);
+const char *f32_form(int type, int DP, const KernelArgs &args);
 bool generic_fwd_variant(int DP, VariantInfo *out);
 bool generic_dq_variant(int DP, VariantInfo *out);
 bool generic_dkv_variant(int DP, VariantInfo *out);

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  if (a.causal) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
   int R = a.R, C = a.C;
   const int D = a.D;
   batch_lengths(a, batch, R, C);
@@ -383,7 +384,9 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
 // backward dQ: D = rowsum(dO*O)/sqrt(D); dQ = sum_c dS K                (+Source.swift:202-242)
 // same grid; one workgroup per compute unit (Q and dO fragments, the dQ accumulators: 192 + 32 registers before any buffer)
 // ----------------------------------------------------------------------------------------------
-template <int DP>
+// ABL (developer builds, timing only -- results are wrong): 1 no softmax arithmetic, 2 no barrier / staging in the loop,
+// 4 no second product, 8 no first products
+template <int DP, int ABL = 0>
 __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd16Grid grid) {
   typedef Geo<DP> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -392,6 +395,7 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   uint32_t rblk, head, batch;
   fwd16_decode_block(grid, blockIdx.x, &rblk, &head, &batch);
+  if (a.causal) rblk = grid.rowBlocks - 1 - rblk;   // later row blocks traverse more keys: start them first
   int R = a.R, C = a.C;
   const int D = a.D;
   batch_lengths(a, batch, R, C);
@@ -443,9 +447,11 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
   for (int j = 0; j < nt; ++j) {
     const int c0 = j * BT;
     const uint32_t stage = (uint32_t)(j & 1) * (2 * G::TILE);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    if (j + 1 < nt) {
+    if constexpr (!(ABL & 2)) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+    if (!(ABL & 2) && j + 1 < nt) {
       ks.issue(kres, smem + (stage ^ (2 * G::TILE)), wave);
       vs.issue(vres, smem + (stage ^ (2 * G::TILE)) + G::TILE, wave);
     }
@@ -453,19 +459,25 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
     // S^T = K Q^T, dP^T = V dO^T
-    first_product_pair<DP>(s, (lbase + stage) + first, qf, dp, (lbase + stage + G::TILE) + first, gf);
+    if constexpr (!(ABL & 8)) first_product_pair<DP>(s, (lbase + stage) + first, qf, dp, (lbase + stage + G::TILE) + first, gf);
     SecondRing<DP> kring;
     second_prefetch<DP>(kring, (lbase + stage) + second);
     // P = exp2(S*scale2 - L); dS = P * (dP*scale - D)     (+Softmax.swift:409-427).  Padded columns: K, V rows are zero, so
     // dS * K contributes nothing (as in the reference, where the zero padding comes from the async copy, +Accumulate.swift:330-346)
+    if constexpr (!(ABL & 1)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float p = fast_exp2(s[r] * scale2 - Lrow);
-      if (causal && c0 + crow(r, hi) > limit) p = 0.f;   // masked column: P = 0, hence dS = 0
-      s[r] = p * (dp[r] * scale - dterm);
+      for (int r = 0; r < 16; ++r) {
+        float p = fast_exp2(s[r] * scale2 - Lrow);
+        if (causal && c0 + crow(r, hi) > limit) p = 0.f;   // masked column: P = 0, hence dS = 0
+        s[r] = p * (dp[r] * scale - dterm);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] += dp[r];
     }
     // dQ^T += K^T dS^T, key index permuted as in forward
-    second_product<DP>(acc, kring, (lbase + stage) + second, s);
+    if constexpr (!(ABL & 4)) second_product<DP>(acc, kring, (lbase + stage) + second, s);
+    else { lds_wait<0>(kring.v[0]); lds_wait<0>(kring.v[1]); lds_wait<0>(kring.v[2]); lds_wait<0>(kring.v[3]); acc[0] += s; acc[1][0] += kring.v[0][0] + kring.v[1][0] + kring.v[2][0] + kring.v[3][0]; }
   }
   store_rows<DP>(acc, a.op[SLOT_dQ], head, batch, row, R, hi, D, 1.f);
   if (hi == 0 && row < R)   // +Caching.swift:381-413

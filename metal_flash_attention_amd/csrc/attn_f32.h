@@ -15,6 +15,17 @@
 //     conflict-free and the image is what a linear LDS-DMA of permuted global addresses produces.
 // The reads are inline asm with counted waits (hipcc drains vmcnt in front of LDS reads it cannot prove disjoint from an
 // LDS-DMA in flight, attn_fwd16_v3.h).
+//
+// v_mfma_f32_32x32x2_f32 runs on the vector ALU: an ordinary VALU instruction beside it is NOT hidden -- a lone v_xor costs
+// ~15 clocks, softmax arithmetic in a batch 6.5-11 per instruction, LDS reads / waits / SALU nothing
+// (tools/probe_f32_mfma.hip, profiles/r04_f32/probe_f32_mfma.txt).  Hence:
+//   * no address arithmetic in the loop: every read address is a register computed once, the stage / operand / row parts are
+//     immediate offsets (the tile loop is unrolled over the two stages); the LDS-DMA's per-lane offsets are constants, the
+//     bounds-checked resource advances instead (scalar ALU);
+//   * scale and subtract ride on the matrix instructions: the cached fragments are pre-multiplied by the softmax scale and
+//     the accumulator of a first product STARTS at -m / -L / -D (srcC of its first instruction), so the softmax arithmetic
+//     left per score is one exponential plus one add (forward) or one multiply (backward);
+//   * masks (ragged edge, causal diagonal) sit behind wave-uniform branches: only the tiles that need them pay.
 #pragma once
 #include "attn_common.h"
 #include "attn_fwd16.h"   // Fwd16Grid, fwd16_decode_block (XCD-aware workgroup order)
@@ -66,7 +77,84 @@ __device__ __forceinline__ void half_swap(float x, float *a, float *b) {
 __device__ __forceinline__ float half_max(float x) { float a, b; half_swap(x, &a, &b); return fmaxf(a, b); }
 __device__ __forceinline__ float half_add(float x) { float a, b; half_swap(x, &a, &b); return a + b; }
 
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// The matrix instructions are inline asm with explicit register files: hipcc's allocator, left to itself, parks fragments and
+// addresses in accumulation registers and moves them back per use (a v_accvgpr_read each -- VALU time, see below), and copies
+// whole accumulators at the loop's back-edge.  Here: cached fragments (the B operand of a first product) and the accumulators
+// of a second product live in AGPRs for the whole kernel; the LDS-fed A operand, the score accumulators (which the softmax
+// arithmetic reads) and P / dS (the B operand of a second product) in VGPRs.  C and D of an instruction share one file.
+// asm volatile keeps the stream in program order.  What hipcc no longer does for these instructions: the wait states between
+// a matrix instruction's write and a VALU / memory read of it -- mfma_fence() (19 for the 16-pass instruction, gfx940 rules).
+// (one asm statement per GROUP of instructions: hipcc puts a wait state between asm statements that touch the same registers)
+#define MFA_MFMA "v_mfma_f32_32x32x2_f32 "
+// four steps of ONE first product: d += a[i] . b[i] (VGPR accumulators, B in AGPRs)
+__device__ __forceinline__ void mfma_group(f32x16 &d, const f32x4 &a, const float *b) {
+  asm volatile(MFA_MFMA "%0, %1, %5, %0\n\t" MFA_MFMA "%0, %2, %6, %0\n\t" MFA_MFMA "%0, %3, %7, %0\n\t" MFA_MFMA "%0, %4, %8, %0"
+               : "+v"(d) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "a"(b[0]), "a"(b[1]), "a"(b[2]), "a"(b[3]));
+}
+// the bias step of the forward: d = ones . bias (all VGPR)
+__device__ __forceinline__ void mfma_bias(f32x16 &d, float a, float b) {   // (s_nop: as in mfma_zero, `b` may be fresh)
+  asm volatile("s_nop 1\n\t" MFA_MFMA "%0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+// four steps of TWO first products, alternating: d0 += a0[i] . b0[i], d1 += a1[i] . b1[i]
+__device__ __forceinline__ void mfma_group_pair(f32x16 &d0, const f32x4 &a0, const float *b0, f32x16 &d1, const f32x4 &a1, const float *b1) {
+  asm volatile(MFA_MFMA "%0, %2, %10, %0\n\t" MFA_MFMA "%1, %6, %14, %1\n\t" MFA_MFMA "%0, %3, %11, %0\n\t" MFA_MFMA "%1, %7, %15, %1\n\t"
+               MFA_MFMA "%0, %4, %12, %0\n\t" MFA_MFMA "%1, %8, %16, %1\n\t" MFA_MFMA "%0, %5, %13, %0\n\t" MFA_MFMA "%1, %9, %17, %1"
+               : "+v"(d0), "+v"(d1)
+               : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+                 "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]));
+}
+// the same with start values: d0 = a0 . b0 + c0, d1 = a1 . b1 + c1 for the first step
+__device__ __forceinline__ void mfma_group_pair_init(f32x16 &d0, const f32x4 &a0, const float *b0, const f32x16 &c0, f32x16 &d1, const f32x4 &a1, const float *b1,
+                                                     const f32x16 &c1) {
+  asm volatile(MFA_MFMA "%0, %2, %10, %18\n\t" MFA_MFMA "%1, %6, %14, %19\n\t" MFA_MFMA "%0, %3, %11, %0\n\t" MFA_MFMA "%1, %7, %15, %1\n\t"
+               MFA_MFMA "%0, %4, %12, %0\n\t" MFA_MFMA "%1, %8, %16, %1\n\t" MFA_MFMA "%0, %5, %13, %0\n\t" MFA_MFMA "%1, %9, %17, %1"
+               : "=&v"(d0), "=&v"(d1)
+               : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
+                 "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]), "v"(c0), "v"(c1));
+}
+// one step of a second product over its NDB accumulator blocks (AGPR accumulators, A and B in VGPRs): acc[db] += a[db] . p
+__device__ __forceinline__ void mfma_out(f32x16 *acc, const f32x4 &a, float p) {
+  asm volatile(MFA_MFMA "%0, %4, %8, %0\n\t" MFA_MFMA "%1, %5, %8, %1\n\t" MFA_MFMA "%2, %6, %8, %2\n\t" MFA_MFMA "%3, %7, %8, %3"
+               : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(p));
+}
+__device__ __forceinline__ void mfma_out(f32x16 *acc, const f32x2 &a, float p) {
+  asm volatile(MFA_MFMA "%0, %2, %4, %0\n\t" MFA_MFMA "%1, %3, %4, %1" : "+a"(acc[0]), "+a"(acc[1]) : "v"(a[0]), "v"(a[1]), "v"(p));
+}
+// one step of TWO second products, alternating
+__device__ __forceinline__ void mfma_out_pair(f32x16 *acc0, const f32x4 &a0, float p0, f32x16 *acc1, const f32x4 &a1, float p1) {
+  asm volatile(MFA_MFMA "%0, %8, %16, %0\n\t" MFA_MFMA "%4, %12, %17, %4\n\t" MFA_MFMA "%1, %9, %16, %1\n\t" MFA_MFMA "%5, %13, %17, %5\n\t"
+               MFA_MFMA "%2, %10, %16, %2\n\t" MFA_MFMA "%6, %14, %17, %6\n\t" MFA_MFMA "%3, %11, %16, %3\n\t" MFA_MFMA "%7, %15, %17, %7"
+               : "+a"(acc0[0]), "+a"(acc0[1]), "+a"(acc0[2]), "+a"(acc0[3]), "+a"(acc1[0]), "+a"(acc1[1]), "+a"(acc1[2]), "+a"(acc1[3])
+               : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(p0), "v"(p1));
+}
+__device__ __forceinline__ void mfma_out_pair(f32x16 *acc0, const f32x2 &a0, float p0, f32x16 *acc1, const f32x2 &a1, float p1) {
+  asm volatile(MFA_MFMA "%0, %4, %8, %0\n\t" MFA_MFMA "%2, %6, %9, %2\n\t" MFA_MFMA "%1, %5, %8, %1\n\t" MFA_MFMA "%3, %7, %9, %3"
+               : "+a"(acc0[0]), "+a"(acc0[1]), "+a"(acc1[0]), "+a"(acc1[1]) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(p0), "v"(p1));
+}
+// an accumulator block in AGPRs, zeroed by the matrix pipe itself (0 . 0 + 0): every definition and use of the block is then an
+// asm operand of the "a" class, and hipcc keeps it there across the loop (a block it zeroes itself starts out in VGPRs and is
+// copied in and out around every asm statement)
+// (s_nop: the zero operand has just been written by a VALU instruction -- hipcc does not know the asm reads it as a matrix operand)
+__device__ __forceinline__ void mfma_zero(f32x16 &d) {
+  asm volatile("s_nop 4\n\t" MFA_MFMA "%0, %1, %1, 0" : "=&a"(d) : "v"(0.f));
+}
+__device__ __forceinline__ void mfma_fence(f32x16 &a, f32x16 &b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void mfma_fence(f32x16 &a) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a)); }
+template <int N> __device__ __forceinline__ void mfma_fence_out(f32x16 *acc) {
+  if constexpr (N == 4) asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+  else asm volatile("s_nop 15\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]));
+}
+// a fragment array, multiplied by `factor`, moves to the accumulation registers (where every later use -- "a" operands -- keeps it)
+template <int N> __device__ __forceinline__ void pin_fragments(float *f, float factor) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float x = f[i] * factor;
+    asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(f[i]) : "v"(x));
+  }
+}
+// (VALU results feed the B operand of the next matrix instructions)
+__device__ __forceinline__ void valu_fence(f32x16 &a) { asm volatile("s_nop 4" : "+v"(a)); }
+__device__ __forceinline__ void valu_fence(f32x16 &a, f32x16 &b) { asm volatile("s_nop 4" : "+v"(a), "+v"(b)); }
 
 template <int DP> struct Geo {
   static_assert(DP == 64 || DP == 128, "head-dimension buckets of the FP32 kernels");
@@ -96,75 +184,94 @@ template <int DP> __device__ __forceinline__ void load_fragments(float *f, const
   });
 }
 
-// the tile stager of one operand: per-lane global offsets of the NI chunks this lane moves per tile
+// the tile stager of one operand: per-lane byte offsets (inside the tile) of the NI chunks this lane moves per tile -- constants;
+// the bounds-checked resource of the tile advances instead (tile_resource: scalar arithmetic)
 template <int DP> struct Stager {
   uint32_t off[Geo<DP>::NI];
-  uint32_t inc;
-  __device__ __forceinline__ void init(int wave, int lane, uint32_t ld, int D, uint32_t row0) {
+  __device__ __forceinline__ void init(int wave, int lane, uint32_t ld, int D) {
     typedef Geo<DP> G;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
       const int p = (wave * G::NI + i) * 64 + lane;
       const int r = p / G::CPR, c = (p % G::CPR) ^ (r & 15);
-      off[i] = (c * 4 < D) ? (row0 + r) * ld * 4u + c * 16 : OOB;
+      off[i] = (c * 4 < D) ? r * ld * 4u + c * 16 : OOB;
     }
-    inc = BT * ld * 4u;
   }
-  // the next tile in sequence -> LDS image at `base` (workgroup-relative bytes)
-  __device__ __forceinline__ void issue(const __amdgpu_buffer_rsrc_t &res, char *base, int wave) {
+  // tile -> LDS image at `base` (workgroup-relative bytes); `res` covers the rows from the tile's first one on
+  __device__ __forceinline__ void issue(const __amdgpu_buffer_rsrc_t &res, char *base, int wave) const {
     typedef Geo<DP> G;
 #pragma unroll
     for (int i = 0; i < G::NI; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass of hipcc does not know this device builtin
       __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (lds_ptr)(base + (wave * G::NI + i) * 1024), 16, off[i], 0, 0, 0);
 #endif
-      off[i] = __builtin_elementwise_add_sat(off[i], inc);
     }
   }
 };
-
-// read addresses of a lane inside a tile (bytes, without the tile's base)
-//   first product:  row i, chunk (2 T + hi) ^ (i & 15)            = first ^ (T << 5)
-//   second product: row crow(t, hi), NDB floats at column NDB i   = second ^ (ct(t) << 4) + ((t & 3) + 8 (t >> 2)) ROWB,
-//                   ct(t) = (t & 3) | 8 ((t >> 2) & 1)  (the row's swizzle bits that do not depend on the lane)
-template <int DP> __device__ __forceinline__ uint32_t first_address(int i, int hi) { return i * Geo<DP>::ROWB + ((hi ^ (i & 15)) << 4); }
-template <int DP> __device__ __forceinline__ uint32_t second_address(int i, int hi) {
-  const int byte = i * Geo<DP>::RB2;
-  return 4 * hi * Geo<DP>::ROWB + ((((byte >> 4) ^ (4 * hi)) << 4) | (byte & 15));
+// resource over rows [row0, rows) of an operand (ld floats per row) of one (head, batch): reads past the end return zero
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_resource(const char *base, uint32_t ld, int rows, int row0) {
+  const int left = rows > row0 ? rows - row0 : 0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base) + (int64_t)row0 * ld * 4, 0, (uint32_t)left * ld * 4u, 0x00020000);
 }
-constexpr int second_ct(int t) { return (t & 3) | (8 * ((t >> 2) & 1)); }
-constexpr int second_row(int t) { return (t & 3) + 8 * (t >> 2); }
 
-// acc (+)= X_tile (first pattern) . f : NG reads, four matrix instructions each, reads RING groups ahead
-template <int DP, typename Acc> __device__ __forceinline__ void first_product(Acc &acc, uint32_t base, const float *f) {
+
+// read addresses of a lane (bytes, the workgroup's LDS base included; stage, operand and row offsets are immediates)
+//   first product:  row i, chunk (2 T + hi) ^ (i & 15), T = 0 .. NG-1
+//   second product: row crow(t, hi), NDB floats at column NDB i: its chunk ^ (row & 15), where row & 15 = 4 hi ^ ct(t),
+//                   ct(t) = (t & 3) | 8 ((t >> 2) & 1) -- eight different addresses, + ((t & 3) + 8 (t >> 2)) ROWB as an immediate
+constexpr int second_ct(int t) { return (t & 3) | (8 * ((t >> 2) & 1)); }
+constexpr int second_index(int t) { return (t & 3) + 4 * ((t >> 2) & 1); }
+constexpr int second_row(int t) { return (t & 3) + 8 * (t >> 2); }
+template <int DP> struct Addresses {
+  uint32_t first[8];    // T & 7; bit 8 of the address is clear, so groups 8 .. 15 (DP = 128) are these + 256 as an immediate
+  uint32_t second[8];
+  __device__ __forceinline__ void init(uint32_t lbase, int i, int hi) {
+    typedef Geo<DP> G;
+    const uint32_t f = lbase + i * G::ROWB + ((hi ^ (i & 15)) << 4);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) first[T] = f ^ (T << 5);
+    const int byte = i * G::RB2;
+    const uint32_t s = lbase + 4 * hi * G::ROWB + ((((byte >> 4) ^ (4 * hi)) << 4) | (byte & 15));
+#pragma unroll
+    for (int c = 0; c < 8; ++c) second[c] = s ^ (((c & 3) | (8 * (c >> 2))) << 4);
+  }
+};
+
+// acc = init + X_tile (first pattern, at immediate offset OFF) . f : NG reads, four matrix instructions each, RING reads ahead
+// (forward: the start value -m arrives as one extra contraction step, ones . bias -- a matrix instruction instead of a block of
+// sixteen registers that every change of m would have to rewrite)
+template <int DP, int OFF, int RING = 4> __device__ __forceinline__ f32x16 first_product(float ones, float bias, const Addresses<DP> &ad, const float *f) {
   typedef Geo<DP> G;
-  constexpr int RING = 4;
   f32x4 ring[RING];
+  f32x16 acc;
+  mfma_bias(acc, ones, bias);
   static_for<RING>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
-    ring[T] = rd128<0>(base ^ (T << 5));
+    ring[T] = rd128<OFF + (T >> 3) * 256>(ad.first[T & 7]);
   });
   static_for<G::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int pending = (G::NG - 1 - T) < (RING - 1) ? (G::NG - 1 - T) : (RING - 1);
     lds_wait<pending>(ring[T % RING]);
     const f32x4 v = ring[T % RING];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = mfma(v[i], f[4 * T + i], acc);
-    if constexpr (T + RING < G::NG) ring[T % RING] = rd128<0>(base ^ ((T + RING) << 5));
+    mfma_group(acc, v, f + 4 * T);
+    if constexpr (T + RING < G::NG) ring[T % RING] = rd128<OFF + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
   });
+  return acc;
 }
 
-// two first products side by side (independent accumulators: the matrix instructions alternate)
-template <int DP> __device__ __forceinline__ void first_product_pair(f32x16 &acc0, uint32_t base0, const float *f0, f32x16 &acc1, uint32_t base1,
-                                                                     const float *f1) {
+// two first products side by side (the matrix instructions alternate): acc0 = init0 + X0 . f0, acc1 = init1 + X1 . f1
+// (INIT = false: the accumulators hold their start values already -- acc += ...)
+template <int DP, int OFF0, int OFF1, bool INIT = true>
+__device__ __forceinline__ void first_product_pair(f32x16 &acc0, const f32x16 &init0, const float *f0, f32x16 &acc1, const f32x16 &init1, const float *f1,
+                                                   const Addresses<DP> &ad) {
   typedef Geo<DP> G;
   constexpr int RING = 3;
   f32x4 r0[RING], r1[RING];
   static_for<RING>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
-    r0[T] = rd128<0>(base0 ^ (T << 5));
-    r1[T] = rd128<0>(base1 ^ (T << 5));
+    r0[T] = rd128<OFF0 + (T >> 3) * 256>(ad.first[T & 7]);
+    r1[T] = rd128<OFF1 + (T >> 3) * 256>(ad.first[T & 7]);
   });
   static_for<G::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
@@ -172,81 +279,72 @@ template <int DP> __device__ __forceinline__ void first_product_pair(f32x16 &acc
     constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1));
     lds_wait<pending>(r0[T % RING], r1[T % RING]);
     const f32x4 v0 = r0[T % RING], v1 = r1[T % RING];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc0 = mfma(v0[i], f0[4 * T + i], acc0);
-      acc1 = mfma(v1[i], f1[4 * T + i], acc1);
-    }
+    if constexpr (T == 0 && INIT) mfma_group_pair_init(acc0, v0, f0, init0, acc1, v1, f1, init1);
+    else mfma_group_pair(acc0, v0, f0 + 4 * T, acc1, v1, f1 + 4 * T);
     if constexpr (T + RING < G::NG) {
-      r0[T % RING] = rd128<0>(base0 ^ ((T + RING) << 5));
-      r1[T % RING] = rd128<0>(base1 ^ ((T + RING) << 5));
+      r0[T % RING] = rd128<OFF0 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
+      r1[T % RING] = rd128<OFF1 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
     }
   });
 }
 
-// one read of the second pattern: step t of the tile at `base` (+ the lane's second_address)
-template <int DP, int T> __device__ __forceinline__ auto second_read(uint32_t base) {
+// one read of the second pattern: step T of the tile at immediate offset OFF
+template <int DP, int OFF, int T> __device__ __forceinline__ auto second_read(const Addresses<DP> &ad) {
   typedef Geo<DP> G;
-  if constexpr (G::NDB == 4) return rd128<second_row(T) * G::ROWB>(base ^ (second_ct(T) << 4));
-  else return rd64<second_row(T) * G::ROWB>(base ^ (second_ct(T) << 4));
+  if constexpr (G::NDB == 4) return rd128<OFF + second_row(T) * G::ROWB>(ad.second[second_index(T)]);
+  else return rd64<OFF + second_row(T) * G::ROWB>(ad.second[second_index(T)]);
 }
-template <int DP> struct SecondRing {
+template <int DP, int N = 4> struct SecondRing {
   typedef std::conditional_t<Geo<DP>::NDB == 4, f32x4, f32x2> Vec;
-  static constexpr int RING = 4;
+  static constexpr int RING = N;
   Vec v[RING];
 };
 // the first RING reads of a second product (issued early: they are in flight during the softmax arithmetic)
-template <int DP> __device__ __forceinline__ void second_prefetch(SecondRing<DP> &ring, uint32_t base) {
-  static_for<SecondRing<DP>::RING>([&](auto T_) {
+template <int DP, int OFF, int N> __device__ __forceinline__ void second_prefetch(SecondRing<DP, N> &ring, const Addresses<DP> &ad) {
+  static_for<N>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
-    ring.v[T] = second_read<DP, T>(base);
+    ring.v[T] = second_read<DP, OFF, T>(ad);
   });
 }
 // the same for two tiles read side by side: a0 b0 a1 b1 ... (second_product_pair waits for them in that order); HALF = 0, 1:
 // the first / second half of the ring (the caller may put a wait between them: the counter holds 15)
-template <int DP, int HALF> __device__ __forceinline__ void second_prefetch_pair(SecondRing<DP> &r0, uint32_t base0, SecondRing<DP> &r1, uint32_t base1) {
+template <int DP, int OFF0, int OFF1, int HALF> __device__ __forceinline__ void second_prefetch_pair(SecondRing<DP> &r0, SecondRing<DP> &r1, const Addresses<DP> &ad) {
   constexpr int H = SecondRing<DP>::RING / 2;
   static_for<H>([&](auto T_) {
     constexpr int T = decltype(T_)::value + HALF * H;
-    r0.v[T] = second_read<DP, T>(base0);
-    r1.v[T] = second_read<DP, T>(base1);
+    r0.v[T] = second_read<DP, OFF0, T>(ad);
+    r1.v[T] = second_read<DP, OFF1, T>(ad);
   });
 }
-// acc[db] += X_tile^T (second pattern) . p : 16 reads, NDB matrix instructions each.  `extra` = LDS reads issued after the
-// prefetch that are still allowed to be pending (none of them older than the ring's)
-template <int DP> __device__ __forceinline__ void second_product(f32x16 *acc, SecondRing<DP> &ring, uint32_t base, const f32x16 &p) {
+// acc[db] += X_tile^T (second pattern) . p : 16 reads, NDB matrix instructions each
+template <int DP, int OFF, int RING> __device__ __forceinline__ void second_product(f32x16 *acc, SecondRing<DP, RING> &ring, const Addresses<DP> &ad, const f32x16 &p) {
   typedef Geo<DP> G;
-  constexpr int RING = SecondRing<DP>::RING;
   static_for<16>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int pending = (15 - T) < (RING - 1) ? (15 - T) : (RING - 1);
     lds_wait<pending>(ring.v[T % RING]);
     const auto v = ring.v[T % RING];
-#pragma unroll
-    for (int db = 0; db < G::NDB; ++db) acc[db] = mfma(v[db], p[T], acc[db]);
-    if constexpr (T + RING < 16) ring.v[T % RING] = second_read<DP, T + RING>(base);
+    mfma_out(acc, v, p[T]);
+    if constexpr (T + RING < 16) ring.v[T % RING] = second_read<DP, OFF, T + RING>(ad);
   });
 }
-// two second products side by side (dV and dK): reads of tile a and tile b alternate
-template <int DP> __device__ __forceinline__ void second_product_pair(f32x16 *acc0, uint32_t base0, const f32x16 &p0, f32x16 *acc1, uint32_t base1,
-                                                                      const f32x16 &p1, SecondRing<DP> &r0, SecondRing<DP> &r1) {
+// two second products side by side (dV and dK): reads of tile 0 and tile 1 alternate
+template <int DP, int OFF0, int OFF1>
+__device__ __forceinline__ void second_product_pair(f32x16 *acc0, const f32x16 &p0, f32x16 *acc1, const f32x16 &p1, SecondRing<DP> &r0, SecondRing<DP> &r1,
+                                                    const Addresses<DP> &ad) {
   typedef Geo<DP> G;
   constexpr int RING = SecondRing<DP>::RING;
   static_for<16>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int left = 15 - T;
     constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1));
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(r0.v[T % RING]), "+v"(r1.v[T % RING]) : "n"(pending < 15 ? pending : 15));
+    lds_wait<pending>(r0.v[T % RING], r1.v[T % RING]);
     const auto v0 = r0.v[T % RING];
     const auto v1 = r1.v[T % RING];
-#pragma unroll
-    for (int db = 0; db < G::NDB; ++db) {
-      acc0[db] = mfma(v0[db], p0[T], acc0[db]);
-      acc1[db] = mfma(v1[db], p1[T], acc1[db]);
-    }
+    mfma_out_pair(acc0, v0, p0[T], acc1, v1, p1[T]);
     if constexpr (T + RING < 16) {
-      r0.v[T % RING] = second_read<DP, T + RING>(base0);
-      r1.v[T % RING] = second_read<DP, T + RING>(base1);
+      r0.v[T % RING] = second_read<DP, OFF0, T + RING>(ad);
+      r1.v[T % RING] = second_read<DP, OFF1, T + RING>(ad);
     }
   });
 }
@@ -266,10 +364,12 @@ template <int DP> __device__ __forceinline__ void store_rows(const f32x16 *acc, 
     }
   }
 }
+__device__ __forceinline__ f32x16 splat16(float x) { return f32x16{x, x, x, x, x, x, x, x, x, x, x, x, x, x, x, x}; }
 
 template <int DP> constexpr int lds_bytes() { return 2 /*stages*/ * 2 /*operands*/ * Geo<DP>::TILE; }
 template <int DP> constexpr int lds_bytes_dkv() { return lds_bytes<DP>() + 2 /*stages*/ * 512; }   // + the L and D slices of a tile
 constexpr int ROWS = 128;   // rows (forward, dQ) or columns (dK/dV) of a workgroup: four waves x 32
+constexpr float RESCALE_ABOVE = 8.f;   // forward: O, l and the reference maximum are re-based when a row's maximum grew by more than 2^8
 
 // ----------------------------------------------------------------------------------------------
 // forward: O = softmax(Q K^T / sqrt(D)) V,  L = m + log2(l)       (+Source.swift:158-200)
@@ -291,90 +391,103 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
   const int64_t r0 = (int64_t)rblk * ROWS;
   if (r0 >= R) return;
   const int64_t row = r0 + wave * 32 + q;
-  const float scale2 = a.scale2;
   const bool causal = a.causal != 0;
 
   const __amdgpu_buffer_rsrc_t qres = rows_resource(a.op[SLOT_Q], head, batch, R);
-  const __amdgpu_buffer_rsrc_t kres = rows_resource(a.op[SLOT_K], head, batch, C);
-  const __amdgpu_buffer_rsrc_t vres = rows_resource(a.op[SLOT_V], head, batch, C);
+  const char *kbase = operand_base(a.op[SLOT_K], head, batch), *vbase = operand_base(a.op[SLOT_V], head, batch);
+  const uint32_t ldk = (uint32_t)a.op[SLOT_K].ld, ldv = (uint32_t)a.op[SLOT_V].ld;
+  // Q fragments, pre-multiplied by log2(e) / sqrt(D): the scores leave the matrix instructions in base-2 units
   float qf[DP / 2];
   load_fragments<DP>(qf, qres, (uint32_t)row * (uint32_t)a.op[SLOT_Q].ld * 4u, row < R, hi, D);
+  pin_fragments<DP / 2>(qf, a.scale2);
 
   f32x16 o[G::NDB];
 #pragma unroll
-  for (int db = 0; db < G::NDB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-  float m = -3.402823466e+38f;          // +Caching.swift:310
-  float l = 1.401298464e-45f;           // +Caching.swift:311 (denorm_min)
+  for (int db = 0; db < G::NDB; ++db) mfma_zero(o[db]);
+  // online softmax (+Softmax.swift:267-324) around a REFERENCE maximum m: the score accumulator starts at -m, so a tile's
+  // scores arrive as s - m; m follows the row maximum when that grew by more than RESCALE_ABOVE (O and l are re-based then,
+  // onlineCorrectO) -- the first tile always sets it
+  float m = 0.f, l = 0.f;
+  const float ones = hi == 0 ? 1.f : 0.f;   // contraction step (hi): A = (1, 0), B = (-m, 0)
+  float bias = 0.f;
 
   // causal extension: row r sees column c iff c <= r + coff; columns past the last row's limit are never visited
   const int coff = causal_offset(R, C);
   const int Cend = causal ? (int)min((int64_t)C, min((int64_t)R, r0 + ROWS) + coff) : C;
   const int nt = (Cend + BT - 1) / BT;
   Stager<DP> ks, vs;
-  ks.init(wave, lane, (uint32_t)a.op[SLOT_K].ld, D, 0);
-  vs.init(wave, lane, (uint32_t)a.op[SLOT_V].ld, D, 0);
-  const uint32_t lbase = lds_addr(smem);
-  const uint32_t first = first_address<DP>(q, hi), second = second_address<DP>(q, hi);
-  const int64_t limit = row + coff;
+  ks.init(wave, lane, ldk, D);
+  vs.init(wave, lane, ldv, D);
+  Addresses<DP> ad;
+  ad.init(lds_addr(smem), q, hi);
+  const int limit = (int)row + coff;
+  const int wavelimit = (int)r0 + wave * 32 + coff;   // the wave's smallest limit: tiles reaching past it mask
   if (nt > 0) {
-    ks.issue(kres, smem, wave);
-    vs.issue(vres, smem + G::TILE, wave);
+    ks.issue(tile_resource(kbase, ldk, C, 0), smem, wave);
+    vs.issue(tile_resource(vbase, ldv, C, 0), smem + G::TILE, wave);
   }
-  for (int j = 0; j < nt; ++j) {
+  auto tile = [&](auto STAGE_, int j) {
+    constexpr int STAGE = decltype(STAGE_)::value;
+    constexpr int KOFF = STAGE * 2 * G::TILE, VOFF = KOFF + G::TILE, NEXT = (STAGE ^ 1) * 2 * G::TILE;
     const int c0 = j * BT;
-    const uint32_t stage = (uint32_t)(j & 1) * (2 * G::TILE);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile j have landed
     __syncthreads();                      // ... everybody's; and every wave has finished tile j - 1, whose stage is written next
     if (j + 1 < nt) {
-      ks.issue(kres, smem + (stage ^ (2 * G::TILE)), wave);
-      vs.issue(vres, smem + (stage ^ (2 * G::TILE)) + G::TILE, wave);
+      ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
+      vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
     }
-    // S^T = K Q^T : lane holds query `row`, keys c0 + crow(r, hi)
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    first_product<DP>(s, (lbase + stage) + first, qf);
-    SecondRing<DP> vring;
-    second_prefetch<DP>(vring, (lbase + stage + G::TILE) + second);
+    // S^T = K Q^T - m : lane holds query `row`, keys c0 + crow(r, hi)
+    f32x16 s = first_product<DP, KOFF, 3>(ones, bias, ad, qf);
+    SecondRing<DP, 3> vring;
+    second_prefetch<DP, VOFF>(vring, ad);
+    mfma_fence(s);
     if (c0 + BT > C) { // maskAttentionMatrixEdge, +Softmax.swift:228-260
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (c0 + crow(r, hi) >= C) s[r] = mask_value();
     }
-    if (causal && c0 + BT - 1 > r0 + wave * 32 + coff) {    // same mechanism, applied to the columns the row may not see
+    if (causal && c0 + BT - 1 > wavelimit) {    // same mechanism, applied to the columns the row may not see
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (c0 + crow(r, hi) > limit) s[r] = mask_value();
     }
-    // onlineReduceMaximum / onlineCorrectO, +Softmax.swift:267-301
-    float mx = s[0];
+    // onlineReduceMaximum, +Softmax.swift:267-288 (relative to m)
+    float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-    const float m_new = half_max(mx) * scale2;
-    // corr = (m_new > m) ? exp2(m - m_new) : 1.  When no lane of the wave saw its maximum grow the correction is exactly 1
-    // everywhere: skip the O-wide multiply (wave-uniform branch, same results)
-    if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {
-      float corr = 1.f;
-      if (m_new > m) { corr = fast_exp2(m - m_new); m = m_new; }
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+    mx = half_max(fmaxf(mx, s[15]));
+    const bool grow = j == 0 || mx > RESCALE_ABOVE;
+    if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // wave-uniform: rare after the first tiles
+      const float delta = grow ? mx : 0.f;
+      const float corr = j == 0 ? 1.f : fast_exp2(-delta);   // onlineCorrectO, +Softmax.swift:290-301 (first tile: O = l = 0)
+      m += delta;
       l *= corr;
+      mfma_fence_out<G::NDB>(o);
 #pragma unroll
       for (int db = 0; db < G::NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] -= delta;
+      bias = hi == 0 ? -m : 0.f;
     }
     // softmax + onlineReduceSum, +Softmax.swift:304-324, :406-417
     float psum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] * scale2 - m); psum += s[r]; }
+    for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r]); psum += s[r]; }
     l += psum;
+    valu_fence(s);
     // O^T += V^T P^T with the key index permuted: step t uses key crow(t, hi)
-    second_product<DP>(o, vring, (lbase + stage + G::TILE) + second, s);
+    second_product<DP, VOFF>(o, vring, ad, s);
+  };
+  for (int j = 0; j < nt; j += 2) {
+    tile(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
   }
 
+  mfma_fence_out<G::NDB>(o);
   const float l_tot = half_add(l);
-  const float inv = (m > -1e37f) ? 1.0f / l_tot : 0.f;   // +Source.swift:165-171 (0: a row whose every block is masked out)
+  const float inv = (m > -1e37f && l_tot > 0.f) ? 1.0f / l_tot : 0.f;   // +Source.swift:165-171 (0: a row whose every block is masked out)
   store_rows<DP>(o, a.op[SLOT_O], head, batch, row, R, hi, D, inv);
   if (hi == 0 && row < R)  // L = m + log2(l), +Caching.swift:373-377
     reinterpret_cast<float *>(operand_base(a.op[SLOT_L], head, batch))[row] = m + log2f(l_tot);
@@ -382,11 +495,9 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
 
 // ----------------------------------------------------------------------------------------------
 // backward dQ: D = rowsum(dO*O)/sqrt(D); dQ = sum_c dS K                (+Source.swift:202-242)
-// same grid; one workgroup per compute unit (Q and dO fragments, the dQ accumulators: 192 + 32 registers before any buffer)
+// same grid; one workgroup per compute unit (Q and dO fragments, the dQ accumulators: 192 registers before any buffer)
 // ----------------------------------------------------------------------------------------------
-// ABL (developer builds, timing only -- results are wrong): 1 no softmax arithmetic, 2 no barrier / staging in the loop,
-// 4 no second product, 8 no first products
-template <int DP, int ABL = 0>
+template <int DP>
 __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd16Grid grid) {
   typedef Geo<DP> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -402,86 +513,89 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
   const int64_t r0 = (int64_t)rblk * ROWS;
   if (r0 >= R) return;
   const int64_t row = r0 + wave * 32 + q;
-  const float scale = a.scale, scale2 = a.scale2;
+  const float scale = a.scale;
   const bool causal = a.causal != 0;
 
   const __amdgpu_buffer_rsrc_t qres = rows_resource(a.op[SLOT_Q], head, batch, R);
   const __amdgpu_buffer_rsrc_t gres = rows_resource(a.op[SLOT_dO], head, batch, R);
   const __amdgpu_buffer_rsrc_t ores = rows_resource(a.op[SLOT_O], head, batch, R);
-  const __amdgpu_buffer_rsrc_t kres = rows_resource(a.op[SLOT_K], head, batch, C);
-  const __amdgpu_buffer_rsrc_t vres = rows_resource(a.op[SLOT_V], head, batch, C);
+  const char *kbase = operand_base(a.op[SLOT_K], head, batch), *vbase = operand_base(a.op[SLOT_V], head, batch);
+  const uint32_t ldk = (uint32_t)a.op[SLOT_K].ld, ldv = (uint32_t)a.op[SLOT_V].ld;
   float qf[DP / 2], gf[DP / 2];
   load_fragments<DP>(qf, qres, (uint32_t)row * (uint32_t)a.op[SLOT_Q].ld * 4u, row < R, hi, D);
   load_fragments<DP>(gf, gres, (uint32_t)row * (uint32_t)a.op[SLOT_dO].ld * 4u, row < R, hi, D);
   // computeD, +Softmax.swift:32-221: D = (sum_d dO*O) * 1/sqrt(D); the two half-waves split the head dimension
-  float dterm = 0.f;
+  float dsum = 0.f;
   {
     float of[DP / 2];
     load_fragments<DP>(of, ores, (uint32_t)row * (uint32_t)a.op[SLOT_O].ld * 4u, row < R, hi, D);
 #pragma unroll
-    for (int t = 0; t < DP / 2; ++t) dterm += of[t] * gf[t];
-    dterm = half_add(dterm) * scale;
+    for (int t = 0; t < DP / 2; ++t) dsum += of[t] * gf[t];
+    dsum = half_add(dsum);
   }
   float Lrow = 0.f;
   if (row < R) Lrow = reinterpret_cast<const float *>(operand_base(a.op[SLOT_L], head, batch))[row];
+  pin_fragments<DP / 2>(qf, a.scale2);   // Q pre-multiplied by log2(e) / sqrt(D): S' = S * scale2
+  pin_fragments<DP / 2>(gf, 1.f);
+  // the accumulators of the first products start at -L and -sum(dO o O): S' - L and dP - D / scale leave the matrix
+  // instructions; dS = P (dP - D / scale), the factor 1 / sqrt(D) is applied to dQ once at the end (+Softmax.swift:409-427)
+  const f32x16 negL = splat16(-Lrow), negD = splat16(-dsum);
 
   f32x16 acc[G::NDB];
 #pragma unroll
-  for (int db = 0; db < G::NDB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[db][r] = 0.f;
+  for (int db = 0; db < G::NDB; ++db) mfma_zero(acc[db]);
 
   const int coff = causal_offset(R, C);
   const int Cend = causal ? (int)min((int64_t)C, min((int64_t)R, r0 + ROWS) + coff) : C;
   const int nt = (Cend + BT - 1) / BT;
   Stager<DP> ks, vs;
-  ks.init(wave, lane, (uint32_t)a.op[SLOT_K].ld, D, 0);
-  vs.init(wave, lane, (uint32_t)a.op[SLOT_V].ld, D, 0);
-  const uint32_t lbase = lds_addr(smem);
-  const uint32_t first = first_address<DP>(q, hi), second = second_address<DP>(q, hi);
-  const int64_t limit = row + coff;
+  ks.init(wave, lane, ldk, D);
+  vs.init(wave, lane, ldv, D);
+  Addresses<DP> ad;
+  ad.init(lds_addr(smem), q, hi);
+  const int limit = (int)row + coff;
+  const int wavelimit = (int)r0 + wave * 32 + coff;
   if (nt > 0) {
-    ks.issue(kres, smem, wave);
-    vs.issue(vres, smem + G::TILE, wave);
+    ks.issue(tile_resource(kbase, ldk, C, 0), smem, wave);
+    vs.issue(tile_resource(vbase, ldv, C, 0), smem + G::TILE, wave);
   }
-  for (int j = 0; j < nt; ++j) {
+  auto tile = [&](auto STAGE_, int j) {
+    constexpr int STAGE = decltype(STAGE_)::value;
+    constexpr int KOFF = STAGE * 2 * G::TILE, VOFF = KOFF + G::TILE, NEXT = (STAGE ^ 1) * 2 * G::TILE;
     const int c0 = j * BT;
-    const uint32_t stage = (uint32_t)(j & 1) * (2 * G::TILE);
-    if constexpr (!(ABL & 2)) {
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (j + 1 < nt) {
+      ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
+      vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
     }
-    if (!(ABL & 2) && j + 1 < nt) {
-      ks.issue(kres, smem + (stage ^ (2 * G::TILE)), wave);
-      vs.issue(vres, smem + (stage ^ (2 * G::TILE)) + G::TILE, wave);
-    }
+    // S'^T = K Q'^T - L, dP^T = V dO^T - D / scale
     f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    // S^T = K Q^T, dP^T = V dO^T
-    if constexpr (!(ABL & 8)) first_product_pair<DP>(s, (lbase + stage) + first, qf, dp, (lbase + stage + G::TILE) + first, gf);
+    first_product_pair<DP, KOFF, VOFF>(s, negL, qf, dp, negD, gf, ad);
     SecondRing<DP> kring;
-    second_prefetch<DP>(kring, (lbase + stage) + second);
-    // P = exp2(S*scale2 - L); dS = P * (dP*scale - D)     (+Softmax.swift:409-427).  Padded columns: K, V rows are zero, so
-    // dS * K contributes nothing (as in the reference, where the zero padding comes from the async copy, +Accumulate.swift:330-346)
-    if constexpr (!(ABL & 1)) {
+    second_prefetch<DP, KOFF>(kring, ad);
+    mfma_fence(s, dp);
+    // P = exp2(S' - L); dS = P * (dP - D / scale).  Padded columns: K, V rows are zero, so dS * K contributes nothing (as in
+    // the reference, where the zero padding comes from the async copy, +Accumulate.swift:330-346)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float p = fast_exp2(s[r] * scale2 - Lrow);
-        if (causal && c0 + crow(r, hi) > limit) p = 0.f;   // masked column: P = 0, hence dS = 0
-        s[r] = p * (dp[r] * scale - dterm);
-      }
-    } else {
+    for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];
+    if (causal && c0 + BT - 1 > wavelimit) {   // masked column: P = 0, hence dS = 0
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] += dp[r];
+      for (int r = 0; r < 16; ++r)
+        if (c0 + crow(r, hi) > limit) s[r] = 0.f;
     }
+    valu_fence(s);
     // dQ^T += K^T dS^T, key index permuted as in forward
-    if constexpr (!(ABL & 4)) second_product<DP>(acc, kring, (lbase + stage) + second, s);
-    else { lds_wait<0>(kring.v[0]); lds_wait<0>(kring.v[1]); lds_wait<0>(kring.v[2]); lds_wait<0>(kring.v[3]); acc[0] += s; acc[1][0] += kring.v[0][0] + kring.v[1][0] + kring.v[2][0] + kring.v[3][0]; }
+    second_product<DP, KOFF>(acc, kring, ad, s);
+  };
+  for (int j = 0; j < nt; j += 2) {
+    tile(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
   }
-  store_rows<DP>(acc, a.op[SLOT_dQ], head, batch, row, R, hi, D, 1.f);
+  mfma_fence_out<G::NDB>(acc);
+  store_rows<DP>(acc, a.op[SLOT_dQ], head, batch, row, R, hi, D, scale);
   if (hi == 0 && row < R)   // +Caching.swift:381-413
-    reinterpret_cast<float *>(operand_base(a.op[SLOT_D], head, batch))[row] = dterm;
+    reinterpret_cast<float *>(operand_base(a.op[SLOT_D], head, batch))[row] = dsum * scale;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -503,92 +617,108 @@ __global__ __launch_bounds__(256) void attn_f32_dkv(const KernelArgs a, const Fw
   const int64_t c0 = (int64_t)cblk * ROWS;
   if (c0 >= C) return;
   const int64_t col = c0 + wave * 32 + kc;
-  const float scale = a.scale, scale2 = a.scale2;
   const bool causal = a.causal != 0;
 
   const __amdgpu_buffer_rsrc_t kres = rows_resource(a.op[SLOT_K], head, batch, C);
   const __amdgpu_buffer_rsrc_t vres = rows_resource(a.op[SLOT_V], head, batch, C);
-  const __amdgpu_buffer_rsrc_t qres = rows_resource(a.op[SLOT_Q], head, batch, R);
-  const __amdgpu_buffer_rsrc_t gres = rows_resource(a.op[SLOT_dO], head, batch, R);
-  const __amdgpu_buffer_rsrc_t lres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_L], head, batch), 0, (uint32_t)R * 4u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(operand_base(a.op[SLOT_D], head, batch), 0, (uint32_t)R * 4u, 0x00020000);
+  const char *qbase = operand_base(a.op[SLOT_Q], head, batch), *gbase = operand_base(a.op[SLOT_dO], head, batch);
+  const char *lbase = operand_base(a.op[SLOT_L], head, batch), *dbase = operand_base(a.op[SLOT_D], head, batch);
+  const uint32_t ldq = (uint32_t)a.op[SLOT_Q].ld, ldg = (uint32_t)a.op[SLOT_dO].ld;
+  // K pre-multiplied by -log2(e) / sqrt(D) and V by -1 / sqrt(D): with accumulators that start at L and D (the slices of the
+  // tile's rows, read from LDS straight into the accumulator registers) the first products deliver L - S' and D - dP / sqrt(D):
+  // P = exp2(-(L - S')), dS = -P (D - dP / sqrt(D))       (+Softmax.swift:409-427); dK accumulates +P (...) and is negated when stored
   float kf[DP / 2], vf[DP / 2];
   load_fragments<DP>(kf, kres, (uint32_t)col * (uint32_t)a.op[SLOT_K].ld * 4u, col < C, hi, D);
   load_fragments<DP>(vf, vres, (uint32_t)col * (uint32_t)a.op[SLOT_V].ld * 4u, col < C, hi, D);
+  pin_fragments<DP / 2>(kf, -a.scale2);
+  pin_fragments<DP / 2>(vf, -a.scale);
 
   f32x16 dk[G::NDB], dv[G::NDB];
 #pragma unroll
-  for (int db = 0; db < G::NDB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+  for (int db = 0; db < G::NDB; ++db) { mfma_zero(dk[db]); mfma_zero(dv[db]); }
 
   // causal extension: rows above the workgroup's first column minus the offset see none of its columns
   const int coff = causal_offset(R, C);
   const int rstart = causal ? (int)(max((int64_t)0, c0 - coff) / BT) * BT : 0;
   const int nt = (R - rstart + BT - 1) / BT;
   Stager<DP> qs, gs;
-  qs.init(wave, lane, (uint32_t)a.op[SLOT_Q].ld, D, (uint32_t)rstart);
-  gs.init(wave, lane, (uint32_t)a.op[SLOT_dO].ld, D, (uint32_t)rstart);
-  const uint32_t lbase = lds_addr(smem);
-  const uint32_t first = first_address<DP>(kc, hi), second = second_address<DP>(kc, hi);
+  qs.init(wave, lane, ldq, D);
+  gs.init(wave, lane, ldg, D);
+  Addresses<DP> ad;
+  ad.init(lds_addr(smem), kc, hi);
   // L and D slices along the traversal dimension (+Softmax.swift:356-381, :472-503): 32 floats each per tile, staged like the
   // tiles (wave 0: L, wave 1: D; one dword per lane, the upper 32 lanes' rows belong to the next tile and are not read)
   char *ldst = smem + lds_bytes<DP>();
-  const uint32_t ldoff = (uint32_t)(rstart + lane) * 4u;
-  auto issue_ld = [&](int tile) {
+  const uint32_t ldread = lds_addr(ldst) + hi * 16;
+  auto issue_ld = [&](int stage, int row0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (wave == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(lres, (lds_ptr)(ldst + (tile & 1) * 512), 4, ldoff + (uint32_t)tile * (BT * 4u), 0, 0, 0);
-    if (wave == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(dres, (lds_ptr)(ldst + (tile & 1) * 512 + 256), 4, ldoff + (uint32_t)tile * (BT * 4u), 0, 0, 0);
+    const int left = R > row0 ? R - row0 : 0;
+    if (wave == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(lbase) + (int64_t)row0 * 4, 0, (uint32_t)left * 4u, 0x00020000),
+                                               (lds_ptr)(ldst + stage * 512), 4, (uint32_t)lane * 4u, 0, 0, 0);
+    if (wave == 1)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(dbase) + (int64_t)row0 * 4, 0, (uint32_t)left * 4u, 0x00020000),
+                                               (lds_ptr)(ldst + stage * 512 + 256), 4, (uint32_t)lane * 4u, 0, 0, 0);
 #endif
   };
+  // the wave's largest column: rows whose limit lies below it mask (causal)
+  const int wavecol = (int)c0 + wave * 32 + 31, icol = (int)col;
   if (nt > 0) {
-    qs.issue(qres, smem, wave);
-    gs.issue(gres, smem + G::TILE, wave);
-    issue_ld(0);
+    qs.issue(tile_resource(qbase, ldq, R, rstart), smem, wave);
+    gs.issue(tile_resource(gbase, ldg, R, rstart), smem + G::TILE, wave);
+    issue_ld(0, rstart);
   }
-  for (int j = 0; j < nt; ++j) {
+  auto tile = [&](auto STAGE_, int j) {
+    constexpr int STAGE = decltype(STAGE_)::value;
+    constexpr int QOFF = STAGE * 2 * G::TILE, GOFF = QOFF + G::TILE, NEXT = (STAGE ^ 1) * 2 * G::TILE;
     const int rr0 = rstart + j * BT;
-    const uint32_t stage = (uint32_t)(j & 1) * (2 * G::TILE);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     if (j + 1 < nt) {
-      qs.issue(qres, smem + (stage ^ (2 * G::TILE)), wave);
-      gs.issue(gres, smem + (stage ^ (2 * G::TILE)) + G::TILE, wave);
-      issue_ld(j + 1);
+      qs.issue(tile_resource(qbase, ldq, R, rr0 + BT), smem + NEXT, wave);
+      gs.issue(tile_resource(gbase, ldg, R, rr0 + BT), smem + NEXT + G::TILE, wave);
+      issue_ld(STAGE ^ 1, rr0 + BT);
     }
-    // S = Q K^T (not swapped): lane holds key `col`, rows rr0 + crow(r, hi); dP = dO V^T
-    f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    first_product_pair<DP>(s, (lbase + stage) + first, kf, dp, (lbase + stage + G::TILE) + first, vf);
-    // rows rr0 + crow(r, hi) of L and D: four reads of four each, then the first reads of the second products (the counter of
-    // pending LDS operations holds 15: the rings are requested in two halves around the wait for the slices)
+    // rows rr0 + crow(r, hi) of L and D: four reads of four each into the registers the first products accumulate in
     f32x4 lv[4], dvv[4];
-    const uint32_t ldbase = lbase + lds_bytes<DP>() + (uint32_t)(j & 1) * 512 + hi * 16;
     static_for<4>([&](auto g_) {
       constexpr int g = decltype(g_)::value;
-      lv[g] = rd128<32 * g>(ldbase);
-      dvv[g] = rd128<256 + 32 * g>(ldbase);
+      lv[g] = rd128<STAGE * 512 + 32 * g>(ldread);
+      dvv[g] = rd128<STAGE * 512 + 256 + 32 * g>(ldread);
     });
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
+    f32x16 s = __builtin_shufflevector(__builtin_shufflevector(lv[0], lv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(lv[2], lv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                       0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    f32x16 dp = __builtin_shufflevector(__builtin_shufflevector(dvv[0], dvv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(dvv[2], dvv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                        0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    // L - S' (S = Q K^T, not swapped: lane holds key `col`, rows rr0 + crow(r, hi)); D - dP / sqrt(D) (dP = dO V^T)
+    first_product_pair<DP, QOFF, GOFF, false>(s, s, kf, dp, dp, vf, ad);
     SecondRing<DP> gring, qring;
-    second_prefetch_pair<DP, 0>(gring, (lbase + stage + G::TILE) + second, qring, (lbase + stage) + second);
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
-    second_prefetch_pair<DP, 1>(gring, (lbase + stage + G::TILE) + second, qring, (lbase + stage) + second);
+    second_prefetch_pair<DP, GOFF, QOFF, 0>(gring, qring, ad);
+    second_prefetch_pair<DP, GOFF, QOFF, 1>(gring, qring, ad);
+    mfma_fence(s, dp);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float Lr = lv[r >> 2][r & 3];
-      const float Dr = dvv[r >> 2][r & 3];
-      float p = fast_exp2(s[r] * scale2 - Lr);
-      if (causal && col > rr0 + crow(r, hi) + coff) p = 0.f;   // masked: P = 0
-      s[r] = p * (dp[r] * scale - Dr);
+      const float p = fast_exp2(-s[r]);
+      s[r] = p * dp[r];   // = -dS: the sign is applied to dK once at the end
       dp[r] = p;
     }
+    if (causal && wavecol > rr0 + coff) {   // masked: P = 0
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (icol > rr0 + crow(r, hi) + coff) { s[r] = 0.f; dp[r] = 0.f; }
+    }
     // dV^T += dO^T P ; dK^T += Q^T dS   (row index permuted; padded rows of Q / dO are zero)
-    // (the two rings were requested dO first: the pair below waits for them in that order)
-    second_product_pair<DP>(dv, (lbase + stage + G::TILE) + second, dp, dk, (lbase + stage) + second, s, gring, qring);
+    second_product_pair<DP, GOFF, QOFF>(dv, dp, dk, s, gring, qring, ad);
+  };
+  for (int j = 0; j < nt; j += 2) {
+    tile(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
   }
+  mfma_fence_out<G::NDB>(dv);
+  mfma_fence_out<G::NDB>(dk);
   store_rows<DP>(dv, a.op[SLOT_dV], head, batch, col, C, hi, D, 1.f);
-  store_rows<DP>(dk, a.op[SLOT_dK], head, batch, col, C, hi, D, 1.f);
+  store_rows<DP>(dk, a.op[SLOT_dK], head, batch, col, C, hi, D, -1.f);
 }
 
 // ---- host side: does a launch of the general kernel's variant go to these kernels?  (the general kernels' launchers ask)

@@ -36,16 +36,6 @@ template <int DP> bool launch(int type, dim3 grid, hipStream_t stream, const Ker
       hipLaunchKernelGGL((f32k::attn_f32_fwd<DP>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g);
       return true;
     case 1:
-#ifdef MFA_DEV_VARIANTS   // timing-only ablations of the dQ loop (attn_f32.h, ABL): MFA_F32_ABL=1|2|4|8|...
-      if constexpr (DP == 128) {
-        if (const char *e = std::getenv("MFA_F32_ABL")) {
-          const int abl = std::atoi(e);
-#define MFA_F32_ABL_CASE(N) case N: raise_lds(&f32k::attn_f32_dq<DP, N>, f32k::lds_bytes<DP>()); hipLaunchKernelGGL((f32k::attn_f32_dq<DP, N>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g); return true;
-          switch (abl) { MFA_F32_ABL_CASE(1) MFA_F32_ABL_CASE(2) MFA_F32_ABL_CASE(3) MFA_F32_ABL_CASE(4) MFA_F32_ABL_CASE(8) MFA_F32_ABL_CASE(5) MFA_F32_ABL_CASE(9) MFA_F32_ABL_CASE(12) default: break; }
-#undef MFA_F32_ABL_CASE
-        }
-      }
-#endif
       if (!raise_lds(&f32k::attn_f32_dq<DP>, f32k::lds_bytes<DP>())) return false;
       hipLaunchKernelGGL((f32k::attn_f32_dq<DP>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g);
       return true;

@@ -87,49 +87,53 @@ __device__ __forceinline__ float half_add(float x) { float a, b; half_swap(x, &a
 // (one asm statement per GROUP of instructions: hipcc puts a wait state between asm statements that touch the same registers)
 #define MFA_MFMA "v_mfma_f32_32x32x2_f32 "
 // four steps of ONE first product: d += a[i] . b[i] (VGPR accumulators, B in AGPRs)
-__device__ __forceinline__ void mfma_group(f32x16 &d, const f32x4 &a, const float *b) {
-  asm volatile(MFA_MFMA "%0, %1, %5, %0\n\t" MFA_MFMA "%0, %2, %6, %0\n\t" MFA_MFMA "%0, %3, %7, %0\n\t" MFA_MFMA "%0, %4, %8, %0"
-               : "+v"(d) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "a"(b[0]), "a"(b[1]), "a"(b[2]), "a"(b[3]));
+// WAIT: the statement starts with s_waitcnt lgkmcnt(WAIT) -- the A operands are LDS reads in flight (at most WAIT younger reads
+// may still be pending; a separate wait statement costs a wait state between the two asm statements)
+template <int WAIT> __device__ __forceinline__ void mfma_group(f32x16 &d, const f32x4 &a, const float *b) {
+  asm volatile("s_waitcnt lgkmcnt(%9)\n\t" MFA_MFMA "%0, %1, %5, %0\n\t" MFA_MFMA "%0, %2, %6, %0\n\t" MFA_MFMA "%0, %3, %7, %0\n\t" MFA_MFMA "%0, %4, %8, %0"
+               : "+v"(d) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "a"(b[0]), "a"(b[1]), "a"(b[2]), "a"(b[3]), "n"(WAIT));
 }
 // the bias step of the forward: d = ones . bias (all VGPR)
 __device__ __forceinline__ void mfma_bias(f32x16 &d, float a, float b) {   // (s_nop: as in mfma_zero, `b` may be fresh)
   asm volatile("s_nop 1\n\t" MFA_MFMA "%0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
 }
 // four steps of TWO first products, alternating: d0 += a0[i] . b0[i], d1 += a1[i] . b1[i]
-__device__ __forceinline__ void mfma_group_pair(f32x16 &d0, const f32x4 &a0, const float *b0, f32x16 &d1, const f32x4 &a1, const float *b1) {
-  asm volatile(MFA_MFMA "%0, %2, %10, %0\n\t" MFA_MFMA "%1, %6, %14, %1\n\t" MFA_MFMA "%0, %3, %11, %0\n\t" MFA_MFMA "%1, %7, %15, %1\n\t"
+template <int WAIT> __device__ __forceinline__ void mfma_group_pair(f32x16 &d0, const f32x4 &a0, const float *b0, f32x16 &d1, const f32x4 &a1, const float *b1) {
+  asm volatile("s_waitcnt lgkmcnt(%18)\n\t" MFA_MFMA "%0, %2, %10, %0\n\t" MFA_MFMA "%1, %6, %14, %1\n\t" MFA_MFMA "%0, %3, %11, %0\n\t" MFA_MFMA "%1, %7, %15, %1\n\t"
                MFA_MFMA "%0, %4, %12, %0\n\t" MFA_MFMA "%1, %8, %16, %1\n\t" MFA_MFMA "%0, %5, %13, %0\n\t" MFA_MFMA "%1, %9, %17, %1"
                : "+v"(d0), "+v"(d1)
                : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
-                 "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]));
+                 "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]), "n"(WAIT));
 }
 // the same with start values: d0 = a0 . b0 + c0, d1 = a1 . b1 + c1 for the first step
+template <int WAIT>
 __device__ __forceinline__ void mfma_group_pair_init(f32x16 &d0, const f32x4 &a0, const float *b0, const f32x16 &c0, f32x16 &d1, const f32x4 &a1, const float *b1,
                                                      const f32x16 &c1) {
-  asm volatile(MFA_MFMA "%0, %2, %10, %18\n\t" MFA_MFMA "%1, %6, %14, %19\n\t" MFA_MFMA "%0, %3, %11, %0\n\t" MFA_MFMA "%1, %7, %15, %1\n\t"
+  asm volatile("s_waitcnt lgkmcnt(%20)\n\t" MFA_MFMA "%0, %2, %10, %18\n\t" MFA_MFMA "%1, %6, %14, %19\n\t" MFA_MFMA "%0, %3, %11, %0\n\t" MFA_MFMA "%1, %7, %15, %1\n\t"
                MFA_MFMA "%0, %4, %12, %0\n\t" MFA_MFMA "%1, %8, %16, %1\n\t" MFA_MFMA "%0, %5, %13, %0\n\t" MFA_MFMA "%1, %9, %17, %1"
                : "=&v"(d0), "=&v"(d1)
                : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]),
-                 "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]), "v"(c0), "v"(c1));
+                 "a"(b0[0]), "a"(b0[1]), "a"(b0[2]), "a"(b0[3]), "a"(b1[0]), "a"(b1[1]), "a"(b1[2]), "a"(b1[3]), "v"(c0), "v"(c1), "n"(WAIT));
 }
 // one step of a second product over its NDB accumulator blocks (AGPR accumulators, A and B in VGPRs): acc[db] += a[db] . p
-__device__ __forceinline__ void mfma_out(f32x16 *acc, const f32x4 &a, float p) {
-  asm volatile(MFA_MFMA "%0, %4, %8, %0\n\t" MFA_MFMA "%1, %5, %8, %1\n\t" MFA_MFMA "%2, %6, %8, %2\n\t" MFA_MFMA "%3, %7, %8, %3"
-               : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(p));
+template <int WAIT> __device__ __forceinline__ void mfma_out(f32x16 *acc, const f32x4 &a, float p) {
+  asm volatile("s_waitcnt lgkmcnt(%9)\n\t" MFA_MFMA "%0, %4, %8, %0\n\t" MFA_MFMA "%1, %5, %8, %1\n\t" MFA_MFMA "%2, %6, %8, %2\n\t" MFA_MFMA "%3, %7, %8, %3"
+               : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(p), "n"(WAIT));
 }
-__device__ __forceinline__ void mfma_out(f32x16 *acc, const f32x2 &a, float p) {
-  asm volatile(MFA_MFMA "%0, %2, %4, %0\n\t" MFA_MFMA "%1, %3, %4, %1" : "+a"(acc[0]), "+a"(acc[1]) : "v"(a[0]), "v"(a[1]), "v"(p));
+template <int WAIT> __device__ __forceinline__ void mfma_out(f32x16 *acc, const f32x2 &a, float p) {
+  asm volatile("s_waitcnt lgkmcnt(%5)\n\t" MFA_MFMA "%0, %2, %4, %0\n\t" MFA_MFMA "%1, %3, %4, %1"
+               : "+a"(acc[0]), "+a"(acc[1]) : "v"(a[0]), "v"(a[1]), "v"(p), "n"(WAIT));
 }
 // one step of TWO second products, alternating
-__device__ __forceinline__ void mfma_out_pair(f32x16 *acc0, const f32x4 &a0, float p0, f32x16 *acc1, const f32x4 &a1, float p1) {
-  asm volatile(MFA_MFMA "%0, %8, %16, %0\n\t" MFA_MFMA "%4, %12, %17, %4\n\t" MFA_MFMA "%1, %9, %16, %1\n\t" MFA_MFMA "%5, %13, %17, %5\n\t"
+template <int WAIT> __device__ __forceinline__ void mfma_out_pair(f32x16 *acc0, const f32x4 &a0, float p0, f32x16 *acc1, const f32x4 &a1, float p1) {
+  asm volatile("s_waitcnt lgkmcnt(%18)\n\t" MFA_MFMA "%0, %8, %16, %0\n\t" MFA_MFMA "%4, %12, %17, %4\n\t" MFA_MFMA "%1, %9, %16, %1\n\t" MFA_MFMA "%5, %13, %17, %5\n\t"
                MFA_MFMA "%2, %10, %16, %2\n\t" MFA_MFMA "%6, %14, %17, %6\n\t" MFA_MFMA "%3, %11, %16, %3\n\t" MFA_MFMA "%7, %15, %17, %7"
                : "+a"(acc0[0]), "+a"(acc0[1]), "+a"(acc0[2]), "+a"(acc0[3]), "+a"(acc1[0]), "+a"(acc1[1]), "+a"(acc1[2]), "+a"(acc1[3])
-               : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(p0), "v"(p1));
+               : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]), "v"(p0), "v"(p1), "n"(WAIT));
 }
-__device__ __forceinline__ void mfma_out_pair(f32x16 *acc0, const f32x2 &a0, float p0, f32x16 *acc1, const f32x2 &a1, float p1) {
-  asm volatile(MFA_MFMA "%0, %4, %8, %0\n\t" MFA_MFMA "%2, %6, %9, %2\n\t" MFA_MFMA "%1, %5, %8, %1\n\t" MFA_MFMA "%3, %7, %9, %3"
-               : "+a"(acc0[0]), "+a"(acc0[1]), "+a"(acc1[0]), "+a"(acc1[1]) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(p0), "v"(p1));
+template <int WAIT> __device__ __forceinline__ void mfma_out_pair(f32x16 *acc0, const f32x2 &a0, float p0, f32x16 *acc1, const f32x2 &a1, float p1) {
+  asm volatile("s_waitcnt lgkmcnt(%10)\n\t" MFA_MFMA "%0, %4, %8, %0\n\t" MFA_MFMA "%2, %6, %9, %2\n\t" MFA_MFMA "%1, %5, %8, %1\n\t" MFA_MFMA "%3, %7, %9, %3"
+               : "+a"(acc0[0]), "+a"(acc0[1]), "+a"(acc1[0]), "+a"(acc1[1]) : "v"(a0[0]), "v"(a0[1]), "v"(a1[0]), "v"(a1[1]), "v"(p0), "v"(p1), "n"(WAIT));
 }
 // an accumulator block in AGPRs, zeroed by the matrix pipe itself (0 . 0 + 0): every definition and use of the block is then an
 // asm operand of the "a" class, and hipcc keeps it there across the loop (a block it zeroes itself starts out in VGPRs and is
@@ -240,21 +244,23 @@ template <int DP> struct Addresses {
 // acc = init + X_tile (first pattern, at immediate offset OFF) . f : NG reads, four matrix instructions each, RING reads ahead
 // (forward: the start value -m arrives as one extra contraction step, ones . bias -- a matrix instruction instead of a block of
 // sixteen registers that every change of m would have to rewrite)
-template <int DP, int OFF, int RING = 4> __device__ __forceinline__ f32x16 first_product(float ones, float bias, const Addresses<DP> &ad, const float *f) {
+// `staging()` runs once the first reads are on their way (the next tile's LDS-DMA is issued in the shadow of their latency)
+template <int DP, int OFF, int RING = 4, typename Staging>
+__device__ __forceinline__ f32x16 first_product(float ones, float bias, const Addresses<DP> &ad, const float *f, Staging &&staging) {
   typedef Geo<DP> G;
   f32x4 ring[RING];
   f32x16 acc;
-  mfma_bias(acc, ones, bias);
   static_for<RING>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     ring[T] = rd128<OFF + (T >> 3) * 256>(ad.first[T & 7]);
   });
+  staging();
+  mfma_bias(acc, ones, bias);
   static_for<G::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int pending = (G::NG - 1 - T) < (RING - 1) ? (G::NG - 1 - T) : (RING - 1);
-    lds_wait<pending>(ring[T % RING]);
     const f32x4 v = ring[T % RING];
-    mfma_group(acc, v, f + 4 * T);
+    mfma_group<pending>(acc, v, f + 4 * T);
     if constexpr (T + RING < G::NG) ring[T % RING] = rd128<OFF + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
   });
   return acc;
@@ -262,9 +268,9 @@ template <int DP, int OFF, int RING = 4> __device__ __forceinline__ f32x16 first
 
 // two first products side by side (the matrix instructions alternate): acc0 = init0 + X0 . f0, acc1 = init1 + X1 . f1
 // (INIT = false: the accumulators hold their start values already -- acc += ...)
-template <int DP, int OFF0, int OFF1, bool INIT = true>
+template <int DP, int OFF0, int OFF1, bool INIT = true, typename Staging>
 __device__ __forceinline__ void first_product_pair(f32x16 &acc0, const f32x16 &init0, const float *f0, f32x16 &acc1, const f32x16 &init1, const float *f1,
-                                                   const Addresses<DP> &ad) {
+                                                   const Addresses<DP> &ad, Staging &&staging) {
   typedef Geo<DP> G;
   constexpr int RING = 3;
   f32x4 r0[RING], r1[RING];
@@ -273,14 +279,14 @@ __device__ __forceinline__ void first_product_pair(f32x16 &acc0, const f32x16 &i
     r0[T] = rd128<OFF0 + (T >> 3) * 256>(ad.first[T & 7]);
     r1[T] = rd128<OFF1 + (T >> 3) * 256>(ad.first[T & 7]);
   });
+  staging();
   static_for<G::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int left = G::NG - 1 - T;
     constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1));
-    lds_wait<pending>(r0[T % RING], r1[T % RING]);
     const f32x4 v0 = r0[T % RING], v1 = r1[T % RING];
-    if constexpr (T == 0 && INIT) mfma_group_pair_init(acc0, v0, f0, init0, acc1, v1, f1, init1);
-    else mfma_group_pair(acc0, v0, f0 + 4 * T, acc1, v1, f1 + 4 * T);
+    if constexpr (T == 0 && INIT) mfma_group_pair_init<pending>(acc0, v0, f0, init0, acc1, v1, f1, init1);
+    else mfma_group_pair<pending>(acc0, v0, f0 + 4 * T, acc1, v1, f1 + 4 * T);
     if constexpr (T + RING < G::NG) {
       r0[T % RING] = rd128<OFF0 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
       r1[T % RING] = rd128<OFF1 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
@@ -322,9 +328,8 @@ template <int DP, int OFF, int RING> __device__ __forceinline__ void second_prod
   static_for<16>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int pending = (15 - T) < (RING - 1) ? (15 - T) : (RING - 1);
-    lds_wait<pending>(ring.v[T % RING]);
     const auto v = ring.v[T % RING];
-    mfma_out(acc, v, p[T]);
+    mfma_out<pending>(acc, v, p[T]);
     if constexpr (T + RING < 16) ring.v[T % RING] = second_read<DP, OFF, T + RING>(ad);
   });
 }
@@ -338,10 +343,9 @@ __device__ __forceinline__ void second_product_pair(f32x16 *acc0, const f32x16 &
     constexpr int T = decltype(T_)::value;
     constexpr int left = 15 - T;
     constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1));
-    lds_wait<pending>(r0.v[T % RING], r1.v[T % RING]);
     const auto v0 = r0.v[T % RING];
     const auto v1 = r1.v[T % RING];
-    mfma_out_pair(acc0, v0, p0[T], acc1, v1, p1[T]);
+    mfma_out_pair<pending>(acc0, v0, p0[T], acc1, v1, p1[T]);
     if constexpr (T + RING < 16) {
       r0.v[T % RING] = second_read<DP, OFF0, T + RING>(ad);
       r1.v[T % RING] = second_read<DP, OFF1, T + RING>(ad);
@@ -432,12 +436,13 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
     const int c0 = j * BT;
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile j have landed
     __syncthreads();                      // ... everybody's; and every wave has finished tile j - 1, whose stage is written next
-    if (j + 1 < nt) {
-      ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
-      vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
-    }
     // S^T = K Q^T - m : lane holds query `row`, keys c0 + crow(r, hi)
-    f32x16 s = first_product<DP, KOFF, 3>(ones, bias, ad, qf);
+    f32x16 s = first_product<DP, KOFF, 3>(ones, bias, ad, qf, [&]() {
+      if (j + 1 < nt) {
+        ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
+        vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
+      }
+    });
     SecondRing<DP, 3> vring;
     second_prefetch<DP, VOFF>(vring, ad);
     mfma_fence(s);
@@ -565,13 +570,14 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
     const int c0 = j * BT;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (j + 1 < nt) {
-      ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
-      vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
-    }
     // S'^T = K Q'^T - L, dP^T = V dO^T - D / scale
     f32x16 s, dp;
-    first_product_pair<DP, KOFF, VOFF>(s, negL, qf, dp, negD, gf, ad);
+    first_product_pair<DP, KOFF, VOFF>(s, negL, qf, dp, negD, gf, ad, [&]() {
+      if (j + 1 < nt) {
+        ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
+        vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
+      }
+    });
     SecondRing<DP> kring;
     second_prefetch<DP, KOFF>(kring, ad);
     mfma_fence(s, dp);
@@ -674,11 +680,6 @@ __global__ __launch_bounds__(256) void attn_f32_dkv(const KernelArgs a, const Fw
     const int rr0 = rstart + j * BT;
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
-    if (j + 1 < nt) {
-      qs.issue(tile_resource(qbase, ldq, R, rr0 + BT), smem + NEXT, wave);
-      gs.issue(tile_resource(gbase, ldg, R, rr0 + BT), smem + NEXT + G::TILE, wave);
-      issue_ld(STAGE ^ 1, rr0 + BT);
-    }
     // rows rr0 + crow(r, hi) of L and D: four reads of four each into the registers the first products accumulate in
     f32x4 lv[4], dvv[4];
     static_for<4>([&](auto g_) {
@@ -686,13 +687,21 @@ __global__ __launch_bounds__(256) void attn_f32_dkv(const KernelArgs a, const Fw
       lv[g] = rd128<STAGE * 512 + 32 * g>(ldread);
       dvv[g] = rd128<STAGE * 512 + 256 + 32 * g>(ldread);
     });
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
-    f32x16 s = __builtin_shufflevector(__builtin_shufflevector(lv[0], lv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(lv[2], lv[3], 0, 1, 2, 3, 4, 5, 6, 7),
-                                       0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    f32x16 dp = __builtin_shufflevector(__builtin_shufflevector(dvv[0], dvv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(dvv[2], dvv[3], 0, 1, 2, 3, 4, 5, 6, 7),
-                                        0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    // L - S' (S = Q K^T, not swapped: lane holds key `col`, rows rr0 + crow(r, hi)); D - dP / sqrt(D) (dP = dO V^T)
-    first_product_pair<DP, QOFF, GOFF, false>(s, s, kf, dp, dp, vf, ad);
+    // L - S' (S = Q K^T, not swapped: lane holds key `col`, rows rr0 + crow(r, hi)); D - dP / sqrt(D) (dP = dO V^T): the slices
+    // ARE the accumulators' start values -- waited for behind the first products' own first reads (six younger reads pending)
+    f32x16 s, dp;
+    first_product_pair<DP, QOFF, GOFF, false>(s, s, kf, dp, dp, vf, ad, [&]() {
+      if (j + 1 < nt) {
+        qs.issue(tile_resource(qbase, ldq, R, rr0 + BT), smem + NEXT, wave);
+        gs.issue(tile_resource(gbase, ldg, R, rr0 + BT), smem + NEXT + G::TILE, wave);
+        issue_ld(STAGE ^ 1, rr0 + BT);
+      }
+      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
+      s = __builtin_shufflevector(__builtin_shufflevector(lv[0], lv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(lv[2], lv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                  0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      dp = __builtin_shufflevector(__builtin_shufflevector(dvv[0], dvv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(dvv[2], dvv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    });
     SecondRing<DP> gring, qring;
     second_prefetch_pair<DP, GOFF, QOFF, 0>(gring, qring, ad);
     second_prefetch_pair<DP, GOFF, QOFF, 1>(gring, qring, ad);

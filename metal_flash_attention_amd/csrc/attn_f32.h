@@ -178,13 +178,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_resource(const OperandVie
 
 // cached fragments of a first product's right-hand operand: f[4 T + i] = X[row][8 T + 4 hi + i]
 template <int DP> __device__ __forceinline__ void load_fragments(float *f, const __amdgpu_buffer_rsrc_t &res, uint32_t rowoff, bool valid, int hi, int D) {
+  // all NG loads go out back to back (offsets by mask arithmetic: a conditional here becomes a branch around each load, with a
+  // wait behind it -- the loads of a prologue then queue up one memory latency after the other)
+  f32x4 raw[Geo<DP>::NG];
   static_for<Geo<DP>::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     const int d0 = 8 * T + 4 * hi;
+    const uint32_t keep = (uint32_t)-(int32_t)(valid & (d0 < D));   // all ones / zero
+    const uint32_t off = ((rowoff + d0 * 4) & keep) | (OOB & ~keep);
     // (the whole vector is cast: __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index, hipcc 7.2)
-    const f32x4 raw = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res, (valid && d0 < D) ? rowoff + d0 * 4 : OOB, 0, 0));
+    raw[T] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res, off, 0, 0));
+  });
+  static_for<Geo<DP>::NG>([&](auto T_) {
+    constexpr int T = decltype(T_)::value;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[4 * T + i] = raw[i];
+    for (int i = 0; i < 4; ++i) f[4 * T + i] = raw[T][i];
   });
 }
 
@@ -200,6 +208,13 @@ template <int DP> struct Stager {
       const int r = p / G::CPR, c = (p % G::CPR) ^ (r & 15);
       off[i] = (c * 4 < D) ? r * ld * 4u + c * 16 : OOB;
     }
+  }
+  // one of the NI pieces (an LDS-DMA instruction costs ~45 clocks of issue when nothing runs beside it, none in the shadow of a
+  // matrix instruction: the kernels deal the pieces out between the steps of a second product)
+  template <int I> __device__ __forceinline__ void piece(const __amdgpu_buffer_rsrc_t &res, char *base, int wave) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (I < Geo<DP>::NI) __builtin_amdgcn_raw_ptr_buffer_load_lds(res, (lds_ptr)(base + (wave * Geo<DP>::NI + I) * 1024), 16, off[I], 0, 0, 0);
+#endif
   }
   // tile -> LDS image at `base` (workgroup-relative bytes); `res` covers the rows from the tile's first one on
   __device__ __forceinline__ void issue(const __amdgpu_buffer_rsrc_t &res, char *base, int wave) const {
@@ -244,9 +259,9 @@ template <int DP> struct Addresses {
 // acc = init + X_tile (first pattern, at immediate offset OFF) . f : NG reads, four matrix instructions each, RING reads ahead
 // (forward: the start value -m arrives as one extra contraction step, ones . bias -- a matrix instruction instead of a block of
 // sixteen registers that every change of m would have to rewrite)
-// `staging()` runs once the first reads are on their way (the next tile's LDS-DMA is issued in the shadow of their latency)
-template <int DP, int OFF, int RING = 4, typename Staging>
-__device__ __forceinline__ f32x16 first_product(float ones, float bias, const Addresses<DP> &ad, const float *f, Staging &&staging) {
+// `between(T)` runs after every group (T an integral_constant): the next tile's LDS-DMA pieces, issued in the matrix instructions' shadow
+template <int DP, int OFF, int RING = 4, typename Between>
+__device__ __forceinline__ f32x16 first_product(float ones, float bias, const Addresses<DP> &ad, const float *f, Between &&between) {
   typedef Geo<DP> G;
   f32x4 ring[RING];
   f32x16 acc;
@@ -254,7 +269,6 @@ __device__ __forceinline__ f32x16 first_product(float ones, float bias, const Ad
     constexpr int T = decltype(T_)::value;
     ring[T] = rd128<OFF + (T >> 3) * 256>(ad.first[T & 7]);
   });
-  staging();
   mfma_bias(acc, ones, bias);
   static_for<G::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
@@ -262,36 +276,48 @@ __device__ __forceinline__ f32x16 first_product(float ones, float bias, const Ad
     const f32x4 v = ring[T % RING];
     mfma_group<pending>(acc, v, f + 4 * T);
     if constexpr (T + RING < G::NG) ring[T % RING] = rd128<OFF + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
+    between(T_);
   });
   return acc;
 }
 
 // two first products side by side (the matrix instructions alternate): acc0 = init0 + X0 . f0, acc1 = init1 + X1 . f1
 // (INIT = false: the accumulators hold their start values already -- acc += ...)
-template <int DP, int OFF0, int OFF1, bool INIT = true, typename Staging>
-__device__ __forceinline__ void first_product_pair(f32x16 &acc0, const f32x16 &init0, const float *f0, f32x16 &acc1, const f32x16 &init1, const float *f1,
-                                                   const Addresses<DP> &ad, Staging &&staging) {
-  typedef Geo<DP> G;
-  constexpr int RING = 3;
-  f32x4 r0[RING], r1[RING];
-  static_for<RING>([&](auto T_) {
+struct FirstRings { static constexpr int RING = 3; f32x4 r0[RING], r1[RING]; };
+// the first RING read pairs of two first products (tiles at immediate offsets OFF0, OFF1)
+template <int DP, int OFF0, int OFF1> __device__ __forceinline__ void first_prefetch_pair(FirstRings &fr, const Addresses<DP> &ad) {
+  static_for<FirstRings::RING>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
-    r0[T] = rd128<OFF0 + (T >> 3) * 256>(ad.first[T & 7]);
-    r1[T] = rd128<OFF1 + (T >> 3) * 256>(ad.first[T & 7]);
+    fr.r0[T] = rd128<OFF0 + (T >> 3) * 256>(ad.first[T & 7]);
+    fr.r1[T] = rd128<OFF1 + (T >> 3) * 256>(ad.first[T & 7]);
   });
-  staging();
+}
+// ... and the products themselves (the prefetch has been issued; nothing younger than it is pending)
+template <int DP, int OFF0, int OFF1, bool INIT = true>
+__device__ __forceinline__ void first_body_pair(f32x16 &acc0, const f32x16 &init0, const float *f0, f32x16 &acc1, const f32x16 &init1, const float *f1,
+                                                FirstRings &fr, const Addresses<DP> &ad) {
+  typedef Geo<DP> G;
+  constexpr int RING = FirstRings::RING;
   static_for<G::NG>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int left = G::NG - 1 - T;
     constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1));
-    const f32x4 v0 = r0[T % RING], v1 = r1[T % RING];
+    const f32x4 v0 = fr.r0[T % RING], v1 = fr.r1[T % RING];
     if constexpr (T == 0 && INIT) mfma_group_pair_init<pending>(acc0, v0, f0, init0, acc1, v1, f1, init1);
     else mfma_group_pair<pending>(acc0, v0, f0 + 4 * T, acc1, v1, f1 + 4 * T);
     if constexpr (T + RING < G::NG) {
-      r0[T % RING] = rd128<OFF0 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
-      r1[T % RING] = rd128<OFF1 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
+      fr.r0[T % RING] = rd128<OFF0 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
+      fr.r1[T % RING] = rd128<OFF1 + ((T + RING) >> 3) * 256>(ad.first[(T + RING) & 7]);
     }
   });
+}
+template <int DP, int OFF0, int OFF1, bool INIT = true, typename Staging>
+__device__ __forceinline__ void first_product_pair(f32x16 &acc0, const f32x16 &init0, const float *f0, f32x16 &acc1, const f32x16 &init1, const float *f1,
+                                                   const Addresses<DP> &ad, Staging &&staging) {
+  FirstRings fr;
+  first_prefetch_pair<DP, OFF0, OFF1>(fr, ad);
+  staging();
+  first_body_pair<DP, OFF0, OFF1, INIT>(acc0, init0, f0, acc1, init1, f1, fr, ad);
 }
 
 // one read of the second pattern: step T of the tile at immediate offset OFF
@@ -323,26 +349,35 @@ template <int DP, int OFF0, int OFF1, int HALF> __device__ __forceinline__ void 
   });
 }
 // acc[db] += X_tile^T (second pattern) . p : 16 reads, NDB matrix instructions each
-template <int DP, int OFF, int RING> __device__ __forceinline__ void second_product(f32x16 *acc, SecondRing<DP, RING> &ring, const Addresses<DP> &ad, const f32x16 &p) {
+// `ahead()` (HOOKED: it issues EXTRA reads) runs once the last read of this product is on its way -- after step 15 - RING; the
+// remaining steps then allow EXTRA more pending reads (all of them younger than this product's)
+// `between(T)` runs after every step (T an integral_constant: staging pieces in the matrix instructions' shadow)
+template <int DP, int OFF, int RING, int EXTRA = 0, typename Ahead, typename Between>
+__device__ __forceinline__ void second_product(f32x16 *acc, SecondRing<DP, RING> &ring, const Addresses<DP> &ad, const f32x16 &p, Ahead &&ahead, Between &&between) {
   typedef Geo<DP> G;
   static_for<16>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
-    constexpr int pending = (15 - T) < (RING - 1) ? (15 - T) : (RING - 1);
+    constexpr int pending = ((15 - T) < (RING - 1) ? (15 - T) : (RING - 1)) + (T > 15 - RING ? EXTRA : 0);
     const auto v = ring.v[T % RING];
     mfma_out<pending>(acc, v, p[T]);
     if constexpr (T + RING < 16) ring.v[T % RING] = second_read<DP, OFF, T + RING>(ad);
+    if constexpr (T == 15 - RING) ahead();
+    between(T_);
   });
 }
-// two second products side by side (dV and dK): reads of tile 0 and tile 1 alternate
-template <int DP, int OFF0, int OFF1>
+template <int DP, int OFF, int RING> __device__ __forceinline__ void second_product(f32x16 *acc, SecondRing<DP, RING> &ring, const Addresses<DP> &ad, const f32x16 &p) {
+  second_product<DP, OFF, RING, 0>(acc, ring, ad, p, []() {}, [](auto) {});
+}
+// two second products side by side (dV and dK): reads of tile 0 and tile 1 alternate; `ahead` / `between` / EXTRA as in second_product
+template <int DP, int OFF0, int OFF1, int EXTRA = 0, typename Ahead, typename Between>
 __device__ __forceinline__ void second_product_pair(f32x16 *acc0, const f32x16 &p0, f32x16 *acc1, const f32x16 &p1, SecondRing<DP> &r0, SecondRing<DP> &r1,
-                                                    const Addresses<DP> &ad) {
+                                                    const Addresses<DP> &ad, Ahead &&ahead, Between &&between) {
   typedef Geo<DP> G;
   constexpr int RING = SecondRing<DP>::RING;
   static_for<16>([&](auto T_) {
     constexpr int T = decltype(T_)::value;
     constexpr int left = 15 - T;
-    constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1));
+    constexpr int pending = 2 * (left < (RING - 1) ? left : (RING - 1)) + (T > 15 - RING ? EXTRA : 0);
     const auto v0 = r0.v[T % RING];
     const auto v1 = r1.v[T % RING];
     mfma_out_pair<pending>(acc0, v0, p0[T], acc1, v1, p1[T]);
@@ -350,6 +385,8 @@ __device__ __forceinline__ void second_product_pair(f32x16 *acc0, const f32x16 &
       r0.v[T % RING] = second_read<DP, OFF0, T + RING>(ad);
       r1.v[T % RING] = second_read<DP, OFF1, T + RING>(ad);
     }
+    if constexpr (T == 15 - RING) ahead();
+    between(T_);
   });
 }
 
@@ -371,7 +408,8 @@ template <int DP> __device__ __forceinline__ void store_rows(const f32x16 *acc, 
 __device__ __forceinline__ f32x16 splat16(float x) { return f32x16{x, x, x, x, x, x, x, x, x, x, x, x, x, x, x, x}; }
 
 template <int DP> constexpr int lds_bytes() { return 2 /*stages*/ * 2 /*operands*/ * Geo<DP>::TILE; }
-template <int DP> constexpr int lds_bytes_dkv() { return lds_bytes<DP>() + 2 /*stages*/ * 512; }   // + the L and D slices of a tile
+template <int DP> constexpr int lds_bytes_dq() { return 3 /*stages*/ * 2 /*operands*/ * Geo<DP>::TILE; }
+template <int DP> constexpr int lds_bytes_dkv() { return lds_bytes_dq<DP>() + 3 /*stages*/ * 512; }   // + the L and D slices of a tile
 constexpr int ROWS = 128;   // rows (forward, dQ) or columns (dK/dV) of a workgroup: four waves x 32
 constexpr float RESCALE_ABOVE = 8.f;   // forward: O, l and the reference maximum are re-based when a row's maximum grew by more than 2^8
 
@@ -437,10 +475,15 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile j have landed
     __syncthreads();                      // ... everybody's; and every wave has finished tile j - 1, whose stage is written next
     // S^T = K Q^T - m : lane holds query `row`, keys c0 + crow(r, hi)
-    f32x16 s = first_product<DP, KOFF, 3>(ones, bias, ad, qf, [&]() {
-      if (j + 1 < nt) {
-        ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
-        vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
+    const bool more = j + 1 < nt;
+    const __amdgpu_buffer_rsrc_t kres1 = tile_resource(kbase, ldk, C, c0 + BT), vres1 = tile_resource(vbase, ldv, C, c0 + BT);
+    f32x16 s = first_product<DP, KOFF, 3>(ones, bias, ad, qf, [&](auto T_) {
+      constexpr int T = decltype(T_)::value;
+      if constexpr (T < 2 * G::NI) {
+        if (more) {
+          if constexpr (T % 2 == 0) ks.template piece<T / 2>(kres1, smem + NEXT, wave);
+          else vs.template piece<T / 2>(vres1, smem + NEXT + G::TILE, wave);
+        }
       }
     });
     SecondRing<DP, 3> vring;
@@ -502,7 +545,8 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd(const KernelArgs a, const
 // backward dQ: D = rowsum(dO*O)/sqrt(D); dQ = sum_c dS K                (+Source.swift:202-242)
 // same grid; one workgroup per compute unit (Q and dO fragments, the dQ accumulators: 192 registers before any buffer)
 // ----------------------------------------------------------------------------------------------
-template <int DP>
+// PROF (developer builds, timing only): phase clocks of wave 0 -- per tile, in shader clocks -- replace dQ[row r0][0..4] (tools/f32_perf.py --prof)
+template <int DP, bool PROF = false>
 __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd16Grid grid) {
   typedef Geo<DP> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -556,30 +600,51 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
   Stager<DP> ks, vs;
   ks.init(wave, lane, ldk, D);
   vs.init(wave, lane, ldv, D);
-  Addresses<DP> ad;
+  // three stages of (K, V) tiles: tile j in stage j % 3.  The barrier of a tile sits in its MIDDLE (between the first products
+  // and the softmax arithmetic): behind it tile j + 1 is complete for everybody and everybody has left tile j - 1, whose stage
+  // receives tile j + 2 -- so no LDS read waits behind a barrier: the first reads of tile j + 1 go out during the last steps of
+  // tile j's second product.  (stage 2 lies beyond the 64 KiB an immediate offset reaches: a second set of addresses)
+  constexpr int STAGEB = 2 * G::TILE;
+  Addresses<DP> ad, ad2;
   ad.init(lds_addr(smem), q, hi);
+  ad2.init(lds_addr(smem) + 2 * STAGEB, q, hi);
   const int limit = (int)row + coff;
   const int wavelimit = (int)r0 + wave * 32 + coff;
-  if (nt > 0) {
-    ks.issue(tile_resource(kbase, ldk, C, 0), smem, wave);
-    vs.issue(tile_resource(vbase, ldv, C, 0), smem + G::TILE, wave);
+  ks.issue(tile_resource(kbase, ldk, C, 0), smem, wave);
+  vs.issue(tile_resource(vbase, ldv, C, 0), smem + G::TILE, wave);
+  if (nt > 1) {
+    ks.issue(tile_resource(kbase, ldk, C, BT), smem + STAGEB, wave);
+    vs.issue(tile_resource(vbase, ldv, C, BT), smem + STAGEB + G::TILE, wave);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  FirstRings fr;
+  first_prefetch_pair<DP, 0, G::TILE>(fr, ad);
+  uint64_t clk[5] = {0, 0, 0, 0, 0};
+  auto stamp = [&](int k, uint64_t &t) {
+    if constexpr (PROF) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      clk[k] += now - t;
+      t = now;
+    }
+  };
   auto tile = [&](auto STAGE_, int j) {
-    constexpr int STAGE = decltype(STAGE_)::value;
-    constexpr int KOFF = STAGE * 2 * G::TILE, VOFF = KOFF + G::TILE, NEXT = (STAGE ^ 1) * 2 * G::TILE;
+    constexpr int STAGE = decltype(STAGE_)::value, NEXT1 = (STAGE + 1) % 3, NEXT2 = (STAGE + 2) % 3;
+    constexpr int KOFF = STAGE == 2 ? 0 : STAGE * STAGEB, VOFF = KOFF + G::TILE;
+    constexpr int K1OFF = NEXT1 == 2 ? 0 : NEXT1 * STAGEB, V1OFF = K1OFF + G::TILE;
+    const Addresses<DP> &here = STAGE == 2 ? ad2 : ad, &next = NEXT1 == 2 ? ad2 : ad;
     const int c0 = j * BT;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
     // S'^T = K Q'^T - L, dP^T = V dO^T - D / scale
     f32x16 s, dp;
-    first_product_pair<DP, KOFF, VOFF>(s, negL, qf, dp, negD, gf, ad, [&]() {
-      if (j + 1 < nt) {
-        ks.issue(tile_resource(kbase, ldk, C, c0 + BT), smem + NEXT, wave);
-        vs.issue(tile_resource(vbase, ldv, C, c0 + BT), smem + NEXT + G::TILE, wave);
-      }
-    });
+    uint64_t t = PROF ? __builtin_amdgcn_s_memtime() : 0;
+    first_body_pair<DP, KOFF, VOFF>(s, negL, qf, dp, negD, gf, fr, here);
     SecondRing<DP> kring;
-    second_prefetch<DP, KOFF>(kring, ad);
+    second_prefetch<DP, KOFF>(kring, here);
+    stamp(0, t);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile j + 1 have landed
+    __syncthreads();
+    stamp(1, t);
+    stamp(2, t);
     mfma_fence(s, dp);
     // P = exp2(S' - L); dS = P * (dP - D / scale).  Padded columns: K, V rows are zero, so dS * K contributes nothing (as in
     // the reference, where the zero padding comes from the async copy, +Accumulate.swift:330-346)
@@ -591,17 +656,39 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
         if (c0 + crow(r, hi) > limit) s[r] = 0.f;
     }
     valu_fence(s);
-    // dQ^T += K^T dS^T, key index permuted as in forward
-    second_product<DP, KOFF>(acc, kring, ad, s);
+    stamp(3, t);
+    // dQ^T += K^T dS^T, key index permuted as in forward; its last steps send the first reads of tile j + 1 ahead
+    // ... and tile j + 2 is requested piece by piece between its first steps
+    const bool more = j + 2 < nt;
+    const __amdgpu_buffer_rsrc_t kres2 = tile_resource(kbase, ldk, C, c0 + 2 * BT), vres2 = tile_resource(vbase, ldv, C, c0 + 2 * BT);
+    second_product<DP, KOFF, 4, 2 * FirstRings::RING>(acc, kring, here, s, [&]() { first_prefetch_pair<DP, K1OFF, V1OFF>(fr, next); }, [&](auto T_) {
+      constexpr int T = decltype(T_)::value;
+      if constexpr (T < 2 * G::NI) {
+        if (more) {
+          if constexpr (T % 2 == 0) ks.template piece<T / 2>(kres2, smem + NEXT2 * STAGEB, wave);
+          else vs.template piece<T / 2>(vres2, smem + NEXT2 * STAGEB + G::TILE, wave);
+        }
+      }
+    });
+    stamp(4, t);
   };
-  for (int j = 0; j < nt; j += 2) {
+  for (int j = 0; j < nt; j += 3) {
     tile(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
+    if (j + 2 < nt) tile(std::integral_constant<int, 2>{}, j + 2);
   }
+  // (the last tile sent reads ahead for a tile that does not exist)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.r0[0]), "+v"(fr.r0[1]), "+v"(fr.r0[2]), "+v"(fr.r1[0]), "+v"(fr.r1[1]), "+v"(fr.r1[2]));
   mfma_fence_out<G::NDB>(acc);
   store_rows<DP>(acc, a.op[SLOT_dQ], head, batch, row, R, hi, D, scale);
   if (hi == 0 && row < R)   // +Caching.swift:381-413
     reinterpret_cast<float *>(operand_base(a.op[SLOT_D], head, batch))[row] = dsum * scale;
+  if constexpr (PROF) {
+    if (tid == 0) {
+      float *dst = reinterpret_cast<float *>(operand_base(a.op[SLOT_dQ], head, batch)) + r0 * a.op[SLOT_dQ].ld;
+      for (int k = 0; k < 5; ++k) dst[k] = (float)clk[k] / (float)nt;
+    }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -650,11 +737,15 @@ __global__ __launch_bounds__(256) void attn_f32_dkv(const KernelArgs a, const Fw
   Stager<DP> qs, gs;
   qs.init(wave, lane, ldq, D);
   gs.init(wave, lane, ldg, D);
-  Addresses<DP> ad;
+  // three stages of (Q, dO) tiles and (L, D) slices, the barrier in the middle of a tile, reads and staging sent ahead from the
+  // second products: as in attn_f32_dq
+  constexpr int STAGEB = 2 * G::TILE;
+  Addresses<DP> ad, ad2;
   ad.init(lds_addr(smem), kc, hi);
+  ad2.init(lds_addr(smem) + 2 * STAGEB, kc, hi);
   // L and D slices along the traversal dimension (+Softmax.swift:356-381, :472-503): 32 floats each per tile, staged like the
   // tiles (wave 0: L, wave 1: D; one dword per lane, the upper 32 lanes' rows belong to the next tile and are not read)
-  char *ldst = smem + lds_bytes<DP>();
+  char *ldst = smem + 3 * STAGEB;
   const uint32_t ldread = lds_addr(ldst) + hi * 16;
   auto issue_ld = [&](int stage, int row0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -669,42 +760,44 @@ __global__ __launch_bounds__(256) void attn_f32_dkv(const KernelArgs a, const Fw
   };
   // the wave's largest column: rows whose limit lies below it mask (causal)
   const int wavecol = (int)c0 + wave * 32 + 31, icol = (int)col;
-  if (nt > 0) {
-    qs.issue(tile_resource(qbase, ldq, R, rstart), smem, wave);
-    gs.issue(tile_resource(gbase, ldg, R, rstart), smem + G::TILE, wave);
-    issue_ld(0, rstart);
+  qs.issue(tile_resource(qbase, ldq, R, rstart), smem, wave);
+  gs.issue(tile_resource(gbase, ldg, R, rstart), smem + G::TILE, wave);
+  issue_ld(0, rstart);
+  if (nt > 1) {
+    qs.issue(tile_resource(qbase, ldq, R, rstart + BT), smem + STAGEB, wave);
+    gs.issue(tile_resource(gbase, ldg, R, rstart + BT), smem + STAGEB + G::TILE, wave);
+    issue_ld(1, rstart + BT);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  FirstRings fr;
+  first_prefetch_pair<DP, 0, G::TILE>(fr, ad);
+  // rows rr0 + crow(r, hi) of L and D: four reads of four each, into the registers the first products accumulate in
+  f32x4 lv[4], dvv[4];
+  static_for<4>([&](auto g_) {
+    constexpr int g = decltype(g_)::value;
+    lv[g] = rd128<32 * g>(ldread);
+    dvv[g] = rd128<256 + 32 * g>(ldread);
+  });
   auto tile = [&](auto STAGE_, int j) {
-    constexpr int STAGE = decltype(STAGE_)::value;
-    constexpr int QOFF = STAGE * 2 * G::TILE, GOFF = QOFF + G::TILE, NEXT = (STAGE ^ 1) * 2 * G::TILE;
+    constexpr int STAGE = decltype(STAGE_)::value, NEXT1 = (STAGE + 1) % 3, NEXT2 = (STAGE + 2) % 3;
+    constexpr int QOFF = STAGE == 2 ? 0 : STAGE * STAGEB, GOFF = QOFF + G::TILE;
+    constexpr int Q1OFF = NEXT1 == 2 ? 0 : NEXT1 * STAGEB, G1OFF = Q1OFF + G::TILE;
+    const Addresses<DP> &here = STAGE == 2 ? ad2 : ad, &next = NEXT1 == 2 ? ad2 : ad;
     const int rr0 = rstart + j * BT;
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    // rows rr0 + crow(r, hi) of L and D: four reads of four each into the registers the first products accumulate in
-    f32x4 lv[4], dvv[4];
-    static_for<4>([&](auto g_) {
-      constexpr int g = decltype(g_)::value;
-      lv[g] = rd128<STAGE * 512 + 32 * g>(ldread);
-      dvv[g] = rd128<STAGE * 512 + 256 + 32 * g>(ldread);
-    });
     // L - S' (S = Q K^T, not swapped: lane holds key `col`, rows rr0 + crow(r, hi)); D - dP / sqrt(D) (dP = dO V^T): the slices
-    // ARE the accumulators' start values -- waited for behind the first products' own first reads (six younger reads pending)
-    f32x16 s, dp;
-    first_product_pair<DP, QOFF, GOFF, false>(s, s, kf, dp, dp, vf, ad, [&]() {
-      if (j + 1 < nt) {
-        qs.issue(tile_resource(qbase, ldq, R, rr0 + BT), smem + NEXT, wave);
-        gs.issue(tile_resource(gbase, ldg, R, rr0 + BT), smem + NEXT + G::TILE, wave);
-        issue_ld(STAGE ^ 1, rr0 + BT);
-      }
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
-      s = __builtin_shufflevector(__builtin_shufflevector(lv[0], lv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(lv[2], lv[3], 0, 1, 2, 3, 4, 5, 6, 7),
-                                  0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-      dp = __builtin_shufflevector(__builtin_shufflevector(dvv[0], dvv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(dvv[2], dvv[3], 0, 1, 2, 3, 4, 5, 6, 7),
-                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-    });
+    // (the youngest reads in flight) ARE the accumulators' start values
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lv[0]), "+v"(lv[1]), "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
+    f32x16 s = __builtin_shufflevector(__builtin_shufflevector(lv[0], lv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(lv[2], lv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                       0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    f32x16 dp = __builtin_shufflevector(__builtin_shufflevector(dvv[0], dvv[1], 0, 1, 2, 3, 4, 5, 6, 7), __builtin_shufflevector(dvv[2], dvv[3], 0, 1, 2, 3, 4, 5, 6, 7),
+                                        0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    first_body_pair<DP, QOFF, GOFF, false>(s, s, kf, dp, dp, vf, fr, here);
     SecondRing<DP> gring, qring;
-    second_prefetch_pair<DP, GOFF, QOFF, 0>(gring, qring, ad);
-    second_prefetch_pair<DP, GOFF, QOFF, 1>(gring, qring, ad);
+    second_prefetch_pair<DP, GOFF, QOFF, 0>(gring, qring, here);
+    second_prefetch_pair<DP, GOFF, QOFF, 1>(gring, qring, here);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tile j + 1 have landed
+    __syncthreads();
     mfma_fence(s, dp);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -717,13 +810,37 @@ __global__ __launch_bounds__(256) void attn_f32_dkv(const KernelArgs a, const Fw
       for (int r = 0; r < 16; ++r)
         if (icol > rr0 + crow(r, hi) + coff) { s[r] = 0.f; dp[r] = 0.f; }
     }
-    // dV^T += dO^T P ; dK^T += Q^T dS   (row index permuted; padded rows of Q / dO are zero)
-    second_product_pair<DP, GOFF, QOFF>(dv, dp, dk, s, gring, qring, ad);
+    valu_fence(s, dp);
+    // dV^T += dO^T P ; dK^T += Q^T dS   (row index permuted; padded rows of Q / dO are zero); tile j + 2 is requested between
+    // the first steps, the last steps send the first reads of tile j + 1 ahead
+    const bool more = j + 2 < nt;
+    const __amdgpu_buffer_rsrc_t qres2 = tile_resource(qbase, ldq, R, rr0 + 2 * BT), gres2 = tile_resource(gbase, ldg, R, rr0 + 2 * BT);
+    second_product_pair<DP, GOFF, QOFF, 2 * FirstRings::RING>(dv, dp, dk, s, gring, qring, here, [&]() { first_prefetch_pair<DP, Q1OFF, G1OFF>(fr, next); }, [&](auto T_) {
+      constexpr int T = decltype(T_)::value;
+      if constexpr (T < 2 * G::NI) {
+        if (more) {
+          if constexpr (T % 2 == 0) qs.template piece<T / 2>(qres2, smem + NEXT2 * STAGEB, wave);
+          else gs.template piece<T / 2>(gres2, smem + NEXT2 * STAGEB + G::TILE, wave);
+        }
+      } else if constexpr (T == 2 * G::NI) {
+        if (more) issue_ld(NEXT2, rr0 + 2 * BT);
+      }
+    });
+    // the slices of tile j + 1 (behind the reads sent ahead: fourteen in flight)
+    static_for<4>([&](auto g_) {
+      constexpr int g = decltype(g_)::value;
+      lv[g] = rd128<NEXT1 * 512 + 32 * g>(ldread);
+      dvv[g] = rd128<NEXT1 * 512 + 256 + 32 * g>(ldread);
+    });
   };
-  for (int j = 0; j < nt; j += 2) {
+  for (int j = 0; j < nt; j += 3) {
     tile(std::integral_constant<int, 0>{}, j);
     if (j + 1 < nt) tile(std::integral_constant<int, 1>{}, j + 1);
+    if (j + 2 < nt) tile(std::integral_constant<int, 2>{}, j + 2);
   }
+  // (the last tile sent reads ahead for a tile that does not exist)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr.r0[0]), "+v"(fr.r0[1]), "+v"(fr.r0[2]), "+v"(fr.r1[0]), "+v"(fr.r1[1]), "+v"(fr.r1[2]), "+v"(lv[0]), "+v"(lv[1]),
+               "+v"(lv[2]), "+v"(lv[3]), "+v"(dvv[0]), "+v"(dvv[1]), "+v"(dvv[2]), "+v"(dvv[3]));
   mfma_fence_out<G::NDB>(dv);
   mfma_fence_out<G::NDB>(dk);
   store_rows<DP>(dv, a.op[SLOT_dV], head, batch, col, C, hi, D, 1.f);

@@ -36,8 +36,17 @@ template <int DP> bool launch(int type, dim3 grid, hipStream_t stream, const Ker
       hipLaunchKernelGGL((f32k::attn_f32_fwd<DP>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g);
       return true;
     case 1:
-      if (!raise_lds(&f32k::attn_f32_dq<DP>, f32k::lds_bytes<DP>())) return false;
-      hipLaunchKernelGGL((f32k::attn_f32_dq<DP>), flat, dim3(256), f32k::lds_bytes<DP>(), stream, args, g);
+#ifdef MFA_DEV_VARIANTS   // MFA_F32_PROF=1: phase clocks instead of dQ (attn_f32.h, PROF)
+      if constexpr (DP == 128) {
+        if (std::getenv("MFA_F32_PROF")) {
+          if (!raise_lds(&f32k::attn_f32_dq<DP, true>, f32k::lds_bytes_dq<DP>())) return false;
+          hipLaunchKernelGGL((f32k::attn_f32_dq<DP, true>), flat, dim3(256), f32k::lds_bytes_dq<DP>(), stream, args, g);
+          return true;
+        }
+      }
+#endif
+      if (!raise_lds(&f32k::attn_f32_dq<DP>, f32k::lds_bytes_dq<DP>())) return false;
+      hipLaunchKernelGGL((f32k::attn_f32_dq<DP>), flat, dim3(256), f32k::lds_bytes_dq<DP>(), stream, args, g);
       return true;
     default:
       if (!raise_lds(&f32k::attn_f32_dkv<DP>, f32k::lds_bytes_dkv<DP>())) return false;

@@ -48,3 +48,9 @@ for D in args.dims or [64, 128]:
         tf = gemms * N * N * D * H * work / ms / 1e9
         line.append(f"{k.launchForm(bufs, **kw).split(' ')[0]}: {ms:.3f} ms {tf:.1f} TF {tf / 157.3:.3f}")
     print("  ".join(line))
+    if os.environ.get("MFA_F32_PROF") and D == 128:   # developer library: dQ[row 0 of a block][0..4] = clocks per tile of the phases
+        dq = bufs[Op.dQ].cpu()
+        names = ("first products", "barrier", "LDS-DMA issue", "softmax arithmetic", "second product")
+        for blk in (0, 7, 31):
+            v = dq[0, 128 * blk, :5].tolist()
+            print(f"    dQ phase clocks per tile, head 0 row block {blk}: " + ", ".join(f"{n} {x:.0f}" for n, x in zip(names, v)) + f"; sum {sum(v):.0f}")

@@ -10,6 +10,14 @@
 using namespace mfa;
 using namespace mfa::f32k;
 
+// (the compiler-scheduled forms the first version of the kernels used)
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+template <int DP> __device__ __forceinline__ uint32_t first_address(int i, int hi) { return i * Geo<DP>::ROWB + ((hi ^ (i & 15)) << 4); }
+template <int DP> __device__ __forceinline__ uint32_t second_address(int i, int hi) {
+  const int byte = i * Geo<DP>::RB2;
+  return 4 * hi * Geo<DP>::ROWB + ((((byte >> 4) ^ (4 * hi)) << 4) | (byte & 15));
+}
+
 template <bool EXP> __device__ __forceinline__ void filler(float &x, float fa, float fb) {
   if constexpr (EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(x));
   else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(fa), "v"(fb));
@@ -39,6 +47,14 @@ template <int MODE, int NV = 0> __global__ __launch_bounds__(256) void probe(flo
   for (int i = 0; i < 8; ++i) b[i] = 0.5f + i + lane * 1e-3f;
   f32x4 a0 = {1.f, 2.f, 3.f, 4.f}, a1 = {0.5f, 0.25f, 0.125f, 1.f};
   float fa = 1.0001f, fb = 1e-6f;
+  float bq[8];
+  f32x16 oacc[4];
+  if constexpr (MODE == 10) {
+    for (int i = 0; i < 8; ++i) bq[i] = b[i];
+    pin_fragments<8>(bq, 1.f);
+  }
+  if constexpr (MODE == 11)
+    for (int k = 0; k < 4; ++k) mfma_zero(oacc[k]);
   f32x4 r0[3], r1[3];
   for (int i = 0; i < 3; ++i) { r0[i] = a0; r1[i] = a1; }
   __builtin_amdgcn_s_barrier();
@@ -48,7 +64,12 @@ template <int MODE, int NV = 0> __global__ __launch_bounds__(256) void probe(flo
     r0[1] = rd128<0>(base0 ^ 32); r1[1] = rd128<0>(base1 ^ 32);
     r0[2] = rd128<0>(base0 ^ 64); r1[2] = rd128<0>(base1 ^ 64);
   }
-  if constexpr (MODE == 2 || MODE == 3) { r0[0] = rd128<0>(base0); r0[1] = rd128<0>(base0 ^ 32); r0[2] = rd128<0>(base0 ^ 64); }
+  if constexpr (MODE == 10) {
+    r0[0] = rd128<0>(base0); r1[0] = rd128<16384>(base0);
+    r0[1] = rd128<0>(base0); r1[1] = rd128<16384>(base0);
+    r0[2] = rd128<0>(base0); r1[2] = rd128<16384>(base0);
+  }
+  if constexpr (MODE == 2 || MODE == 3 || MODE == 11) { r0[0] = rd128<0>(base0); r0[1] = rd128<0>(base0 ^ 32); r0[2] = rd128<0>(base0 ^ 64); }
   for (int it = 0; it < iters; ++it) {
     static_for<3>([&](auto S_) {
       constexpr int S = decltype(S_)::value;
@@ -121,6 +142,18 @@ template <int MODE, int NV = 0> __global__ __launch_bounds__(256) void probe(flo
             filler<i % 6 == 4>(b[(i + 1) & 7], fa, fb);
           });
         }
+      } else if constexpr (MODE == 10) {   // the kernels' own statement: two score accumulators in VGPRs, B operands in AGPRs
+        const f32x4 v0 = r0[S], v1 = r1[S];
+        mfma_group_pair<4>(acc[0], v0, bq, acc[1], v1, bq + 4);
+        r0[S] = rd128<0>(base0);
+        r1[S] = rd128<16384>(base0);
+      } else if constexpr (MODE == 11) {   // ... four output accumulators in AGPRs, A and B in VGPRs
+        const f32x4 v0 = r0[S];
+        mfma_out<2>(oacc, v0, b[S]);
+        r0[S] = rd128<0>(base0);
+        const f32x4 v1 = r0[(S + 1) % 3];
+        mfma_out<2>(oacc, v1, b[S + 4]);
+        r0[(S + 1) % 3] = rd128<512>(base0);
       } else {
         lds_wait<2>(r0[S]);
         const f32x4 v0 = r0[S];
@@ -137,6 +170,11 @@ template <int MODE, int NV = 0> __global__ __launch_bounds__(256) void probe(flo
   }
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]));
   float sum = 0.f;
+  if constexpr (MODE == 10) mfma_fence(acc[0], acc[1]);
+  if constexpr (MODE == 11) {
+    mfma_fence_out<4>(oacc);
+    for (int k = 0; k < 4; ++k) acc[k] = oacc[k];
+  }
   for (int k = 0; k < 4; ++k)
     for (int r = 0; r < 16; ++r) sum += acc[k][r];
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -166,6 +204,8 @@ int main() {
   run<4>("the same, reads in the middle of the group", out, cyc, iters);
   run<2>("ONE accumulator, 1 ds_read_b128 + wait per 4 (first_product, forward)", out, cyc, iters);
   run<3>("four accumulators rotate, 1 ds_read_b128 + wait per 4 (second_product)", out, cyc, iters);
+  run<10>("the kernels' first-product statement (asm, scores in VGPRs, B in AGPRs), immediates", out, cyc, iters);
+  run<11>("the kernels' second-product statement (asm, outputs in AGPRs), immediates", out, cyc, iters);
   run<6>("three accumulators rotate, 1 read per 3", out, cyc, iters);
   run<7>("four accumulators (s_a, dp_a, s_b, dp_b), 2 reads + wait per group of 8", out, cyc, iters);
   run<8, 6>("four accumulators rotate, per 4: 1 read + 6 VALU (5 fma, 1 exp)", out, cyc, iters);

@@ -271,7 +271,10 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
  * the kernel object (mfa_attention_kernel_variant); the FORM is a property of the launch: the general kernel when the launch
  * does not meet the matrix-core kernels' requirements, a re-layout pass in front, column-parallel pieces + combine through
  * the workspace, or (dense and causal forward launches at D <= 128 without per-batch lengths) the persistent form
- * `attn_fwd16_p4p`, which is the name rocprofv3 shows for such launches.  `buffers` as for mfa_attention_kernel_launch. */
+ * `attn_fwd16_p4p`, which is the name rocprofv3 shows for such launches.  FP32 descriptors (head blocks 64 and 128): the general
+ * kernel's variant launches `attn_f32_{fwd,dq,dkv}_d{64,128}_w4x32` when every operand of the launch is FP32, row-major with
+ * 16-byte aligned rows (pointer, leading dimension, head / batch strides multiples of 4 elements), D % 4 == 0 and there is no
+ * block mask; the general kernel itself otherwise.  `buffers` as for mfa_attention_kernel_launch. */
 mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, void *const buffers[MFA_BUFFER_SLOTS],
                                             const mfa_launch_params *params, char *out, size_t capacity);
 

@@ -77,6 +77,32 @@ def _record_launched_variants():
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     from metal_flash_attention_amd import _abi
-    with open(os.path.join(out, "variant_coverage.json"), "w") as f:
+    worker = os.environ.get("PYTEST_XDIST_WORKER")   # pytest -n N: every worker records its own part, the controller merges them below
+    with open(os.path.join(out, "variant_coverage.%s.json" % worker if worker else "variant_coverage.json"), "w") as f:
         json.dump({"library": os.path.basename(_abi.library_path()), "variants": dict(sorted(_COVERAGE["variants"].items())),
                    "forms": dict(sorted(_COVERAGE["forms"].items()))}, f, indent=1)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """pytest -n N: merge the workers' parts of the variant coverage map (the controller runs this after the last worker has finished)"""
+    if os.environ.get("PYTEST_XDIST_WORKER"):
+        return
+    import glob
+    import json
+    parts = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "variant_coverage.gw*.json")))
+    if not parts:
+        return
+    merged = {"library": None, "variants": {}, "forms": {}}
+    for part in parts:
+        data = json.load(open(part))
+        merged["library"] = data["library"]
+        for name, tests in data["variants"].items():
+            have = merged["variants"].setdefault(name, [])
+            have.extend(t for t in tests if t not in have and len(have) < 4)
+        for name, count in data["forms"].items():
+            merged["forms"][name] = merged["forms"].get(name, 0) + count
+        os.remove(part)
+    merged["variants"] = dict(sorted(merged["variants"].items()))
+    merged["forms"] = dict(sorted(merged["forms"].items()))
+    with open(os.path.join(ROOT, "gpurun_out", "variant_coverage.json"), "w") as f:
+        json.dump(merged, f, indent=1)

@@ -10,12 +10,15 @@ OUT=gpurun_out/${ROUND}_final
 mkdir -p "$OUT"
 sha256sum metal_flash_attention_amd/libmfa_hip.so > "$OUT/library.sha256"
 if [ -z "$FAST" ]; then
-  timeout 1100 python -m pytest tests -q -m gpu 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
+  timeout 1100 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
   tail -3 "$OUT/pytest_gpu.txt"
 fi
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.txt" 2>&1; tail -1 "$OUT/smoke.txt"
 timeout 300 python bench.py 2> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_default.json"; cut -c1-300 "$OUT/bench_default.json"
 # kernel trace + the separate PMC passes of the headline (MI355X_MICROARCH.md's recipe), summary + traffic.json
+if [ -z "$FAST" ]; then   # (first: the headline's pass below leaves ITS traffic.json behind)
+  ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof_f32" --steps 5 --warmup 2 --no-cpu-baseline --workload fwdbwd_f32_d128 > "$OUT/prof_f32.log" 2>&1
+fi
 ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof.log" 2>&1; tail -25 "$OUT/prof.log" | head -40
 if [ -z "$FAST" ]; then
   for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_1head \
@@ -42,6 +45,13 @@ PY
   if [ -f metal_flash_attention_amd/libmfa_hip_dev.so ]; then
     for D in 256 160; do timeout 200 python tools/bwd5_prof.py --D $D 2>&1 | grep -v amdgpu.ids > "$OUT/bwd5_prof_d$D.txt"; done
   fi
+  # the FP32 path (BASELINE config 3) kernel by kernel, its phase clocks (developer library) and the fp32 matrix-instruction probe
+  (timeout 200 python tools/f32_perf.py; timeout 200 python tools/f32_perf.py --causal; timeout 200 python tools/f32_perf.py --fill zero 128) 2>&1 | grep -v amdgpu.ids > "$OUT/f32_perf.txt"; cat "$OUT/f32_perf.txt"
+  if [ -f metal_flash_attention_amd/libmfa_hip_dev.so ]; then
+    MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_dev.so MFA_F32_PROF=1 timeout 200 python tools/f32_perf.py 128 2>&1 | grep -v amdgpu.ids > "$OUT/f32_dq_phase_clocks.txt"
+    MFA_LIBRARY=metal_flash_attention_amd/libmfa_hip_dev.so MFA_F32_GENERAL=1 timeout 200 python tools/f32_perf.py 2>&1 | grep -v amdgpu.ids > "$OUT/f32_perf_general_kernels.txt"
+  fi
+  [ -x tools/probe_f32_mfma.out ] && timeout 100 tools/probe_f32_mfma.out > "$OUT/probe_f32_mfma.txt" 2>&1
   timeout 200 python tools/time_single_head.py 2>&1 | grep -v amdgpu.ids > "$OUT/single_head.txt"
   timeout 300 python tools/fuzz_shapes.py 120 1 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_120_seed1.txt"; grep "random problems" "$OUT/fuzz_120_seed1.txt"
   timeout 300 python tools/fuzz_shapes.py 120 2 --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_120_seed2.txt"; grep "random problems" "$OUT/fuzz_transposed_120_seed2.txt"

@@ -2,8 +2,8 @@
 // 16-byte aligned, head dimension a multiple of 4 and <= DP (64 or 128).  Same arithmetic as the general kernels of
 // attn_generic.h (all products on v_mfma_f32_32x32x2_f32, exact online softmax), which keep every other layout / type / mask;
 // what differs is how the operands travel:
-//   * the traversal-side tiles (K, V / Q, dO: 32 rows x DP floats) go from memory to LDS by LDS-DMA, two stages, one barrier
-//     per tile; bounds-checked buffer resources zero-fill ragged rows and the columns past D (what the reference gets from
+//   * the traversal-side tiles (K, V / Q, dO: 32 rows x DP floats) go from memory to LDS by LDS-DMA, two (forward) or three
+//     (backward) stages, one barrier per tile; bounds-checked buffer resources zero-fill ragged rows and the columns past D (what the reference gets from
 //     simdgroup_event::async_copy, GEMMHeaders.swift:166-193);
 //   * the cached left-hand operands (+Caching.swift:18-281) are read from memory straight into their fragment registers;
 //   * every LDS read is a ds_read_b128 that feeds four matrix instructions.  The contraction index of the first product of
@@ -57,16 +57,6 @@ template <int OFF> __device__ __forceinline__ f32x2 rd64(uint32_t addr) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
-// at most N younger LDS reads may still be pending when `a` is used (LDS returns in order, asm volatile keeps its order)
-template <int N> __device__ __forceinline__ void lds_wait(f32x4 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N < 15 ? N : 15)); }
-template <int N> __device__ __forceinline__ void lds_wait(f32x2 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N < 15 ? N : 15)); }
-template <int N> __device__ __forceinline__ void lds_wait(f32x4 &a, f32x4 &b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N < 15 ? N : 15));
-}
-template <int N> __device__ __forceinline__ void lds_wait(f32x2 &a, f32x2 &b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N < 15 ? N : 15));
-}
-
 // lane l <-> lane l ^ 32 (v_permlane32_swap; the s_nop covers the VALU-write -> permlane-read hazard inside the asm string)
 __device__ __forceinline__ void half_swap(float x, float *a, float *b) {
   uint32_t b0 = __builtin_bit_cast(uint32_t, x), b1 = b0;
@@ -311,15 +301,6 @@ __device__ __forceinline__ void first_body_pair(f32x16 &acc0, const f32x16 &init
     }
   });
 }
-template <int DP, int OFF0, int OFF1, bool INIT = true, typename Staging>
-__device__ __forceinline__ void first_product_pair(f32x16 &acc0, const f32x16 &init0, const float *f0, f32x16 &acc1, const f32x16 &init1, const float *f1,
-                                                   const Addresses<DP> &ad, Staging &&staging) {
-  FirstRings fr;
-  first_prefetch_pair<DP, OFF0, OFF1>(fr, ad);
-  staging();
-  first_body_pair<DP, OFF0, OFF1, INIT>(acc0, init0, f0, acc1, init1, f1, fr, ad);
-}
-
 // one read of the second pattern: step T of the tile at immediate offset OFF
 template <int DP, int OFF, int T> __device__ __forceinline__ auto second_read(const Addresses<DP> &ad) {
   typedef Geo<DP> G;

@@ -323,6 +323,41 @@ def test_transposed_launches_are_routed_to_the_in_place_streams():
         assert k.launchForm(b, row=N, column=N, causal=True).startswith("attn_fwd16_p5_tr")
 
 
+def test_fp32_launches_are_handed_to_the_fp32_kernels():
+    """FP32 descriptors of the 64 / 128 head blocks: the general kernel's variant launches attn_f32_* when every operand is FP32,
+    row-major, rows 16-byte aligned, D % 4 == 0 and no block mask is given (csrc/attn_f32.h, f32k::serves) -- planned without a
+    GPU: host pointers only decide the alignment"""
+    torch = pytest.importorskip("torch")
+    R, C = 300, 520
+    names = {T.forward: "attn_f32_fwd", T.backwardQuery: "attn_f32_dq", T.backwardKeyValue: "attn_f32_dkv"}
+
+    def buffers(D, ld=None):
+        ld = ld or D
+        b = {op: torch.zeros((R if op in (Op.Q, Op.O, Op.dO, Op.dQ) else C, ld)) for op in (Op.Q, Op.K, Op.V, Op.O, Op.dO, Op.dQ, Op.dK, Op.dV)}
+        b[Op.L], b[Op.D] = torch.zeros(R), torch.zeros(R)
+        return b
+
+    for D, block in ((128, 128), (100, 128), (64, 64), (36, 64)):
+        d = _desc(dims=(R, C, D))
+        for t, name in names.items():
+            k = AttentionKernel(d.kernelDescriptor(t))
+            assert k.variant.startswith("attn_generic_") and "_d%d_" % block in k.variant
+            b = buffers(D)
+            assert k.launchForm(b, row=R, column=C) == "%s_d%d_w4x32" % (name, block)
+            assert k.launchForm(b, row=R, column=C, causal=True) == "%s_d%d_w4x32" % (name, block)
+            # rows of D + 1 floats are not 16-byte aligned; rows of D + 4 are
+            assert k.launchForm(buffers(D, D + 1), row=R, column=C, leadingDimensions={op: D + 1 for op in b if op not in (Op.L, Op.D)}) == k.variant
+            assert k.launchForm(buffers(D, D + 4), row=R, column=C, leadingDimensions={op: D + 4 for op in b if op not in (Op.L, Op.D)}).startswith(name)
+            # a block mask keeps the general kernel's own sparse code object
+            mask = torch.full((2, 1), -1, dtype=torch.int32)
+            assert "attn_f32_" not in k.launchForm(b, row=R, column=C, blockMask=mask, blockMaskWords=1)
+    for D in (30, 200):   # D % 4 != 0; the 256 head block
+        d = _desc(dims=(R, C, D))
+        for t in names:
+            k = AttentionKernel(d.kernelDescriptor(t))
+            assert k.launchForm(buffers(D), row=R, column=C) == k.variant
+
+
 def test_low_precision_intermediates_select_the_folded_scale_stream():
     """S and P in FP32 registers (lowPrecisionIntermediates = false): the scale is applied in fp32 per score; with
     lowPrecisionIntermediates the reference itself keeps S / P in 16 bits (+Precisions.swift:149-215) and the kernel may

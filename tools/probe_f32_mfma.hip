@@ -11,6 +11,8 @@ using namespace mfa;
 using namespace mfa::f32k;
 
 // (the compiler-scheduled forms the first version of the kernels used)
+template <int N> __device__ __forceinline__ void lds_wait(f32x4 &a) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lds_wait(f32x4 &a, f32x4 &b) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N)); }
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 template <int DP> __device__ __forceinline__ uint32_t first_address(int i, int hi) { return i * Geo<DP>::ROWB + ((hi ^ (i & 15)) << 4); }
 template <int DP> __device__ __forceinline__ uint32_t second_address(int i, int hi) {

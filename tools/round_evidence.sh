@@ -54,6 +54,7 @@ PY
   [ -x tools/probe_f32_mfma.out ] && timeout 100 tools/probe_f32_mfma.out > "$OUT/probe_f32_mfma.txt" 2>&1
   timeout 200 python tools/time_single_head.py 2>&1 | grep -v amdgpu.ids > "$OUT/single_head.txt"
   timeout 300 python tools/fuzz_shapes.py 120 1 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_120_seed1.txt"; grep "random problems" "$OUT/fuzz_120_seed1.txt"
+  timeout 300 python tools/fuzz_shapes.py 120 5 --fp32 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_fp32_120_seed5.txt"; grep "random problems" "$OUT/fuzz_fp32_120_seed5.txt"
   timeout 300 python tools/fuzz_shapes.py 120 2 --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_120_seed2.txt"; grep "random problems" "$OUT/fuzz_transposed_120_seed2.txt"
   timeout 400 python tools/fuzz_shapes.py 90 3 --transposed --backward 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_backward_90_seed3.txt"; grep "random problems" "$OUT/fuzz_transposed_backward_90_seed3.txt"
 fi

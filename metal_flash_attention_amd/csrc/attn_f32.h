@@ -3,8 +3,8 @@
 // attn_generic.h (all products on v_mfma_f32_32x32x2_f32, exact online softmax), which keep every other layout / type / mask;
 // what differs is how the operands travel:
 //   * the traversal-side tiles (K, V / Q, dO: 32 rows x DP floats) go from memory to LDS by LDS-DMA, two (forward) or three
-//     (backward) stages, one barrier per tile; bounds-checked buffer resources zero-fill ragged rows and the columns past D (what the reference gets from
-//     simdgroup_event::async_copy, GEMMHeaders.swift:166-193);
+//     (backward) stages, one barrier per tile; bounds-checked buffer resources zero-fill ragged rows and the columns past D
+//     (what the reference gets from simdgroup_event::async_copy, GEMMHeaders.swift:166-193);
 //   * the cached left-hand operands (+Caching.swift:18-281) are read from memory straight into their fragment registers;
 //   * every LDS read is a ds_read_b128 that feeds four matrix instructions.  The contraction index of the first product of
 //     a pair and the head-dimension index of the second are both PERMUTED so that the four values lie next to each other in a
@@ -20,12 +20,15 @@
 // ~15 clocks, softmax arithmetic in a batch 6.5-11 per instruction, LDS reads / waits / SALU nothing
 // (tools/probe_f32_mfma.hip, profiles/r04_f32/probe_f32_mfma.txt).  Hence:
 //   * no address arithmetic in the loop: every read address is a register computed once, the stage / operand / row parts are
-//     immediate offsets (the tile loop is unrolled over the two stages); the LDS-DMA's per-lane offsets are constants, the
+//     immediate offsets (the tile loop is unrolled over the stages); the LDS-DMA's per-lane offsets are constants, the
 //     bounds-checked resource advances instead (scalar ALU);
 //   * scale and subtract ride on the matrix instructions: the cached fragments are pre-multiplied by the softmax scale and
-//     the accumulator of a first product STARTS at -m / -L / -D (srcC of its first instruction), so the softmax arithmetic
-//     left per score is one exponential plus one add (forward) or one multiply (backward);
-//   * masks (ragged edge, causal diagonal) sit behind wave-uniform branches: only the tiles that need them pay.
+//     the accumulator of a first product STARTS at -L / -D (srcC of its first instruction; forward: -m as one more contraction
+//     step, ones . (-m)), so the softmax arithmetic left per score is one exponential plus one add (forward) or one multiply
+//     (backward);
+//   * masks (ragged edge, causal diagonal) sit behind wave-uniform branches: only the tiles that need them pay;
+//   * staging is issued in the matrix instructions' shadow: an LDS-DMA instruction alone costs ~45 clocks of issue, ~12 between
+//     two groups of matrix instructions (phase clocks: MFA_F32_PROF=1 in the developer library, tools/f32_perf.py).
 #pragma once
 #include "attn_common.h"
 #include "attn_fwd16.h"   // Fwd16Grid, fwd16_decode_block (XCD-aware workgroup order)

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   auto voffs = [](int stage) { return KV32 ? 2 * KTILE + stage * TILE : stage * STAGE; };
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
   // ABL: timing-only ablations (WRONG RESULTS): 2 = exp2 replaced by an FMA, 3 = one K fragment address, 8 = no
-  // per-tile barrier, 20 = no fragment reads from LDS in the loop, 21 = no softmax arithmetic, 22 = 20 + 21
+  // per-tile barrier, 20 = no fragment reads from LDS in the loop, 21 = no softmax arithmetic, 22 = 20 + 21, 23 = no row maximum
   constexpr bool NOLDS = (ABL == 20 || ABL == 22), NOSOFTMAX = (ABL == 21 || ABL == 22);
 
   const int tid = threadIdx.x;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   float m[RB], l[RB];
 #pragma unroll
   for (int b = 0; b < RB; ++b) {
-    m[b] = -3.402823466e+38f;   // +Caching.swift:310
+    m[b] = ABL == 23 ? 0.f : -3.402823466e+38f;   // +Caching.swift:310
     l[b] = 0.f;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -406,6 +406,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   };
   auto block_max = [&](const f32x16 (&s)[RB], float (&m_new)[RB]) {   // onlineReduceMaximum
     if constexpr (NOSOFTMAX) { m_new[0] = 0.f; return; }
+    if constexpr (ABL == 23) {   // timing only: what the row maximum costs (the reference maximum stays 0, nothing is ever re-based)
+#pragma unroll
+      for (int b = 0; b < RB; ++b) m_new[b] = 0.f;
+      return;
+    }
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
       float mx0 = fmaxf(s[b][0], s[b][1]), mx1 = fmaxf(s[b][2], s[b][3]);

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   // (K swizzle and V sub-tiling applied on the source address).  No staging registers, no ds_write_b128.  Needs
   // 16-byte aligned rows (the host checks) and reads its fragments through the asm helpers above.
   constexpr bool LDMA = (VD & 32) != 0;
+  constexpr bool VSPLIT = (VD & 64) != 0;   // developer schedule: V staging writes one sub-tile per half-wave (below)
   // LDMA with RING == 2 (D = 256, where three whole stages do not fit): the K images form a ring of THREE and the
   // V images a ring of TWO (3 x 32 + 2 x 32 KiB = all 160 KiB).  K(j+2) and V(j+1) are requested right behind the
   // barrier of iteration j: both have a whole iteration to land, and the second barrier of the register-staged
@@ -236,6 +237,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
     }
     klds[i] = row * ROWB + (KPAD ? c : kswz<D>(row, c)) * 16;
     vlds[i] = KTILE + ((c >> 2) * BC + row) * 64 + (c & 3) * 16;
+    if constexpr (VSPLIT) {
+      // the V image is [D / 32 sub-tiles][64 keys][64 bytes]: with (row, c) = (id / CPR, id % CPR) the sixteen lanes of a
+      // ds_write_b128 group write the same 64-byte columns of DIFFERENT sub-tiles (4096 bytes apart: the same banks).  Here a
+      // half-wave takes ONE sub-tile: 8 keys x 64 bytes = 512 contiguous bytes (D = 64 forward: 9.4 % of the LDS-active cycles
+      // were bank conflicts, profiles/r04_fwd_bf16_d64_summary.txt)
+      const int vrow = (id / (32 * NDB)) * 8 + ((id >> 2) & 7), vc = ((id >> 5) % NDB) * 4 + (id & 3);
+      voff[i] = (vc * 8 < Dr) ? (tile0 * BC + vrow) * ldv2 + vc * 16 : OOB;
+      vlds[i] = KTILE + ((vc >> 2) * BC + vrow) * 64 + (vc & 3) * 16;
+    }
     // K^T image: [2 blocks of 32 keys][D elements][64 bytes]; V^T image: [D elements][64 keys], chunks XOR-swizzled
     if constexpr (KT) klds[i] = (((id & 7) >> 2) * D + id / 8) * 64 + (id & 3) * 16;
     // (within a 16-key step the keys are stored in the order P^T holds them -- 4 h + {0..3, 8..11} in chunk 2 u + h -- so that

@@ -53,6 +53,9 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
     if (D == 128 && impl == 4) { fill<__bf16, 128, 8, 1, 8, 1, 0, 3, 12>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_prek_vpipe_wspread"); return true; }
     if (D == 128 && impl == 5) { fill<__bf16, 128, 8, 1, 8, 0, 0, 3, 8>(out, "attn_fwd16v3_bf16_d128_w8x32_thr8_wmid"); return true; }
     if (D == 64 && impl == 6) { fill<__bf16, 64, 8, 1, 8, 0, 0, 3, 64>(out, "attn_fwd16v3_bf16_d64_w8x32_thr8_vsplit"); return true; }
+    if (D == 64 && impl == 50) { fill<__bf16, 64, 8, 1, 8, 0, 20>(out, "ablate_no_lds_reads_WRONG_RESULTS"); return true; }
+    if (D == 64 && impl == 52) { fill<__bf16, 64, 8, 1, 8, 0, 22>(out, "ablate_no_lds_reads_no_softmax_WRONG_RESULTS"); return true; }
+    if (D == 64 && impl == 14) { fill<__bf16, 64, 8, 1, 8, 0, 8>(out, "ablate_no_tile_barrier_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 53) { fill<__bf16, 64, 8, 1, 8, 0, 23>(out, "ablate_no_row_maximum_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 51) { fill<__bf16, 64, 8, 1, 8, 0, 21>(out, "ablate_no_softmax_WRONG_RESULTS"); return true; }
     if (D == 64 && impl == 11) { fill<__bf16, 64, 8, 1, 8, 0, 2>(out, "ablate_no_exp_WRONG_RESULTS"); return true; }

@@ -634,6 +634,11 @@ __global__ __launch_bounds__(256) void attn_f32_dq(const KernelArgs a, const Fwd
     // the reference, where the zero padding comes from the async copy, +Accumulate.swift:330-346)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r]) * dp[r];
+    if (c0 + BT > C) {   // ragged last tile: a padded column has S' = -L, and a row with L < -128 (base 2) would make exp2 = inf and
+#pragma unroll           // inf x 0 = NaN in the whole dQ row -- dS of a column beyond C is zero by definition (wave-uniform branch)
+      for (int r = 0; r < 16; ++r)
+        if (c0 + crow(r, hi) >= C) s[r] = 0.f;
+    }
     if (causal && c0 + BT - 1 > wavelimit) {   // masked column: P = 0, hence dS = 0
 #pragma unroll
       for (int r = 0; r < 16; ++r)

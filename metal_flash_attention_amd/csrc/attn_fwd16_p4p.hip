@@ -3,6 +3,7 @@
 #include "launchers.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 namespace mfa {
@@ -73,6 +74,19 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   if constexpr (!FOLD && __is_same(T, __bf16)) {
     if (std::getenv("MFA_P4P_PROF") && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == PREC_FP32)
       return launch_stream<T, p4p::S_BF16_EXACT_PROF>(grid, stream, args);
+  }
+  // MFA_P4P_DEV_STREAM=<name of a developer stream of tools/p4pgen.py>: dense bf16 launches with FP32 O whose mode (mixed: FP16 L;
+  // fp32 intermediates: FP32 L) the stream was generated for run that stream (schedule experiments and timing-only ablations,
+  // tools/p4p_streams_ab.py)
+  if constexpr (__is_same(T, __bf16)) {
+    const char *want = std::getenv("MFA_P4P_DEV_STREAM");
+    if (want && *want && !args.causal && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == (FOLD ? PREC_FP16 : PREC_FP32)) {
+#define MFA_P4P_BYNAME(name, f16, fold, o16, l16, causal) \
+      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD && !causal) { if (std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
+      MFA_P4P_DEV_STREAM_LIST(MFA_P4P_BYNAME)
+#undef MFA_P4P_BYNAME
+      return false;   // (an unknown name must not silently time the product stream)
+    }
   }
 #endif
   const int po = args.op[SLOT_O].precision, pl = args.op[SLOT_L].precision;

@@ -428,6 +428,9 @@ struct LaunchPlan {
   Relayout relayouts[MFA_BUFFER_SLOTS];
   int nRelayouts = 0;
   uint32_t heads = 1, batches = 1;
+  // the missing workspace is the ONLY reason this launch left the matrix-core kernel (every operand meets the alignment and
+  // 32-bit slice-size requirements of the buffer descriptors): the condition under which the in-place backward kernels may take it
+  bool onlyWorkspaceMissing = false;
 };
 
 // ---- re-layout pass: element (r, d) of a [seq][D] matrix between a transposed view ([D][seq], leading dimension ld) and a
@@ -635,11 +638,12 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
       relayoutMissing = true;   // no (or too small a) workspace: the general kernel reads the transposed operands in place
     }
   }
-  plan->useFallback = kernel->hasFallback && (relayoutMissing || !meets_fast_requirements(kernel, *args) ||
-                                              (args->causal && !kernel->variant.causal) ||
-                                              (args->mask && !kernel->variant.launchSparse && !kernel->variant.sparse) ||
-                                              // attn_dkv16_rs lists at most 4096 active 256-row blocks in LDS
-                                              (args->mask && type == MFA_BACKWARD_KEY_VALUE && p->row > 4096u * 256u));
+  const bool otherReasons = !meets_fast_requirements(kernel, *args) || (args->causal && !kernel->variant.causal) ||
+                            (args->mask && !kernel->variant.launchSparse && !kernel->variant.sparse) ||
+                            // attn_dkv16_rs lists at most 4096 active 256-row blocks in LDS
+                            (args->mask && type == MFA_BACKWARD_KEY_VALUE && p->row > 4096u * 256u);
+  plan->useFallback = kernel->hasFallback && (relayoutMissing || otherReasons);
+  plan->onlyWorkspaceMissing = kernel->hasFallback && relayoutMissing && !otherReasons;
   if (plan->useFallback && plan->nRelayouts) {   // (alignment, mask limits ...): the general kernel takes the user's views
     for (int i = 0; i < plan->nRelayouts; ++i) args->op[plan->relayouts[i].slot] = plan->relayouts[i].user;
     plan->nRelayouts = 0;
@@ -689,7 +693,9 @@ static auto split_launcher(const LaunchPlan &plan) -> decltype(plan.variant->lau
 
 // does this launch go to the in-place backward kernels? (transposed operands, no workspace)
 static bool dev_in_place_backward(const mfa_attention_kernel *kernel, const LaunchPlan &plan) {
-  if (!plan.useFallback || !kernel->relayout || kernel->desc.type == MFA_FORWARD) return false;
+  // (a launch that ALSO misses the 16-byte alignment or the 32-bit slice size of the buffer descriptors stays with the general
+  // kernel and its 64-bit addressing: the in-place kernels address every operand through such descriptors)
+  if (!plan.useFallback || !plan.onlyWorkspaceMissing || !kernel->relayout || kernel->desc.type == MFA_FORWARD) return false;
 #ifdef MFA_DEV_VARIANTS
   const char *knob = std::getenv("MFA_BWD16_TR");   // developer library: MFA_BWD16_TR=0 -- never (A/B runs against the general kernel)
   if (knob && std::strcmp(knob, "0") == 0) return false;

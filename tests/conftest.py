@@ -22,9 +22,10 @@ def built_library():
 
 
 # ---- which code objects do the GPU tests launch?  (-m gpu sessions on a GPU box only) -----------------------------------------
-# Every AttentionKernel.dispatch / .time of the session is recorded as variant name -> the test ids that launched it, written to
-# gpurun_out/variant_coverage.json at session end; a copy of a full `-m gpu` run is committed as tests/golden/variant_coverage.json
-# and tests/test_variant_coverage.py (CPU) holds the library's variant names against it.
+# OPT-IN (MFA_VARIANT_COVERAGE=1; the default session leaves AttentionKernel untouched -- no extra prepare_launch per dispatch in
+# the timing-sensitive tests): every AttentionKernel.dispatch / .time of the session is recorded as variant name -> the test ids
+# that launched it, written to gpurun_out/variant_coverage.json at session end; a copy of a full `-m gpu` run is committed as
+# tests/golden/variant_coverage.json and tests/test_variant_coverage.py (CPU) holds the library's variant names against it.
 _COVERAGE = {"variants": {}, "forms": {}}
 _CURRENT = {"id": None}
 
@@ -46,7 +47,7 @@ def _current_test_id(request):
 
 @pytest.fixture(autouse=True, scope="session")
 def _record_launched_variants():
-    if not _gpu_session():
+    if os.environ.get("MFA_VARIANT_COVERAGE", "0") != "1" or not _gpu_session():
         yield
         return
     import json
@@ -54,7 +55,7 @@ def _record_launched_variants():
     real = {name: getattr(AttentionKernel, name) for name in ("dispatch", "time")}
 
     def wrap(name):
-        def method(self, buffers, **kw):
+        def method(self, buffers, *args, **kw):
             tests = _COVERAGE["variants"].setdefault(self.variant, [])
             tid = _CURRENT["id"] or "?"
             if tid not in tests and len(tests) < 4:
@@ -64,9 +65,9 @@ def _record_launched_variants():
                 import re
                 for form in set(re.findall(r"attn_[A-Za-z0-9_]+", self.launchForm(buffers, **form_kw))):   # (incl. a named sibling)
                     _COVERAGE["forms"][form] = _COVERAGE["forms"].get(form, 0) + 1
-            except Exception:  # noqa: BLE001 -- a launch that is about to fail validation: let the real call report it
-                pass
-            return real[name](self, buffers, **kw)
+            except Exception as exc:  # noqa: BLE001 -- a launch that is about to fail validation: the real call below reports it
+                _COVERAGE.setdefault("form_errors", []).append("%s: %s" % (tid, exc))
+            return real[name](self, buffers, *args, **kw)
         return method
 
     for name in real:
@@ -80,7 +81,7 @@ def _record_launched_variants():
     worker = os.environ.get("PYTEST_XDIST_WORKER")   # pytest -n N: every worker records its own part, the controller merges them below
     with open(os.path.join(out, "variant_coverage.%s.json" % worker if worker else "variant_coverage.json"), "w") as f:
         json.dump({"library": os.path.basename(_abi.library_path()), "variants": dict(sorted(_COVERAGE["variants"].items())),
-                   "forms": dict(sorted(_COVERAGE["forms"].items()))}, f, indent=1)
+                   "forms": dict(sorted(_COVERAGE["forms"].items())), "form_errors": _COVERAGE.get("form_errors", [])[:50]}, f, indent=1)
 
 
 def pytest_sessionfinish(session, exitstatus):

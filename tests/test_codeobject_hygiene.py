@@ -12,7 +12,16 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-OBJECTS = ["attn_fwd16_p4", "attn_fwd16_p5", "attn_dq16_p4", "attn_dkv16_p4"]
+OBJECTS = ["attn_fwd16_p4", "attn_fwd16_p4p", "attn_fwd16_p5", "attn_dq16_p4", "attn_dkv16_p4", "attn_dq16_p5", "attn_dkv16_p5", "attn_f32",
+           "attn_fwd16_p4_tr", "attn_fwd16_p5_tr", "attn_bwd16_p4_tr"]
+# scratch instructions hipcc may leave AROUND a hand-placed statement, per translation unit (the worst kernel of the unit today;
+# pinned so that they cannot grow unnoticed -- the statements themselves never touch scratch)
+SCRATCH_BUDGET = {"attn_fwd16_p4": 40, "attn_fwd16_p4p": 0, "attn_fwd16_p5": 40, "attn_dq16_p4": 40, "attn_dkv16_p4": 40, "attn_dq16_p5": 0,
+                  "attn_dkv16_p5": 8, "attn_f32": 8, "attn_fwd16_p4_tr": 60, "attn_fwd16_p5_tr": 100, "attn_bwd16_p4_tr": 210}
+# (kernels of the unit that spill at all, most spilled vector registers in one kernel): the state of the round-5 build
+SPILL_BUDGET = {"attn_fwd16_p4p": (0, 0), "attn_dq16_p5": (0, 0), "attn_dkv16_p5": (4, 1), "attn_dq16_p4": (2, 2), "attn_dkv16_p4": (21, 6),
+                "attn_f32": (1, 2), "attn_fwd16_p4": (4, 15), "attn_fwd16_p5": (12, 2), "attn_fwd16_p4_tr": (24, 19),
+                "attn_fwd16_p5_tr": (56, 34), "attn_bwd16_p4_tr": (24, 73)}
 
 
 def _kernels(obj):
@@ -54,7 +63,7 @@ def test_scratch_stays_out_of_the_way(obj):
     """a handful of spills around the statement are fine (values the epilogue needs); dozens mean loop invariants again"""
     for name, ins in _kernels(obj).items():
         n = sum(1 for t in ins if t.startswith("scratch_"))
-        assert n <= 40, (name, n)
+        assert n <= SCRATCH_BUDGET[obj], (name, n)
 
 
 # translation units whose kernels are allowed to CALL a device function hipcc did not inline (by-reference captures in scratch): none.
@@ -94,3 +103,16 @@ def test_transposed_code_objects_have_the_tile_loads_inline(build):
     for tu in ("attn_fwd16_v3_tr_d160", "attn_fwd16_v3_tr_d192"):
         if tu in report:
             assert not report[tu]["stack"], report[tu]["stack"]
+
+
+def test_spills_of_the_hand_placed_units_stay_within_their_budgets():
+    """llvm-readelf notes of the product build: `.vgpr_spill_count` per kernel.  The hand-placed statements own ~480 of the 512
+    registers, so hipcc's share around them spills a few values in some wrappers (masked / transposed variants); the budgets are
+    today's numbers -- a change that makes a wrapper spill more fails here instead of showing up as per-block cost"""
+    report = _audit("build")
+    for tu, (kernels, most) in SPILL_BUDGET.items():
+        if tu not in report:
+            continue
+        spills = report[tu]["spills"]
+        assert len(spills) <= kernels, (tu, len(spills), kernels)
+        assert max([n for _, n in spills] or [0]) <= most, (tu, sorted(spills, key=lambda x: -x[1])[:3])

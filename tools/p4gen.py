@@ -59,7 +59,7 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64, tr=0):
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64, tr=0, bal=0, cap=7, maxa=1, va0=0):
         """tr: bit 0 = K, bit 1 = V stored transposed (attn_fwd16_p4_tr.h)"""
         """fold: Q arrives pre-multiplied by log2(e)/sqrt(D) and the running maximum is subtracted INSIDE the matrix pipe (an
         extra k-step whose A operand is -1.0 and whose B operand carries m as a bf16/f16 pair): no s * scale2 - m per
@@ -89,6 +89,20 @@ class Cfg:
         # in front of the step's first read (vta / vtb, operands of the statement).
         self.tr = tr
         self.kt, self.vt = tr & 1, (tr >> 1) & 1
+        # bal (round 5, FOLD streams): the fillers of both phases re-dealt by ISSUE SLOTS.  A wave alone on its SIMD issues one
+        # instruction per ~4 clocks, a matrix instruction holds the pipe for 32: eight slots per gap, of which the matrix
+        # instruction takes one, a transcendental two, anything else one (SQ_ACTIVE_INST_VALU of the round-4 stream: 1429 clocks
+        # per tile = 64 x 4 + 163 x 4 + 64 x 8).  The round-2 tables put 1029 clocks of issue into phase B's 1024 and 768 into
+        # phase A's, with phase A's transcendentals bunched in its last twelve gaps (up to nine slots).  Here: the row maxima of
+        # the first key block move to phase A of their own tile (its score blocks are complete after 16 matrix instructions),
+        # the exponentials are dealt out one per gap over the whole of phase A and up to `cap` slots per gap in phase B, the V^T
+        # reads of phase A sit in its first sixteen gaps, the K fragment reads of phase B in front of the LDS-DMA pieces (which
+        # then sit in gaps without LDS reads), the scalar bookkeeping where slots are free.  No gap above `cap` slots.
+        self.bal, self.cap, self.maxa, self.va0 = bal, cap, maxa, va0
+        assert not (bal and (tr or dma != "b")), "bal: row-major K / V"
+        assert not (bal == 1 and not fold)
+        # number of scores per tile whose exponential phase B takes (the rest: phase A of the next tile)
+        self.nexpb = (self.xb if fold else xe) if bal else None
         # ksplit: the second key block's K fragments are requested in the first gaps of phase A (they are first multiplied sixteen
         # matrix instructions later) instead of in phase B of the previous tile, the longer phase.  Always with K^T (32 reads).
         self.ksplit = 1 if self.kt else 0
@@ -256,6 +270,8 @@ class Stream:
     def phase_a(self, par, mfma, softmax, zero_o):
         """A(j), par = j & 1: S[par] = K Q^T | finish-softmax of S[par ^ 1] | V^T reads of fragments 0..7"""
         cfg = self.cfg
+        if cfg.bal:
+            return self.phase_a_bal(par, mfma, softmax, zero_o)
         prev = par ^ 1
         vids = {}
         if softmax and cfg.tr != 3:   # (K^T + V^T: phase B of the previous tile has left the eight V^T addresses)
@@ -342,6 +358,8 @@ class Stream:
     def phase_b(self, par, mfma, softmax, vids):
         """B(j): O += V^T(j-1) P^T(j-1) | start-softmax of S[par], K(j+1) fragments, V^T fragments 8..15, DMA"""
         cfg = self.cfg
+        if cfg.bal:
+            return self.phase_b_bal(par, mfma, softmax, vids)
         if not mfma and softmax:
             self.emit("s_nop", None, [I(15)], note="S(0) is still leaving the matrix pipe")
         if softmax:
@@ -430,6 +448,201 @@ class Stream:
             self.outofline.append(("resc", resc, back, par, False))
             self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK", par, not mfma))
 
+    # ------------------------------------------------------------ slot-balanced phases (cfg.bal)
+    def phase_a_bal(self, par, mfma, softmax, zero_o):
+        """A(j) dealt by issue slots: per gap one matrix instruction, the sum / sum / pack of one score pair of tile j-1, one
+        exponential of tile j-1 (the scores phase B(j-1) left), one V^T read (gaps 0..15), one row-maximum step of the FIRST
+        key block of tile j (gaps 17..31: its score blocks are complete behind matrix instruction 15)"""
+        cfg = self.cfg
+        abl = cfg.abl if (mfma and softmax) else frozenset()
+        prev = par ^ 1
+        vids = {}
+        if softmax:
+            self.emit("v_add_u32", V(T_VADDR), [SN("vrd"), VN("vbase")], note="V^T read base of tile j-1")
+        mlist = self.qk_list(par)
+        assert len(mlist) == 32 and cfg.order_a == "kb"
+        ea = list(range(cfg.nexpb, 64))                    # exponentials left to this phase, dealt evenly over the 32 gaps
+        exp_gap = {e: (t * 32) // len(ea) for t, e in enumerate(ea)} if ea else {}
+        pack_gap, g_prev = {}, 0                            # pair p = elements 2p, 2p + 1: one pair per gap, in order, once ready
+        for p in range(32):
+            ready = max(exp_gap.get(2 * p, -1), exp_gap.get(2 * p + 1, -1))
+            g_prev = min(32, max(g_prev + 1, ready + 1))
+            pack_gap[p] = g_prev
+        maxa_gap = {k: min(17 + k, 31) for k in range(16 if cfg.maxa else 0)}  # row-maximum steps of score blocks (rb0, kb0), (rb1, kb0) of THIS tile
+        for g in range(33):
+            if g < 32 and mfma:
+                self.mfma(*mlist[g])
+            if g < 32 and zero_o:
+                for i in range(4):
+                    self.emit("v_accvgpr_write_b32", A(O_BASE + 4 * g + i), [I(0)])
+            if softmax:
+                for p in range(32):
+                    if pack_gap[p] == g:
+                        self.sum_pack_abl(prev, 2 * p, abl)
+                for e in ea:
+                    if exp_gap[e] == g and "exp" not in abl:
+                        rb_, kb_, r_ = elem(e)
+                        x = s_elem(prev, rb_, kb_, r_)
+                        self.emit("v_exp_f32", x, [x])
+                if cfg.va0 <= g < cfg.va0 + 16:
+                    vids[g - cfg.va0] = self.v_read(g - cfg.va0) if "lds" not in abl else 0
+            if mfma and g < 32:
+                for k in maxa_gap:
+                    if maxa_gap[k] == g and "max" not in abl:
+                        self.max_op(par, k)
+        return vids
+
+    def sum_pack_abl(self, prev, e, abl):
+        rb, kb, r = elem(e)
+        x0, x1 = s_elem(prev, rb, kb, r), s_elem(prev, rb, kb, r + 1)
+        if "sum" not in abl:
+            self.emit("v_add_f32", VN("l%d" % rb), [x0, VN("l%d" % rb)])
+            self.emit("v_add_f32", V(T_LB + rb), [x1, V(T_LB + rb)])
+        if "pack" not in abl:
+            self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, p_word(prev, rb, 2 * kb + r // 8, (r % 8) // 2), [x0, x1])
+
+    def phase_b_bal(self, par, mfma, softmax, vids):
+        """B(j) dealt by issue slots: row maxima of the second key block (gaps 0..3), decision (4..6), exponentials from gap 7
+        wherever a gap has two slots left below `cap`, K(j+1) fragments in gaps 7..22, V^T fragments 8..15 as their ring slots
+        fall free, LDS-DMA of K(j+2) in gaps 23..26 and of V(j+1) in 27..30 (gaps without LDS reads)"""
+        cfg = self.cfg
+        abl = cfg.abl if (mfma and softmax) else frozenset()
+        if not mfma and softmax:
+            self.emit("s_nop", None, [I(15)], note="S(0) is still leaving the matrix pipe")
+        if softmax:
+            self.mask_section(par, after_mfma=mfma)
+        fill = [[] for _ in range(32)]
+        slots = [1] * 32
+
+        def at(g, fn, cost=1):
+            fill[g].append(fn)
+            slots[g] += cost
+
+        if mfma:
+            for f in range(8, 16):   # fragment f reuses the slot of f - 8, free once the two products of f - 8 (gaps 2 (f - 8), + 1) are issued
+                g0 = 2 * (f - 8) + 2
+                if "lds" in abl:
+                    vids[2 * f] = vids[2 * f + 1] = 0
+                    continue
+                at(g0, lambda f=f: vids.__setitem__(2 * f, self.v_read(2 * f)))
+                at(g0 + 1, lambda f=f: vids.__setitem__(2 * f + 1, self.v_read(2 * f + 1)))
+        if softmax and cfg.bal == 1:
+            for i in range(16, 32):
+                if "max" not in abl:
+                    at((i - 16) // 4, lambda i=i: self.max_op(par, i))
+            at(4, lambda: self.decide_1(), 4)
+            at(5, lambda: self.decide_2(), 5)
+            dec_lbl = self.newlabel("DEC")
+            first = not mfma
+            at(6, lambda: self.decide_4_fold(dec_lbl, first), 5)
+            for i in range(16):
+                if "lds" not in abl:
+                    at(7 + i, lambda i=i: self.k_read(par ^ 1, i))
+            at(18, lambda: self.vrd_advance(), 3)
+            if getattr(self, "persistent", False):
+                self.b_hook(lambda g, fn: at(g, fn, 2), par, mfma)
+            if "dma" not in abl:
+                at(22, lambda: self.vwr_update(), 3)
+                for i in range(4):
+                    at(23 + i, lambda i=i: self.dma_piece("k", par, i), 4)
+                    at(27 + i, lambda i=i: self.dma_piece("v", par, i), 4)
+                    at(27 + i, lambda i=i: self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1))
+                    at(31, lambda i=i: self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1))
+            exp_from = 7
+        elif softmax:
+            # bal = 2: the LDS-DMA pieces of K(j+2) and V(j+1) FIRST.  Their images fell free at the barrier in front of this phase
+            # (K(j) and V(j-2) were last read in phase B(j-1)) and their deadline is the next barrier: issued here they have two
+            # phases of flight instead of one and a quarter.  On all-zero operands (2.4 GHz) the stream without the pieces ran
+            # 19 % faster and without the wait + barrier 25 % faster (profiles/r05_p4p_bal_ablations.txt): the wait for pieces
+            # issued in the last gaps of this phase was what the loop spent a fifth of its time in
+            ksw_g, vsw_g = 0, 4
+            if getattr(self, "persistent", False):
+                self.b_hook(lambda g, fn: at(g, fn, 2), par, mfma, gaps=(ksw_g, vsw_g))
+            if "dma" not in abl:
+                for n in range(4):
+                    at(n, lambda n=n: self.dma_piece("k", par, n), 2)
+                at(3, lambda: self.vwr_update(), 3)
+                for n in range(4):
+                    at(4 + n, lambda n=n: self.dma_piece("v", par, n), 2)
+            # row-maximum steps this phase owes (the second key block's, or all four blocks'), greedily under the cap from gap 0
+            gm = 0
+            for i in range(16 if cfg.maxa else 0, 32):
+                while slots[gm] + 1 > cfg.cap:
+                    gm += 1
+                if "max" not in abl:
+                    at(gm, lambda i=i: self.max_op(par, i))
+                else:
+                    slots[gm] += 1
+            at(gm + 1, lambda: self.decide_1(), 4)
+            at(gm + 2, lambda: self.decide_2(), 5)
+            dec_lbl = self.newlabel("DEC")
+            first = not mfma
+            if cfg.fold:
+                at(gm + 3, lambda: self.decide_4_fold(dec_lbl, first), 5)
+                exp_from = gm + 4
+            else:
+                at(gm + 3, lambda: self.decide_3(), 4)
+                at(gm + 4, lambda: self.decide_4(dec_lbl), 5)
+                exp_from = gm + 5
+            assert exp_from + 16 <= 32
+            for n in range(16):
+                if "lds" not in abl:
+                    at(exp_from + n, lambda n=n: self.k_read(par ^ 1, n))
+            at(26, lambda: self.vrd_advance(), 3)
+            if "dma" not in abl:
+                for n in range(4):
+                    at(28 + n, lambda n=n: self.emit("v_add_u32_e64", VN("koff%d" % n), [VN("koff%d" % n), SN("kinc")], clamp=1))
+                    at(28 + n, lambda n=n: self.emit("v_add_u32_e64", VN("voff%d" % n), [VN("voff%d" % n), SN("vinc")], clamp=1))
+        if softmax:
+            # exponentials of the scores e < xb: behind the decision, two slots each, greedily under the cap (then cap + 1, ...)
+            if cfg.fold:
+                todo = [] if "exp" in abl else [(2, lambda e=e: self.exp_in_b(par, e)) for e in range(cfg.nexpb)]
+            else:   # exact-scale streams: s * scale2 - m of every score, the exponential of the first nexpb two scores behind it
+                todo = []
+                for e in range(64 + 2):
+                    if e < 64:
+                        todo.append((1, lambda e=e: self.fma_plain(par, e)))
+                    if 0 <= e - 2 < cfg.nexpb and "exp" not in abl:
+                        todo.append((2, lambda e=e: self.exp_in_b(par, e - 2)))
+            # in order (an exponential follows its own multiply-subtract), each gap filled up to the cap; the smallest cap >= cfg.cap
+            # under which the whole list fits in front of the phase's end
+
+            def pack(cap):
+                g, local, where = exp_from, list(slots), []
+                for c, _ in todo:
+                    while g <= 31 and local[g] + c > cap:
+                        g += 1
+                    if g > 31:
+                        return None
+                    where.append(g)
+                    local[g] += c
+                return where
+
+            cap = cfg.cap
+            where = pack(cap)
+            while where is None:
+                cap += 1
+                where = pack(cap)
+            for (c, fn), g in zip(todo, where):
+                at(g, fn, c)
+        for g in range(32):
+            if mfma:
+                u, db, rb = g // 8, (g % 8) // 2, g % 2
+                f = 4 * u + db
+                if rb == 0 and f % 2 == 0:
+                    self.lds_need(vids[2 * f + 3])
+                self.mfma(o_acc(rb, db), vf_frag(f), p_frag(par ^ 1, rb, u), o_acc(rb, db))
+            for fn in fill[g]:
+                fn()
+        self.lds_flush()
+        if softmax:
+            resc, back = self.newlabel("RESC"), self.newlabel("RESCBACK")
+            self.emit("s_cmp_eq_u32", None, [SN("pend"), I(0)])
+            self.emit("s_cbranch_scc0", None, [], target=resc)
+            self.label(back)
+            self.outofline.append(("resc", resc, back, par, False))
+            self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK", par, not mfma))
+
     def max_op(self, par, i):
         # op i: block i // 8 in the order (rb0,kb0) (rb1,kb0) (rb0,kb1) (rb1,kb1); step i % 8 covers 3, 2, ..., 2, 1 values
         blk, st = divmod(i, 8)
@@ -484,6 +697,11 @@ class Stream:
         rb, kb, r = elem(e)
         x = s_elem(par, rb, kb, r)
         self.emit("v_exp_f32", x, [x])
+
+    def fma_plain(self, par, e):
+        rb, kb, r = elem(e)
+        x = s_elem(par, rb, kb, r)
+        self.emit("v_fma_f32", x, [x, SN("scale2"), VN("m%d" % rb)], neg2=1)
 
     def fma_only(self, par, e):
         rb, kb, r = elem(e)
@@ -557,6 +775,9 @@ class Stream:
                     x = s_elem(par, rb, kb, r)
                     self.emit("v_cmp_gt_i32", VCC, [I(c), V(T_TL + rb)])
                     self.emit("v_cndmask_b32", x, [x, V(T_MASKV), VCC])
+        if self.cfg.bal and self.cfg.maxa:   # the first key block's row maxima were taken in phase A, from the unmasked scores
+            for i in range(16):
+                self.max_op(par, i)
         self.label(skip)
 
     # ------------------------------------------------------------ out-of-line sections
@@ -841,15 +1062,18 @@ def write_inc(path):
 
 
 VARIANTS = {
-    "BF16_THR8": Cfg("bf16", 8, 0),
-    "BF16_THR0": Cfg("bf16", 0, 0),
-    "F16_THR8": Cfg("f16", 8, 0),
+    # product streams: the round-5 schedule (bal = 2: LDS-DMA first in phase B, fillers dealt by issue slots)
+    "BF16_THR8": Cfg("bf16", 8, xe=32, bal=2, cap=8),
+    "BF16_THR0": Cfg("bf16", 0, xe=32, bal=2, cap=8),
+    "F16_THR8": Cfg("f16", 8, xe=32, bal=2, cap=8),
+    "R4_BF16_THR8": Cfg("bf16", 8, 0),                 # the round-4 schedules (developer library, A/B baselines)
+    "R4_BF16_FOLD": Cfg("bf16", 8, fold=1, xb=40),
     "BF16_THR8_XE16": Cfg("bf16", 8, 16),
     "BF16_THR8_ROT": Cfg("bf16", 8, 0, order_a="rot4"),
     "BF16_THR8_PAD": Cfg("bf16", 8, 0, pad=1),
     "BF16_THR8_PROF": Cfg("bf16", 8, 0, prof=1),
-    "BF16_FOLD": Cfg("bf16", 8, fold=1, xb=40),
-    "F16_FOLD": Cfg("f16", 8, fold=1, xb=40),
+    "BF16_FOLD": Cfg("bf16", 8, fold=1, xb=40, bal=2),
+    "F16_FOLD": Cfg("f16", 8, fold=1, xb=40, bal=2),
     "BF16_FOLD_XB24": Cfg("bf16", 8, fold=1, xb=24),
     "BF16_FOLD_PROF": Cfg("bf16", 8, fold=1, xb=40, prof=1),
     "BF16_THR8_TR": Cfg("bf16", 8, 0, tr=3),

@@ -32,6 +32,7 @@ workgroup, LDS-DMA landing early / late, stores retiring late.
 Usage: python tools/p4pgen.py   (rewrites metal_flash_attention_amd/csrc/attn_fwd16_p4p_stream.inc)
 """
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -73,8 +74,8 @@ IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qre
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None):
-        Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb)
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0):
+        Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0)
         self.o16, self.l16 = o16, l16
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
         # computed per block inside the stream; the block table lists the blocks in pairs (long, short) like attn_fwd16_p4's
@@ -143,7 +144,7 @@ class PStream(Stream):
         return self.ins
 
     # ---- hooks called by p4gen.Stream.phase_b
-    def b_hook(self, at, par, mfma):
+    def b_hook(self, at, par, mfma, gaps=(16, 17)):
         """phase B(j) of the persistent stream: the LDS-DMA pieces of the block's last two tiles belong to the NEXT block"""
         ksw, vsw = self.newlabel("KSW"), self.newlabel("VSW")
 
@@ -151,8 +152,8 @@ class PStream(Stream):
             self.emit("s_cmp_eq_u32", None, [SN("j"), s(reg)])
             self.emit("s_cbranch_scc1", None, [], target=lbl)
             self.label(lbl + "_BACK")
-        at(16, lambda: check("ntm2", ksw))
-        at(17, lambda: check("ntm1", vsw))
+        at(gaps[0], lambda: check("ntm2", ksw))
+        at(gaps[1], lambda: check("ntm1", vsw))
         self.outofline.append(("ksw", ksw, ksw + "_BACK", par, False))
         self.outofline.append(("vsw", vsw, vsw + "_BACK", par, False))
         if self.cfg.merge:      # the next block's Q is needed right behind this block's last tile: requested three tiles earlier
@@ -580,6 +581,8 @@ class PStream(Stream):
         blk_lbl, loop, end_even, end_odd, done, fin, nonext, after_epi = (
             self.newlabel(x) for x in ("BLOCK", "LOOP", "ENDEVEN", "ENDODD", "DONE", "FIN", "NONEXT", "AFTEREPI"))
         # ---- once per workgroup
+        if cfg.pad:     # developer streams: every instruction behind it moves by four bytes (MI355X_MICROARCH: code placement)
+            self.emit("s_nop", None, [I(0)], note="code placement pad")
         for ks in range(8):
             self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
         if not cfg.causal:
@@ -645,8 +648,9 @@ class PStream(Stream):
             vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
             self.lds_flush()
             self.pstamp("loop_a")
-            self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j) (and, in tile 1, the stores)
-            self.emit("s_barrier")
+            if "bar" not in cfg.abl:
+                self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j) (and, in tile 1, the stores)
+                self.emit("s_barrier")
             self.pstamp("loop_wait")
             if cfg.pprof and par == 1:                      # the wait of tile 1 separately (it includes the previous block's stores)
                 self.emit("s_cmp_eq_u32", None, [SN("j"), I(1)])
@@ -771,27 +775,73 @@ def render(instrs):
 
 VARIANTS = {
     # name: cfg            (X-macro columns: folds the scale, 16-bit O, FP16 L)
-    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1),          # headline: mixed-precision mode, fp32 O, FP16 L
-    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1),
-    "BF16_EXACT": PCfg("bf16", 8, fold=0),                    # lowPrecisionInputs only: scale in fp32, fp32 O and L
-    "BF16_EXACT_O16": PCfg("bf16", 8, fold=0, o16=1),
-    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1),
-    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1),
-    "F16_EXACT": PCfg("f16", 8, fold=0),
-    "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1),
-    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1),
-    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1),
-    "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1),
-    "BF16_EXACT_O16_CAUSAL": PCfg("bf16", 8, fold=0, o16=1, causal=1),
-    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1),
-    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1),
-    "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1),
-    "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1),
+    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40),          # headline: mixed-precision mode, fp32 O, FP16 L
+    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1, bal=2, xb=40),
+    "BF16_EXACT": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8),                    # lowPrecisionInputs only: scale in fp32, fp32 O and L
+    "BF16_EXACT_O16": PCfg("bf16", 8, fold=0, o16=1, bal=2, xe=32, cap=8),
+    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1, bal=2, xb=40),
+    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1, bal=2, xb=40),
+    "F16_EXACT": PCfg("f16", 8, fold=0, bal=2, xe=32, cap=8),
+    "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1, bal=2, xe=32, cap=8),
+    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=40),
+    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=40),
+    "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1, bal=2, xe=32, cap=8),
+    "BF16_EXACT_O16_CAUSAL": PCfg("bf16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8),
+    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1, bal=2, xb=40),
+    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=40),
+    "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1, bal=2, xe=32, cap=8),
+    "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8),
     "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
     "BF16_FOLD_L16_MERGE": PCfg("bf16", 8, fold=1, l16=1, merge=1),   # developer builds only: merged block switch (lost)
     "BF16_FOLD_L16_FUSE": PCfg("bf16", 8, fold=1, l16=1, fuse=1),     # developer builds only: epilogue dealt out under the last P V (no gain)
+    "R4_BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1),        # the round-4 schedule of the headline stream (A/B baseline)
+    "R4_BF16_EXACT": PCfg("bf16", 8, fold=0),
+    # round 5, developer builds: slot-balanced phases (p4gen Cfg.bal) and their timing-only ablations (WRONG RESULTS)
+    "BF16_FOLD_L16_BAL32": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32),
+    "BF16_FOLD_L16_BAL40": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=40),
+    "BF16_FOLD_L16_BAL24": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=24),
+    "BF16_FOLD_L16_BAL32C6": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, cap=6),
+    "BF16_FOLD_L16_BAL32C8": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, cap=8),
+    "BF16_FOLD_L16_BAL2_32": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32),
+    "BF16_FOLD_L16_BAL2_40": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40),
+    "BF16_FOLD_L16_BAL2_24": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=24),
+    "BF16_FOLD_L16_BAL2_32_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, pad=1),
+    "ABL_BAL2_EXP": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("exp",)),
+    "ABL_BAL2_MAX": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("max",)),
+    "ABL_BAL2_SUMPACK": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("sum", "pack")),
+    "ABL_BAL2_LDS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("lds",)),
+    "ABL_BAL2_DMA": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("dma",)),
+    "ABL_BAL2_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("bar",)),
+    "ABL_BAL2_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
+    "BAL2_48": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48),
+    "BAL2_56": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=56),
+    "BAL2_40_C8": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, cap=8),
+    "BAL2_48_C8": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, cap=8),
+    "BAL2_40_C6": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, cap=6),
+    "BAL2_40_MB": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, maxa=0),
+    "BAL2_48_MB": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, maxa=0),
+    "BAL2_32_MB": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, maxa=0),
+    "BAL2_40_MB_V16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, maxa=0, va0=16),
+    "BAL2_40_MB_V8": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, maxa=0, va0=8),
+    "BAL2_40_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, pad=1),
+    "EXACT_BAL2_XE16": PCfg("bf16", 8, fold=0, bal=2, xe=16),
+    "EXACT_BAL2_XE24": PCfg("bf16", 8, fold=0, bal=2, xe=24),
+    "EXACT_BAL2_XE32": PCfg("bf16", 8, fold=0, bal=2, xe=32),
+    "EXACT_BAL2_XE24_C8": PCfg("bf16", 8, fold=0, bal=2, xe=24, cap=8),
+    "EXACT_BAL2_XE32_C8": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8),
+    "EXACT_BAL2_XE40_C8": PCfg("bf16", 8, fold=0, bal=2, xe=40, cap=8),
+    "BF16_FOLD_L16_PAD": PCfg("bf16", 8, fold=1, l16=1, pad=1),
+    "BF16_FOLD_L16_BAL32_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, pad=1),
+    "BF16_FOLD_L16_BAL40_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=40, pad=1),
+    "ABL_BAL32_EXP": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp",)),
+    "ABL_BAL32_MAX": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("max",)),
+    "ABL_BAL32_SUMPACK": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("sum", "pack")),
+    "ABL_BAL32_LDS": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("lds",)),
+    "ABL_BAL32_DMA": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("dma",)),
+    "ABL_BAL32_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("bar",)),
+    "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if not c.pprof and not c.merge and not c.fuse)
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL', n))
 
 
 def write_inc(path):

@@ -67,8 +67,11 @@ WORKLOADS = {
     # same shape with the attention matrix kept in FP32 registers (lowPrecisionIntermediates = false): the scale is applied
     # in fp32 per score instead of being folded into Q
     "fwd_bf16_d128_fp32mid": dict(N=4096, D=128, dtype="bf16", batch=8, heads=32, types=("forward",)),
-    "fwd_bf16_d64": dict(N=4096, D=64, dtype="bf16", batch=8, heads=32, types=("forward",)),     # config 2, batched
-    "fwd_bf16_d64_1head": dict(N=4096, D=64, dtype="bf16", batch=1, heads=1, types=("forward",)),  # config 2 as written
+    # config 2 (batched / as written): like the headline in the reference's mixed-precision mode (round 5: attn_fwd16_p6 serves it);
+    # _fp32mid = lowPrecisionInputs only (the eight-wave kernel attn_fwd16_v3)
+    "fwd_bf16_d64": dict(N=4096, D=64, dtype="bf16", batch=8, heads=32, types=("forward",), low_mid=True),
+    "fwd_bf16_d64_fp32mid": dict(N=4096, D=64, dtype="bf16", batch=8, heads=32, types=("forward",)),
+    "fwd_bf16_d64_1head": dict(N=4096, D=64, dtype="bf16", batch=1, heads=1, types=("forward",), low_mid=True),
     "fwd_bf16_d256": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",)),   # config 4, batched
     "fwd_bf16_d256_mixed": dict(N=8192, D=256, dtype="bf16", batch=2, heads=16, types=("forward",), low_mid=True),
     "fwdbwd_f32_d128": dict(N=4096, D=128, dtype="f32", batch=2, heads=16,

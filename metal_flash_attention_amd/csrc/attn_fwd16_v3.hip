@@ -73,4 +73,10 @@ bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out) {
   return false;
 }
 
+// dense launches of the D = 64 bucket that the persistent kernel (attn_fwd16_p6.hip) does not serve
+void fwd16_v3_d64_launch(int precision, dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if (precision == PREC_BF16) launch_v3<__bf16, 64, 8, 1, 8, 0>(grid, stream, args);
+  else launch_v3<_Float16, 64, 8, 1, 8, 0>(grid, stream, args);
+}
+
 } // namespace mfa

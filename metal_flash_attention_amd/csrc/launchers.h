@@ -69,6 +69,12 @@ bool fwd16_v2_variant(int precision, int D, int impl, VariantInfo *out);
 bool fwd16_v3_variant(int precision, int D, int impl, VariantInfo *out);
 // four waves x 64 rows, one wave per SIMD, hand-placed instruction stream (attn_fwd16_p4.h); D <= 128 only
 bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out);
+// D <= 64: four waves x 64 rows, persistent (attn_fwd16_p6.h; fold = the descriptor holds the attention matrix in 16-bit registers:
+// scale folded into Q, row sums in the matrix pipe); `out` arrives filled by fwd16_v3_variant(precision, 64, 0), whose kernel keeps
+// the launches this one does not serve
+bool fwd16_p6_variant(int precision, bool fold, VariantInfo *out);
+bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const KernelArgs &args);
+const char *p6_form(int precision, bool fold, const KernelArgs &args);
 // 128 < D <= 256: four waves x 64 rows, 32-key steps (attn_fwd16_p5.h); `out` arrives filled by fwd16_v3_variant
 bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out);
 // backwardKeyValue counterpart: four waves x 64 keys (attn_dkv16_p4.h); `out` arrives filled by dkv16_rs_variant, whose

@@ -55,7 +55,7 @@ static const char *kDefaultTables[3][2] = {
      // D in (128, 256] -> 4 waves x 64 rows, 32-key steps (attn_fwd16_p5.h; buckets 160, 192, 256); | D | 128 | 32 | D | selects
      // the 4 waves x 32 rows objects
      "| 32  | 128 | 32 | 32  | Q, O |\n"
-     "| 64  | 256 | 32 | 64  | Q, O |\n"
+     "| 64  | 256 | 64 | 64  | Q, O |\n"
      "| 128 | 256 | 64 | 128 | Q, O |\n"
      "| 160 | 256 | 32 | 160 | Q, O |\n"
      "| 192 | 256 | 32 | 192 | Q, O |\n"

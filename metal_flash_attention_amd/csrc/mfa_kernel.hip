@@ -167,6 +167,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         v = v3;
         add(fwd16_p4_variant(pq, 128, lowS ? 10 : 0, &v), v);
       }
+      if (have3 && b16 == 64) {
+        // D <= 64 (buckets 32 and 64 of the eight-wave kernel): four waves x 64 rows, persistent, 64-key steps (attn_fwd16_p6.h, round 5);
+        // mixed-precision descriptors get the streams with the row sums in the matrix pipe.  | 64 | 256 | 32 | 64 | selects the eight
+        // 32-row waves of attn_fwd16_v3.h, which also keep this kernel's causal / block-sparse / column-parallel launches
+        v = v3;
+        add(fwd16_p6_variant(pq, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v), v);
+      }
       if (have3 && (b16 == 160 || b16 == 192 || b16 == 256)) {   // four waves x 64 rows, 32-key steps (attn_fwd16_p5.h)
         const bool lowS = kdesc->registerPrecisions[MFA_P] > MFA_FP32;
         v = v3;

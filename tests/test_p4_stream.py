@@ -162,13 +162,13 @@ def test_stream_file_is_current(built_library):
         assert open(path).read() == open(tmp.name).read(), "run python tools/p4gen.py"
 
 
-@pytest.mark.parametrize("name,most,mean", [("BF16_FOLD", 9, 6.8), ("BF16_THR8", 10, 7.8)])
+@pytest.mark.parametrize("name,most,mean", [("BF16_FOLD", 11, 6.8), ("BF16_THR8", 10, 7.8)])
 def test_filler_budget(name, most, mean):
     """issue slots per gap of the steady-state phases (round-5 schedule, p4gen Cfg.bal): a wave alone on its SIMD issues one
     instruction per ~4 clocks and a matrix instruction holds the pipe for 32, so a gap has eight slots -- the matrix instruction
     takes one, a transcendental two, anything else (counted waits included) one.  The generator deals the fillers under a cap of
-    7 (FOLD streams) or 8 (exact-scale streams: 64 more multiply-subtracts per tile); the counted waits and the decision's
-    scalar instructions come on top in a few gaps"""
+    7 (FOLD streams) or 8 (exact-scale streams: 64 more multiply-subtracts per tile); the counted waits and the decision (seven
+    slots in one gap of the FOLD streams) come on top in a few gaps"""
     ins = p4gen.Stream(p4gen.VARIANTS[name]).build()
     loop = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("LOOP"))
     end = next(i for i, x in enumerate(ins) if x.op == "label" and x.mod["name"].startswith("ENDEVEN"))
@@ -204,7 +204,7 @@ def test_lds_dma_pieces_lead_phase_b():
             elif x.op == "ds_read_b128":
                 kread_gaps.append(g % 64)
         assert len(dma_gaps) == 16 and all(32 <= d < 40 for d in dma_gaps), dma_gaps
-        assert min(kread_gaps) > max(dma_gaps)
+        assert min(kread_gaps) >= max(dma_gaps)
 
 
 def test_model_executes_buffer_stores():

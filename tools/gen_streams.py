@@ -13,7 +13,8 @@ sys.path.insert(0, HERE)
 JOBS = [("p4gen", "write_inc", "attn_fwd16_p4_stream.inc"), ("p4pgen", "write_inc", "attn_fwd16_p4p_stream.inc"),
         ("dq4gen", "write_inc", "attn_dq16_p4_stream.inc"), ("dkv4gen", "write_inc", "attn_dkv16_p4_stream.inc"),
         ("f256gen", "write_inc", "attn_fwd16_p5_stream.inc"), ("f256gen", "write_one_operand_inc", "attn_fwd16_p5_tr1_stream.inc"),
-        ("dkv5gen", "write_inc", "attn_dkv16_p5_stream.inc"), ("dq5gen", "write_inc", "attn_dq16_p5_stream.inc")]
+        ("dkv5gen", "write_inc", "attn_dkv16_p5_stream.inc"), ("dq5gen", "write_inc", "attn_dq16_p5_stream.inc"),
+        ("p6gen", "write_inc", "attn_fwd16_p6_stream.inc")]
 
 
 def render(job):

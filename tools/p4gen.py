@@ -59,7 +59,7 @@ IN_S = ["kres", "vres", "nt", "wnt", "scale2", "kinc", "vinc", "ldsk", "ldsv", "
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64, tr=0, bal=0, cap=7, maxa=1, va0=0):
+    def __init__(self, dtype="bf16", thr=8.0, xe=0, order_a="kb", pad=0, prof=0, fold=0, xb=40, dma="b", abl=(), xf=64, tr=0, bal=0, cap=7, maxa=1, va0=0, fastdec=0, fdpos=0):
         """tr: bit 0 = K, bit 1 = V stored transposed (attn_fwd16_p4_tr.h)"""
         """fold: Q arrives pre-multiplied by log2(e)/sqrt(D) and the running maximum is subtracted INSIDE the matrix pipe (an
         extra k-step whose A operand is -1.0 and whose B operand carries m as a bf16/f16 pair): no s * scale2 - m per
@@ -99,6 +99,11 @@ class Cfg:
         # reads of phase A sit in its first sixteen gaps, the K fragment reads of phase B in front of the LDS-DMA pieces (which
         # then sit in gaps without LDS reads), the scalar bookkeeping where slots are free.  No gap above `cap` slots.
         self.bal, self.cap, self.maxa, self.va0 = bal, cap, maxa, va0
+        # fastdec (FOLD streams, bal = 2): the rescale decision from ONE half-wave exchange -- the two row blocks' partial maxima
+        # swapped against each other give [row maxima of block 0 | of block 1] in the two half-waves, enough for the branch; the
+        # per-lane maxima of both blocks are rebuilt in the out-of-line section only (7 issue slots instead of 14 per tile)
+        self.fastdec, self.fdpos = fastdec, fdpos   # fdpos: 0 = the gap behind the last row-maximum step, 1 = behind the LDS-DMA gaps, 2 = split over two gaps
+        assert not (fastdec and not (fold and bal == 2))
         assert not (bal and (tr or dma != "b")), "bal: row-major K / V"
         assert not (bal == 1 and not fold)
         # number of scores per tile whose exponential phase B takes (the rest: phase A of the next tile)
@@ -573,11 +578,20 @@ class Stream:
                     at(gm, lambda i=i: self.max_op(par, i))
                 else:
                     slots[gm] += 1
-            at(gm + 1, lambda: self.decide_1(), 4)
-            at(gm + 2, lambda: self.decide_2(), 5)
             dec_lbl = self.newlabel("DEC")
             first = not mfma
-            if cfg.fold:
+            if not cfg.fastdec:
+                at(gm + 1, lambda: self.decide_1(), 4)
+                at(gm + 2, lambda: self.decide_2(), 5)
+            if cfg.fastdec and cfg.fdpos == 2:
+                at(gm + 1, lambda: self.decide_fast(dec_lbl, first, part=1), 5)
+                at(gm + 2, lambda: self.decide_fast(dec_lbl, first, part=2), 2)
+                exp_from = gm + 3
+            elif cfg.fastdec:
+                gd = max(gm + 1, 8) if cfg.fdpos == 1 else gm + 1
+                at(gd, lambda: self.decide_fast(dec_lbl, first), 7)
+                exp_from = gd + 1
+            elif cfg.fold:
                 at(gm + 3, lambda: self.decide_4_fold(dec_lbl, first), 5)
                 exp_from = gm + 4
             else:
@@ -667,6 +681,22 @@ class Stream:
             self.emit("v_permlane32_swap_b32", V(T_SW + rb), [V(T_MN + rb)], swap=1)
         for rb in range(2):
             self.emit("v_max_f32", V(T_MN + rb), [V(T_SW + rb), V(T_MN + rb)])
+
+    def decide_fast(self, lbl, first, part=0):
+        if part in (0, 1):
+            for rb in range(2):
+                self.emit("v_max_f32", V(T_MN + rb), [V(T_MX + 2 * rb), V(T_MX + 2 * rb + 1)])
+            self.emit("s_nop", None, [I(1)], note="VALU write -> permlane read")
+            self.emit("v_permlane32_swap_b32", V(T_MN), [V(T_MN + 1)], swap=1)
+            self.emit("v_max_f32", V(T_SW), [V(T_MN), V(T_MN + 1)])    # [row maxima of row block 0 | of row block 1]
+        if part == 1:
+            return
+        if first:
+            self.emit("s_branch", None, [], target=lbl)
+        else:
+            self.emit("v_cmp_lt_f32", VCC, [F(self.cfg.thr), V(T_SW)])
+            self.emit("s_cbranch_vccnz", None, [], target=lbl)
+        self.label(lbl + "_BACK")
 
     def decide_3(self):
         for rb in range(2):
@@ -787,6 +817,11 @@ class Stream:
         for kind, lbl, back, par, first in self.outofline:
             self.label(lbl)
             if kind == "dec" and cfg.fold:
+                if cfg.fastdec:   # v[T_SW] = [maxima of row block 0 | of row block 1] -> both blocks' row maxima in every lane
+                    self.emit("v_mov_b32", V(T_MN), [V(T_SW)])
+                    self.emit("v_mov_b32", V(T_MN + 1), [V(T_SW)])
+                    self.emit("s_nop", None, [I(1)], note="VALU write -> permlane read")
+                    self.emit("v_permlane32_swap_b32", V(T_MN), [V(T_MN + 1)], swap=1)
                 # m_up = m + max(mx', 0) (first tile: m + mx'); shift = m_up - m re-bases this tile's scores, corr = 2^-shift
                 # re-bases O and l at the end of phase B (+Softmax.swift:290-301); the start block of the following tiles = -m_up
                 ta, tb = V(T_SW), V(T_SW + 1)
@@ -1072,8 +1107,8 @@ VARIANTS = {
     "BF16_THR8_ROT": Cfg("bf16", 8, 0, order_a="rot4"),
     "BF16_THR8_PAD": Cfg("bf16", 8, 0, pad=1),
     "BF16_THR8_PROF": Cfg("bf16", 8, 0, prof=1),
-    "BF16_FOLD": Cfg("bf16", 8, fold=1, xb=40, bal=2),
-    "F16_FOLD": Cfg("f16", 8, fold=1, xb=40, bal=2),
+    "BF16_FOLD": Cfg("bf16", 8, fold=1, xb=48, bal=2, fastdec=1),
+    "F16_FOLD": Cfg("f16", 8, fold=1, xb=48, bal=2, fastdec=1),
     "BF16_FOLD_XB24": Cfg("bf16", 8, fold=1, xb=24),
     "BF16_FOLD_PROF": Cfg("bf16", 8, fold=1, xb=40, prof=1),
     "BF16_THR8_TR": Cfg("bf16", 8, 0, tr=3),

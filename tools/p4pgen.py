@@ -74,8 +74,8 @@ IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qre
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0):
-        Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0)
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0):
+        Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
         # computed per block inside the stream; the block table lists the blocks in pairs (long, short) like attn_fwd16_p4's
@@ -775,20 +775,20 @@ def render(instrs):
 
 VARIANTS = {
     # name: cfg            (X-macro columns: folds the scale, 16-bit O, FP16 L)
-    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40),          # headline: mixed-precision mode, fp32 O, FP16 L
-    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1, bal=2, xb=40),
+    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1),          # headline: mixed-precision mode, fp32 O, FP16 L
+    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1),
     "BF16_EXACT": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8),                    # lowPrecisionInputs only: scale in fp32, fp32 O and L
     "BF16_EXACT_O16": PCfg("bf16", 8, fold=0, o16=1, bal=2, xe=32, cap=8),
-    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1, bal=2, xb=40),
-    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1, bal=2, xb=40),
+    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1),
+    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1),
     "F16_EXACT": PCfg("f16", 8, fold=0, bal=2, xe=32, cap=8),
     "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1, bal=2, xe=32, cap=8),
-    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=40),
-    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=40),
+    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
+    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
     "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1, bal=2, xe=32, cap=8),
     "BF16_EXACT_O16_CAUSAL": PCfg("bf16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8),
-    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1, bal=2, xb=40),
-    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=40),
+    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
+    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
     "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1, bal=2, xe=32, cap=8),
     "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8),
     "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
@@ -813,6 +813,11 @@ VARIANTS = {
     "ABL_BAL2_DMA": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("dma",)),
     "ABL_BAL2_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("bar",)),
     "ABL_BAL2_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
+    "BAL2_40_FD": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, fastdec=1),
+    "BAL2_48_FD": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1),
+    "BAL2_48_FD1": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fdpos=1),
+    "BAL2_48_FD2": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fdpos=2),
+    "BAL2_56_FD": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=56, fastdec=1),
     "BAL2_48": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48),
     "BAL2_56": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=56),
     "BAL2_40_C8": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=40, cap=8),

@@ -26,16 +26,16 @@ namespace p6 {
 constexpr int VRING = MFA_P6_VRING, QIMG = MFA_P6_QIMG, TABLE = MFA_P6_TABLE, TABLE_ENTRIES = MFA_P6_TABLE_ENTRIES, STAGE = MFA_P6_STAGE,
               LDS_BYTES = MFA_P6_LDS_BYTES;
 
-#define MFA_P6_ENUM(name, f16, fold, o16, l16) S_##name,
+#define MFA_P6_ENUM(name, f16, fold, o16, l16, causal) S_##name,
 enum : int { MFA_P6_STREAM_LIST(MFA_P6_ENUM) S_COUNT };
 #undef MFA_P6_ENUM
 
-struct StreamTraits { bool f16, fold, o16, l16; };
+struct StreamTraits { bool f16, fold, o16, l16, causal; };
 constexpr StreamTraits traits(int s) {
-#define MFA_P6_TRAITS(name, f16, fold, o16, l16) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0};
+#define MFA_P6_TRAITS(name, f16, fold, o16, l16, causal) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, causal != 0};
   MFA_P6_STREAM_LIST(MFA_P6_TRAITS)
 #undef MFA_P6_TRAITS
-  return StreamTraits{false, false, false, false};
+  return StreamTraits{false, false, false, false, false};
 }
 
 }  // namespace p6
@@ -45,11 +45,12 @@ constexpr StreamTraits traits(int s) {
                : [lim0] "+v"(lim0), [lim1] "+v"(lim1)                                                                     \
                : [kbase] "v"(kbase), [vbase] "v"(vbase), [kv0] "v"(kv[0]), [kv1] "v"(kv[1]), [vv] "v"(vv),                \
                  [qv0] "v"(qv[0]), [qv1] "v"(qv[1]), [ov0] "v"(ov[0]), [ov1] "v"(ov[1]), [lv] "v"(lv),                    \
-                 [ewa] "v"(ewa), [era] "v"(era),                                                                          \
+                 [ewa] "v"(ewa), [era] "v"(era), [qlane] "v"(qlane), [hi4] "v"(hi4),                                      \
                  [nt] "s"(nt), [maskfrom] "s"(maskfrom), [scale2] "s"(a.scale2), [kinc] "s"(kinc), [vinc] "s"(vinc),      \
                  [ldsk] "s"(ldsk), [ldsv] "s"(ldsv), [ldsq] "s"(ldsq), [qrel] "s"(qrel), [ldsst] "s"(ldsst),              \
                  [nblk] "s"(nblk), [tbl] "s"(tbl), [wave64] "s"(wave64), [ldq2] "s"(ldq2), [ldo] "s"(ldob),               \
-                 [nrecq] "s"(nrecq), [nreck] "s"(nreck), [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl)       \
+                 [nrecq] "s"(nrecq), [nreck] "s"(nreck), [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl),      \
+                 [coff] "s"(coff), [cm1] "s"(cm1), [rr] "s"(R), [ttot] "s"(ttot)                                          \
                : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_P6_OWNED_VGPRS, MFA_P6_OWNED_SGPRS)
 
 // T: __bf16 or _Float16 (must match the stream); STREAM: p6::S_*.  `total` = row blocks x heads x batches; workgroup w of G takes
@@ -67,23 +68,45 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   const int lane = tid & 63, q = lane & 31, hi = lane >> 5;
   const uint32_t G = gridDim.x, first = blockIdx.x;
   if (first >= total) return;
-  const uint32_t nblocks = (total - first + G - 1) / G;   // <= TABLE_ENTRIES - 1 (the launcher sizes the grid)
+  const uint32_t nunits = (total - first + G - 1) / G;   // blocks per unit x nunits <= TABLE_ENTRIES - 1 (the launcher sizes the grid)
 
-  // ---- block table (64-byte entries: Q, K, V, O, L base of the block's head, first row), once per workgroup
+  // ---- block table (64-byte entries: Q, K, V, O, L base of the block's head, first row), once per workgroup.  A unit is one row
+  // block (dense streams) or the PAIR of row blocks (last - i, i) (causal streams: row block i walks 4 (i + 1) key tiles, every pair
+  // the same number), the long one first
   uint32_t *table = reinterpret_cast<uint32_t *>(smem + TABLE);
-  for (uint32_t n = tid; n < nblocks; n += 256) {
+  Fwd16Grid dgrid = grid;
+  const uint32_t RB = grid.rowBlocks;
+  if constexpr (TR.causal) dgrid.rowBlocks = (RB + 1) / 2;
+  for (uint32_t n = tid; n < nunits; n += 256) {
     uint32_t r, head, batch;
-    fwd16_decode_block_lane(grid, first + n * G, &r, &head, &batch);
+    fwd16_decode_block_lane(dgrid, first + n * G, &r, &head, &batch);
     const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
                               (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
                               (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
-    uint32_t *e = table + 16 * n;
+    // causal, odd block count: the middle block is its own pair -- the units before it in this workgroup's list hold two entries
+    // each unless they are middle blocks themselves (counted, not assumed)
+    uint32_t pos = TR.causal ? 2 * n : n;
+    if constexpr (TR.causal) {
+      if (RB & 1u) {
+        for (uint32_t i = 0; i < n; ++i) {
+          uint32_t ri, hi_, bi;
+          fwd16_decode_block_lane(dgrid, first + i * G, &ri, &hi_, &bi);
+          if (ri == RB - 1 - ri) --pos;
+        }
+      }
+    }
+    const uint32_t rows[2] = {TR.causal ? RB - 1 - r : r, r};
+    const int count = (TR.causal && rows[0] != rows[1]) ? 2 : 1;
+    for (int w = 0; w < count; ++w) {
+      uint32_t *e = table + 16 * (pos + w);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
-    e[10] = r * GROWS;
+      for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
+      e[10] = rows[w] * GROWS;
+    }
+    if (n == nunits - 1) table[16 * TABLE_ENTRIES - 1] = pos + count;   // blocks of this workgroup (the last table word is never an entry's)
   }
   __syncthreads();
-  const uint32_t nblk = nblocks;
+  const uint32_t nblk = __builtin_amdgcn_readfirstlane(table[16 * TABLE_ENTRIES - 1]);
 
   const uint32_t R = a.R, C = a.C, dr = a.D;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2, ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
@@ -97,7 +120,8 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   uint32_t nt = ((C + BC - 1) / BC + 3u) / 4u * 4u;
   const uint32_t maskfrom = C / BC;
   // register r of a lane covers key (r & 3) + 8 (r >> 2) + 4 hi of its 32-key block; every row sees all C keys
-  int lim0 = (int)C - 1 - 4 * hi, lim1 = lim0;
+  int lim0 = (int)C - 1 - 4 * hi, lim1 = lim0;   // (causal streams recompute both limits per block: min(C - 1, row + C - R) - 4 hi)
+  const uint32_t qlane = q, hi4 = 4 * hi, coff = C - R, cm1 = C - 1, ttot = (C + BC - 1) / BC;
 
   // ---- lane parts of the LDS-DMA source offsets (the stream adds the scalar parts).  K-shaped images (K tiles, the wave's Q
   // image): rows of 128 bytes, a 1 KiB piece = 8 rows; the 16-byte position (lane & 7) of row 8 i + (lane >> 3) holds chunk
@@ -131,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   const uint32_t ldsk = lds0 + wave * 2048, ldsv = lds0 + VRING + (wave >> 1) * 4096 + (wave & 1) * 2048;
   const uint32_t qrel = QIMG + wave * 8192, ldsq = lds0 + qrel, tbl = lds0 + TABLE, wave64 = wave * 64, ldsst = lds0 + STAGE + wave * 4096;
 
-#define MFA_P6_RUN(name, f16, fold, o16, l16) if constexpr (STREAM == S_##name) MFA_P6_RUN_STREAM(MFA_P6_STREAM_##name);
+#define MFA_P6_RUN(name, f16, fold, o16, l16, causal) if constexpr (STREAM == S_##name) MFA_P6_RUN_STREAM(MFA_P6_STREAM_##name);
   MFA_P6_STREAM_LIST(MFA_P6_RUN)
 #undef MFA_P6_RUN
 }

@@ -35,15 +35,18 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
       d.attrMask[STREAM] = 1;
     }
   }
-  const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
+  // units: row blocks, or (causal) pairs of row blocks -- two table entries each
+  constexpr bool CAUSAL = p6::traits(STREAM).causal;
+  constexpr uint64_t PER_UNIT = CAUSAL ? 2 : 1;
+  const uint64_t total = (uint64_t)(CAUSAL ? (grid.x + 1) / 2 : grid.x) * grid.y * grid.z;
   // one workgroup per compute unit; more only when a workgroup's share would not fit the block table.  A multiple of 8 keeps
   // fwd16_decode_block's head -> XCD affinity for every block of a workgroup
   uint64_t groups = total < (uint64_t)cus ? total : (uint64_t)cus;
-  constexpr uint64_t MAX_BLOCKS = p6::TABLE_ENTRIES - 1;
-  if ((total + groups - 1) / groups > MAX_BLOCKS) groups = (total + MAX_BLOCKS - 1) / MAX_BLOCKS;
+  constexpr uint64_t MAX_UNITS = (p6::TABLE_ENTRIES - 1) / PER_UNIT;   // (the table's last word holds the block count)
+  if ((total + groups - 1) / groups > MAX_UNITS) groups = (total + MAX_UNITS - 1) / MAX_UNITS;
   if (groups >= 8) groups = (groups + 7) / 8 * 8;
   if (groups > total) groups = total;
-  if ((total + groups - 1) / groups > MAX_BLOCKS) return false;
+  if ((total + groups - 1) / groups > MAX_UNITS) return false;
   Fwd16Grid g{grid.x, grid.y, grid.z};
   hipLaunchKernelGGL((attn_fwd16_p6<T, STREAM>), dim3((uint32_t)groups), dim3(256), p6::LDS_BYTES, stream, args, g, (uint32_t)total);
   return true;
@@ -51,7 +54,8 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
 
 bool serves(int precision, bool fold, const KernelArgs &args) {
   if (precision != PREC_BF16 && precision != PREC_FP16) return false;
-  if (args.rowLen || args.colLen || args.mask || args.causal) return false;
+  if (args.rowLen || args.colLen || args.mask) return false;
+  if (args.causal && args.C < args.R) return false;
   if (args.D > 64 || args.D % 8) return false;
   const int po = args.op[SLOT_O].precision, pl = args.op[SLOT_L].precision;
   if (po != precision && po != PREC_FP32) return false;
@@ -70,8 +74,8 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
   if (std::getenv("MFA_P6_OFF")) return false;
   if (const char *want = std::getenv("MFA_P6_DEV_STREAM")) {
     if (*want && precision == PREC_BF16 && args.op[SLOT_O].precision == PREC_FP32) {
-#define MFA_P6_BYNAME(name, f16, sfold, o16, l16) \
-      if constexpr (!f16 && !o16) { if ((sfold != 0) == fold && std::strcmp(want, #name) == 0) return launch_stream<__bf16, p6::S_##name>(grid, stream, args); }
+#define MFA_P6_BYNAME(name, f16, sfold, o16, l16, scausal) \
+      if constexpr (!f16 && !o16) { if ((sfold != 0) == fold && (scausal != 0) == (args.causal != 0) && std::strcmp(want, #name) == 0) return launch_stream<__bf16, p6::S_##name>(grid, stream, args); }
       MFA_P6_DEV_STREAM_LIST(MFA_P6_BYNAME)
 #undef MFA_P6_BYNAME
       return false;
@@ -79,12 +83,16 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
   }
 #endif
   const bool o16 = args.op[SLOT_O].precision != PREC_FP32;
-  if (precision == PREC_BF16) {
-    if (fold) return o16 ? launch_stream<__bf16, p6::S_BF16_FOLD_O16_L16>(grid, stream, args) : launch_stream<__bf16, p6::S_BF16_FOLD_L16>(grid, stream, args);
-    return o16 ? launch_stream<__bf16, p6::S_BF16_EXACT_O16>(grid, stream, args) : launch_stream<__bf16, p6::S_BF16_EXACT>(grid, stream, args);
-  }
-  if (fold) return o16 ? launch_stream<_Float16, p6::S_F16_FOLD_O16_L16>(grid, stream, args) : launch_stream<_Float16, p6::S_F16_FOLD_L16>(grid, stream, args);
-  return o16 ? launch_stream<_Float16, p6::S_F16_EXACT_O16>(grid, stream, args) : launch_stream<_Float16, p6::S_F16_EXACT>(grid, stream, args);
+#define MFA_P6_PICK(T, PFX)                                                                                                          \
+  if (args.causal) {                                                                                                                 \
+    if (fold) return o16 ? launch_stream<T, p6::S_##PFX##_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p6::S_##PFX##_FOLD_L16_CAUSAL>(grid, stream, args); \
+    return o16 ? launch_stream<T, p6::S_##PFX##_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p6::S_##PFX##_EXACT_CAUSAL>(grid, stream, args); \
+  }                                                                                                                                  \
+  if (fold) return o16 ? launch_stream<T, p6::S_##PFX##_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p6::S_##PFX##_FOLD_L16>(grid, stream, args); \
+  return o16 ? launch_stream<T, p6::S_##PFX##_EXACT_O16>(grid, stream, args) : launch_stream<T, p6::S_##PFX##_EXACT>(grid, stream, args);
+  if (precision == PREC_BF16) { MFA_P6_PICK(__bf16, BF16) }
+  MFA_P6_PICK(_Float16, F16)
+#undef MFA_P6_PICK
 }
 
 const char *p6_form(int precision, bool fold, const KernelArgs &args) {
@@ -92,6 +100,9 @@ const char *p6_form(int precision, bool fold, const KernelArgs &args) {
 #ifdef MFA_DEV_VARIANTS
   if (std::getenv("MFA_P6_OFF")) return nullptr;
 #endif
+  if (args.causal)
+    return fold ? "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row-block pairs; row sums in the matrix pipe)"
+                : "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row-block pairs)";
   return fold ? "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row blocks; row sums in the matrix pipe)"
               : "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row blocks)";
 }
@@ -101,6 +112,11 @@ void fwd16_v3_d64_launch(int precision, dim3 grid, hipStream_t stream, const Ker
 template <int PREC, bool FOLD> static void launch_p6_or_v3(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   if (launch_p6(PREC, FOLD, grid, stream, args)) return;
   fwd16_v3_d64_launch(PREC, grid, stream, args);
+}
+void fwd16_v3_d64_launch_causal(int precision, dim3 grid, hipStream_t stream, const KernelArgs &args);   // attn_fwd16_v3.hip
+template <int PREC, bool FOLD> static void launch_p6_or_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+  if (launch_p6(PREC, FOLD, grid, stream, args)) return;
+  fwd16_v3_d64_launch_causal(PREC, grid, stream, args);
 }
 template <int PREC, bool FOLD> static const char *p6_form_of(const KernelArgs &args) { return p6_form(PREC, FOLD, args); }
 
@@ -118,11 +134,11 @@ bool fwd16_p6_variant(int precision, bool fold, VariantInfo *out) {
   out->threads = 256;
   out->ldsBytes = out->ldsBytes > (uint32_t)p6::LDS_BYTES ? out->ldsBytes : (uint32_t)p6::LDS_BYTES;
   if (precision == PREC_BF16) {
-    if (fold) { out->launch = &launch_p6_or_v3<PREC_BF16, true>; out->launchForm = &p6_form_of<PREC_BF16, true>; }
-    else { out->launch = &launch_p6_or_v3<PREC_BF16, false>; out->launchForm = &p6_form_of<PREC_BF16, false>; }
+    if (fold) { out->launch = &launch_p6_or_v3<PREC_BF16, true>; out->launchCausal = &launch_p6_or_v3_causal<PREC_BF16, true>; out->launchForm = &p6_form_of<PREC_BF16, true>; }
+    else { out->launch = &launch_p6_or_v3<PREC_BF16, false>; out->launchCausal = &launch_p6_or_v3_causal<PREC_BF16, false>; out->launchForm = &p6_form_of<PREC_BF16, false>; }
   } else {
-    if (fold) { out->launch = &launch_p6_or_v3<PREC_FP16, true>; out->launchForm = &p6_form_of<PREC_FP16, true>; }
-    else { out->launch = &launch_p6_or_v3<PREC_FP16, false>; out->launchForm = &p6_form_of<PREC_FP16, false>; }
+    if (fold) { out->launch = &launch_p6_or_v3<PREC_FP16, true>; out->launchCausal = &launch_p6_or_v3_causal<PREC_FP16, true>; out->launchForm = &p6_form_of<PREC_FP16, true>; }
+    else { out->launch = &launch_p6_or_v3<PREC_FP16, false>; out->launchCausal = &launch_p6_or_v3_causal<PREC_FP16, false>; out->launchForm = &p6_form_of<PREC_FP16, false>; }
   }
   return true;
 }

@@ -16,6 +16,18 @@ import p4psim  # noqa: E402
 FOLD = p6gen.VARIANTS["BF16_FOLD_L16"]
 
 
+def _pairs(H, R):
+    """the causal launch's table order: per head the pairs (last - i, i) of row blocks, the long one first"""
+    nrb = (R + 255) // 256
+    out = []
+    for h in range(H):
+        for p in range((nrb + 1) // 2):
+            out.append((h, nrb - 1 - p))
+            if p != nrb - 1 - p:
+                out.append((h, p))
+    return out
+
+
 def _check(H, R, C, cfg=FOLD, blocks=None, seed=0, D=64, spike=None, tol_o=None, **kw):
     rng = np.random.default_rng(seed)
     f16 = cfg.dtype == "f16"
@@ -26,12 +38,12 @@ def _check(H, R, C, cfg=FOLD, blocks=None, seed=0, D=64, spike=None, tol_o=None,
         k[0, krow] = p4psim.f32_to_h16((qf * gain).astype(np.float32), f16).astype(np.uint16)
     nrb = (R + 255) // 256
     if blocks is None:
-        blocks = [(h, rb) for h in range(H) for rb in range(nrb)]
+        blocks = _pairs(H, R) if cfg.causal else [(h, rb) for h in range(H) for rb in range(nrb)]
     O, L, wg, raw = p6sim.run_workgroup(q, k, v, blocks, cfg, D=D, **kw)
     tol_o = tol_o or ((3e-2 if not f16 else 4e-3) if cfg.o16 else 6e-3)   # (bf16 P, few keys: the rounding of P does not average out)
     tol_l = (2e-2 if cfg.l16 else 2e-5) + (6e-4 if f16 else 5e-3)
     for h, rb in blocks:
-        Oref, Lref = p4psim.reference(q[h], k[h], v[h], causal=False, f16=f16)
+        Oref, Lref = p4psim.reference(q[h], k[h], v[h], causal=bool(cfg.causal), f16=f16)
         rows = slice(rb * 256, min(R, rb * 256 + 256))
         dO, dL = np.abs(O[h, rows] - Oref[rows]).max(), np.abs(L[h, rows] - Lref[rows]).max()
         assert dO < tol_o and dL < tol_l * max(1.0, np.abs(Lref[rows]).max() / 8), (h, rb, dO, dL)
@@ -102,7 +114,28 @@ def test_every_stream(name):
     cfg = p6gen.VARIANTS[name]
     if cfg.abl:
         pytest.skip("timing-only ablation")
-    _check(2, 256, 200, cfg=cfg, seed=6)
+    _check(2, 256, 320 if cfg.causal else 200, cfg=cfg, seed=6)     # (causal needs C >= R)
+
+
+CAUSAL_FOLD = p6gen.VARIANTS["BF16_FOLD_L16_CAUSAL"]
+CAUSAL_EXACT = p6gen.VARIANTS["BF16_EXACT_CAUSAL"]
+
+
+@pytest.mark.parametrize("H,R,C", [(1, 512, 512), (2, 768, 768), (1, 300, 400), (1, 700, 1000), (1, 256, 256), (1, 1280, 1280)])
+def test_causal_pairs(H, R, C):
+    """row r sees key c iff c <= r + C - R: per block the stream computes its tile count (a multiple of four), the first masked
+    tile of each wave and the lanes' limits; every wave walks all of the block's tiles (keys beyond its diagonal are masked)"""
+    _check(H, R, C, cfg=CAUSAL_FOLD, seed=10, dma_mode="late")
+
+
+@pytest.mark.parametrize("order", [(0, 1, 2, 3), (3, 2, 1, 0)])
+def test_causal_exact_and_wave_orders(order):
+    _check(1, 768, 832, cfg=CAUSAL_EXACT, seed=11, order=order)
+    _check(2, 512, 512, cfg=CAUSAL_FOLD, seed=12, order=order, stores="early")
+
+
+def test_causal_blocks_in_any_table_order():
+    _check(1, 1024, 1024, cfg=CAUSAL_FOLD, blocks=[(0, 0), (0, 3), (0, 1), (0, 2)], seed=13)
 
 
 @pytest.mark.parametrize("D", [8, 40, 56])

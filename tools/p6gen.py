@@ -66,19 +66,19 @@ UNROLL = 4                       # tiles per loop body = ring size: a block walk
 PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
              qbn=(56, 2), kbn=(58, 2), vbn=(60, 2), obn=(62, 2), lbn=(64, 2), row0n=(66, 1),
              ob=(68, 2), lb=(70, 2), row0=(72, 1), blk=(73, 1), hasnext=(74, 1), ntm2=(75, 1), ntm3=(76, 1),
-             j=(77, 1), ring=(78, 1), rk1=(79, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
-             kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), rk2=(89, 1), rk3=(90, 1), q8=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1))
+             j=(77, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
+             kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), maskb=(90, 1), q8=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1))
 FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 97
 FIRST_OWNED_VGPR = 28
 
 INOUT_V = ["lim0", "lim1"]
-IN_V = ["kbase", "vbase", "kv0", "kv1", "vv", "qv0", "qv1", "ov0", "ov1", "lv", "ewa", "era"]
+IN_V = ["kbase", "vbase", "kv0", "kv1", "vv", "qv0", "qv1", "ov0", "ov1", "lv", "ewa", "era", "qlane", "hi4"]
 IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qrel", "ldsst", "nblk", "tbl", "wave64", "ldq2", "ldo",
-        "nrecq", "nreck", "nrecv", "nreco", "nrecl"]
+        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "coff", "cm1", "rr", "ttot"]
 
 
 class Cfg6(p4gen.Cfg):
-    def __init__(self, dtype="bf16", thr=8.0, xb=56, o16=0, l16=1, lsum=1, abl=(), pad=0, vlast=7, kearly=1, fold=1):
+    def __init__(self, dtype="bf16", thr=8.0, xb=56, o16=0, l16=1, lsum=1, abl=(), pad=0, vlast=7, kearly=1, fold=1, causal=0):
         """fold = 0: EXACT-SCALE streams (descriptors that keep the attention matrix in FP32 registers): Q stays as stored, the scale
         is applied in fp32 per score (s * scale2 - m, 64 more vector instructions per tile), the row sums are fp32 additions of
         the unrounded P (no `lsum`), L is stored in FP32.  xb = scores per tile whose exponential phase B takes (both kinds)"""
@@ -88,7 +88,11 @@ class Cfg6(p4gen.Cfg):
         if not fold:
             lsum, l16 = 0, 0
         self.o16, self.l16, self.lsum = o16, l16, lsum
-        self.causal = 0
+        # causal (extension: row r sees key c iff c <= r + C - R): tile count (a multiple of four), first masked tile and the lanes'
+        # mask limits are computed per block inside the stream; EVERY wave walks the block's tiles (the keys beyond a wave's own
+        # diagonal are masked like a ragged edge: 1.5 of a block's 4 (rb + 1) tiles on average) -- no per-wave traversal bound, no
+        # skip loop.  The block table lists the blocks in pairs (long, short) so that every workgroup walks the same number of tiles
+        self.causal = causal
         # vlast: last gap of phase A with a V^T read; kearly: the K(j+1) fragment reads right behind the LDS-DMA pieces of phase B
         # (else spread between its exponentials, the last one near the phase's end -- the first GPU runs lost ~250 clocks per tile
         # to the two `lgkmcnt(0)` in front of the phase seams, profiles/r05_p6_ablations_first.txt)
@@ -156,6 +160,8 @@ class Stream6(Stream):
                 return None
             if o[0] == "V" and o[1] in self.vfixed:
                 return V(self.vfixed[o[1]])
+            if o[0] == "S" and self.cfg.causal and o[1] in ("nt", "maskfrom"):
+                return SR(PSGPR[{"nt": "ntb", "maskfrom": "maskb"}[o[1]]][0], 1)
             if o[0] == "S" and o[1] == "wnt":
                 return ("S", "nt", 1)
             if o[0] == "S" and o[1] in PSGPR:
@@ -630,6 +636,8 @@ class Stream6(Stream):
             self.emit("s_mov_b32", s(name, 1, 0), [s(name + "n", 1, 0)])
             self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
         self.emit("s_mov_b32", s("row0"), [s("row0n")])
+        if self.cfg.causal:
+            self.block_geometry()
         self.emit("s_add_u32", s("blk"), [s("blk"), I(1)])
         self.emit("s_mov_b32", s("hasnext"), [I(0)])
         self.emit("s_cmp_ge_u32", None, [s("blk"), SN("nblk")])
@@ -637,6 +645,34 @@ class Stream6(Stream):
         self.emit("s_mov_b32", s("hasnext"), [I(1)])
         self.load_next()
         self.label(nonext)
+
+    def block_geometry(self):
+        """causal streams, per block: tile count (made a multiple of four), first tile that needs masking for this wave, the lanes'
+        mask limits min(C - 1, row + C - R) - 4 hi"""
+        t0, t2, t3 = s("t0"), s("t2"), s("t3")
+        self.emit("s_add_u32", t0, [s("row0"), I(256)])
+        self.emit("s_min_u32", t0, [t0, SN("rr")])
+        self.emit("s_sub_u32", t0, [t0, I(1)])                       # last row of the block
+        self.emit("s_add_u32", t0, [t0, SN("coff")])
+        self.emit("s_lshr_b32", t0, [t0, I(6)])
+        self.emit("s_add_u32", t0, [t0, I(1)])
+        self.emit("s_min_u32", t0, [t0, SN("ttot")])                 # tiles the block's last row can see
+        self.emit("s_add_u32", t0, [t0, I(3)])
+        self.emit("s_and_b32", s("ntb"), [t0, I(0xFFFFFFFC)])
+        self.emit("s_sub_u32", s("ntm2"), [s("ntb"), I(2)])
+        self.emit("s_sub_u32", s("ntm3"), [s("ntb"), I(3)])
+        self.emit("s_add_u32", t2, [s("row0"), SN("wave64")])        # first row of the wave
+        self.emit("s_add_u32", t3, [t2, SN("coff")])
+        self.emit("s_min_u32", t0, [t3, SN("cm1")])
+        self.emit("s_add_u32", t0, [t0, I(1)])
+        self.emit("s_lshr_b32", s("maskb"), [t0, I(6)])              # first tile with a key the wave's first row may not see (or >= C)
+        for rb in range(2):
+            if rb:
+                self.emit("s_add_u32", t3, [t3, I(32)])
+            lim = VN("lim%d" % rb)
+            self.emit("v_add_u32", lim, [t3, VN("qlane")])
+            self.emit("v_min_u32", lim, [SN("cm1"), lim])
+            self.emit("v_sub_u32", lim, [lim, VN("hi4")])
 
     def block_init(self):
         cfg = self.cfg
@@ -663,8 +699,9 @@ class Stream6(Stream):
         one = 0x3F803F80 if cfg.dtype == "bf16" else 0x3C003C00
         for r in range(4):
             self.emit("v_mov_b32", V(ONES + r), [I(one)])
-        self.emit("s_sub_u32", s("ntm2"), [SN("nt"), I(2)])
-        self.emit("s_sub_u32", s("ntm3"), [SN("nt"), I(3)])
+        if not cfg.causal:
+            self.emit("s_sub_u32", s("ntm2"), [SN("nt"), I(2)])
+            self.emit("s_sub_u32", s("ntm3"), [SN("nt"), I(3)])
         # scalar parts of the LDS-DMA start offsets: K piece i begins at row 16 wave + 8 i, V piece i at key 16 i (+ the lane part)
         self.emit("s_lshr_b32", s("t0"), [SN("kinc"), I(6)])                 # 2 ld(K)
         self.emit("s_lshr_b32", s("t2"), [SN("wave64"), I(2)])               # 16 wave
@@ -748,6 +785,14 @@ VARIANTS = {
     "BF16_FOLD_O16_L16": Cfg6("bf16", 8, o16=1, l16=1),
     "F16_FOLD_L16": Cfg6("f16", 8, l16=1),
     "F16_FOLD_O16_L16": Cfg6("f16", 8, o16=1, l16=1),
+    "BF16_FOLD_L16_CAUSAL": Cfg6("bf16", 8, l16=1, causal=1),
+    "BF16_FOLD_O16_L16_CAUSAL": Cfg6("bf16", 8, o16=1, l16=1, causal=1),
+    "F16_FOLD_L16_CAUSAL": Cfg6("f16", 8, l16=1, causal=1),
+    "F16_FOLD_O16_L16_CAUSAL": Cfg6("f16", 8, o16=1, l16=1, causal=1),
+    "BF16_EXACT_CAUSAL": Cfg6("bf16", 8, fold=0, xb=8, causal=1),
+    "BF16_EXACT_O16_CAUSAL": Cfg6("bf16", 8, fold=0, xb=8, o16=1, causal=1),
+    "F16_EXACT_CAUSAL": Cfg6("f16", 8, fold=0, xb=8, causal=1),
+    "F16_EXACT_O16_CAUSAL": Cfg6("f16", 8, fold=0, xb=8, o16=1, causal=1),
     "BF16_EXACT": Cfg6("bf16", 8, fold=0, xb=8),               # lowPrecisionInputs only: scale in fp32, fp32 row sums, FP32 L
     "BF16_EXACT_O16": Cfg6("bf16", 8, fold=0, xb=8, o16=1),
     "F16_EXACT": Cfg6("f16", 8, fold=0, xb=8),
@@ -771,7 +816,8 @@ VARIANTS = {
     "ABL_ALL": Cfg6("bf16", 8, l16=1, abl=("dma", "exp", "max", "pack", "lds")),
     "ABL_ALL_NOBAR": Cfg6("bf16", 8, l16=1, abl=("dma", "exp", "max", "pack", "lds", "bar")),
 }
-PRODUCT_STREAMS = ("BF16_FOLD_L16", "BF16_FOLD_O16_L16", "F16_FOLD_L16", "F16_FOLD_O16_L16", "BF16_EXACT", "BF16_EXACT_O16", "F16_EXACT", "F16_EXACT_O16")
+PRODUCT_STREAMS = tuple(n for n in VARIANTS if n.split("_")[0] in ("BF16", "F16") and n.split("_")[1] in ("FOLD", "EXACT") and
+                        all(t in ("BF16", "F16", "FOLD", "EXACT", "O16", "L16", "CAUSAL") for t in n.split("_")))
 
 
 def write_inc(path):
@@ -783,17 +829,17 @@ def write_inc(path):
                       ("LDS_BYTES", LDS_BYTES)):
         lines.append("#define MFA_P6_%s %d" % (name, val))
     lines.append("")
-    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16)")
+    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16, causal)")
     lines.append("#define MFA_P6_PRODUCT_STREAM_LIST(X) \\")
     for name in PRODUCT_STREAMS:
         cfg = VARIANTS[name]
-        lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16))
+        lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates")
     lines.append("#define MFA_P6_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name not in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
     lines.append("")
     lines.append("#ifdef MFA_DEV_VARIANTS")
     lines.append("#define MFA_P6_STREAM_LIST(X) MFA_P6_PRODUCT_STREAM_LIST(X) MFA_P6_DEV_STREAM_LIST(X)")
@@ -807,8 +853,8 @@ def write_inc(path):
         if name not in PRODUCT_STREAMS:
             lines.append("#ifdef MFA_DEV_VARIANTS")
         n_mfma = sum(1 for i in ins if i.op.startswith("v_mfma"))
-        lines.append("// %s: dtype=%s thr=%g fold=%d xb=%d o16=%d l16=%d lsum=%d -- %d instructions, %d matrix instructions"
-                     % (name, cfg.dtype, cfg.thr, cfg.fold, cfg.xb, cfg.o16, cfg.l16, cfg.lsum, len(txt), n_mfma))
+        lines.append("// %s: dtype=%s thr=%g fold=%d xb=%d o16=%d l16=%d lsum=%d causal=%d -- %d instructions, %d matrix instructions"
+                     % (name, cfg.dtype, cfg.thr, cfg.fold, cfg.xb, cfg.o16, cfg.l16, cfg.lsum, cfg.causal, len(txt), n_mfma))
         lines.append("#define MFA_P6_STREAM_%s \\" % name)
         for t in txt:
             lines.append('  "%s\\n\\t" \\' % t)

@@ -60,6 +60,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=64, dma_mode="late", stores="late", or
             "ewa": (qq * 128 + ((hi ^ (qq & 7)) << 4)).astype(np.uint32),
             "era": ((lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4)).astype(np.uint32),
             "kv0": kv[0], "kv1": kv[1], "qv0": qv[0], "qv1": qv[1],
+            "qlane": qq.astype(np.uint32), "hi4": (4 * hi).astype(np.uint32),
         })
         for db in range(2):
             col = 32 * db + 4 * (lane & 7)
@@ -69,7 +70,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=64, dma_mode="late", stores="late", or
                      "ldsq": p6gen.QIMG + wave * 8192, "qrel": p6gen.QIMG + wave * 8192, "ldsst": p6gen.STAGE + wave * 4096,
                      "nblk": len(blocks), "tbl": p6gen.TABLE, "wave64": wave * 64,
                      "ldq2": ldq2, "ldo": ldo * osz, "nrecq": R * ldq2, "nreck": C * ldk2, "nrecv": C * ldv2,
-                     "nreco": R * ldo * osz, "nrecl": R * lsz})
+                     "nreco": R * ldo * osz, "nrecl": R * lsz, "coff": C - R, "cm1": C - 1, "rr": R, "ttot": (C + 63) // 64})
     wg.run(order)
     for w in wg.waves:
         assert not w.lds_q, "LDS reads left in flight"

@@ -303,7 +303,7 @@ def main():
     # i.e. lowPrecisionIntermediates = false (scale applied in fp32 per score, L stored in FP32): the same shape, same inputs,
     # same process, timed right behind it and reported in config.fp32_intermediates
     other_mode = None
-    if args.workload == "fwd_bf16_d128":
+    if args.workload in ("fwd_bf16_d128", "fwd_bf16_d64"):
         desc2 = AttentionDescriptor()
         desc2.lowPrecisionInputs, desc2.lowPrecisionIntermediates = True, False
         desc2.lowPrecisionInputType = P.BF16
@@ -364,7 +364,10 @@ def main():
                    "control_plane": "gloo" if world > 1 else "none", "devices_visible": ndev,
                    "spinup_steps": spinup_steps,
                    "cold_start_ms_per_step": round(cold_ms_per_step, 4),
-                   "per_gpu_roofline_frac": round(achieved_tflops / peak, 4)},
+                   # (ranks SHARING a device, i.e. fewer devices than ranks: their launches serialize on it and a per-rank fraction of the
+                   # roof means nothing -- reported only with one device per rank)
+                   "per_gpu_roofline_frac": round(achieved_tflops / peak, 4) if ndev >= world else None,
+                   "ranks_share_a_device": bool(ndev < world)},
         "mfma_tflops": round(achieved_tflops * world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved_tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved_tflops / peak, 4),

@@ -77,4 +77,38 @@ const char *f32_form(int type, int DP, const KernelArgs &args) {
   return names[type][DP == 128];
 }
 
+namespace {
+template <int TYPE, int DP> const char *form_or_general(const KernelArgs &args) {
+  if (taken(TYPE, DP, args)) return nullptr;   // (the variant's own name: the FP32 production kernel runs)
+  static const char *const general[3][2] = {
+      {"attn_generic_fwd_f32mfma_d64_w4_cached (general kernel: an operand's rows are not 16-byte aligned)",
+       "attn_generic_fwd_f32mfma_d128_w4_cached (general kernel: an operand's rows are not 16-byte aligned)"},
+      {"attn_generic_dq_f32mfma_d64_w4_cached (general kernel: an operand's rows are not 16-byte aligned)",
+       "attn_generic_dq_f32mfma_d128_w4_cached (general kernel: an operand's rows are not 16-byte aligned)"},
+      {"attn_generic_dkv_f32mfma_d64_w4_cached (general kernel: an operand's rows are not 16-byte aligned)",
+       "attn_generic_dkv_f32mfma_d128_w4_cached (general kernel: an operand's rows are not 16-byte aligned)"}};
+  return general[TYPE][DP == 128];
+}
+template <int TYPE, int DP> void fill_f32(VariantInfo *v) {
+  static const char *const names[3][2] = {{"attn_f32_fwd_d64_w4x32", "attn_f32_fwd_d128_w4x32"},
+                                          {"attn_f32_dq_d64_w4x32", "attn_f32_dq_d128_w4x32"},
+                                          {"attn_f32_dkv_d64_w4x32", "attn_f32_dkv_d128_w4x32"}};
+  v->siblingName = v->name;
+  v->name = names[TYPE][DP == 128];
+  v->attrLdsBytes = v->ldsBytes;
+  v->ldsBytes = TYPE == 0 ? f32k::lds_bytes<DP>() : TYPE == 1 ? f32k::lds_bytes_dq<DP>() : f32k::lds_bytes_dkv<DP>();
+  v->launchForm = &form_or_general<TYPE, DP>;
+}
+}  // namespace
+
+bool f32_variant(int type, int DP, VariantInfo *out) {
+  if (DP != 64 && DP != 128) return false;
+  switch (type) {
+    case 0: if (DP == 64) fill_f32<0, 64>(out); else fill_f32<0, 128>(out); break;
+    case 1: if (DP == 64) fill_f32<1, 64>(out); else fill_f32<1, 128>(out); break;
+    default: if (DP == 64) fill_f32<2, 64>(out); else fill_f32<2, 128>(out); break;
+  }
+  return true;
+}
+
 }  // namespace mfa

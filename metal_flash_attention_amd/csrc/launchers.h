@@ -18,7 +18,9 @@ struct VariantInfo {
   uint16_t traversal = 0;       // columns (fwd, dQ) or rows (dK/dV) per main-loop step
   uint16_t headBlock = 0;       // padded head dimension the code object is unrolled for
   uint32_t threads = 0;         // work-items per workgroup
-  uint32_t ldsBytes = 0;        // dynamic LDS
+  uint32_t ldsBytes = 0;        // dynamic LDS of the variant's code object (mfa_attention_kernel_threadgroup_memory_allocation)
+  uint32_t attrLdsBytes = 0;    // what `func` (+ siblings) is raised to when that differs (0: ldsBytes): the FP32 production variants keep
+                                // the general kernel in `func` for the launches it still serves (attn_f32.hip raises its own kernels)
   bool cacheLeft = false;       // left-hand operands cached in VGPRs (Q / Q,dO / K,V)
   bool cacheSecond = false;     // the second of them alone (dO / V); fill code sets it = cacheLeft unless a variant splits the pair
   bool pagedAccumulators = false;   // accumulators paged through the output buffers (any-D kernels, attn_paged.h); else in registers
@@ -57,6 +59,10 @@ bool paged_variant(int type, VariantInfo *out);
 // 2 backwardKeyValue; grid as the general kernel's (blocks of 128, heads, batches).  false / nullptr: not one of theirs
 bool f32_launch(int type, int DP, dim3 grid, hipStream_t stream, const KernelArgs &args);
 const char *f32_form(int type, int DP, const KernelArgs &args);
+// FP32 descriptors with row-major operands and D % 4 == 0 at the 64 / 128 head blocks: the variant IS the FP32 production kernel
+// (own name, own LDS bytes); `out` arrives filled by generic_*_variant(DP), whose kernel becomes the sibling that keeps block-sparse
+// launches and launches whose operands miss the 16-byte row alignment
+bool f32_variant(int type, int DP, VariantInfo *out);
 bool generic_fwd_variant(int DP, VariantInfo *out);
 bool generic_dq_variant(int DP, VariantInfo *out);
 bool generic_dkv_variant(int DP, VariantInfo *out);

@@ -120,6 +120,20 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
     found = paged_variant(type, &general);
   }
   if (!found) return fail(MFA_ERR_UNSUPPORTED, "no gfx950 code object for head dimension " + std::to_string(D));
+  {
+    // FP32 descriptors (every operand FP32, nothing transposed, D % 4 == 0) at the 64 / 128 head blocks ARE the FP32 production
+    // kernels of attn_f32.h: own variant name, own LDS bytes, same block dimensions as the general kernel that stays their sibling
+    bool allF32 = (D % 4) == 0;
+    for (int slot = 0; slot < MFA_BUFFER_SLOTS && allF32; ++slot) {
+      if (!slot_used(type, slot)) continue;
+      const int op = slot_operand(slot);
+      allF32 = kdesc->memoryPrecisions[op] == MFA_FP32 && (op == MFA_L || op == MFA_D || kdesc->transposeState[op] == 0);
+    }
+#ifdef MFA_DEV_VARIANTS
+    if (std::getenv("MFA_F32_GENERAL")) allF32 = false;
+#endif
+    if (allF32) f32_variant(type, bucket, &general);
+  }
   const int pq = kdesc->memoryPrecisions[MFA_Q];
   const bool same16 = pq != MFA_FP32 && pq == kdesc->memoryPrecisions[MFA_K] && pq == kdesc->memoryPrecisions[MFA_V];
   auto f32_or_inputs = [&](int op) { return kdesc->memoryPrecisions[op] == MFA_FP32 || kdesc->memoryPrecisions[op] == pq; };
@@ -651,6 +665,18 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
                             (args->mask && type == MFA_BACKWARD_KEY_VALUE && p->row > 4096u * 256u);
   plan->useFallback = kernel->hasFallback && (relayoutMissing || otherReasons);
   plan->onlyWorkspaceMissing = kernel->hasFallback && relayoutMissing && !otherReasons;
+  // strictBlockDimensions: a backward launch on 16-bit transposed operands that has no workspace for the re-layout path and is not
+  // one the in-place kernels take would run the general fp32 kernel -- 20-50 x slower than the code object the descriptor selected
+  // (the reference reads transposed operands in place at every head dimension, AttentionKernel.swift:189-204).  A strict caller
+  // gets an error that names the remedy instead of the silent fallback
+  if (kernel->desc.strictBlockDimensions && kernel->hasFallback && relayoutMissing && type != MFA_FORWARD &&
+      !(plan->onlyWorkspaceMissing && bwd16_p4_tr_form(type, *args) != nullptr)) {
+    return fail(MFA_ERR_UNSUPPORTED,
+                std::string("strictBlockDimensions: this launch of ") + kernel->variant.name + " on transposed operands has no (or too small / "
+                "misaligned) workspace and would run the general kernel " + kernel->fallback.name + "; pass a 256-byte aligned workspace of " +
+                std::to_string(plan->workspaceNeeded) + " bytes (mfa_attention_kernel_workspace_size) for the re-layout path" +
+                ((args->rowLen || args->colLen) ? " -- not available with per-batch lengths: store the operands row-major" : ""));
+  }
   if (plan->useFallback && plan->nRelayouts) {   // (alignment, mask limits ...): the general kernel takes the user's views
     for (int i = 0; i < plan->nRelayouts; ++i) args->op[plan->relayouts[i].slot] = plan->relayouts[i].user;
     plan->nRelayouts = 0;
@@ -711,24 +737,25 @@ static bool dev_in_place_backward(const mfa_attention_kernel *kernel, const Laun
 }
 
 static mfa_status ensure_lds_attribute(mfa_attention_kernel *kernel, const LaunchPlan &plan) {
-  if (plan.variant->ldsBytes <= 64 * 1024) return MFA_OK;
+  const uint32_t attrBytes = plan.variant->attrLdsBytes > plan.variant->ldsBytes ? plan.variant->attrLdsBytes : plan.variant->ldsBytes;
+  if (attrBytes <= 64 * 1024) return MFA_OK;
   int device = 0;
   hipError_t err = hipGetDevice(&device);
   if (err != hipSuccess) return hip_fail(err, "hipGetDevice");
   std::lock_guard<std::mutex> lock(kernel->attrMutex);
   uint64_t &mask = plan.useFallback ? kernel->attrDeviceMaskFallback : kernel->attrDeviceMask;
   if (device < 64 && (mask >> device) & 1ull) return MFA_OK;
-  err = hipFuncSetAttribute(plan.variant->func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+  err = hipFuncSetAttribute(plan.variant->func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attrBytes);
   if (err == hipSuccess && plan.variant->funcCausal)
-    err = hipFuncSetAttribute(plan.variant->funcCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+    err = hipFuncSetAttribute(plan.variant->funcCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attrBytes);
   if (err == hipSuccess && plan.variant->funcSparse)
-    err = hipFuncSetAttribute(plan.variant->funcSparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+    err = hipFuncSetAttribute(plan.variant->funcSparse, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attrBytes);
   if (err == hipSuccess && plan.variant->funcSparseCausal)
-    err = hipFuncSetAttribute(plan.variant->funcSparseCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+    err = hipFuncSetAttribute(plan.variant->funcSparseCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attrBytes);
   if (err == hipSuccess && plan.variant->funcSplit)
-    err = hipFuncSetAttribute(plan.variant->funcSplit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+    err = hipFuncSetAttribute(plan.variant->funcSplit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attrBytes);
   if (err == hipSuccess && plan.variant->funcSplitCausal)
-    err = hipFuncSetAttribute(plan.variant->funcSplitCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.variant->ldsBytes);
+    err = hipFuncSetAttribute(plan.variant->funcSplitCausal, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attrBytes);
   if (err != hipSuccess) return hip_fail(err, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   if (device < 64) mask |= 1ull << device;
   return MFA_OK;

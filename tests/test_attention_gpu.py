@@ -448,6 +448,7 @@ def _full_size(R, D, low, in_type=P.BF16, backward=False, seed=0):
 
 def test_config2_forward_n4096_d64_bf16_single_head():
     ref, got, run = _full_size(4096, 64, True)
+    assert run.kernels[AttentionKernelType.forward].variant.startswith("attn_fwd16p6")   # (one head: its column-parallel sibling runs)
     assert np.abs(got["O"] - ref["O"]).max() < 5e-3 and np.abs(got["L"] - ref["L"]).max() < 1e-3
     assert all(run.tails_ok.values())
 
@@ -528,6 +529,26 @@ def test_config4_code_object_forward_n8192_d256_bf16_mixed():
     """bench.py's fwd_bf16_d256_mixed: the FOLD stream of the 64-rows-per-wave D <= 256 kernel at N = 8192."""
     report, variants = _full_size_mixed(8192, 256, P.BF16, backward=False)
     assert variants["forward"].startswith("attn_fwd16p5") and variants["forward"].endswith("_fold"), variants
+    print("full-size mixed", variants, report)
+    assert report["O"] < 5e-3 and report["L"] < 7e-3, report
+
+
+def test_d256_code_objects_forward_backward_n4096_bf16_mixed():
+    """bench.py's fwdbwd_bf16_d256_mixed: the role-split backward streams attn_dq16_p5 / attn_dkv16_p5 (and the D <= 256 forward) at
+    FULL size against the oracle, all six outputs -- the D = 128 test above covers the four-wave streams only"""
+    report, variants = _full_size_mixed(4096, 256, P.BF16, backward=True, seed=3)
+    assert variants["forward"].startswith("attn_fwd16p5") and variants["backwardQuery"].startswith("attn_dq16p5") and \
+        variants["backwardKeyValue"].startswith("attn_dkv16p5"), variants
+    print("full-size mixed", variants, report)
+    assert max(report[k] for k in ("dQ", "dK", "dV")) < 2e-2 and report["D"] < 5e-2, report
+
+
+def test_config2_code_object_forward_n4096_d64_bf16_mixed():
+    """bench.py's fwd_bf16_d64 (BASELINE config 2 in the reference's mixed-precision mode): the persistent D <= 64 stream with the
+    row sums in the matrix pipe (attn_fwd16_p6) at N = 4096: O and L against the oracle; l is the sum of the 16-bit P the second
+    product multiplies (what the reference's mixed mode sums: P lives in 16-bit registers there)"""
+    report, variants = _full_size_mixed(4096, 64, P.BF16, backward=False, seed=4)
+    assert variants["forward"].startswith("attn_fwd16p6") and variants["forward"].endswith("_fold"), variants
     print("full-size mixed", variants, report)
     assert report["O"] < 5e-3 and report["L"] < 7e-3, report
 

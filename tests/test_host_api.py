@@ -323,13 +323,48 @@ def test_transposed_launches_are_routed_to_the_in_place_streams():
         assert k.launchForm(b, row=N, column=N, causal=True).startswith("attn_fwd16_p5_tr")
 
 
-def test_fp32_launches_are_handed_to_the_fp32_kernels():
-    """FP32 descriptors of the 64 / 128 head blocks: the general kernel's variant launches attn_f32_* when every operand is FP32,
-    row-major, rows 16-byte aligned, D % 4 == 0 and no block mask is given (csrc/attn_f32.h, f32k::serves) -- planned without a
-    GPU: host pointers only decide the alignment"""
+def test_strict_descriptors_refuse_the_silent_general_kernel_on_transposed_backward_launches():
+    """A transposed backward launch without workspace that no in-place kernel takes (every bucket but 128) would run the general
+    fp32 kernel, 20-50 x slower than the selected code object: with strictBlockDimensions the launch fails with MFA_ERR_UNSUPPORTED
+    and the message names the workspace to pass; without the flag it keeps running (launch form says 'general kernel'); in the
+    128 bucket the in-place kernels take it either way.  Planned without a GPU."""
+    torch = pytest.importorskip("torch")
+    N = 512
+    tt = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
+    for D, in_place in ((64, False), (128, True), (192, False)):
+        d = _desc(dims=(N, N, D), low_in=True, low_mid=True, in_type=P.BF16, tr=(True,) * 4)
+        mem = d.memoryPrecisions
+        b = {op: torch.zeros((D, N), dtype=tt[mem[op]]) for op in (Op.Q, Op.K, Op.V, Op.O, Op.dO, Op.dQ, Op.dK, Op.dV)}
+        b[Op.L], b[Op.D] = torch.zeros(N, dtype=tt[mem[Op.L]]), torch.zeros(N, dtype=tt[mem[Op.D]])
+        for t in (T.backwardQuery, T.backwardKeyValue):
+            kd = d.kernelDescriptor(t)
+            loose = AttentionKernel(kd).launchForm(b, row=N, column=N)
+            assert ("general kernel" in loose) == (not in_place), (D, t, loose)
+            kd.strictBlockDimensions = True
+            k = AttentionKernel(kd)
+            if in_place:
+                assert k.launchForm(b, row=N, column=N).startswith(("attn_dq16_p4_tr", "attn_dkv16_p4_tr"))
+                continue
+            with pytest.raises(MFAError) as e:
+                k.launchForm(b, row=N, column=N)
+            need = k.workspaceSize(row=N, column=N)
+            assert e.value.status == 3 and "workspace of %d bytes" % need in str(e.value), str(e.value)
+            ws = torch.zeros(need + 256, dtype=torch.uint8)     # with the workspace the re-layout path of the selected code object runs
+            off = (-ws.data_ptr()) % 256
+            form = k.launchForm(b, row=N, column=N, workspace=ws[off:off + need])
+            assert form.startswith("attn_relayout") and "general kernel" not in form, form
+
+
+def test_fp32_descriptors_are_the_fp32_production_kernels():
+    """FP32 descriptors of the 64 / 128 head blocks with row-major operands and D % 4 == 0 ARE the FP32 production kernels
+    (csrc/attn_f32.h; round 5: own variant name and own LDS bytes -- what rocprofv3 shows as kernel name and lds_bytes); the general
+    kernel is their sibling: it keeps block-sparse launches and launches whose rows are not 16-byte aligned, and the launch form says
+    so -- planned without a GPU: host pointers only decide the alignment"""
     torch = pytest.importorskip("torch")
     R, C = 300, 520
     names = {T.forward: "attn_f32_fwd", T.backwardQuery: "attn_f32_dq", T.backwardKeyValue: "attn_f32_dkv"}
+    lds = {(T.forward, 128): 65536, (T.backwardQuery, 128): 98304, (T.backwardKeyValue, 128): 99840,
+           (T.forward, 64): 32768, (T.backwardQuery, 64): 49152, (T.backwardKeyValue, 64): 50688}
 
     def buffers(D, ld=None):
         ld = ld or D
@@ -341,21 +376,26 @@ def test_fp32_launches_are_handed_to_the_fp32_kernels():
         d = _desc(dims=(R, C, D))
         for t, name in names.items():
             k = AttentionKernel(d.kernelDescriptor(t))
-            assert k.variant.startswith("attn_generic_") and "_d%d_" % block in k.variant
+            assert k.variant == "%s_d%d_w4x32" % (name, block)
+            assert k.blockDimensions == (128, 32, block) and k.threadgroupMemoryAllocation == lds[(t, block)]
             b = buffers(D)
-            assert k.launchForm(b, row=R, column=C) == "%s_d%d_w4x32" % (name, block)
-            assert k.launchForm(b, row=R, column=C, causal=True) == "%s_d%d_w4x32" % (name, block)
-            # rows of D + 1 floats are not 16-byte aligned; rows of D + 4 are
-            assert k.launchForm(buffers(D, D + 1), row=R, column=C, leadingDimensions={op: D + 1 for op in b if op not in (Op.L, Op.D)}) == k.variant
-            assert k.launchForm(buffers(D, D + 4), row=R, column=C, leadingDimensions={op: D + 4 for op in b if op not in (Op.L, Op.D)}).startswith(name)
-            # a block mask keeps the general kernel's own sparse code object
+            assert k.launchForm(b, row=R, column=C) == k.variant
+            assert k.launchForm(b, row=R, column=C, causal=True) == k.variant
+            # rows of D + 1 floats are not 16-byte aligned: the general kernel serves the launch; rows of D + 4 are
+            form = k.launchForm(buffers(D, D + 1), row=R, column=C, leadingDimensions={op: D + 1 for op in b if op not in (Op.L, Op.D)})
+            assert form.startswith("attn_generic_") and "_d%d_" % block in form and "general kernel" in form
+            assert k.launchForm(buffers(D, D + 4), row=R, column=C, leadingDimensions={op: D + 4 for op in b if op not in (Op.L, Op.D)}) == k.variant
+            # a block mask keeps the general kernel's own sparse code object (named as the sibling)
             mask = torch.full((2, 1), -1, dtype=torch.int32)
-            assert "attn_f32_" not in k.launchForm(b, row=R, column=C, blockMask=mask, blockMaskWords=1)
-    for D in (30, 200):   # D % 4 != 0; the 256 head block
+            form = k.launchForm(b, row=R, column=C, blockMask=mask, blockMaskWords=1)
+            assert "attn_generic_" in form and "block-sparse" in form
+    for D in (30, 200):   # D % 4 != 0; the 256 head block: the general kernels
         d = _desc(dims=(R, C, D))
         for t in names:
             k = AttentionKernel(d.kernelDescriptor(t))
-            assert k.launchForm(buffers(D), row=R, column=C) == k.variant
+            assert k.variant.startswith("attn_generic_") and k.launchForm(buffers(D), row=R, column=C) == k.variant
+    k = AttentionKernel(_desc(dims=(R, C, 128), tr=(False, True, False, False)).kernelDescriptor(T.forward))   # a transposed operand
+    assert k.variant.startswith("attn_generic_")
 
 
 def test_low_precision_intermediates_select_the_folded_scale_stream():

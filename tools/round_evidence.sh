@@ -19,9 +19,11 @@ timeout 300 python bench.py 2> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_
 if [ -z "$FAST" ]; then   # (first: the headline's pass below leaves ITS traffic.json behind)
   ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof_f32" --steps 5 --warmup 2 --no-cpu-baseline --workload fwdbwd_f32_d128 > "$OUT/prof_f32.log" 2>&1
 fi
+# BASELINE config 2 (attn_fwd16_p6): kernel trace + PMC passes
+ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof_d64" --steps 20 --warmup 5 --no-cpu-baseline --workload fwd_bf16_d64 > "$OUT/prof_d64.log" 2>&1; tail -12 "$OUT/prof_d64.log" | head -12
 ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof.log" 2>&1; tail -25 "$OUT/prof.log" | head -40
 if [ -z "$FAST" ]; then
-  for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_1head \
+  for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_fp32mid fwd_bf16_d64_1head \
            fwd_bf16_d256 fwd_bf16_d256_mixed fwdbwd_bf16_d128 fwdbwd_bf16_d128_mixed fwdbwd_bf16_d128_causal fwdbwd_bf16_d128_transposed \
            fwdbwd_bf16_d128_transposed_ws fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128 fwdbwd_bf16_d256_mixed dq_bf16_d256 dkv_bf16_d256; do
     timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_$w.json"
@@ -40,6 +42,9 @@ PY
   timeout 200 python tools/bucket_perf.py 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_fp32mid.txt"
   timeout 200 python tools/bucket_perf.py --mixed --fill zero 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_fill_zero.txt"; cat "$OUT/bucket_perf_mixed_fill_zero.txt"
   timeout 200 python tools/bucket_perf.py --mixed --causal 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_causal.txt"
+  timeout 200 python tools/bucket_perf.py --mixed --heads 256 64 128 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_256heads.txt"
+  timeout 200 python tools/bucket_perf.py --mixed --causal --heads 256 64 128 2>&1 | grep -v amdgpu.ids >> "$OUT/bucket_perf_mixed_256heads.txt"
+  timeout 200 bash tools/zero_vs_random.sh "$OUT/zero_vs_random_d64" fwd_bf16_d64 > /dev/null 2>&1; cp "$OUT/zero_vs_random_d64/zero_vs_random.txt" "$OUT/d64_zero_vs_random.txt"; rm -rf "$OUT/zero_vs_random_d64"
   timeout 200 python tools/bucket_perf.py --mixed --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/bucket_perf_mixed_transposed_no_workspace.txt"
   timeout 300 bash tools/zero_vs_random.sh "$OUT/zero_vs_random" > /dev/null 2>&1; cp "$OUT/zero_vs_random/zero_vs_random.txt" "$OUT/headline_zero_vs_random.txt"; rm -rf "$OUT/zero_vs_random"
   if [ -f metal_flash_attention_amd/libmfa_hip_dev.so ]; then

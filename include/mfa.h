@@ -25,10 +25,14 @@
  *     also when lowPrecisionIntermediates is 0 and the reference would keep them in FP32 registers
  *     (+Precisions.swift:201-205).  S, the accumulators, L and D arithmetic are fp32.
  *   - lowPrecisionIntermediates = 1 (the reference then holds P, and with FP16 also S, in 16-bit registers) lets the
- *     hand-placed kernels (forward 64 < D <= 256, backward D <= 128) multiply one operand of S = Q K^T
+ *     hand-placed kernels (forward D <= 256, backward D <= 128) multiply one operand of S = Q K^T
  *     by log2(e)/sqrt(D) once, rounded to the inputs' type (forward and backwardQuery: Q; backwardKeyValue: K), instead
  *     of scaling every score in fp32: L moves by up to ~2e-3 (BF16) / 2e-4 (FP16) natural-log units, P by the same
  *     relative amount.  With the flag clear the scale is applied in fp32 per score.
+ *   - lowPrecisionIntermediates = 1, forward, D <= 64 (attn_fwd16_p6): the softmax denominator l is the sum of the P values
+ *     AFTER their rounding to the inputs' 16-bit type, accumulated in fp32 by the matrix pipe (L^T += ONES P^T) -- the
+ *     reference's mixed mode also sums its 16-bit P (+Precisions.swift:149-215); O = (sum P v) / (sum P) then uses ONE set of
+ *     P values.  With the flag clear l is the fp32 sum of the unrounded P.
  *   - backwardKeyValue, D <= 128: the per-row terms L and D enter S and dP through the matrix pipe as the sum of two
  *     16-bit values (16 / 22 bits of mantissa for BF16 / FP16 inputs): an absolute error of ~2^-16 |L| in the exponent of P.
  *   - FP16 Q, K, V with BF16 dO (the reference's own low-precision mix), backwardKeyValue, D <= 128: the two products that
@@ -38,7 +42,9 @@
  *     (any leading dimension).  The backward kernels of the 128 bucket (64 < D <= 128) read them in place too when the launch
  *     is whole tiles of 16-byte aligned rows and carries no workspace (attn_dq16_p4_tr / attn_dkv16_p4_tr); every other
  *     transposed backward launch runs on the matrix cores when it is given a workspace
- *     (mfa_attention_kernel_needs_workspace_for_fast_path: re-layout pass), and on the fp32-arithmetic kernels without one.
+ *     (mfa_attention_kernel_needs_workspace_for_fast_path: re-layout pass), and on the fp32-arithmetic kernels without one --
+ *     20-50 x slower; a kernel created with strictBlockDimensions returns MFA_ERR_UNSUPPORTED for such a launch instead, the
+ *     message naming the workspace size.
  *   - Head dimensions: any.  16-bit matrix-core code objects exist up to D = 256; 256 < D <= 384 runs on the fp32-arithmetic
  *     kernels whatever the storage type, accumulators in registers; D > 384 (beyond the reference's tables, which fall through
  *     to their last row, +Parameters.swift:60-65) runs D-blocked kernels that page the accumulators through the output

@@ -26,16 +26,16 @@ namespace p6 {
 constexpr int VRING = MFA_P6_VRING, QIMG = MFA_P6_QIMG, TABLE = MFA_P6_TABLE, TABLE_ENTRIES = MFA_P6_TABLE_ENTRIES, STAGE = MFA_P6_STAGE,
               LDS_BYTES = MFA_P6_LDS_BYTES;
 
-#define MFA_P6_ENUM(name, f16, fold, o16, l16, causal) S_##name,
+#define MFA_P6_ENUM(name, f16, fold, o16, l16, causal, split) S_##name,
 enum : int { MFA_P6_STREAM_LIST(MFA_P6_ENUM) S_COUNT };
 #undef MFA_P6_ENUM
 
-struct StreamTraits { bool f16, fold, o16, l16, causal; };
+struct StreamTraits { bool f16, fold, o16, l16, causal, split; };
 constexpr StreamTraits traits(int s) {
-#define MFA_P6_TRAITS(name, f16, fold, o16, l16, causal) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, causal != 0};
+#define MFA_P6_TRAITS(name, f16, fold, o16, l16, causal, split) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, causal != 0, split != 0};
   MFA_P6_STREAM_LIST(MFA_P6_TRAITS)
 #undef MFA_P6_TRAITS
-  return StreamTraits{false, false, false, false, false};
+  return StreamTraits{false, false, false, false, false, false};
 }
 
 }  // namespace p6
@@ -78,11 +78,22 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   const uint32_t RB = grid.rowBlocks;
   if constexpr (TR.causal) dgrid.rowBlocks = (RB + 1) / 2;
   for (uint32_t n = tid; n < nunits; n += 256) {
-    uint32_t r, head, batch;
-    fwd16_decode_block_lane(dgrid, first + n * G, &r, &head, &batch);
-    const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
-                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
-                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
+    uint32_t r, head, batch, unit = first + n * G, piece = 0;
+    if constexpr (TR.split) { piece = unit % grid.splits; unit /= grid.splits; }   // SPLIT: a unit is (row block, piece of the key range)
+    fwd16_decode_block_lane(dgrid, unit, &r, &head, &batch);
+    uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
+                        (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
+                        (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
+    if constexpr (TR.split) {
+      // K / V start at the piece (C / splits keys, a multiple of 256: the launcher checks); O and (m, l) go to the piece's slabs of
+      // the caller's workspace: wsO [splits][heads x batches][R][D] fp32, wsML [splits][heads x batches][R][2] (attn_fwd_combine)
+      const uint64_t keys = (uint64_t)piece * (a.C / grid.splits);
+      base[1] += keys * (uint64_t)a.op[SLOT_K].ld * 2;
+      base[2] += keys * (uint64_t)a.op[SLOT_V].ld * 2;
+      const uint64_t slab = ((uint64_t)piece * grid.heads * grid.batches + (uint64_t)batch * grid.heads + head) * a.R;
+      base[3] = (uint64_t)(uintptr_t)(grid.wsO + slab * a.D);
+      base[4] = (uint64_t)(uintptr_t)(grid.wsML + slab * 2);
+    }
     // causal, odd block count: the middle block is its own pair -- the units before it in this workgroup's list hold two entries
     // each unless they are middle blocks themselves (counted, not assumed)
     uint32_t pos = TR.causal ? 2 * n : n;
@@ -108,10 +119,12 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   __syncthreads();
   const uint32_t nblk = __builtin_amdgcn_readfirstlane(table[16 * TABLE_ENTRIES - 1]);
 
-  const uint32_t R = a.R, C = a.C, dr = a.D;
+  // (SPLIT: every workgroup sees its piece as the key range; the division runs on the vector ALU and hipcc does not move its result
+  // back to a scalar register by itself when the asm statement asks for "s" operands derived from it)
+  const uint32_t R = a.R, C = TR.split ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.C / grid.splits)) : a.C, dr = a.D;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2, ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
-  constexpr uint32_t OSZ = TR.o16 ? 2 : 4, LSZ = TR.l16 ? 2 : 4;
-  const uint32_t ldob = (uint32_t)a.op[SLOT_O].ld * OSZ;
+  constexpr uint32_t OSZ = TR.o16 ? 2 : 4, LSZ = TR.split ? 8 : TR.l16 ? 2 : 4;
+  const uint32_t ldob = TR.split ? dr * 4 : (uint32_t)a.op[SLOT_O].ld * OSZ;
   const uint32_t nrecq = R * ldq2, nreck = C * ldk2, nrecv = C * ldv2, nreco = R * ldob, nrecl = R * LSZ;
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
   // a block walks a MULTIPLE OF FOUR key tiles (the loop body is four tiles = the ring of four K / V images: every ring position is
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   const uint32_t ldsk = lds0 + wave * 2048, ldsv = lds0 + VRING + (wave >> 1) * 4096 + (wave & 1) * 2048;
   const uint32_t qrel = QIMG + wave * 8192, ldsq = lds0 + qrel, tbl = lds0 + TABLE, wave64 = wave * 64, ldsst = lds0 + STAGE + wave * 4096;
 
-#define MFA_P6_RUN(name, f16, fold, o16, l16, causal) if constexpr (STREAM == S_##name) MFA_P6_RUN_STREAM(MFA_P6_STREAM_##name);
+#define MFA_P6_RUN(name, f16, fold, o16, l16, causal, split) if constexpr (STREAM == S_##name) MFA_P6_RUN_STREAM(MFA_P6_STREAM_##name);
   MFA_P6_STREAM_LIST(MFA_P6_RUN)
 #undef MFA_P6_RUN
 }

@@ -15,7 +15,7 @@ std::mutex g_mutex;
 DeviceInfo g_devices[64];
 
 template <typename T, int STREAM>
-bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args, uint32_t splits = 1, float *wsO = nullptr, float *wsML = nullptr) {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return false;
   int cus;
@@ -38,7 +38,7 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   // units: row blocks, or (causal) pairs of row blocks -- two table entries each
   constexpr bool CAUSAL = p6::traits(STREAM).causal;
   constexpr uint64_t PER_UNIT = CAUSAL ? 2 : 1;
-  const uint64_t total = (uint64_t)(CAUSAL ? (grid.x + 1) / 2 : grid.x) * grid.y * grid.z;
+  const uint64_t total = (uint64_t)(CAUSAL ? (grid.x + 1) / 2 : grid.x) * grid.y * grid.z * splits;
   // one workgroup per compute unit; more only when a workgroup's share would not fit the block table.  A multiple of 8 keeps
   // fwd16_decode_block's head -> XCD affinity for every block of a workgroup
   uint64_t groups = total < (uint64_t)cus ? total : (uint64_t)cus;
@@ -47,7 +47,7 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   if (groups >= 8) groups = (groups + 7) / 8 * 8;
   if (groups > total) groups = total;
   if ((total + groups - 1) / groups > MAX_UNITS) return false;
-  Fwd16Grid g{grid.x, grid.y, grid.z};
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
   hipLaunchKernelGGL((attn_fwd16_p6<T, STREAM>), dim3((uint32_t)groups), dim3(256), p6::LDS_BYTES, stream, args, g, (uint32_t)total);
   return true;
 }
@@ -74,8 +74,8 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
   if (std::getenv("MFA_P6_OFF")) return false;
   if (const char *want = std::getenv("MFA_P6_DEV_STREAM")) {
     if (*want && precision == PREC_BF16 && args.op[SLOT_O].precision == PREC_FP32) {
-#define MFA_P6_BYNAME(name, f16, sfold, o16, l16, scausal) \
-      if constexpr (!f16 && !o16) { if ((sfold != 0) == fold && (scausal != 0) == (args.causal != 0) && std::strcmp(want, #name) == 0) return launch_stream<__bf16, p6::S_##name>(grid, stream, args); }
+#define MFA_P6_BYNAME(name, f16, sfold, o16, l16, scausal, ssplit) \
+      if constexpr (!f16 && !o16 && !ssplit) { if ((sfold != 0) == fold && (scausal != 0) == (args.causal != 0) && std::strcmp(want, #name) == 0) return launch_stream<__bf16, p6::S_##name>(grid, stream, args); }
       MFA_P6_DEV_STREAM_LIST(MFA_P6_BYNAME)
 #undef MFA_P6_BYNAME
       return false;
@@ -93,6 +93,27 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
   if (precision == PREC_BF16) { MFA_P6_PICK(__bf16, BF16) }
   MFA_P6_PICK(_Float16, F16)
 #undef MFA_P6_PICK
+}
+
+// Column-parallel launch (few-workgroup problems: one head, BASELINE config 2 as written): pieces of the key range on the persistent
+// kernel, then the combine pass.  false = not one it serves (pieces that are not whole multiples of four tiles, ...): the caller
+// launches the eight-wave kernel's split sibling
+bool launch_p6_split(int precision, bool fold, dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  if (!serves(precision, fold, args) || args.causal || splits < 2) return false;
+  if (args.C % (256u * splits) != 0) return false;
+#ifdef MFA_DEV_VARIANTS
+  if (std::getenv("MFA_P6_OFF") || std::getenv("MFA_P6_NO_SPLIT")) return false;
+#endif
+  bool ok;
+  if (precision == PREC_BF16) ok = fold ? launch_stream<__bf16, p6::S_BF16_FOLD_SPLIT>(grid, stream, args, splits, wsO, wsML)
+                                        : launch_stream<__bf16, p6::S_BF16_EXACT_SPLIT>(grid, stream, args, splits, wsO, wsML);
+  else ok = fold ? launch_stream<_Float16, p6::S_F16_FOLD_SPLIT>(grid, stream, args, splits, wsO, wsML)
+                 : launch_stream<_Float16, p6::S_F16_EXACT_SPLIT>(grid, stream, args, splits, wsO, wsML);
+  if (!ok) return false;
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
+  hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
+  return true;
 }
 
 const char *p6_form(int precision, bool fold, const KernelArgs &args) {
@@ -114,9 +135,21 @@ template <int PREC, bool FOLD> static void launch_p6_or_v3(dim3 grid, hipStream_
   fwd16_v3_d64_launch(PREC, grid, stream, args);
 }
 void fwd16_v3_d64_launch_causal(int precision, dim3 grid, hipStream_t stream, const KernelArgs &args);   // attn_fwd16_v3.hip
+void fwd16_v3_d64_launch_split(int precision, dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args);
+template <int PREC, bool FOLD> static void launch_p6_or_v3_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  if (launch_p6_split(PREC, FOLD, grid, splits, wsO, wsML, stream, args)) return;
+  fwd16_v3_d64_launch_split(PREC, grid, splits, wsO, wsML, stream, args);
+}
 template <int PREC, bool FOLD> static void launch_p6_or_v3_causal(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   if (launch_p6(PREC, FOLD, grid, stream, args)) return;
   fwd16_v3_d64_launch_causal(PREC, grid, stream, args);
+}
+template <int PREC, bool FOLD> static const char *p6_split_form_of(const KernelArgs &args, uint32_t splits) {
+  if (!p6_form(PREC, FOLD, args) || args.causal || splits < 2 || args.C % (256u * splits) != 0) return nullptr;
+#ifdef MFA_DEV_VARIANTS
+  if (std::getenv("MFA_P6_NO_SPLIT")) return nullptr;
+#endif
+  return "pieces by attn_fwd16_p6, persistent";
 }
 template <int PREC, bool FOLD> static const char *p6_form_of(const KernelArgs &args) { return p6_form(PREC, FOLD, args); }
 
@@ -133,12 +166,13 @@ bool fwd16_p6_variant(int precision, bool fold, VariantInfo *out) {
   out->headBlock = 64;
   out->threads = 256;
   out->ldsBytes = out->ldsBytes > (uint32_t)p6::LDS_BYTES ? out->ldsBytes : (uint32_t)p6::LDS_BYTES;
+  out->splitTarget = 256;   // one workgroup per compute unit
   if (precision == PREC_BF16) {
-    if (fold) { out->launch = &launch_p6_or_v3<PREC_BF16, true>; out->launchCausal = &launch_p6_or_v3_causal<PREC_BF16, true>; out->launchForm = &p6_form_of<PREC_BF16, true>; }
-    else { out->launch = &launch_p6_or_v3<PREC_BF16, false>; out->launchCausal = &launch_p6_or_v3_causal<PREC_BF16, false>; out->launchForm = &p6_form_of<PREC_BF16, false>; }
+    if (fold) { out->launch = &launch_p6_or_v3<PREC_BF16, true>; out->launchCausal = &launch_p6_or_v3_causal<PREC_BF16, true>; out->launchSplit = &launch_p6_or_v3_split<PREC_BF16, true>; out->splitForm = &p6_split_form_of<PREC_BF16, true>; out->launchForm = &p6_form_of<PREC_BF16, true>; }
+    else { out->launch = &launch_p6_or_v3<PREC_BF16, false>; out->launchCausal = &launch_p6_or_v3_causal<PREC_BF16, false>; out->launchSplit = &launch_p6_or_v3_split<PREC_BF16, false>; out->splitForm = &p6_split_form_of<PREC_BF16, false>; out->launchForm = &p6_form_of<PREC_BF16, false>; }
   } else {
-    if (fold) { out->launch = &launch_p6_or_v3<PREC_FP16, true>; out->launchCausal = &launch_p6_or_v3_causal<PREC_FP16, true>; out->launchForm = &p6_form_of<PREC_FP16, true>; }
-    else { out->launch = &launch_p6_or_v3<PREC_FP16, false>; out->launchCausal = &launch_p6_or_v3_causal<PREC_FP16, false>; out->launchForm = &p6_form_of<PREC_FP16, false>; }
+    if (fold) { out->launch = &launch_p6_or_v3<PREC_FP16, true>; out->launchCausal = &launch_p6_or_v3_causal<PREC_FP16, true>; out->launchSplit = &launch_p6_or_v3_split<PREC_FP16, true>; out->splitForm = &p6_split_form_of<PREC_FP16, true>; out->launchForm = &p6_form_of<PREC_FP16, true>; }
+    else { out->launch = &launch_p6_or_v3<PREC_FP16, false>; out->launchCausal = &launch_p6_or_v3_causal<PREC_FP16, false>; out->launchSplit = &launch_p6_or_v3_split<PREC_FP16, false>; out->splitForm = &p6_split_form_of<PREC_FP16, false>; out->launchForm = &p6_form_of<PREC_FP16, false>; }
   }
   return true;
 }

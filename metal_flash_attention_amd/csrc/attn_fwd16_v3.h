@@ -908,35 +908,56 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd16_v3(const KernelArgs a, con
   }
 }
 
-// Merge the pieces of a column-parallel forward launch.  One wave per query row; lane c owns the four
-// head-dimension elements 4c..4c+3.  m* = max_s m_s;  w_s = exp2(m_s - m*);  l* = sum_s w_s l_s;
-// O = sum_s w_s O_s / l*;  L = m* + log2 l*  -- the online-softmax merge (+Softmax.swift:290-324) applied
-// across pieces instead of across tiles.  HBM-bound: reads splits x (D + 2) floats per row.
+// Merge the pieces of a column-parallel forward launch.  One wave per query row.  m* = max_s m_s;  w_s = exp2(m_s - m*);
+// l* = sum_s w_s l_s;  O = sum_s w_s O_s / l*;  L = m* + log2 l*  -- the online-softmax merge (+Softmax.swift:290-324) applied across
+// pieces instead of across tiles.  Round 5: LATENCY-bound, not bandwidth-bound (one head: 16 pieces x 4096 rows x 264 bytes = 17 MB),
+// and the first version walked the pieces in two serial loops of dependent loads (~2 x 16 round trips to memory: 20 of the 33 us of
+// BASELINE config 2 as written).  Now lane s loads (m_s, l_s) of piece s (splits <= 64) and the wave reduces; for O the wave is
+// CL = D / 4 column lanes (four consecutive elements each) x 64 / CL piece groups, every lane walks splits / groups pieces with
+// independent loads and the groups are summed with half-wave exchanges: two to three round trips in all.
 static __global__ __launch_bounds__(256) void attn_fwd_combine(const KernelArgs a, const Fwd16Grid grid) {
   const int lane = threadIdx.x & 63;
-  const uint32_t R = a.R, Dr = a.D, HB = grid.heads * grid.batches;
+  const uint32_t R = a.R, Dr = a.D, HB = grid.heads * grid.batches, S = grid.splits;
   const uint64_t rowid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // over HB * R
   if (rowid >= (uint64_t)HB * R) return;
   const uint32_t hb = (uint32_t)(rowid / R), row = (uint32_t)(rowid % R);
   const uint32_t head = hb % grid.heads, batch = hb / grid.heads;
-  float mstar = -3.402823466e+38f;
-  for (uint32_t s = 0; s < grid.splits; ++s) mstar = fmaxf(mstar, grid.wsML[(((uint64_t)s * HB + hb) * R + row) * 2]);
-  float lstar = 0.f;
+  auto slab_of = [&](uint32_t s_) { return ((uint64_t)s_ * HB + hb) * R + row; };
+  // (m, l) of piece `lane`
+  float ms = -3.402823466e+38f, ls = 0.f;
+  if ((uint32_t)lane < S) {
+    const float2 ml = *reinterpret_cast<const float2 *>(grid.wsML + slab_of((uint32_t)lane) * 2);
+    ms = ml.x; ls = ml.y;
+  }
+  float mstar = ms;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mstar = fmaxf(mstar, __shfl_xor(mstar, off, 64));
+  const float w = (uint32_t)lane < S ? fast_exp2(ms - mstar) : 0.f;
+  float lstar = w * ls;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lstar += __shfl_xor(lstar, off, 64);
+  // O: column lane c = lane % CL owns elements 4c .. 4c + 3, group g = lane / CL walks the pieces g, g + G, ...
+  uint32_t CL = 1;
+  while (CL * 4 < Dr) CL <<= 1;                 // (D <= 256: at most 64 column lanes)
+  const uint32_t G = 64 / CL, c = (uint32_t)lane % CL, g = (uint32_t)lane / CL;
+  const bool active = c * 4 < Dr;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool active = (uint32_t)lane * 4 < Dr;
-  for (uint32_t s = 0; s < grid.splits; ++s) {
-    const uint64_t slab = ((uint64_t)s * HB + hb) * R + row;
-    const float w = fast_exp2(grid.wsML[slab * 2] - mstar);
-    lstar += w * grid.wsML[slab * 2 + 1];
-    if (active) {
-      const float4 v = *reinterpret_cast<const float4 *>(grid.wsO + slab * Dr + lane * 4);
-      acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+  for (uint32_t s0 = 0; s0 < S; s0 += G) {
+    const uint32_t s_ = s0 + g;
+    const float ws = __shfl(w, (int)(s_ < 64 ? s_ : 63), 64);     // (every lane takes part in the exchange)
+    if (s_ < S && active) {
+      const float4 v = *reinterpret_cast<const float4 *>(grid.wsO + slab_of(s_) * Dr + c * 4);
+      acc.x += ws * v.x; acc.y += ws * v.y; acc.z += ws * v.z; acc.w += ws * v.w;
     }
   }
+  for (uint32_t off = CL; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, (int)off, 64); acc.y += __shfl_xor(acc.y, (int)off, 64);
+    acc.z += __shfl_xor(acc.z, (int)off, 64); acc.w += __shfl_xor(acc.w, (int)off, 64);
+  }
   const float inv = 1.0f / lstar;
-  if (active) {
+  if (active && g == 0) {
     char *obase = operand_base(a.op[SLOT_O], head, batch);
-    const int64_t idx = (int64_t)row * a.op[SLOT_O].ld + lane * 4;
+    const int64_t idx = (int64_t)row * a.op[SLOT_O].ld + c * 4;
     const int oprec = a.op[SLOT_O].precision;
     if (oprec == PREC_FP32) {
       *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obase) + idx) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);

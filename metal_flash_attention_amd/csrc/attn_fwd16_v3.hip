@@ -79,6 +79,11 @@ void fwd16_v3_d64_launch(int precision, dim3 grid, hipStream_t stream, const Ker
   else launch_v3<_Float16, 64, 8, 1, 8, 0>(grid, stream, args);
 }
 
+void fwd16_v3_d64_launch_split(int precision, dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  if (precision == PREC_BF16) launch_v3_split<__bf16, 64, 8, 1, 8, 0>(grid, splits, wsO, wsML, stream, args);
+  else launch_v3_split<_Float16, 64, 8, 1, 8, 0>(grid, splits, wsO, wsML, stream, args);
+}
+
 void fwd16_v3_d64_launch_causal(int precision, dim3 grid, hipStream_t stream, const KernelArgs &args) {
   if (precision == PREC_BF16) launch_v3_causal<__bf16, 64, 8, 1, 8, 0, 3, 0>(grid, stream, args);
   else launch_v3_causal<_Float16, 64, 8, 1, 8, 0, 3, 0>(grid, stream, args);

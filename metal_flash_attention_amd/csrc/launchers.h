@@ -30,6 +30,9 @@ struct VariantInfo {
   // dense / causal launches that `launch` / `launchCausal` hand to another code object (the persistent form of the D <= 128
   // forward kernel): its name for such a launch, nullptr when the variant's own kernel runs (mfa_attention_kernel_launch_form)
   const char *(*launchForm)(const KernelArgs &args) = nullptr;
+  // the same for a column-parallel launch whose pieces `launchSplit` hands to another code object than the sibling's (the persistent
+  // D <= 64 forward kernel cuts launches of whole four-tile pieces itself): text for the launch form, nullptr = the sibling's pieces
+  const char *(*splitForm)(const KernelArgs &args, uint32_t splits) = nullptr;
   // forward only: column-parallel launch (key range cut into `splits` pieces, partial results in the
   // caller's workspace, then the combine kernel); nullptr if the variant has none
   void (*launchSplit)(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream,
@@ -81,6 +84,7 @@ bool fwd16_p4_variant(int precision, int D, int impl, VariantInfo *out);
 bool fwd16_p6_variant(int precision, bool fold, VariantInfo *out);
 bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const KernelArgs &args);
 const char *p6_form(int precision, bool fold, const KernelArgs &args);
+bool launch_p6_split(int precision, bool fold, dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args);
 // 128 < D <= 256: four waves x 64 rows, 32-key steps (attn_fwd16_p5.h); `out` arrives filled by fwd16_v3_variant
 bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out);
 // backwardKeyValue counterpart: four waves x 64 keys (attn_dkv16_p4.h); `out` arrives filled by dkv16_rs_variant, whose

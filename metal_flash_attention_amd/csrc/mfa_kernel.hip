@@ -810,7 +810,9 @@ mfa_status mfa_attention_kernel_launch_form(const mfa_attention_kernel *kernel, 
   } else if (plan.splits > 1) {
     text += std::string(plan.variant->name) + " column-parallel x" + std::to_string(plan.splits) + " + combine";
     const bool own = plan.variant->splitParallelization && !(plan.args.causal && plan.variant->launchSplitCausal);
-    if (!own && plan.variant->siblingName) text += std::string(" (pieces by the sibling kernel ") + plan.variant->siblingName + ")";
+    const char *pieces = plan.variant->splitForm ? plan.variant->splitForm(plan.args, plan.splits) : nullptr;
+    if (pieces) text += std::string(" (") + pieces + ")";
+    else if (!own && plan.variant->siblingName) text += std::string(" (pieces by the sibling kernel ") + plan.variant->siblingName + ")";
   } else {
     const bool sparse = plan.args.mask && plan.variant->launchSparse;
     const char *form = (!sparse && plan.variant->launchForm) ? plan.variant->launchForm(plan.args) : nullptr;

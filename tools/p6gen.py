@@ -78,7 +78,7 @@ IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qre
 
 
 class Cfg6(p4gen.Cfg):
-    def __init__(self, dtype="bf16", thr=8.0, xb=56, o16=0, l16=1, lsum=1, abl=(), pad=0, vlast=7, kearly=1, fold=1, causal=0):
+    def __init__(self, dtype="bf16", thr=8.0, xb=56, o16=0, l16=1, lsum=1, abl=(), pad=0, vlast=7, kearly=1, fold=1, causal=0, split=0):
         """fold = 0: EXACT-SCALE streams (descriptors that keep the attention matrix in FP32 registers): Q stays as stored, the scale
         is applied in fp32 per score (s * scale2 - m, 64 more vector instructions per tile), the row sums are fp32 additions of
         the unrounded P (no `lsum`), L is stored in FP32.  xb = scores per tile whose exponential phase B takes (both kinds)"""
@@ -93,6 +93,14 @@ class Cfg6(p4gen.Cfg):
         # diagonal are masked like a ragged edge: 1.5 of a block's 4 (rb + 1) tiles on average) -- no per-wave traversal bound, no
         # skip loop.  The block table lists the blocks in pairs (long, short) so that every workgroup walks the same number of tiles
         self.causal = causal
+        # split (column-parallel launches of few-workgroup problems: one head, BASELINE config 2 as written): a table entry is one
+        # (row block, piece of the key range) -- its K / V bases start at the piece, its O / L bases are the piece's slabs in the
+        # caller's workspace -- and the epilogue leaves the UN-normalised O^T (fp32) and (m, l) per row there for attn_fwd_combine
+        # (attn_fwd16_v3.h), like the split siblings of the other forward kernels.  Pieces are whole multiples of four tiles
+        self.split = split
+        if split:
+            self.o16, self.l16 = 0, 0
+        assert not (split and causal)
         # vlast: last gap of phase A with a V^T read; kearly: the K(j+1) fragment reads right behind the LDS-DMA pieces of phase B
         # (else spread between its exponentials, the last one near the phase's end -- the first GPU runs lost ~250 clocks per tile
         # to the two `lgkmcnt(0)` in front of the phase seams, profiles/r05_p6_ablations_first.txt)
@@ -565,6 +573,8 @@ class Stream6(Stream):
                 self.emit("v_permlane32_swap_b32", ta, [tb], swap=1)
                 self.emit("v_add_f32", lt, [ta, tb])
             self.emit("v_add_f32", lt, [I(1), lt], note="+ denorm_min (+Caching.swift:311)")
+            if cfg.split:
+                continue
             self.emit("v_rcp_f32", iv, [lt])
             self.emit("s_nop", None, [I(0)], note="trans -> VALU")
             self.emit("v_fma_f32", ta, [lt, iv, F(1.0)], neg0=1)
@@ -604,8 +614,9 @@ class Stream6(Stream):
             src, dst = S_BASE[0] + 16 * i, S_BASE[1] + 16 * i
             for r in range(16):
                 self.emit("v_accvgpr_read_b32", V(src + r), [A(O_BASE + 16 * (2 * rb + db) + r)])
-            for r in range(16):
-                self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])
+            if not cfg.split:
+                for r in range(16):
+                    self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])
             for g in range(4):
                 self.lds_write("ds_write_b128", V(wa[g]), V(src + 4 * g, 4), 0)
             ids = [self.lds_read("ds_read_b128", V(dst + 4 * k, 4), V(ra), 1024 * k, note="O(%d,%d) rows %d.." % (rb, db, 8 * k)) for k in range(4)]
@@ -615,6 +626,19 @@ class Stream6(Stream):
         stores(*pending)
         self.lds_flush()
         for rb in range(2):
+            if cfg.split:     # (m, l) of the lane's row, two floats at 8 bytes per row (attn_fwd_combine merges the pieces)
+                self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
+                if rb:
+                    self.emit("s_add_u32", s("t0"), [s("t0"), I(32)])
+                self.emit("s_lshl_b32", s("t0"), [s("t0"), I(3)])
+                self.emit("v_add_u32_e64", vo, [VN("lv"), s("t0")], clamp=1)
+                # (one 8-byte store: an instruction offset on top of an out-of-range lane offset would wrap past 2^32 into the buffer)
+                pair = T_CORR + 1      # v242:243 -- the staging addresses are dead here; an EVEN-aligned pair (gfx950: 64-bit VGPR tuples)
+                assert pair % 2 == 0
+                self.emit("v_mov_b32", V(pair), [VN("m%d" % rb)])
+                self.emit("v_mov_b32", V(pair + 1), [V(ltot[rb])])
+                self.emit("buffer_store_dwordx2", None, [V(pair, 2), vo, s("lres", 4)], offset=0)
+                continue
             x = V(T_SW + rb)
             self.emit("v_log_f32", x, [V(ltot[rb])])
             self.emit("s_nop", None, [I(0)], note="trans -> VALU")
@@ -793,6 +817,10 @@ VARIANTS = {
     "BF16_EXACT_O16_CAUSAL": Cfg6("bf16", 8, fold=0, xb=8, o16=1, causal=1),
     "F16_EXACT_CAUSAL": Cfg6("f16", 8, fold=0, xb=8, causal=1),
     "F16_EXACT_O16_CAUSAL": Cfg6("f16", 8, fold=0, xb=8, o16=1, causal=1),
+    "BF16_FOLD_SPLIT": Cfg6("bf16", 8, split=1),               # column-parallel pieces: un-normalised O and (m, l) into the workspace
+    "F16_FOLD_SPLIT": Cfg6("f16", 8, split=1),
+    "BF16_EXACT_SPLIT": Cfg6("bf16", 8, fold=0, xb=8, split=1),
+    "F16_EXACT_SPLIT": Cfg6("f16", 8, fold=0, xb=8, split=1),
     "BF16_EXACT": Cfg6("bf16", 8, fold=0, xb=8),               # lowPrecisionInputs only: scale in fp32, fp32 row sums, FP32 L
     "BF16_EXACT_O16": Cfg6("bf16", 8, fold=0, xb=8, o16=1),
     "F16_EXACT": Cfg6("f16", 8, fold=0, xb=8),
@@ -817,7 +845,7 @@ VARIANTS = {
     "ABL_ALL_NOBAR": Cfg6("bf16", 8, l16=1, abl=("dma", "exp", "max", "pack", "lds", "bar")),
 }
 PRODUCT_STREAMS = tuple(n for n in VARIANTS if n.split("_")[0] in ("BF16", "F16") and n.split("_")[1] in ("FOLD", "EXACT") and
-                        all(t in ("BF16", "F16", "FOLD", "EXACT", "O16", "L16", "CAUSAL") for t in n.split("_")))
+                        all(t in ("BF16", "F16", "FOLD", "EXACT", "O16", "L16", "CAUSAL", "SPLIT") for t in n.split("_")))
 
 
 def write_inc(path):
@@ -829,17 +857,17 @@ def write_inc(path):
                       ("LDS_BYTES", LDS_BYTES)):
         lines.append("#define MFA_P6_%s %d" % (name, val))
     lines.append("")
-    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16, causal)")
+    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16, causal, split)")
     lines.append("#define MFA_P6_PRODUCT_STREAM_LIST(X) \\")
     for name in PRODUCT_STREAMS:
         cfg = VARIANTS[name]
-        lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
+        lines.append("  X(%s, %d, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal, cfg.split))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates")
     lines.append("#define MFA_P6_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name not in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
+            lines.append("  X(%s, %d, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal, cfg.split))
     lines.append("")
     lines.append("#ifdef MFA_DEV_VARIANTS")
     lines.append("#define MFA_P6_STREAM_LIST(X) MFA_P6_PRODUCT_STREAM_LIST(X) MFA_P6_DEV_STREAM_LIST(X)")

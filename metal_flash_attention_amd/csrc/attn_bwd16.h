@@ -323,19 +323,31 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
 static __global__ __launch_bounds__(256) void attn_bwd_combine(const KernelArgs a, const Fwd16Grid grid, int slot, uint32_t rows,
                                                                const float *ws) {
   const int lane = threadIdx.x & 63;
-  const uint32_t Dr = a.D, HB = grid.heads * grid.batches;
+  const uint32_t Dr = a.D, HB = grid.heads * grid.batches, S = grid.splits;
   const uint64_t rowid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // over HB * rows
   if (rowid >= (uint64_t)HB * rows) return;
   const uint32_t hb = (uint32_t)(rowid / rows), row = (uint32_t)(rowid % rows);
   const uint32_t head = hb % grid.heads, batch = hb / grid.heads;
-  if ((uint32_t)lane * 4 >= Dr) return;
+  // (round 5, as attn_fwd_combine: latency-bound) CL = D / 4 column lanes x 64 / CL piece groups: every lane walks splits / groups
+  // pieces with independent loads, the groups are summed with half-wave exchanges
+  uint32_t CL = 1;
+  while (CL * 4 < Dr) CL <<= 1;                 // (D <= 256: at most 64 column lanes)
+  const uint32_t G = 64 / CL, c = (uint32_t)lane % CL, g = (uint32_t)lane / CL;
+  const bool active = c * 4 < Dr;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (uint32_t s = 0; s < grid.splits; ++s) {
-    const float4 v = *reinterpret_cast<const float4 *>(ws + (((uint64_t)s * HB + hb) * rows + row) * Dr + lane * 4);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  if (active) {
+    for (uint32_t s = g; s < S; s += G) {
+      const float4 v = *reinterpret_cast<const float4 *>(ws + (((uint64_t)s * HB + hb) * rows + row) * Dr + c * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   }
+  for (uint32_t off = CL; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, (int)off, 64); acc.y += __shfl_xor(acc.y, (int)off, 64);
+    acc.z += __shfl_xor(acc.z, (int)off, 64); acc.w += __shfl_xor(acc.w, (int)off, 64);
+  }
+  if (!active || g != 0) return;
   char *obase = operand_base(a.op[slot], head, batch);
-  const int64_t idx = (int64_t)row * a.op[slot].ld + lane * 4;
+  const int64_t idx = (int64_t)row * a.op[slot].ld + c * 4;
   const int prec = a.op[slot].precision;
   if (prec == PREC_FP32) {
     *reinterpret_cast<float4 *>(reinterpret_cast<float *>(obase) + idx) = acc;

@@ -181,7 +181,9 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         v = v3;
         add(fwd16_p4_variant(pq, 128, lowS ? 10 : 0, &v), v);
       }
-      if (have3 && b16 == 64) {
+      // (D <= 32: the same kernel on zero-padded chunks, selected by a | 32 | 256 | 64 | 64 | row -- the FOLD streams from D = 16 on: with
+      // fewer terms per score the rounding of Q' = Q log2(e)/sqrt(D) to BF16 no longer averages out and L leaves the reference's 7e-3)
+      if (have3 && (b16 == 64 || (b16 == 32 && (D >= 16 || kdesc->registerPrecisions[MFA_P] <= MFA_FP32)))) {
         // D <= 64 (buckets 32 and 64 of the eight-wave kernel): four waves x 64 rows, persistent, 64-key steps (attn_fwd16_p6.h, round 5);
         // mixed-precision descriptors get the streams with the row sums in the matrix pipe.  | 64 | 256 | 32 | 64 | selects the eight
         // 32-row waves of attn_fwd16_v3.h, which also keep this kernel's causal / block-sparse / column-parallel launches

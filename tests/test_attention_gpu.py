@@ -59,6 +59,10 @@ DQ_W4 = (AttentionKernelType.backwardQuery, True, "| 64 | 256 | 64 | 64 | Q, dO,
 DKV_W4 = (AttentionKernelType.backwardKeyValue, True, "| 64 | 128 | 64 | 64 | K, V, dV, dK |\n| 128 | 128 | 64 | 128 | K, V, dV, dK |\n| 256 | 64 | 32 | 256 | K, V, dV, dK |\n")
 
 
+# forward: the persistent four-wave kernel (attn_fwd16_p6) also for D <= 32, which keeps its own 4 x 32 object by default
+FWD_4x64_D32 = (AttentionKernelType.forward, True, "| 32 | 256 | 64 | 64 | Q, O |\n| 64 | 256 | 64 | 64 | Q, O |\n| 128 | 256 | 64 | 128 | Q, O |\n| 256 | 256 | 32 | 256 | Q, O |\n")
+
+
 def round_inputs(net, desc):
     """Give the oracle the values the device really sees (the reference's CPU side keeps the
     unrounded ones; its loose mixed tolerances absorb the FP16 input quantisation)."""
@@ -111,6 +115,24 @@ def test_rectangular_random_bf16_inputs(index, case):
     run_case(case["row"], case["column"], case["head"], seed=100 + index, low_in=True,
              low_mid=case["lowPrecisionIntermediates"], tr=case["transposeState"], in_type=P.BF16,
              rounded_oracle=True)
+
+
+@pytest.mark.parametrize("low_mid", [False, True])
+@pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
+def test_head_dimensions_up_to_32_on_the_persistent_four_wave_kernel(low_mid, in_type):
+    """| 32 | 256 | 64 | 64 | selects attn_fwd16_p6 for D <= 32 too (zero-padded chunks of its 64-wide code object): forward and
+    the backward kernels that consume its L, ragged rows and keys, causal"""
+    with parameter_rows(FWD_4x64_D32):
+        for (R, C, D), causal in (((300, 520, 32), False), ((257, 1000, 24), False), ((512, 512, 16 if low_mid else 8), False), ((384, 640, 32), True)):
+            net = Network(NetworkDescriptor(R, C, D), seed=D + R)
+            desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type)
+            run = harness.DeviceRun(desc, net, causal=causal)
+            assert run.kernels[AttentionKernelType.forward].variant.startswith("attn_fwd16p6"), run.kernels[AttentionKernelType.forward].variant
+            got = run.execute()
+            round_inputs(net, desc)
+            ref = net.run(causal=causal)
+            failures, report = harness.compare(ref, got, TOL_MIXED)
+            assert not failures and all(run.tails_ok.values()), (failures, R, C, D, causal, report)
 
 
 @pytest.mark.parametrize("tr", [(True, True, True, True), (True, False, False, True), (False, True, True, False)])

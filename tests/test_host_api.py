@@ -235,6 +235,17 @@ def test_parameter_table_row_selects_the_code_object():
         mfa.setParameterFile(T.forward, True, "| 64 | 256 | 32 | 64 | Q, O |\n| 128 | 256 | 32 | 128 | Q, O |\n| 256 | 128 | 32 | 256 | Q, O |\n")
         k = AttentionKernel(d.kernelDescriptor(T.forward))
         assert k.variant.startswith("attn_fwd16v3_bf16_d128_w8x32") and k.blockDimensions == (256, 32, 128)
+        # D <= 64: the default row (256, 64, 64) is the persistent four-wave kernel (round 5); 32-key steps select the eight-wave one;
+        # D <= 32 keeps its own 4 x 32 object by default and takes the four-wave kernel (zero-padded chunks) with a (256, 64, 64) row
+        d64, d32 = _low((4096, 4096, 64), low_mid=True), _low((4096, 4096, 32), low_mid=True)
+        assert AttentionKernel(d64.kernelDescriptor(T.forward)).variant.startswith("attn_fwd16v3_bf16_d64_w8x32")
+        mfa.resetParameterFiles()
+        assert AttentionKernel(d64.kernelDescriptor(T.forward)).variant == "attn_fwd16p6_bf16_d64_w4x64_thr8_fold"
+        assert AttentionKernel(d32.kernelDescriptor(T.forward)).variant.startswith("attn_fwd16v3_bf16_d32_w4x32")
+        mfa.setParameterFile(T.forward, True, "| 32 | 256 | 64 | 64 | Q, O |\n| 64 | 256 | 64 | 64 | Q, O |\n| 128 | 256 | 64 | 128 | Q, O |\n")
+        for dd in (d64, d32):
+            k = AttentionKernel(dd.kernelDescriptor(T.forward))
+            assert k.variant == "attn_fwd16p6_bf16_d64_w4x64_thr8_fold" and k.blockDimensions == (256, 64, 64), k.variant
         mfa.setParameterFile(T.backwardKeyValue, True, "| 128 | 128 | 64 | 128 | K, V, dV, dK |\n")
         assert AttentionKernel(d.kernelDescriptor(T.backwardKeyValue)).variant.startswith("attn_dkv16_bf16_d128_w4x32")
         mfa.setParameterFile(T.backwardKeyValue, True, "| 128 | 128 | 32 | 128 | K, V, dV, dK |\n")

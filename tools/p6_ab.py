@@ -37,6 +37,7 @@ def main():
     desc.lowPrecisionInputType = P.BF16
     desc.matrixDimensions = (N, N, D)
     desc.transposeState = (False,) * 4
+    mfa.setParameterFile(T.forward, True, "| 32 | 256 | 64 | 64 | Q, O |\n| 64 | 256 | 64 | 64 | Q, O |\n| 128 | 256 | 64 | 128 | Q, O |\n")
     k6 = AttentionKernel(desc.kernelDescriptor(T.forward))
     mfa.setParameterFile(T.forward, True, "| 32 | 128 | 32 | 32 | Q, O |\n| 64 | 256 | 32 | 64 | Q, O |\n| 128 | 256 | 64 | 128 | Q, O |\n")
     k3 = AttentionKernel(desc.kernelDescriptor(T.forward))

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--D", type=int, default=256)
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--heads", type=int, default=64)
+    ap.add_argument("--fill", default="normal", choices=("normal", "zero"))
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -33,7 +34,10 @@ def main():
     desc.transposeState = (False,) * 4
     g = torch.Generator(device="cuda")
     g.manual_seed(0)
-    bufs = {op: torch.randn((H, N, D), generator=g, device="cuda").to(torch.bfloat16) for op in (Op.Q, Op.K, Op.V, Op.dO)}
+    if args.fill == "zero":
+        bufs = {op: torch.zeros((H, N, D), device="cuda", dtype=torch.bfloat16) for op in (Op.Q, Op.K, Op.V, Op.dO)}
+    else:
+        bufs = {op: torch.randn((H, N, D), generator=g, device="cuda").to(torch.bfloat16) for op in (Op.Q, Op.K, Op.V, Op.dO)}
     mem = desc.memoryPrecisions
     tp = {P.FP32: torch.float32, P.FP16: torch.float16, P.BF16: torch.bfloat16}
     bufs[Op.O] = torch.zeros((H, N, D), device="cuda", dtype=tp[mem[Op.O]])
@@ -69,6 +73,33 @@ def main():
             name = {("dq", 0): "S-role", ("dq", 1): "P-role", ("dkv", 0): "V-role", ("dkv", 1): "K-role"}[(kind, role)]
             print(f"   {name}: per full iteration  tail+phase A {per[0]:7.0f}   phase B {per[1]:7.0f}   seam wait+barrier {per[2]:7.0f}   "
                   f"sum {per.sum():7.0f} shader clocks   (blocks {n:.0f})")
+            if kind == "dq" and role == 0:
+                words = bufs[Op.dQ].view(torch.int32).view(H, N, D)[:, 0::128, :11].reshape(-1, 11).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                timeline(words)
+
+
+def timeline(rows):
+    """rows: int64 array [waves][11] of the dQ PROF words (one wave per row).  Per compute unit (XCC_ID, HW_ID's se / sh / cu
+    fields) the workgroups in start order: prologue, traversal, epilogue, and the gap from a workgroup's end to the next one's
+    start on the same compute unit, in microseconds of the 100 MHz wall clock."""
+    import numpy as np
+    t_in = rows[:, 4] + (rows[:, 5] << 32)
+    pro, trav, epi = rows[:, 6], rows[:, 7] - rows[:, 6], rows[:, 8] - rows[:, 7]
+    cu = ((rows[:, 10] & 0xF) << 8) | ((rows[:, 9] >> 8) & 0xFF)
+    gaps, per_cu = [], []
+    for c in np.unique(cu):
+        idx = np.nonzero(cu == c)[0]
+        idx = idx[np.argsort(t_in[idx])]
+        per_cu.append(len(idx))
+        for a, b in zip(idx[:-1], idx[1:]):
+            gaps.append(t_in[b] - (t_in[a] + rows[a, 8]))
+    gaps = np.array(gaps, dtype=np.float64)
+    span = (t_in + rows[:, 8]).max() - t_in.min()
+    print("   timeline (one S-role wave per workgroup, 10 ns ticks -> us): %d compute units, %.1f workgroups each, launch span %.1f us" % (
+        len(per_cu), np.mean(per_cu), span / 100.0))
+    print("   prologue %.2f us   traversal %.2f us   epilogue + stores %.2f us   end -> next start on the same CU: mean %.2f us, "
+          "median %.2f us, p90 %.2f us" % (pro.mean() / 100.0, trav.mean() / 100.0, epi.mean() / 100.0, gaps.mean() / 100.0,
+                                          np.median(gaps) / 100.0, np.percentile(gaps, 90) / 100.0))
 
 
 if __name__ == "__main__":

@@ -66,6 +66,33 @@ def test_scratch_stays_out_of_the_way(obj):
         assert n <= SCRATCH_BUDGET[obj], (name, n)
 
 
+# prologue loads of the hand-placed units: a global load whose s_waitcnt vmcnt(0) comes before the next load is a round trip to
+# memory of its own.  Round 5 found the backward prologues written one (row block, k-step) at a time around asm statements --
+# hipcc keeps loads on their side of a volatile statement or a branch -- 133 of attn_dq16_p5's 166 loads were serial
+# (profiles/r05_prologue_loads.txt); the budgets are today's numbers (single loads of L / per-batch lengths and the last of a batch)
+SERIAL_LOAD_BUDGET = {"attn_dq16_p5": 8, "attn_dkv16_p5": 3, "attn_dq16_p4": 8, "attn_dkv16_p4": 4, "attn_fwd16_p5": 6}
+
+
+@pytest.mark.parametrize("obj", sorted(SERIAL_LOAD_BUDGET))
+def test_prologue_loads_are_in_flight_together(obj):
+    def is_load(t):
+        return (t.startswith("buffer_load") or t.startswith("global_load")) and not t.endswith("lds")
+    for name, ins in _kernels(obj).items():
+        if "combine" in name:
+            continue
+        serial = 0
+        for i, t in enumerate(ins):
+            if not is_load(t):
+                continue
+            for w in ins[i + 1:i + 40]:
+                if is_load(w):
+                    break
+                if w.startswith("s_waitcnt") and "vmcnt(0)" in w:
+                    serial += 1
+                    break
+        assert serial <= SERIAL_LOAD_BUDGET[obj], (name, serial)
+
+
 # translation units whose kernels are allowed to CALL a device function hipcc did not inline (by-reference captures in scratch): none.
 # (Round 3 found the transposed 8 x 32 code objects at D > 128 calling the tile-load lambda of attn_fwd16_v3.h -- ~0.1 PFLOP/s,
 # profiles/r03_dev_transposed_streams.txt; MFA_V3_INLINE_LOADS forces it inline in every build since round 4.)

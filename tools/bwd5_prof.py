@@ -73,8 +73,8 @@ def main():
             name = {("dq", 0): "S-role", ("dq", 1): "P-role", ("dkv", 0): "V-role", ("dkv", 1): "K-role"}[(kind, role)]
             print(f"   {name}: per full iteration  tail+phase A {per[0]:7.0f}   phase B {per[1]:7.0f}   seam wait+barrier {per[2]:7.0f}   "
                   f"sum {per.sum():7.0f} shader clocks   (blocks {n:.0f})")
-            if kind == "dq" and role == 0:
-                words = bufs[Op.dQ].view(torch.int32).view(H, N, D)[:, 0::128, :11].reshape(-1, 11).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            if kind == "dq":
+                words = bufs[Op.dQ].view(torch.int32).view(H, N, D)[:, 32 * role::128, :16].reshape(-1, 16).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
                 timeline(words)
 
 
@@ -95,8 +95,13 @@ def timeline(rows):
             gaps.append(t_in[b] - (t_in[a] + rows[a, 8]))
     gaps = np.array(gaps, dtype=np.float64)
     span = (t_in + rows[:, 8]).max() - t_in.min()
-    print("   timeline (one S-role wave per workgroup, 10 ns ticks -> us): %d compute units, %.1f workgroups each, launch span %.1f us" % (
+    print("   timeline (one wave of this role per workgroup, 10 ns ticks -> us): %d compute units, %.1f workgroups each, launch span %.1f us" % (
         len(per_cu), np.mean(per_cu), span / 100.0))
+    print("   entry -> arguments decoded %.2f us -> fragments cached %.2f us -> statement %.2f us;   statement end -> workgroup barrier %.2f us" % (
+        rows[:, 11].mean() / 100.0, (rows[:, 12] - rows[:, 11]).mean() / 100.0, (rows[:, 6] - rows[:, 12]).mean() / 100.0,
+        (rows[:, 13] - rows[:, 7]).mean() / 100.0))
+    print("   first batch of loads (S-role: its only one): issued at %.2f us, all data at %.2f us after entry" % (
+        rows[:, 14].mean() / 100.0, rows[:, 15].mean() / 100.0))
     print("   prologue %.2f us   traversal %.2f us   epilogue + stores %.2f us   end -> next start on the same CU: mean %.2f us, "
           "median %.2f us, p90 %.2f us" % (pro.mean() / 100.0, trav.mean() / 100.0, epi.mean() / 100.0, gaps.mean() / 100.0,
                                           np.median(gaps) / 100.0, np.percentile(gaps, 90) / 100.0))

@@ -3,6 +3,7 @@
 #include "attn_dq16_p5.h"
 #include "launchers.h"
 #include <cstdlib>
+#include <cstring>
 
 namespace mfa {
 
@@ -40,6 +41,16 @@ bool dq16_p5_variant(int precision, int gprecision, int D, int impl, VariantInfo
   if (std::getenv("MFA_BWD5_PROF") && impl == 10 && precision == PREC_BF16 && gprecision == PREC_BF16) {
     if (D == 256) { fill_dq_p5<__bf16, dq5::S_D256_BF16_FOLD_PROF>(out, "attn_dq16p5_DEV_D256_BF16_FOLD_PROF"); return true; }
     if (D == 160) { fill_dq_p5<__bf16, dq5::S_D160_BF16_FOLD_PROF>(out, "attn_dq16p5_DEV_D160_BF16_FOLD_PROF"); return true; }
+  }
+#endif
+#ifdef MFA_DEV_VARIANTS   // MFA_DQ5_DEV_STREAM=<name>: a timing-only ablation of the D = 256 BF16 stream (tools/dq5gen.py DEV_ABLATIONS)
+  if (const char *e = std::getenv("MFA_DQ5_DEV_STREAM")) {
+    if (impl == 10 && precision == PREC_BF16 && gprecision == PREC_BF16 && D == 256) {
+#define MFA_DQ5_DEV_PICK(name) \
+      if (std::strcmp(e, #name) == 0) { fill_dq_p5<__bf16, dq5::S_##name>(out, "attn_dq16p5_DEV_" #name); return true; }
+      MFA_DQ5_DEV_ABL_LIST(MFA_DQ5_DEV_PICK)
+#undef MFA_DQ5_DEV_PICK
+    }
   }
 #endif
   if (impl != 0 && impl != 10) return false;

@@ -66,7 +66,7 @@ IN_S = ["kres", "vres", "nt", "kinc", "vinc", "wrk0", "wrv0", "kend", "vend", "m
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", exact=0, D=256, abl=(), prof=0):
+    def __init__(self, dtype="bf16", exact=0, D=256, abl=(), prof=0, xwe=0, pv0=4):
         """exact: Q stays as stored, -L arrives divided by log2(e)/sqrt(D) and the scale is applied in fp32 before the exp2 (one
         packed multiply per two scores); otherwise Q arrives pre-multiplied, rounded to the 16-bit type.  dO arrives in dtype (the
         kernel converts BF16 gradients next to FP16 operands while it loads the fragments, as attn_dq16_p4.h)."""
@@ -81,6 +81,8 @@ class Cfg:
         self.XP0 = (KRING + VRING) * self.TI
         self.XS0 = self.XP0 + 4 * XPAR
         self.LDS = self.XS0 + 4 * XPAR
+        self.pv0 = pv0        # P-role: first gap of the dS' arithmetic (the partner's P fragments are requested in gaps 0, 1)
+        self.xwe = xwe        # S-role: the second row block's exp2 / pack work ends, and its two exchange writes go out, xwe gaps earlier
         self.prof = prof      # developer streams: shader-clock sums per wave -- pa: behind the barrier .. end of phase A, pb: phase B up to
         self.abl = frozenset(abl)   # the seam, pc: the seam's waits + barrier (full iterations only; every stamp costs an lgkmcnt(0))
 
@@ -120,6 +122,24 @@ class Stream(_P4Stream):
     def __init__(self, cfg):
         _P4Stream.__init__(self, cfg)
         self.rid = {}
+        self.in_loop = False      # (ablations only touch the full iterations)
+
+    # timing-only ablations (developer streams; results are garbage): classes of instructions that are simply not emitted.  The
+    # wait bookkeeping stays as generated -- an s_waitcnt for a read that was never issued returns at once.
+    ABL = {"rowrd": lambda op, note: op == "ds_read_b128" and note.startswith("rows"),
+           "trrd": lambda op, note: op == "ds_read_b64_tr_b16",
+           "xr": lambda op, note: op == "ds_read_b128" and not note.startswith("rows"),
+           "xw": lambda op, note: op == "ds_write_b128",
+           "exp": lambda op, note: op == "v_exp_f32",
+           "valu": lambda op, note: op in ("v_exp_f32", "v_pk_mul_f32", "v_mul_f32", "v_lshlrev_b32", "v_and_b32", "v_fma_mix_f32") or op.startswith("v_cvt_pk"),
+           "bar": lambda op, note: op == "s_barrier",
+           "wait": lambda op, note: op == "s_waitcnt"}
+
+    def emit(self, op, d=None, s=(), note="", **mod):
+        for a in self.cfg.abl:
+            if a in self.ABL and self.in_loop and self.ABL[a](op, note):
+                return
+        _P4Stream.emit(self, op, d, s, note=note, **mod)
 
     def lds_write(self, addr, data, offset):
         self.emit("ds_write_b128", None, [addr, data], offset=offset)
@@ -319,11 +339,13 @@ class Stream(_P4Stream):
             ops = [lambda: self.mask_branch(1)] + self.s_valu(1)
             writes = self.s_writes(1, par)
             if phase_b:
-                lo, hi = 2 * nks + 1, NM - 6
+                # (the writes must be PERFORMED before the seam's lgkmcnt(0) + barrier at NM - 4: issued one gap ahead, their
+                # latency is the wave's -- and so the workgroup's -- wait; cfg.xwe moves them and the arithmetic up)
+                lo, hi = 2 * nks + 1, max(2 * nks + 4, NM - 6 - cfg.xwe)
                 for n, fn in enumerate(ops):
                     at(lo + (n * (hi - lo + 1)) // len(ops), fn)
                 for fn in writes:
-                    at(NM - 5, fn)
+                    at(hi + 1, fn)
             else:                       # iterations 0 and 1: nothing to hide row block 1's work behind
                 for fn in ops + writes:
                     at(NM - 1, fn)
@@ -441,7 +463,7 @@ class Stream(_P4Stream):
         if phase_b and phase_a:      # the partner's four P fragments are requested at once, the arithmetic starts four gaps later
             for n, fn in enumerate(valu[:4]):
                 at(n // 2, fn)
-            lo, hi = 4, nA - 3
+            lo, hi = cfg.pv0, nA - 3
             for n, fn in enumerate(valu[4:]):
                 at(lo + (n * (hi - lo + 1)) // len(valu[4:]), fn)
         seam_g = NM - 4 if (phase_a and phase_b) else NM - 1
@@ -532,9 +554,11 @@ class Stream(_P4Stream):
             self.stamp0()
             self.enter(6, keys)
             self.label(L["LOOP"])
+            self.in_loop = True
             st0 = self.s_iteration(0, True, True, L["ALT0"])                   # i even
             self.enter(6, keys)
             st1 = self.s_iteration(1, True, True, L["ALT1"])                   # i odd
+            self.in_loop = False
             self.enter(6, keys)
             self.emit("s_branch", None, [], target=L["LOOP"])
             # exits.  i = 1 >= n (n = 1): an idle iteration, then block 0's update (iteration 2)
@@ -566,9 +590,11 @@ class Stream(_P4Stream):
             self.stamp0()
             self.enter(2, keys)
             self.label(L["LOOP"])
+            self.in_loop = True
             st1 = self.p_iteration(1, True, True, L["ALT1"])                   # i odd
             self.enter(2, keys)
             st0 = self.p_iteration(0, True, True, L["ALT0"])                   # i even
+            self.in_loop = False
             self.enter(2, keys)
             self.emit("s_branch", None, [], target=L["LOOP"])
             self.alt_tail(L["ALTA"], st_a, L["T1"])                            # i = 1 = n
@@ -612,6 +638,8 @@ def write_inc(path):
     for name, cfg in VARIANTS.items():
         lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.exact, cfg.D, cfg.prof))
     lines.append("")
+    lines.append("// timing-only ablations of the D = 256 BF16 stream (developer library: MFA_DQ5_DEV_STREAM=<name>, tools/dq5_ab.py)")
+    lines.append("#define MFA_DQ5_DEV_ABL_LIST(X) " + " ".join("X(D256_BF16_FOLD_%s)" % n for n in list(DEV_ABLATIONS) + ["XWE2", "XWE4", "PV8", "XWE4_PV8"]))
     lines.append("")
     for name, cfg in VARIANTS.items():
         ins = Stream(cfg).build()
@@ -626,6 +654,11 @@ def write_inc(path):
         f.write("\n".join(lines))
 
 
+DEV_ABLATIONS = {"ABL_ROWRD": ("rowrd",), "ABL_TRRD": ("trrd",), "ABL_XCH": ("xr", "xw"), "ABL_VALU": ("valu",), "ABL_BAR": ("bar",),
+                 "ABL_DMA": ("dma",), "ABL_LDS": ("rowrd", "trrd", "xr", "xw"), "ABL_LDS_VALU": ("rowrd", "trrd", "xr", "xw", "valu"),
+                 "ABL_ALL": ("rowrd", "trrd", "xr", "xw", "valu", "dma", "bar", "wait")}
+
+
 def _variants():
     out = {}
     for D in (160, 192, 256):
@@ -634,6 +667,12 @@ def _variants():
             out["D%d_%s_EXACT" % (D, dt.upper())] = Cfg(dt, exact=1, D=D)
     out["D256_BF16_FOLD_PROF"] = Cfg("bf16", D=256, prof=1)       # developer library only (tools/bwd5_prof.py)
     out["D160_BF16_FOLD_PROF"] = Cfg("bf16", D=160, prof=1)
+    for e in (2, 4):                                            # developer schedules: the S-role's second pair of exchange writes earlier
+        out["D256_BF16_FOLD_XWE%d" % e] = Cfg("bf16", D=256, xwe=e)
+    out["D256_BF16_FOLD_PV8"] = Cfg("bf16", D=256, pv0=8)
+    out["D256_BF16_FOLD_XWE4_PV8"] = Cfg("bf16", D=256, xwe=4, pv0=8)
+    for name, abl in DEV_ABLATIONS.items():                     # developer library only: timing-only ablations (tools/dq5_ab.py)
+        out["D256_BF16_FOLD_" + name] = Cfg("bf16", D=256, abl=abl)
     return out
 
 

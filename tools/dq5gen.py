@@ -66,7 +66,7 @@ IN_S = ["kres", "vres", "nt", "kinc", "vinc", "wrk0", "wrv0", "kend", "vend", "m
 
 
 class Cfg:
-    def __init__(self, dtype="bf16", exact=0, D=256, abl=(), prof=0, xwe=0, pv0=4):
+    def __init__(self, dtype="bf16", exact=0, D=256, abl=(), prof=0, xwe=0, pv0=4, wa=None):
         """exact: Q stays as stored, -L arrives divided by log2(e)/sqrt(D) and the scale is applied in fp32 before the exp2 (one
         packed multiply per two scores); otherwise Q arrives pre-multiplied, rounded to the 16-bit type.  dO arrives in dtype (the
         kernel converts BF16 gradients next to FP16 operands while it loads the fragments, as attn_dq16_p4.h)."""
@@ -81,6 +81,7 @@ class Cfg:
         self.XP0 = (KRING + VRING) * self.TI
         self.XS0 = self.XP0 + 4 * XPAR
         self.LDS = self.XS0 + 4 * XPAR
+        self.wa = WAIT_AHEAD if wa is None else wa   # matrix instructions whose fragments one s_waitcnt may cover
         self.pv0 = pv0        # P-role: first gap of the dS' arithmetic (the partner's P fragments are requested in gaps 0, 1)
         self.xwe = xwe        # S-role: the second row block's exp2 / pack work ends, and its two exchange writes go out, xwe gaps earlier
         self.prof = prof      # developer streams: shader-clock sums per wave -- pa: behind the barrier .. end of phase A, pb: phase B up to
@@ -366,7 +367,7 @@ class Stream(_P4Stream):
             fn()
         state = None
         for g, (d, a_, b_, c_, keys) in enumerate(mm):
-            self.need(keys, [k for m in mm[g + 1:g + 1 + WAIT_AHEAD] for k in m[4]])
+            self.need(keys, [k for m in mm[g + 1:g + 1 + cfg.wa] for k in m[4]])
             self.emit("v_mfma_f32_32x32x16_" + cfg.dtype, d, [a_, b_, c_])
             for fn in fill[g]:
                 fn()
@@ -484,7 +485,7 @@ class Stream(_P4Stream):
             fn()
         state = None
         for g, (d, a_, b_, c_, keys) in enumerate(mm):
-            self.need(keys, [k for m in mm[g + 1:g + 1 + WAIT_AHEAD] for k in m[4]])
+            self.need(keys, [k for m in mm[g + 1:g + 1 + cfg.wa] for k in m[4]])
             self.emit("v_mfma_f32_32x32x16_" + cfg.dtype, d, [a_, b_, c_])
             for fn in fill[g]:
                 fn()
@@ -639,7 +640,7 @@ def write_inc(path):
         lines.append("  X(%s, %d, %d, %d) \\" % (name, cfg.exact, cfg.D, cfg.prof))
     lines.append("")
     lines.append("// timing-only ablations of the D = 256 BF16 stream (developer library: MFA_DQ5_DEV_STREAM=<name>, tools/dq5_ab.py)")
-    lines.append("#define MFA_DQ5_DEV_ABL_LIST(X) " + " ".join("X(D256_BF16_FOLD_%s)" % n for n in list(DEV_ABLATIONS) + ["XWE2", "XWE4", "PV8", "XWE4_PV8"]))
+    lines.append("#define MFA_DQ5_DEV_ABL_LIST(X) " + " ".join("X(D256_BF16_FOLD_%s)" % n for n in list(DEV_ABLATIONS) + ["XWE2", "XWE4", "PV8", "XWE4_PV8", "PV12", "PV16", "WA4", "PV12_WA4"]))
     lines.append("")
     for name, cfg in VARIANTS.items():
         ins = Stream(cfg).build()
@@ -670,6 +671,10 @@ def _variants():
     for e in (2, 4):                                            # developer schedules: the S-role's second pair of exchange writes earlier
         out["D256_BF16_FOLD_XWE%d" % e] = Cfg("bf16", D=256, xwe=e)
     out["D256_BF16_FOLD_PV8"] = Cfg("bf16", D=256, pv0=8)
+    out["D256_BF16_FOLD_PV12"] = Cfg("bf16", D=256, pv0=12)
+    out["D256_BF16_FOLD_PV16"] = Cfg("bf16", D=256, pv0=16)
+    out["D256_BF16_FOLD_WA4"] = Cfg("bf16", D=256, wa=4)
+    out["D256_BF16_FOLD_PV12_WA4"] = Cfg("bf16", D=256, pv0=12, wa=4)
     out["D256_BF16_FOLD_XWE4_PV8"] = Cfg("bf16", D=256, xwe=4, pv0=8)
     for name, abl in DEV_ABLATIONS.items():                     # developer library only: timing-only ablations (tools/dq5_ab.py)
         out["D256_BF16_FOLD_" + name] = Cfg("bf16", D=256, abl=abl)

@@ -116,6 +116,15 @@ bool launch_p6_split(int precision, bool fold, dim3 grid, uint32_t splits, float
   return true;
 }
 
+// what runs instead when this kernel does not serve a launch (launch_p6_or_v3*): the name rocprofv3 shows is the eight-wave kernel's
+static const char *unserved_form(int precision, const KernelArgs &args) {
+  if (precision == PREC_BF16)
+    return args.causal ? "attn_fwd16v3_bf16_d64_w8x32_thr8 causal (eight-wave kernel: the launch is not one attn_fwd16_p6 serves)"
+                       : "attn_fwd16v3_bf16_d64_w8x32_thr8 (eight-wave kernel: the launch is not one attn_fwd16_p6 serves)";
+  return args.causal ? "attn_fwd16v3_f16_d64_w8x32_thr8 causal (eight-wave kernel: the launch is not one attn_fwd16_p6 serves)"
+                     : "attn_fwd16v3_f16_d64_w8x32_thr8 (eight-wave kernel: the launch is not one attn_fwd16_p6 serves)";
+}
+
 const char *p6_form(int precision, bool fold, const KernelArgs &args) {
   if (!serves(precision, fold, args)) return nullptr;
 #ifdef MFA_DEV_VARIANTS
@@ -145,13 +154,18 @@ template <int PREC, bool FOLD> static void launch_p6_or_v3_causal(dim3 grid, hip
   fwd16_v3_d64_launch_causal(PREC, grid, stream, args);
 }
 template <int PREC, bool FOLD> static const char *p6_split_form_of(const KernelArgs &args, uint32_t splits) {
-  if (!p6_form(PREC, FOLD, args) || args.causal || splits < 2 || args.C % (256u * splits) != 0) return nullptr;
+  static const char *const sibling = PREC == PREC_BF16 ? "pieces by the eight-wave kernel attn_fwd16v3_bf16_d64_w8x32_thr8 (not a split attn_fwd16_p6 serves)"
+                                                       : "pieces by the eight-wave kernel attn_fwd16v3_f16_d64_w8x32_thr8 (not a split attn_fwd16_p6 serves)";
+  if (!p6_form(PREC, FOLD, args) || args.causal || splits < 2 || args.C % (256u * splits) != 0) return sibling;
 #ifdef MFA_DEV_VARIANTS
-  if (std::getenv("MFA_P6_NO_SPLIT")) return nullptr;
+  if (std::getenv("MFA_P6_NO_SPLIT")) return sibling;
 #endif
   return "pieces by attn_fwd16_p6, persistent";
 }
-template <int PREC, bool FOLD> static const char *p6_form_of(const KernelArgs &args) { return p6_form(PREC, FOLD, args); }
+template <int PREC, bool FOLD> static const char *p6_form_of(const KernelArgs &args) {
+  const char *form = p6_form(PREC, FOLD, args);
+  return form ? form : unserved_form(PREC, args);
+}
 
 // `out` arrives filled by fwd16_v3_variant(precision, 64, 0): its causal, block-sparse and column-parallel launches (and the dense
 // launches this kernel does not serve: transposed operands, other storage types of L) stay with that kernel, which becomes the sibling

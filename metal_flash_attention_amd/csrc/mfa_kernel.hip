@@ -188,6 +188,10 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         // mixed-precision descriptors get the streams with the row sums in the matrix pipe.  | 64 | 256 | 32 | 64 | selects the eight
         // 32-row waves of attn_fwd16_v3.h, which also keep this kernel's causal / block-sparse / column-parallel launches
         v = v3;
+        // (D <= 32 on this kernel: the launches it does not serve -- per-batch lengths, an L of the other storage type, pieces that
+        // are not whole multiples of four tiles -- go to the D = 64 eight-wave kernels, so the base must be THEIR variant: functions
+        // whose dynamic LDS attribute ensure_lds_attribute raises, 256-row blocks for split grids and choose_splits)
+        if (b16 == 32 && !fwd16_v3_variant(pq, 64, 0, &v)) v = v3;
         add(fwd16_p6_variant(pq, kdesc->registerPrecisions[MFA_P] > MFA_FP32, &v), v);
       }
       if (have3 && (b16 == 160 || b16 == 192 || b16 == 256)) {   // four waves x 64 rows, 32-key steps (attn_fwd16_p5.h)

@@ -135,6 +135,88 @@ def test_head_dimensions_up_to_32_on_the_persistent_four_wave_kernel(low_mid, in
             assert not failures and all(run.tails_ok.values()), (failures, R, C, D, causal, report)
 
 
+def test_head_dimensions_up_to_32_launches_the_persistent_kernel_does_not_serve():
+    """| 32 | 256 | 64 | 64 | at D <= 32: what attn_fwd16_p6 does not take (per-batch lengths, an L of the other storage type, a one-head
+    split whose key range is not whole multiples of four tiles per piece) runs on the D = 64 EIGHT-wave kernels -- the variant must then
+    carry their functions (dynamic LDS above 64 KiB: a fresh process fails otherwise), their 256-row blocks for the split grid, and
+    the launch form must name them."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def pack16(a):
+        return torch.from_numpy((np.ascontiguousarray(a).view(np.uint32) >> 16).astype(np.uint16).view(np.int16)).cuda()
+
+    with parameter_rows(FWD_4x64_D32):
+        # (1) per-batch lengths
+        B, H, Rmax, Cmax, D = 3, 2, 300, 400, 32
+        rlen, clen = [300, 77, 130], [400, 100, 333]
+        desc = make_desc(Rmax, Cmax, D, low_in=True, low_mid=True, in_type=P.BF16)
+        kernel = AttentionKernel(desc.kernelDescriptor(AttentionKernelType.forward))
+        assert kernel.variant.startswith("attn_fwd16p6"), kernel.variant
+        rng = np.random.default_rng(5)
+        host = {n: round_trip(rng.standard_normal((B, H, Rmax if n == "Q" else Cmax, D)).astype(np.float32), int(P.BF16)) for n in ("Q", "K", "V")}
+        lprec = desc.memoryPrecisions[Op.L]
+        bufs = {Op.Q: pack16(host["Q"]), Op.K: pack16(host["K"]), Op.V: pack16(host["V"]),
+                Op.O: torch.full((B, H, Rmax, D), float("nan"), device="cuda"),
+                Op.L: torch.zeros((B, H, Rmax), device="cuda", dtype=torch.float16 if lprec == P.FP16 else torch.float32)}
+        hs = {Op.Q: Rmax * D, Op.K: Cmax * D, Op.V: Cmax * D, Op.O: Rmax * D, Op.L: Rmax}
+        bs = {op: v * H for op, v in hs.items()}
+        rl, cl = (torch.tensor(x, dtype=torch.int32, device="cuda") for x in (rlen, clen))
+        kw = dict(row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs, rowLengths=rl, columnLengths=cl)
+        form = kernel.launchForm(bufs, **kw)
+        assert form.startswith("attn_fwd16v3_bf16_d64_w8x32"), form
+        kernel.dispatch(bufs, stream=stream, **kw)
+        torch.cuda.synchronize()
+        o, l = bufs[Op.O].cpu().numpy(), bufs[Op.L].float().cpu().numpy() / np.float32(harness.LOG2E)
+        for b in range(B):
+            R, C = rlen[b], clen[b]
+            for h in range(H):
+                net = Network(NetworkDescriptor(R, C, D), seed=0)
+                net.Q, net.K, net.V = (np.ascontiguousarray(host[n][b, h, :(R if n == "Q" else C)]) for n in ("Q", "K", "V"))
+                net.invalidate()
+                ref = net.run(backward=False)
+                assert np.abs(o[b, h, :R] - ref["O"]).max() < 1.5e-2 and np.abs(l[b, h, :R] - ref["L"]).max() < 7e-3, (b, h)
+                assert np.isnan(o[b, h, R:]).all()
+        # (2) one head, a workspace, C not a multiple of 256 x pieces: the eight-wave kernel's column-parallel sibling, 256-row blocks
+        R, C, D = 512, 2944, 24
+        desc = make_desc(R, C, D, low_in=True, low_mid=True, in_type=P.BF16)
+        net = Network(NetworkDescriptor(R, C, D), seed=8)
+        run = harness.DeviceRun(desc, net, run_backward=False)
+        kernel = run.kernels[AttentionKernelType.forward]
+        assert kernel.variant.startswith("attn_fwd16p6"), kernel.variant
+        need = kernel.workspaceSize(row=R, column=C)
+        assert need > 0
+        ws = torch.empty(need + 64, dtype=torch.uint8, device="cuda")
+        form = kernel.launchForm(run.buffers, row=R, column=C, workspace=ws)
+        assert "column-parallel x" in form and "attn_fwd16v3_bf16_d64_w8x32" in form, form
+        kernel.dispatch(run.buffers, row=R, column=C, stream=stream, workspace=ws)
+        torch.cuda.synchronize()
+        got = run.results()
+        round_inputs(net, desc)
+        ref = net.run(backward=False)
+        assert np.abs(got["O"] - ref["O"]).max() < 1.5e-2 and np.abs(got["L"] - ref["L"]).max() < 7e-3
+        # (3) an L of the other storage type (FP32 L beside 16-bit intermediates): hand-edited kernel descriptor
+        R, C, D = 300, 520, 32
+        desc = make_desc(R, C, D, low_in=True, low_mid=True, in_type=P.BF16)
+        kd = desc.kernelDescriptor(AttentionKernelType.forward)
+        mp = dict(kd.memoryPrecisions)
+        mp[Op.L] = P.FP32
+        kd.memoryPrecisions = mp
+        kernel = AttentionKernel(kd)
+        assert kernel.variant.startswith("attn_fwd16p6"), kernel.variant
+        net = Network(NetworkDescriptor(R, C, D), seed=12)
+        round_inputs(net, desc)
+        bufs = {Op.Q: pack16(net.Q), Op.K: pack16(net.K), Op.V: pack16(net.V), Op.O: torch.full((R, D), float("nan"), device="cuda"),
+                Op.L: torch.zeros((R,), device="cuda")}
+        form = kernel.launchForm(bufs, row=R, column=C)
+        assert form.startswith("attn_fwd16v3_bf16_d64_w8x32"), form
+        kernel.dispatch(bufs, row=R, column=C, stream=stream)
+        torch.cuda.synchronize()
+        ref = net.run(backward=False)
+        assert np.abs(bufs[Op.O].cpu().numpy() - ref["O"]).max() < 1.5e-2
+        assert np.abs(bufs[Op.L].cpu().numpy() / np.float32(harness.LOG2E) - ref["L"]).max() < 7e-3
+
+
 @pytest.mark.parametrize("tr", [(True, True, True, True), (True, False, False, True), (False, True, True, False)])
 @pytest.mark.parametrize("shape", [(130, 67, 72), (33, 200, 128), (257, 129, 200)])
 def test_transposes_fp32(shape, tr):

@@ -514,7 +514,7 @@ class Stream:
         abl = cfg.abl if (mfma and softmax) else frozenset()
         if not mfma and softmax:
             self.emit("s_nop", None, [I(15)], note="S(0) is still leaving the matrix pipe")
-        if softmax:
+        if softmax and "ctl" not in abl:
             self.mask_section(par, after_mfma=mfma)
         fill = [[] for _ in range(32)]
         slots = [1] * 32
@@ -561,7 +561,7 @@ class Stream:
             # 19 % faster and without the wait + barrier 25 % faster (profiles/r05_p4p_bal_ablations.txt): the wait for pieces
             # issued in the last gaps of this phase was what the loop spent a fifth of its time in
             ksw_g, vsw_g = 0, 4
-            if getattr(self, "persistent", False):
+            if getattr(self, "persistent", False) and "ctl" not in abl:
                 self.b_hook(lambda g, fn: at(g, fn, 2), par, mfma, gaps=(ksw_g, vsw_g))
             if "dma" not in abl:
                 for n in range(4):
@@ -603,7 +603,7 @@ class Stream:
                 if "lds" not in abl:
                     at(exp_from + n, lambda n=n: self.k_read(par ^ 1, n))
             at(26, lambda: self.vrd_advance(), 3)
-            if "dma" not in abl:
+            if "dma" not in abl and "offs" not in abl:
                 for n in range(4):
                     at(28 + n, lambda n=n: self.emit("v_add_u32_e64", VN("koff%d" % n), [VN("koff%d" % n), SN("kinc")], clamp=1))
                     at(28 + n, lambda n=n: self.emit("v_add_u32_e64", VN("voff%d" % n), [VN("voff%d" % n), SN("vinc")], clamp=1))
@@ -651,8 +651,9 @@ class Stream:
         self.lds_flush()
         if softmax:
             resc, back = self.newlabel("RESC"), self.newlabel("RESCBACK")
-            self.emit("s_cmp_eq_u32", None, [SN("pend"), I(0)])
-            self.emit("s_cbranch_scc0", None, [], target=resc)
+            if "ctl" not in abl:
+                self.emit("s_cmp_eq_u32", None, [SN("pend"), I(0)])
+                self.emit("s_cbranch_scc0", None, [], target=resc)
             self.label(back)
             self.outofline.append(("resc", resc, back, par, False))
             self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK", par, not mfma))

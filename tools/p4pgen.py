@@ -98,12 +98,18 @@ class PCfg(Cfg):
         assert not (self.fuse and (causal or merge))
         # pprof (developer builds, exact-scale streams only: their -m blocks v168.. are free): shader-clock sums per segment of
         # the block loop in v168..v183, written to O[first row of the wave's last block][0:16] when the workgroup ends
+        # pprof = 2 (round 6; any dense stream): the sums live in SCALAR registers the dense streams leave unused (SPROF_ACC) -- the
+        # product schedule itself can be stamped, FOLD streams included: phase A | wait for this wave's LDS-DMA pieces | barrier | phase B
         self.pprof = pprof
-        assert not (pprof and fold)
+        assert not (pprof == 1 and fold)
+        assert not (pprof == 2 and (causal or merge))
 
 
 PROF_ACC = 168
 PROF_MAGIC = 0x50524F46
+# pprof = 2: name -> scalar accumulator (s67 is free; s89..s93 are the causal streams' block geometry, unused by dense streams)
+SPROF_NAMES = ["loop_a", "loop_vm", "loop_bar", "loop_b", "rest", "blocks"]
+SPROF_ACC = {"loop_a": 67, "loop_vm": 89, "loop_bar": 90, "loop_b": 91, "rest": 92, "blocks": 93}
 PROF_NAMES = ["table", "wait_q", "qfrag", "tile0_a", "tile0_b", "loop_a", "loop_wait", "loop_b", "tile1_wait", "tail", "epilogue", "blocks"]
 
 
@@ -169,6 +175,13 @@ class PStream(Stream):
         self.emit("s_memtime", SR(98, 2))
         self.emit("s_waitcnt", None, [], lgkmcnt=0)
         self.lds_done = self.lds_issued
+        if self.cfg.pprof == 2:
+            if not first:
+                acc = SR(SPROF_ACC.get(name, SPROF_ACC["rest"]))
+                self.emit("s_sub_u32", s("t3"), [SR(98), s("plast")])
+                self.emit("s_add_u32", acc, [acc, s("t3")])
+            self.emit("s_mov_b32", s("plast"), [SR(98)])
+            return
         if not first:
             self.emit("s_sub_u32", s("t3"), [SR(98), s("plast")])
             acc = V(PROF_ACC + PROF_NAMES.index(name))
@@ -615,9 +628,12 @@ class PStream(Stream):
         self.issue_tile("k", 1)
         self.emit("s_waitcnt", None, [], vmcnt=0)
         # ================= block loop =================
-        if cfg.pprof:
+        if cfg.pprof == 1:
             for i in range(16):
                 self.emit("v_mov_b32", V(PROF_ACC + i), [I(0)])
+        elif cfg.pprof == 2:
+            for r in SPROF_ACC.values():
+                self.emit("s_mov_b32", SR(r), [I(0)])
         self.label(blk_lbl)
         self.pstamp("table", first=True)
         self.block_head(nonext)
@@ -649,10 +665,13 @@ class PStream(Stream):
             self.lds_flush()
             self.pstamp("loop_a")
             if "bar" not in cfg.abl:
-                self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j) (and, in tile 1, the stores)
+                if "vm" not in cfg.abl:
+                    self.emit("s_waitcnt", None, [], vmcnt=0)        # this wave's pieces of K(j+1) and V(j) (and, in tile 1, the stores)
+                if cfg.pprof == 2:
+                    self.pstamp("loop_vm")
                 self.emit("s_barrier")
-            self.pstamp("loop_wait")
-            if cfg.pprof and par == 1:                      # the wait of tile 1 separately (it includes the previous block's stores)
+            self.pstamp("loop_bar" if cfg.pprof == 2 else "loop_wait")
+            if cfg.pprof == 1 and par == 1:                      # the wait of tile 1 separately (it includes the previous block's stores)
                 self.emit("s_cmp_eq_u32", None, [SN("j"), I(1)])
                 self.emit("s_cselect_b32", s("t3"), [s("t3"), I(0)])
                 acc = V(PROF_ACC + PROF_NAMES.index("tile1_wait"))
@@ -712,9 +731,11 @@ class PStream(Stream):
         if cfg.fuse:
             self.label(after_epi)
         self.pstamp("epilogue")
-        if cfg.pprof:
+        if cfg.pprof == 1:
             acc = V(PROF_ACC + PROF_NAMES.index("blocks"))
             self.emit("v_add_u32", acc, [I(1), acc])
+        elif cfg.pprof == 2:
+            self.emit("s_add_u32", SR(SPROF_ACC["blocks"]), [SR(SPROF_ACC["blocks"]), I(1)])
         post = self.newlabel("POST")
         self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(1)])
         self.emit("s_cbranch_scc1", None, [], target=post if cfg.merge else blk_lbl)
@@ -723,10 +744,15 @@ class PStream(Stream):
             self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
             self.emit("s_mul_i32", s("t0"), [s("t0"), SN("ldo")])
             self.emit("v_mov_b32", V(T_TL), [s("t0")])
-            self.emit("v_mov_b32", V(PROF_ACC + 15), [I(PROF_MAGIC)])
+            pacc = PROF_ACC
+            if cfg.pprof == 2:   # (the score registers are dead behind the last block)
+                pacc = S_BASE[0]
+                for i in range(15):
+                    self.emit("v_mov_b32", V(pacc + i), [SR(SPROF_ACC[SPROF_NAMES[i]]) if i < len(SPROF_NAMES) else I(0)])
+            self.emit("v_mov_b32", V(pacc + 15), [I(PROF_MAGIC)])
             self.emit("s_mov_b64", ("exec",), [I(1)])
             for i in range(4):
-                self.emit("buffer_store_dwordx4", None, [V(PROF_ACC + 4 * i, 4), V(T_TL), s("tres", 4)], offset=16 * i)
+                self.emit("buffer_store_dwordx4", None, [V(pacc + 4 * i, 4), V(T_TL), s("tres", 4)], offset=16 * i)
             self.emit("s_mov_b64", ("exec",), [I(-1)])
             self.emit("s_waitcnt", None, [], vmcnt=0)
         self.emit("s_branch", None, [], target=fin)
@@ -835,6 +861,21 @@ VARIANTS = {
     "EXACT_BAL2_XE24_C8": PCfg("bf16", 8, fold=0, bal=2, xe=24, cap=8),
     "EXACT_BAL2_XE32_C8": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8),
     "EXACT_BAL2_XE40_C8": PCfg("bf16", 8, fold=0, bal=2, xe=40, cap=8),
+    # round 6, developer builds: the product schedule stamped per phase (scalar accumulators) and its timing-only ablations (WRONG RESULTS)
+    "BF16_FOLD_L16_SPROF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, pprof=2),
+    "ABL6_EXP": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp",)),
+    "ABL6_MAX": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("max",)),
+    "ABL6_SUMPACK": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("sum", "pack")),
+    "ABL6_SUM": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("sum",)),
+    "ABL6_LDS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("lds",)),
+    "ABL6_DMA": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("dma",)),
+    "ABL6_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("bar",)),
+    "ABL6_VM": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("vm",)),
+    "ABL6_CTL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("ctl",)),
+    "ABL6_OFFS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("offs",)),
+    "ABL6_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack")),
+    "ABL6_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack", "lds", "dma")),
+    "ABL6_ALL_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack", "lds", "dma", "bar", "ctl")),
     "BF16_FOLD_L16_PAD": PCfg("bf16", 8, fold=1, l16=1, pad=1),
     "BF16_FOLD_L16_BAL32_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, pad=1),
     "BF16_FOLD_L16_BAL40_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=40, pad=1),
@@ -847,6 +888,7 @@ VARIANTS = {
     "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
 PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL', n))
+assert "BF16_FOLD_L16_SPROF" not in PRODUCT_STREAMS
 
 
 def write_inc(path):

@@ -12,14 +12,14 @@ import pytest
 
 CSRC = os.path.join(os.path.dirname(__file__), "..", "metal_flash_attention_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
-OBJECTS = ["attn_fwd16_p4", "attn_fwd16_p4p", "attn_fwd16_p5", "attn_dq16_p4", "attn_dkv16_p4", "attn_dq16_p5", "attn_dkv16_p5", "attn_f32",
+OBJECTS = ["attn_fwd16_p4", "attn_fwd16_p4p", "attn_fwd16_p6", "attn_fwd16_p5", "attn_dq16_p4", "attn_dkv16_p4", "attn_dq16_p5", "attn_dkv16_p5", "attn_f32",
            "attn_fwd16_p4_tr", "attn_fwd16_p5_tr", "attn_bwd16_p4_tr"]
 # scratch instructions hipcc may leave AROUND a hand-placed statement, per translation unit (the worst kernel of the unit today;
 # pinned so that they cannot grow unnoticed -- the statements themselves never touch scratch)
-SCRATCH_BUDGET = {"attn_fwd16_p4": 40, "attn_fwd16_p4p": 0, "attn_fwd16_p5": 40, "attn_dq16_p4": 40, "attn_dkv16_p4": 40, "attn_dq16_p5": 0,
+SCRATCH_BUDGET = {"attn_fwd16_p4": 40, "attn_fwd16_p4p": 0, "attn_fwd16_p6": 0, "attn_fwd16_p5": 40, "attn_dq16_p4": 40, "attn_dkv16_p4": 40, "attn_dq16_p5": 0,
                   "attn_dkv16_p5": 8, "attn_f32": 8, "attn_fwd16_p4_tr": 60, "attn_fwd16_p5_tr": 100, "attn_bwd16_p4_tr": 540}   # (attn_dq16_p4_tr gathers Q^T / dO^T / O^T in its C++ prologue: 526 today)
 # (kernels of the unit that spill at all, most spilled vector registers in one kernel): the state of the round-5 build
-SPILL_BUDGET = {"attn_fwd16_p4p": (0, 0), "attn_dq16_p5": (0, 0), "attn_dkv16_p5": (16, 1), "attn_dq16_p4": (18, 2), "attn_dkv16_p4": (21, 6),
+SPILL_BUDGET = {"attn_fwd16_p4p": (0, 0), "attn_fwd16_p6": (0, 0), "attn_dq16_p5": (0, 0), "attn_dkv16_p5": (16, 1), "attn_dq16_p4": (18, 2), "attn_dkv16_p4": (21, 6),
                 "attn_f32": (1, 2), "attn_fwd16_p4": (4, 15), "attn_fwd16_p5": (12, 2), "attn_fwd16_p4_tr": (24, 19),
                 "attn_fwd16_p5_tr": (56, 34), "attn_bwd16_p4_tr": (24, 73)}
 
@@ -54,7 +54,11 @@ def test_lds_dma_pieces_are_issued_back_to_back(obj):
         for i, t in enumerate(ins):
             if t.startswith("buffer_load") and t.endswith("lds"):
                 window = ins[max(0, i - 4):i]
-                assert not any(w.startswith("s_waitcnt vmcnt(0)") for w in window), (name, i, window)
+                # (a wait FOLLOWED BY THE TILE'S BARRIER is the seam of the hand-placed streams, whose first LDS-DMA piece leads the
+                # phase behind it by design -- round 6: the branch-free loop has no block-switch test between the two any more)
+                for k, w in enumerate(window):
+                    if w.startswith("s_waitcnt vmcnt(0)"):
+                        assert any(x.startswith("s_barrier") for x in window[k + 1:]), (name, i, window)
                 assert not any(w.startswith("scratch_load") for w in window), (name, i, window)
 
 

@@ -112,6 +112,45 @@ def test_head_dimensions_below_the_bucket(D, name):
     assert wg.waves[0].count["buffer_store_dwordx2" if cfg.o16 else "buffer_store_dwordx4"] == 2 * 32
 
 
+# ---- round 6: the branch-free loop (PCfg.fastloop) -- tiles 1 .. fend - 1 of a block run in a copy of the loop without the mask,
+# block-switch and pending-rescale tests; a rescale decided there continues in the ordinary copy of the same phase
+@pytest.mark.parametrize("C", [256, 320, 384, 448, 512, 576, 640, 700, 1100])
+@pytest.mark.parametrize("cfg", [FOLD, EXACT], ids=["fold", "exact"])
+def test_branch_free_loop_boundaries(cfg, C):
+    """every number of branch-free tile pairs from none (C <= 256) upwards, even and odd tile counts, a ragged last tile: the tiles
+    behind the loop -- the last two of a block (block switch) and the masked ones -- run in the ordinary copy"""
+    assert cfg.fastloop
+    wg, _, _ = _check(2, 256, C, cfg=cfg, seed=C)
+    nt = (C + 63) // 64
+    nt += nt & 1
+    fend = (min(C // 64, nt - 2) - 1) | 1
+    pairs = max(0, (fend - 1) // 2)
+    # per block: tile 0, the loop tiles and the tail multiply 64 times each
+    assert wg.waves[0].count["v_mfma_f32_32x32x16_bf16"] == 2 * 64 * nt
+    assert wg.waves[0].count.get("s_cmp_lg_u32", 0) == 2 * pairs      # (the loop's back-edge test: once per tile pair and block)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("cfg", [FOLD, EXACT], ids=["fold", "exact"])
+def test_rescale_decided_in_the_branch_free_loop(cfg, tile):
+    """a key aligned with a query in tile `tile` of ten forces the deferred rescale there: tiles 1 .. 6 are branch-free tiles of
+    either parity (the decision jumps into the ordinary copy, which applies the rescale and returns to the loop head), 7 .. 9 are not"""
+    _check(2, 256, 640, cfg=cfg, seed=7, spike=(17, 64 * tile + 5, 3.0), tol_o=1.2e-2)
+
+
+@pytest.mark.parametrize("dma_mode,stores,order", [("early", "late", (3, 2, 1, 0)), ("late", "early", (0, 1, 2, 3)), ("late", "late", (2, 0, 3, 1))])
+def test_branch_free_loop_ring_discipline(dma_mode, stores, order):
+    _check(3, 256, 704, cfg=FOLD, dma_mode=dma_mode, stores=stores, order=order, seed=21)
+    _check(2, 300, 520, cfg=EXACT, dma_mode=dma_mode, stores=stores, order=order, seed=22)
+
+
+def test_round5_streams_are_still_generated_for_the_developer_library():
+    """the A/B baselines of tools/p4p_streams_ab.py: same results as the product streams (same arithmetic, other loop)"""
+    for dev, prod in (("R5_BF16_FOLD_L16", FOLD), ("R5_BF16_EXACT", EXACT)):
+        _check(1, 256, 449, cfg=p4pgen.VARIANTS[dev], seed=3)
+        assert not p4pgen.VARIANTS[dev].fastloop and prod.fastloop
+
+
 CAUSAL_FOLD = p4pgen.VARIANTS["BF16_FOLD_L16_CAUSAL"]
 CAUSAL_EXACT = p4pgen.VARIANTS["BF16_EXACT_CAUSAL"]
 
@@ -136,6 +175,17 @@ def test_causal_skip_loop_keeps_the_ring_and_the_block_switch_going(dma_mode, st
 
 def test_causal_spike_below_the_diagonal():
     wg, _, _ = _check(1, 512, 512, cfg=CAUSAL_FOLD, spike=(300, 200, 3.0), seed=12, tol_o=1.2e-2)
+
+
+@pytest.mark.parametrize("cfg", [CAUSAL_FOLD, CAUSAL_EXACT], ids=["fold", "exact"])
+def test_causal_branch_free_loop(cfg):
+    """causal streams: the loop's end is per block AND per wave (its first masked tile); waves leave it at different tiles and keep
+    meeting at the same barriers; rescales decided inside it in a long block"""
+    assert cfg.fastloop
+    _check(1, 1024, 1024, cfg=cfg, spike=(700, 200, 3.0), seed=12, tol_o=1.2e-2)
+    _check(1, 1024, 1024, cfg=cfg, spike=(900, 330, 3.0), seed=13, tol_o=1.2e-2)
+    wg, _, _ = _check(1, 768, 1280, cfg=cfg, seed=14, tol_o=8e-3)
+    assert len(set(w.count["s_barrier"] for w in wg.waves)) == 1, "waves disagree on the barriers"
 
 
 @pytest.mark.parametrize("C", [64, 128, 256, 449])

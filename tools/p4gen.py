@@ -205,6 +205,14 @@ class Stream:
         # LDS queue bookkeeping for counted waits: ids of issued LDS reads in order, index of the last one known complete
         self.lds_issued = 0
         self.lds_done = 0
+        # round 6 (persistent streams, tools/p4pgen.py): `fast` phases are the copies of the steady-state phases that the branch-free
+        # loop runs -- no mask-section test, no block-switch tests, no pending-rescale test; their rare rescale decision continues in
+        # the ordinary copy of the same phase (slow_dec_back: parity -> the label behind that copy's decision)
+        self.fast = False
+        self.slow_dec_back = {}
+        # second partial row sum per row block, mask value: module constants unless a stream re-maps them (p4pgen, pksum)
+        self.r_lb = [T_LB, T_LB + 1]
+        self.r_maskv = T_MASKV
 
     def emit(self, op, d=None, s=(), note="", **mod):
         self.ins.append(Ins(op, d, s, mod, note))
@@ -339,7 +347,7 @@ class Stream:
         x0, x1 = s_elem(prev, rb, kb, r), s_elem(prev, rb, kb, r + 1)
         if not (steady and "sum" in self.cfg.abl):
             self.emit("v_add_f32", VN("l%d" % rb), [x0, VN("l%d" % rb)])
-            self.emit("v_add_f32", V(T_LB + rb), [x1, V(T_LB + rb)])
+            self.emit("v_add_f32", V(self.r_lb[rb]), [x1, V(self.r_lb[rb])])
         if steady and "pack" in self.cfg.abl:
             return
         # MFMA step u (16 keys) of key block kb uses registers 8 (u & 1) .. + 7
@@ -500,9 +508,13 @@ class Stream:
     def sum_pack_abl(self, prev, e, abl):
         rb, kb, r = elem(e)
         x0, x1 = s_elem(prev, rb, kb, r), s_elem(prev, rb, kb, r + 1)
-        if "sum" not in abl:
+        if "sum" not in abl and getattr(self.cfg, "pksum", 0):
+            # (l, second partial sum) are an aligned register pair: both additions in one packed instruction
+            lp = V(self.r_lb[rb] - 1, 2)
+            self.emit("v_pk_add_f32", lp, [V(x0[1], 2), lp])
+        elif "sum" not in abl:
             self.emit("v_add_f32", VN("l%d" % rb), [x0, VN("l%d" % rb)])
-            self.emit("v_add_f32", V(T_LB + rb), [x1, V(T_LB + rb)])
+            self.emit("v_add_f32", V(self.r_lb[rb]), [x1, V(self.r_lb[rb])])
         if "pack" not in abl:
             self.emit("v_cvt_pk_%s_f32" % self.cfg.dtype, p_word(prev, rb, 2 * kb + r // 8, (r % 8) // 2), [x0, x1])
 
@@ -514,7 +526,7 @@ class Stream:
         abl = cfg.abl if (mfma and softmax) else frozenset()
         if not mfma and softmax:
             self.emit("s_nop", None, [I(15)], note="S(0) is still leaving the matrix pipe")
-        if softmax and "ctl" not in abl:
+        if softmax and "ctl" not in abl and not self.fast:
             self.mask_section(par, after_mfma=mfma)
         fill = [[] for _ in range(32)]
         slots = [1] * 32
@@ -561,8 +573,11 @@ class Stream:
             # 19 % faster and without the wait + barrier 25 % faster (profiles/r05_p4p_bal_ablations.txt): the wait for pieces
             # issued in the last gaps of this phase was what the loop spent a fifth of its time in
             ksw_g, vsw_g = 0, 4
-            if getattr(self, "persistent", False) and "ctl" not in abl:
+            if getattr(self, "persistent", False) and "ctl" not in abl and not self.fast:
                 self.b_hook(lambda g, fn: at(g, fn, 2), par, mfma, gaps=(ksw_g, vsw_g))
+            elif self.fast:   # (the same slot accounting as the ordinary copy: the two copies must agree gap by gap, see slow_dec_back)
+                slots[ksw_g] += 2
+                slots[vsw_g] += 2
             if "dma" not in abl:
                 for n in range(4):
                     at(n, lambda n=n: self.dma_piece("k", par, n), 2)
@@ -603,7 +618,12 @@ class Stream:
                 if "lds" not in abl:
                     at(exp_from + n, lambda n=n: self.k_read(par ^ 1, n))
             at(26, lambda: self.vrd_advance(), 3)
-            if "dma" not in abl and "offs" not in abl:
+            if "dma" not in abl and "offs" not in abl and getattr(cfg, "soff", 0):
+                # round 6: the tile advance is the SCALAR offset of the loads (part of the range check on gfx950 like the vector offset,
+                # tools/probe_soffset.hip): two scalar additions per tile instead of eight vector ones
+                at(28, lambda: self.emit("s_add_u32", SN("ksoff"), [SN("ksoff"), SN("kinc")]))
+                at(29, lambda: self.emit("s_add_u32", SN("vsoff"), [SN("vsoff"), SN("vinc")]))
+            elif "dma" not in abl and "offs" not in abl:
                 for n in range(4):
                     at(28 + n, lambda n=n: self.emit("v_add_u32_e64", VN("koff%d" % n), [VN("koff%d" % n), SN("kinc")], clamp=1))
                     at(28 + n, lambda n=n: self.emit("v_add_u32_e64", VN("voff%d" % n), [VN("voff%d" % n), SN("vinc")], clamp=1))
@@ -649,7 +669,12 @@ class Stream:
             for fn in fill[g]:
                 fn()
         self.lds_flush()
-        if softmax:
+        if softmax and self.fast:
+            # the decision of a fast phase continues behind the decision of the ordinary copy of this phase (same parity, same gap:
+            # the two copies issue the same LDS reads and LDS-DMA pieces in the same order, so every counted wait behind that
+            # point means the same instructions), which ends with the pending-rescale test
+            self.outofline.append(("dec", dec_lbl, None, par, False))
+        elif softmax:
             resc, back = self.newlabel("RESC"), self.newlabel("RESCBACK")
             if "ctl" not in abl:
                 self.emit("s_cmp_eq_u32", None, [SN("pend"), I(0)])
@@ -657,6 +682,8 @@ class Stream:
             self.label(back)
             self.outofline.append(("resc", resc, back, par, False))
             self.outofline.append(("dec", dec_lbl, dec_lbl + "_BACK", par, not mfma))
+            if mfma:
+                self.slow_dec_back[par] = dec_lbl + "_BACK"
 
     def max_op(self, par, i):
         # op i: block i // 8 in the order (rb0,kb0) (rb1,kb0) (rb0,kb1) (rb1,kb1); step i % 8 covers 3, 2, ..., 2, 1 values
@@ -771,12 +798,13 @@ class Stream:
         self.emit("s_cselect_b32", SN("vwr"), [SN("ldsv"), SN("vwr")])
 
     def dma_piece(self, which, par, i):
+        so = getattr(self.cfg, "soff", 0)
         if which == "k":   # K(j+2) -> K image j & 1
             self.emit("s_add_u32", M0, [SN("ldsk"), I(par * KSLOT + i * 1024)])
-            self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), SN("kres", 4)])
+            self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), SN("kres", 4)] + ([SN("ksoff")] if so else []))
         else:              # V(j+1) -> V image (j + 1) % 3
             self.emit("s_add_u32", M0, [SN("vwr"), I(i * 1024)])
-            self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), SN("vres", 4)])
+            self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), SN("vres", 4)] + ([SN("vsoff")] if so else []))
 
     def last_v_tile(self):
         """transposed streams, in front of the pieces of V(j+1): the tile advances ALONG the rows of V^T, so the end of the
@@ -798,14 +826,14 @@ class Stream:
         self.emit("s_lshl_b32", SN("t0"), [SN("j"), I(6)])
         for rb in range(2):
             self.emit("v_subrev_u32", V(T_TL + rb), [SN("t0"), VN("lim%d" % rb)])   # lim - 4 hi - 64 j
-        self.emit("v_mov_b32", V(T_MASKV), [F(-(0.875 / 1.44269504089) * 3.402823466e+38)])   # +Softmax.swift:242-243
+        self.emit("v_mov_b32", V(self.r_maskv), [F(-(0.875 / 1.44269504089) * 3.402823466e+38)])   # +Softmax.swift:242-243
         for rb in range(2):
             for kb in range(2):
                 for r in range(16):
                     c = kb * 32 + (r & 3) + 8 * (r >> 2)
                     x = s_elem(par, rb, kb, r)
                     self.emit("v_cmp_gt_i32", VCC, [I(c), V(T_TL + rb)])
-                    self.emit("v_cndmask_b32", x, [x, V(T_MASKV), VCC])
+                    self.emit("v_cndmask_b32", x, [x, V(self.r_maskv), VCC])
         if self.cfg.bal and self.cfg.maxa:   # the first key block's row maxima were taken in phase A, from the unmasked scores
             for i in range(16):
                 self.max_op(par, i)
@@ -816,6 +844,8 @@ class Stream:
         cfg = self.cfg
         rs = VF_BASE if cfg.fold else T_RS      # rescale temporaries (FOLD: V^T ring slots 0, 1 are idle at the end of phase B)
         for kind, lbl, back, par, first in self.outofline:
+            if back is None:
+                back = self.slow_dec_back[par]
             self.label(lbl)
             if kind == "dec" and cfg.fold:
                 if cfg.fastdec:   # v[T_SW] = [maxima of row block 0 | of row block 1] -> both blocks' row maxima in every lane
@@ -865,7 +895,7 @@ class Stream:
                         for t in range(8):
                             self.emit("v_accvgpr_write_b32", A(O_BASE + 64 * rb + i0 + t), [V(rs + t)])
                     self.emit("v_mul_f32", VN("l%d" % rb), [V(T_CORR + rb), VN("l%d" % rb)])
-                    self.emit("v_mul_f32", V(T_LB + rb), [V(T_CORR + rb), V(T_LB + rb)])
+                    self.emit("v_mul_f32", V(self.r_lb[rb]), [V(T_CORR + rb), V(self.r_lb[rb])])
                 self.emit("s_mov_b32", SN("pend"), [I(0)])
                 self.emit("s_nop", None, [I(4)], note="accvgpr write -> MFMA SrcC")
                 self.emit("s_branch", None, [], target=back)
@@ -889,7 +919,7 @@ class Stream:
             if not self.cfg.kt:
                 self.emit("v_xor_b32", V(T_KADDR + ks), [I(ks << 5), VN("kbase")])
         for rb in range(2):
-            self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
+            self.emit("v_mov_b32", V(self.r_lb[rb]), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
         if self.cfg.fold:
             for r in range(32):
@@ -963,7 +993,7 @@ class Stream:
                 self.emit("s_branch", None, [], target=skip_odd)
         self.label(done)
         for rb in range(2):
-            self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
+            self.emit("v_add_f32", VN("l%d" % rb), [V(self.r_lb[rb]), VN("l%d" % rb)])
         self.emit("s_branch", None, [], target=fin)
         self.emit_outofline()
         self.label(fin)
@@ -1015,7 +1045,7 @@ def render_one(ins, suffix="%="):
     if op in ("s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccnz", "s_branch"):
         return "%s %s_%s" % (op, m["target"], suffix)
     if op == "buffer_load_dwordx4_lds":
-        return "buffer_load_dwordx4 %s, %s, 0 offen lds" % (fmt(ins.s[0]), fmt(ins.s[1]))
+        return "buffer_load_dwordx4 %s, %s, %s offen lds" % (fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]) if len(ins.s) > 2 else "0")
     if op in ("buffer_load_dword", "buffer_load_ushort"):
         return "%s %s, %s, %s, 0 offen" % (op, fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
     if op == "buffer_store_dwordx4":     # s = (four data registers, per-lane byte offset, buffer resource)

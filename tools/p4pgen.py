@@ -60,7 +60,8 @@ PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
              ob=(68, 2), lb=(70, 2), row0=(72, 1), blk=(73, 1), hasnext=(74, 1), ntm1=(75, 1), ntm2=(76, 1),
              j=(77, 1), vrd=(78, 1), vwr=(79, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
              kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), wntb=(90, 1), maskb=(91, 1), ntu=(92, 1), t5=(93, 1),
-             q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1), qswj=(101, 1))
+             q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1), qswj=(101, 1),
+             fend=(101, 1), fcnt=(93, 1), ksoff=(67, 1), vsoff=(98, 1))   # branch-free loop (dense streams without the merged block switch): first tile it does not take, iterations left
 FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 101
 
 # inputs of the statement (hipcc allocates them below s40 / v28)
@@ -74,9 +75,27 @@ IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qre
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
-    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0):
+    def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0,
+                 fastloop=0, align=0, soff=0, pksum=0):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
+        # fastloop (round 6, dense streams): the timing-only ablation that dropped the per-tile tests of the loop -- block switch
+        # (two not-taken branches), mask section (one TAKEN branch), pending rescale (one not-taken branch) -- ran 9.6 % faster on
+        # all-zero operands (profiles/r06_p4p_ablations.txt, ABL6_CTL): a wave alone on its SIMD has nobody to hide an instruction
+        # fetch redirect or a branch's issue bubble behind.  The tiles that cannot need any of those tests -- j < maskfrom and
+        # j <= nt - 3 -- run in a BRANCH-FREE copy of the loop: two tiles per iteration, one back-edge, and the rescale decision
+        # (the one test online softmax cannot lose), whose rare taken path continues in the ordinary copy of the same phase.
+        # fastloop = N: N tile pairs per iteration (1 or 2); align: the loop head on a 64-byte line
+        self.fastloop, self.align = fastloop, align
+        # soff (round 6): the LDS-DMA loads take the tile advance as their SCALAR offset; the lanes' offsets are then constants of the
+        # workgroup (set once), a block switch is a new resource base and a scalar offset of zero
+        self.soff = soff
+        assert not (soff and pprof == 1)
+        # pksum (round 6 experiment): the two partial row sums of a row block live in an aligned register pair (l0 | v31, v244 | v245)
+        # and a score pair is added with ONE v_pk_add_f32: 32 vector instructions per tile less
+        self.pksum = pksum
+        assert not (pksum and bal != 2)
+        assert not (fastloop and (merge or bal != 2))
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
         # computed per block inside the stream; the block table lists the blocks in pairs (long, short) like attn_fwd16_p4's
         # causal launch, so that every workgroup walks the same number of tiles
@@ -109,7 +128,7 @@ PROF_ACC = 168
 PROF_MAGIC = 0x50524F46
 # pprof = 2: name -> scalar accumulator (s67 is free; s89..s93 are the causal streams' block geometry, unused by dense streams)
 SPROF_NAMES = ["loop_a", "loop_vm", "loop_bar", "loop_b", "rest", "blocks"]
-SPROF_ACC = {"loop_a": 67, "loop_vm": 89, "loop_bar": 90, "loop_b": 91, "rest": 92, "blocks": 93}
+SPROF_ACC = {"loop_a": 99, "loop_vm": 89, "loop_bar": 90, "loop_b": 91, "rest": 92, "blocks": 73}   # (blocks: the table index `blk` itself)
 PROF_NAMES = ["table", "wait_q", "qfrag", "tile0_a", "tile0_b", "loop_a", "loop_wait", "loop_b", "tile1_wait", "tail", "epilogue", "blocks"]
 
 
@@ -125,6 +144,10 @@ class PStream(Stream):
         Stream.__init__(self, cfg)
         dma_base = 248 if cfg.fold else 160
         self.vfixed = {"m0": 28, "m1": 29, "l0": 30, "l1": 31}
+        if cfg.pksum:
+            self.vfixed["l1"] = 244
+            self.r_lb = [31, 245]
+            self.r_maskv = 243
         for i in range(4):
             self.vfixed["koff%d" % i] = dma_base + i
             self.vfixed["voff%d" % i] = dma_base + 4 + i
@@ -172,16 +195,20 @@ class PStream(Stream):
         through lgkmcnt: a stamp sits only where no LDS read is in flight)"""
         if not self.cfg.pprof:
             return
+        if self.cfg.pprof == 2:   # (s[84:85] = `sv`: the fast-decision FOLD streams do not use it; s98 is the V loads' scalar offset)
+            assert self.cfg.fastdec
+            self.emit("s_memtime", SR(84, 2))
+            self.emit("s_waitcnt", None, [], lgkmcnt=0)
+            self.lds_done = self.lds_issued
+            if not first:
+                acc = SR(SPROF_ACC.get(name, SPROF_ACC["rest"]))
+                self.emit("s_sub_u32", s("t3"), [SR(84), s("plast")])
+                self.emit("s_add_u32", acc, [acc, s("t3")])
+            self.emit("s_mov_b32", s("plast"), [SR(84)])
+            return
         self.emit("s_memtime", SR(98, 2))
         self.emit("s_waitcnt", None, [], lgkmcnt=0)
         self.lds_done = self.lds_issued
-        if self.cfg.pprof == 2:
-            if not first:
-                acc = SR(SPROF_ACC.get(name, SPROF_ACC["rest"]))
-                self.emit("s_sub_u32", s("t3"), [SR(98), s("plast")])
-                self.emit("s_add_u32", acc, [acc, s("t3")])
-            self.emit("s_mov_b32", s("plast"), [SR(98)])
-            return
         if not first:
             self.emit("s_sub_u32", s("t3"), [SR(98), s("plast")])
             acc = V(PROF_ACC + PROF_NAMES.index(name))
@@ -215,18 +242,26 @@ class PStream(Stream):
             self.emit("v_readfirstlane_b32", s(name, 1, off), [V(tb + i)])
         self.emit("s_nop", None, [I(4)], note="v_readfirstlane -> SALU / VMEM use of the scalar")
 
-    def switch_k(self):
-        self.emit("s_mov_b32", s("kres", 1, 0), [s("kbn", 1, 0)])
-        self.emit("s_and_b32", s("kres", 1, 1), [s("kbn", 1, 1), I(0xFFFF)])
+    def switch_k(self, init=False):
+        if not init:
+            self.emit("s_mov_b32", s("kres", 1, 0), [s("kbn", 1, 0)])
+            self.emit("s_and_b32", s("kres", 1, 1), [s("kbn", 1, 1), I(0xFFFF)])
+            if self.cfg.soff:
+                self.emit("s_mov_b32", s("ksoff"), [I(0)])
+                return
         self.emit("s_mov_b32", s("t3"), [s("kc0")])
         for i in range(4):
             self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("kv%d" % i), s("t3")], clamp=1)
             if i != 3:
                 self.emit("s_add_u32", s("t3"), [s("t3"), s("kstep")])
 
-    def switch_v(self):
-        self.emit("s_mov_b32", s("vres", 1, 0), [s("vbn", 1, 0)])
-        self.emit("s_and_b32", s("vres", 1, 1), [s("vbn", 1, 1), I(0xFFFF)])
+    def switch_v(self, init=False):
+        if not init:
+            self.emit("s_mov_b32", s("vres", 1, 0), [s("vbn", 1, 0)])
+            self.emit("s_and_b32", s("vres", 1, 1), [s("vbn", 1, 1), I(0xFFFF)])
+            if self.cfg.soff:
+                self.emit("s_mov_b32", s("vsoff"), [I(0)])
+                return
         self.emit("s_mov_b32", s("t3"), [I(0)])
         for i in range(4):
             self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("vv"), s("t3")], clamp=1)
@@ -286,13 +321,16 @@ class PStream(Stream):
                 self.switch_k()
             else:
                 self.switch_v()
-                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
+                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             self.label(over)
         for i in range(4):
             self.dma_piece("k", par, i)
         for i in range(4):
             self.dma_piece("v", par, i)
-        for i in range(4):
+        if self.cfg.soff:
+            self.emit("s_add_u32", s("ksoff"), [s("ksoff"), SN("kinc")])
+            self.emit("s_add_u32", s("vsoff"), [s("vsoff"), SN("vinc")])
+        for i in range(0 if self.cfg.soff else 4):
             self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1)
             self.emit("v_add_u32_e64", VN("voff%d" % i), [VN("voff%d" % i), SN("vinc")], clamp=1)
         self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
@@ -311,13 +349,18 @@ class PStream(Stream):
                 self.emit("s_add_u32", s("qrow"), [s("qrow"), s("q4")])
 
     def issue_tile(self, which, image, advance=True):
+        so = self.cfg.soff
         for i in range(4):
             if which == "k":
                 self.emit("s_add_u32", M0, [SN("ldsk"), I(image * KSLOT + i * 1024)])
-                self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), s("kres", 4)])
+                self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), s("kres", 4)] + ([s("ksoff")] if so else []))
             else:
                 self.emit("s_add_u32", M0, [SN("vwr"), I(i * 1024)])
-                self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), s("vres", 4)])
+                self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), s("vres", 4)] + ([s("vsoff")] if so else []))
+        if so:
+            name = "k" if which == "k" else "v"
+            self.emit("s_add_u32", s(name + "soff"), [s(name + "soff"), SN(name + "inc")])
+            return
         for i in range(4):
             if which == "k":
                 self.emit("v_add_u32_e64", VN("koff%d" % i), [VN("koff%d" % i), SN("kinc")], clamp=1)
@@ -355,7 +398,9 @@ class PStream(Stream):
         self.lds_flush()
 
     EPI_LTOT, EPI_INV = (T_MX, T_MX + 1), (T_MN, T_MN + 1)
-    EPI_WA, EPI_RA, EPI_VO = [T_CORR, T_CORR + 1, T_LB, T_LB + 1], T_MASKV, T_TL   # (re-initialised by the next block / dead after the loop)
+    EPI_VO = T_TL   # (re-initialised by the next block / dead after the loop)
+    EPI_WA = property(lambda self: [T_CORR, T_CORR + 1, self.r_lb[0], self.r_lb[1]])
+    EPI_RA = property(lambda self: self.r_maskv)
 
     def epi_prepare(self):
         """what the per-block work of the epilogue needs: resources of O and L, l of the row (half swap), 1 / l, the LDS staging
@@ -499,7 +544,7 @@ class PStream(Stream):
                               note="V^T f%d.%d" % (f, h))
         self.lds_flush()
         for rb in range(2):
-            self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
+            self.emit("v_add_f32", VN("l%d" % rb), [V(self.r_lb[rb]), VN("l%d" % rb)])
         self.emit("s_barrier")       # every wave is done with the V image O is staged in (last read in phase B(nt-1))
         self.epi_prepare()
         regs = lambda i: (S_BASE[0] + 16 * (i & 1), S_BASE[0] + 32 + 16 * (i & 1))   # the even tiles' score registers are free
@@ -544,9 +589,9 @@ class PStream(Stream):
             elif kind == "vsw":
                 self.switch_v()
                 if not self.cfg.merge:
-                    self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
+                    self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             else:
-                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, T_MASKV))
+                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             self.emit("s_branch", None, [], target=back)
 
     def block_head(self, nonext):
@@ -558,6 +603,8 @@ class PStream(Stream):
         self.emit("s_mov_b32", s("row0"), [s("row0n")])
         if cfg.causal:
             self.block_geometry()
+            if cfg.fastloop:
+                self.fast_end()
             # waves that skipped tiles did not walk the V read pointer: V(-1)'s image is the one before V(0)'s
             self.emit("s_sub_u32", s("t0"), [s("vwr"), SN("ldsv")])
             self.emit("s_sub_u32", s("t0"), [s("t0"), I(VSLOT)])
@@ -575,7 +622,7 @@ class PStream(Stream):
     def block_init(self):
         cfg = self.cfg
         for rb in range(2):
-            self.emit("v_mov_b32", V(T_LB + rb), [I(0)])
+            self.emit("v_mov_b32", V(self.r_lb[rb]), [I(0)])
             self.emit("v_mov_b32", V(T_CORR + rb), [F(1.0)])
             self.emit("v_mov_b32", VN("l%d" % rb), [I(0)])
             self.emit("v_mov_b32", VN("m%d" % rb), [F(0.0) if cfg.fold else F(-3.402823466e+38)])
@@ -584,6 +631,35 @@ class PStream(Stream):
                 self.emit("v_mov_b32", V(CM_BASE + r), [I(0)])
         self.emit("s_mov_b32", SN("pend"), [I(0)])
         self.emit("s_mov_b32", SN("j"), [I(0)])
+
+    def fast_end(self):
+        """fend = the largest odd number <= min(maskfrom, nt - 2): tiles 1 .. fend - 1 run in the branch-free loop (causal streams:
+        per block and per wave -- its first masked tile, and its own traversal bound for a wave beyond the last row)"""
+        self.emit("s_sub_u32", s("fend"), [SN("nt"), I(2)])
+        self.emit("s_min_i32", s("fend"), [s("fend"), SN("maskfrom")])
+        if self.cfg.causal:
+            self.emit("s_min_i32", s("fend"), [s("fend"), SN("wnt")])
+        self.emit("s_sub_u32", s("fend"), [s("fend"), I(1)])
+        self.emit("s_or_b32", s("fend"), [s("fend"), I(1)])
+
+    def fast_pair(self, cfg):
+        """two tiles (parities 1, 0) of the branch-free loop"""
+        self.fast = True
+        for par in (1, 0):
+            vids = self.phase_a(par, mfma=True, softmax=True, zero_o=False)
+            self.lds_flush()
+            self.pstamp("loop_a")
+            if "bar" not in cfg.abl:
+                if "vm" not in cfg.abl:
+                    self.emit("s_waitcnt", None, [], vmcnt=0)
+                if cfg.pprof == 2:
+                    self.pstamp("loop_vm")
+                self.emit("s_barrier")
+            self.pstamp("loop_bar" if cfg.pprof == 2 else "loop_wait")
+            self.phase_b(par, mfma=True, softmax=True, vids=vids)
+            self.pstamp("loop_b")
+            self.emit("s_add_u32", SN("j"), [SN("j"), I(1)])
+        self.fast = False
 
     # ------------------------------------------------------------ whole stream
     def build(self):
@@ -604,6 +680,8 @@ class PStream(Stream):
         if cfg.merge:
             self.emit("s_sub_u32", s("t0"), [SN("nt"), I(3)])
             self.emit("s_max_i32", s("qswj"), [s("t0"), I(0)])   # tile whose phase B requests the next block's Q
+        if cfg.fastloop and not cfg.causal:
+            self.fast_end()
         self.emit("s_mov_b32", s("vrd"), [I(2 * VSLOT)])     # "image of V(-1)"
         self.emit("s_mov_b32", s("vwr"), [SN("ldsv")])       # V(0) goes to image 0
         self.emit("s_add_u32", s("t1"), [SN("ldsv"), I(VRING * VSLOT)])
@@ -621,6 +699,9 @@ class PStream(Stream):
         self.emit("s_mov_b32", s("blk"), [I(0)])
         self.load_next()
         self.issue_q((S_BASE[0] + 0, S_BASE[0] + 1, S_BASE[0] + 2, S_BASE[0] + 3))
+        if cfg.soff:
+            self.switch_k(init=True)
+            self.switch_v(init=True)
         self.switch_k()
         self.issue_tile("k", 0)
         self.switch_v()
@@ -632,8 +713,9 @@ class PStream(Stream):
             for i in range(16):
                 self.emit("v_mov_b32", V(PROF_ACC + i), [I(0)])
         elif cfg.pprof == 2:
-            for r in SPROF_ACC.values():
-                self.emit("s_mov_b32", SR(r), [I(0)])
+            for name, r in SPROF_ACC.items():
+                if name != "blocks":
+                    self.emit("s_mov_b32", SR(r), [I(0)])
         self.label(blk_lbl)
         self.pstamp("table", first=True)
         self.block_head(nonext)
@@ -658,6 +740,30 @@ class PStream(Stream):
         self.emit("s_mov_b32", SN("j"), [I(1)])
         self.pstamp("tile0_b")
         self.label(loop)
+        if cfg.fastloop:
+            # (j is odd here: the tile about to run has parity 1)
+            slow, fast = self.newlabel("SLOW"), self.newlabel("FAST")
+            self.emit("s_sub_u32", s("fcnt"), [s("fend"), SN("j")])
+            self.emit("s_cmp_lt_i32", None, [s("fcnt"), I(2)])
+            self.emit("s_cbranch_scc1", None, [], target=slow)
+            self.emit("s_lshr_b32", s("fcnt"), [s("fcnt"), I(cfg.fastloop)])     # iterations of fastloop tile pairs ...
+            if cfg.fastloop == 2:   # ... (an odd number of pairs: the first pair on its own)
+                odd = self.newlabel("FASTODD")
+                self.emit("s_sub_u32", s("t3"), [s("fend"), SN("j")])
+                self.emit("s_bitcmp1_b32", None, [s("t3"), I(1)])
+                self.emit("s_cbranch_scc0", None, [], target=fast)
+                self.fast_pair(cfg)
+                self.emit("s_cmp_eq_u32", None, [s("fcnt"), I(0)])
+                self.emit("s_cbranch_scc1", None, [], target=slow)
+            if cfg.align:
+                self.emit("align", None, [I(6)])
+            self.label(fast)
+            for _ in range(cfg.fastloop):
+                self.fast_pair(cfg)
+            self.emit("s_sub_u32", s("fcnt"), [s("fcnt"), I(1)])
+            self.emit("s_cmp_lg_u32", None, [s("fcnt"), I(0)])
+            self.emit("s_cbranch_scc1", None, [], target=fast)
+            self.label(slow)
         for par, endl in ((1, end_even), (0, end_odd)):
             self.emit("s_cmp_ge_i32", None, [SN("j"), SN("wnt")])     # (dense streams: wnt = nt)
             self.emit("s_cbranch_scc1", None, [], target=endl)
@@ -726,7 +832,7 @@ class PStream(Stream):
         self.emit("s_barrier")       # every wave is done with the V image the epilogue stages O in (last read in phase B(nt-1))
         self.pstamp("tail")
         for rb in range(2):
-            self.emit("v_add_f32", VN("l%d" % rb), [V(T_LB + rb), VN("l%d" % rb)])
+            self.emit("v_add_f32", VN("l%d" % rb), [V(self.r_lb[rb]), VN("l%d" % rb)])
         self.epilogue()
         if cfg.fuse:
             self.label(after_epi)
@@ -734,8 +840,7 @@ class PStream(Stream):
         if cfg.pprof == 1:
             acc = V(PROF_ACC + PROF_NAMES.index("blocks"))
             self.emit("v_add_u32", acc, [I(1), acc])
-        elif cfg.pprof == 2:
-            self.emit("s_add_u32", SR(SPROF_ACC["blocks"]), [SR(SPROF_ACC["blocks"]), I(1)])
+
         post = self.newlabel("POST")
         self.emit("s_cmp_eq_u32", None, [s("hasnext"), I(1)])
         self.emit("s_cbranch_scc1", None, [], target=post if cfg.merge else blk_lbl)
@@ -786,6 +891,10 @@ def render_one(ins):
         return "s_cmp_lt_u32 %s, %s" % (f(ins.s[0]), f(ins.s[1]))
     if op == "s_memtime":
         return "s_memtime %s" % f(ins.d)
+    if op == "align":
+        return ".p2align %d" % ins.s[0][1]
+    if op in ("s_cmp_lg_u32", "s_bitcmp1_b32"):
+        return "%s %s, %s" % (op, f(ins.s[0]), f(ins.s[1]))
     if op == "s_mov_b64" and ins.d == ("exec",):
         return "s_mov_b64 exec, %s" % f(ins.s[0])
     if op == "ds_write_b128":
@@ -801,26 +910,28 @@ def render(instrs):
 
 VARIANTS = {
     # name: cfg            (X-macro columns: folds the scale, 16-bit O, FP16 L)
-    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1),          # headline: mixed-precision mode, fp32 O, FP16 L
-    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1),
-    "BF16_EXACT": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8),                    # lowPrecisionInputs only: scale in fp32, fp32 O and L
-    "BF16_EXACT_O16": PCfg("bf16", 8, fold=0, o16=1, bal=2, xe=32, cap=8),
-    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1),
-    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1),
-    "F16_EXACT": PCfg("f16", 8, fold=0, bal=2, xe=32, cap=8),
-    "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1, bal=2, xe=32, cap=8),
-    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
-    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
-    "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1, bal=2, xe=32, cap=8),
-    "BF16_EXACT_O16_CAUSAL": PCfg("bf16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8),
-    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
-    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),
-    "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1, bal=2, xe=32, cap=8),
-    "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8),
+    "BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),          # headline: mixed-precision mode, fp32 O, FP16 L
+    "BF16_FOLD_O16_L16": PCfg("bf16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "BF16_EXACT": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1),                    # lowPrecisionInputs only: scale in fp32, fp32 O and L
+    "BF16_EXACT_O16": PCfg("bf16", 8, fold=0, o16=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "F16_FOLD_L16": PCfg("f16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "F16_EXACT": PCfg("f16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "BF16_EXACT_O16_CAUSAL": PCfg("bf16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "F16_FOLD_L16_CAUSAL": PCfg("f16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "F16_FOLD_O16_L16_CAUSAL": PCfg("f16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "F16_EXACT_CAUSAL": PCfg("f16", 8, fold=0, causal=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "F16_EXACT_O16_CAUSAL": PCfg("f16", 8, fold=0, o16=1, causal=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
     "BF16_EXACT_PROF": PCfg("bf16", 8, fold=0, pprof=1),      # developer builds only (tools/p4p_prof.py)
     "BF16_FOLD_L16_MERGE": PCfg("bf16", 8, fold=1, l16=1, merge=1),   # developer builds only: merged block switch (lost)
     "BF16_FOLD_L16_FUSE": PCfg("bf16", 8, fold=1, l16=1, fuse=1),     # developer builds only: epilogue dealt out under the last P V (no gain)
     "R4_BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1),        # the round-4 schedule of the headline stream (A/B baseline)
+    "R5_BF16_FOLD_L16": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1),   # the round-5 product stream (per-tile tests in the loop)
+    "R5_BF16_EXACT": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8),
     "R4_BF16_EXACT": PCfg("bf16", 8, fold=0),
     # round 5, developer builds: slot-balanced phases (p4gen Cfg.bal) and their timing-only ablations (WRONG RESULTS)
     "BF16_FOLD_L16_BAL32": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32),
@@ -876,6 +987,18 @@ VARIANTS = {
     "ABL6_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack")),
     "ABL6_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack", "lds", "dma")),
     "ABL6_ALL_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack", "lds", "dma", "bar", "ctl")),
+    "BF16_FOLD_L16_FL1": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1),
+    "BF16_FOLD_L16_FL2": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=2),
+    "BF16_FOLD_L16_FL1_AL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
+    "BF16_FOLD_L16_FL1_SPROF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, pprof=2),
+    "BF16_EXACT_FL1": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1),
+    "BF16_FOLD_L16_SOFF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, soff=1),
+    "BF16_FOLD_L16_PKS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, pksum=1),
+    "BF16_FOLD_L16_FL1_SOFF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, soff=1),
+    "BF16_FOLD_L16_FL1_SOFF_PKS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, soff=1, pksum=1),
+    "BF16_FOLD_L16_FL2_SOFF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=2, soff=1),
+    "BF16_EXACT_FL1_SOFF": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, soff=1),
+    "R5_BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),   # the round-5 causal stream (A/B baseline)
     "BF16_FOLD_L16_PAD": PCfg("bf16", 8, fold=1, l16=1, pad=1),
     "BF16_FOLD_L16_BAL32_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, pad=1),
     "BF16_FOLD_L16_BAL40_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=40, pad=1),
@@ -887,7 +1010,7 @@ VARIANTS = {
     "ABL_BAL32_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("bar",)),
     "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL', n))
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS', n))
 assert "BF16_FOLD_L16_SPROF" not in PRODUCT_STREAMS
 
 

@@ -88,7 +88,9 @@ class PWorkgroup(Workgroup):
     def execute(self, w, ins):
         op, d, s, m = ins.op, ins.d, ins.s, ins.mod
         scalar_kinds = ("sr",)
-        if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_min_u32", "s_max_u32", "s_max_i32"):
+        if op == "align":
+            return None
+        if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_or_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_min_u32", "s_max_u32", "s_max_i32", "s_min_i32"):
             vals = [self.sval(w, x) for x in s]
             if op == "s_mov_b32":
                 r = vals[0]
@@ -96,7 +98,9 @@ class PWorkgroup(Workgroup):
                     r = int(np.float32(r).view(np.uint32))
             else:
                 a, b = int(vals[0]) & 0xFFFFFFFF, int(vals[1]) & 0xFFFFFFFF
-                r = {"s_add_u32": a + b, "s_sub_u32": a - b, "s_and_b32": a & b, "s_lshl_b32": a << (b & 31),
+                sgn = lambda x: int(np.int32(np.uint32(x)))
+                r = {"s_add_u32": a + b, "s_sub_u32": a - b, "s_and_b32": a & b, "s_or_b32": a | b, "s_lshl_b32": a << (b & 31),
+                     "s_min_i32": min(sgn(a), sgn(b)),
                      "s_lshr_b32": a >> (b & 31), "s_mul_i32": a * b, "s_min_u32": min(a, b), "s_max_u32": max(a, b),
                      "s_max_i32": max(int(np.int32(np.uint32(a))), int(np.int32(np.uint32(b))))}[op]
                 if op == "s_add_u32":
@@ -106,12 +110,15 @@ class PWorkgroup(Workgroup):
             else:
                 w.swr(d, r)
             return None
-        if op in ("s_cmp_lt_i32", "s_cmp_ge_i32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_cmp_lt_u32"):
+        if op == "s_bitcmp1_b32":
+            w.scc = (int(self.sval(w, s[0])) >> (int(self.sval(w, s[1])) & 31)) & 1
+            return None
+        if op in ("s_cmp_lt_i32", "s_cmp_ge_i32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_cmp_lt_u32", "s_cmp_lg_u32"):
             a, b = int(self.sval(w, s[0])) & 0xFFFFFFFF, int(self.sval(w, s[1])) & 0xFFFFFFFF
             if op.endswith("i32"):
                 a, b = int(np.int32(np.uint32(a))), int(np.int32(np.uint32(b)))
             w.scc = int({"s_cmp_lt_i32": a < b, "s_cmp_ge_i32": a >= b, "s_cmp_ge_u32": a >= b, "s_cmp_eq_u32": a == b,
-                         "s_cmp_lt_u32": a < b}[op])
+                         "s_cmp_lt_u32": a < b, "s_cmp_lg_u32": a != b}[op])
             return None
         if op == "s_cselect_b32":
             self.sset(w, d, self.sval(w, s[0]) if w.scc else self.sval(w, s[1]))
@@ -142,9 +149,10 @@ class PWorkgroup(Workgroup):
         if op == "buffer_load_dwordx4_lds" and s[1][0] == "sr":
             off = w.rd(s[0]).astype(np.int64)
             arr, base, nrec = self.resource(w, s[1])
+            soff = (int(self.sval(w, s[2])) & 0xFFFFFFFF) if len(s) > 2 else 0   # scalar offset: part of the range check, no 32-bit wrap (tools/probe_soffset.hip)
             data = np.zeros((64, 16), np.uint8)
             for l in range(64):
-                o = int(off[l])
+                o = int(off[l]) + soff
                 if o + 16 <= nrec:
                     data[l] = arr[base + o:base + o + 16]
             addrs = (w.m0 + 16 * np.arange(64)).astype(np.int64)

@@ -45,6 +45,7 @@ template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char
   v->launchSplit = &launch_p4_split<T, STREAM>;   // (block-sparse launches keep the sibling of the 8 x 32 kernel)
   v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false, true>);
   v->splitTarget = 256;   // one workgroup per compute unit
+  v->splitParallelization = 256;   // (the pieces of a column-parallel launch are THIS kernel's: attn_fwd16_p4<..., split>, not the sibling's)
   if constexpr (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD)
     v->launchForm = &p4p_form<T, p4::stream_folds(STREAM)>;
 }

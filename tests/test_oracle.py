@@ -117,3 +117,38 @@ def test_causal_extension_matches_fp64_restatement(shape):
     net2.V[C - 1] += 100.0   # only the last row may see the last column
     got2 = net2.run(causal=True)
     assert np.array_equal(got2["O"][:-1], got["O"][:-1])
+
+
+def test_swift_pin_kit_round_trip(tmp_path):
+    """tests/golden/swift_pin.py: the exported input file carries the seeded inputs of the golden npz,
+    and an output file in the format the Swift test writes -- here filled from the oracle itself -- passes the checker; a
+    perturbed one does not."""
+    import importlib.util
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("swift_pin", os.path.join(here, "swift_pin.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    kit.export(str(tmp_path))
+    g = np.load(os.path.join(here, "network_golden.npz"))
+    raw = open(tmp_path / "network_golden_inputs.bin", "rb").read()
+    assert int(np.frombuffer(raw[:4], np.int32)[0]) == len(g["cases"])
+    seed, R, C, D = (int(x) for x in np.frombuffer(raw[4:20], np.int32))
+    assert np.array_equal(np.frombuffer(raw[20:20 + 4 * R * D], np.float32), np.asarray(g[f"s{seed}_Q"], np.float32).reshape(-1))
+
+    def write(perturb):
+        with open(tmp_path / "network_golden_swift.bin", "wb") as f:
+            f.write(np.int32(len(g["cases"])).tobytes())
+            for seed, R, C, D in g["cases"]:
+                f.write(np.array([seed, R, C, D], np.int32).tobytes())
+                for name in ("O", "L", "D", "dV", "dK", "dQ"):
+                    a = np.ascontiguousarray(g[f"s{seed}_{name}"], np.float32).reshape(-1).copy()
+                    if perturb and name == "dK":
+                        a[0] += 1e-2
+                    f.write(a.tobytes())
+    write(False)
+    kit.check(str(tmp_path))
+    write(True)
+    with pytest.raises(AssertionError):
+        kit.check(str(tmp_path))

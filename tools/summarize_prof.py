@@ -56,6 +56,12 @@ def write_traffic_json(out, workload):
         print("traffic.json not written: counters missing", vals)
         return
     kernel = vals["FETCH_SIZE"][0]
+    # matrix-pipe busy cycles and GPU-active cycles of the same kernel (pmc1): bench.py derives `mfma_busy` from them
+    extra = {}
+    for db in sorted(glob.glob(os.path.join(out, "pmc1", "*.db"))):
+        con = sqlite3.connect(db)
+        for r in con.execute("select counter_name, avg(value) from counters_collection where kernel_name = ? group by counter_name", (kernel,)):
+            extra[r[0]] = r[1]
     bytes_per_launch = (2.0 * vals["FETCH_SIZE"][1] + vals["WRITE_SIZE"][1]) * 1024.0
     from metal_flash_attention_amd import AttentionKernel  # noqa: F401  (loads the library named below)
     digest = hashlib.sha256(open(_abi.library_path(), "rb").read()).hexdigest()
@@ -69,6 +75,8 @@ def write_traffic_json(out, workload):
     table["entries"].append({"workload": workload, "variant": variant, "kernel": kernel, "lib_sha256": digest,
                              "bytes_per_launch": bytes_per_launch, "fetch_size_kib": vals["FETCH_SIZE"][1],
                              "write_size_kib": vals["WRITE_SIZE"][1],
+                             "mfma_busy_cycles": extra.get("SQ_VALU_MFMA_BUSY_CYCLES"), "gui_active": extra.get("GRBM_GUI_ACTIVE"),
+                             "insts_mfma": extra.get("SQ_INSTS_MFMA"),
                              "source": os.path.join(out, "summary.txt") + " (copied to profiles/)"})
     json.dump(table, open(path, "w"), indent=1)
     print("wrote", path, "-", bytes_per_launch, "bytes/launch for", variant)

@@ -53,14 +53,16 @@ static const char *kDefaultTables[3][2] = {
      // forward, mixed: D <= 128 -> 4 waves x 64 rows, 64-key steps (attn_fwd16_p4.h); | 128 | 256 | 32 | 128 | selects the
      // 8 waves x 32 rows kernel with 32-key pipeline steps (attn_fwd16_v3.h), which also serves the other buckets;
      // D in (128, 256] -> 4 waves x 64 rows, 32-key steps (attn_fwd16_p5.h; buckets 160, 192, 256); | D | 128 | 32 | D | selects
-     // the 4 waves x 32 rows objects
+     // the 4 waves x 32 rows objects; D in (256, 384] -> 4 waves x 32 rows, 32-key steps, Q' and O^T in registers (attn_fwd16_wide.h, round 6:
+     // the reference's `| 384 | ... |` rows on the 16-bit matrix cores; with FP32 inputs the row is the general kernel's | 384 | 64 | 32 | 384 |)
      "| 32  | 128 | 32 | 32  | Q, O |\n"
      "| 64  | 256 | 64 | 64  | Q, O |\n"
      "| 128 | 256 | 64 | 128 | Q, O |\n"
      "| 160 | 256 | 32 | 160 | Q, O |\n"
      "| 192 | 256 | 32 | 192 | Q, O |\n"
      "| 256 | 256 | 32 | 256 | Q, O |\n"
-     "| 384 | 64  | 32 | 384 | Q, O |\n"},
+     "| 320 | 128 | 32 | 320 | Q, O |\n"
+     "| 384 | 128 | 32 | 384 | Q, O |\n"},
     {// backwardQuery, FP32
      "| 32  | 128 | 32 | 32  | Q, dO, dQ |\n"
      "| 64  | 128 | 32 | 64  | Q, dO, dQ |\n"

@@ -801,10 +801,10 @@ class Stream:
         so = getattr(self.cfg, "soff", 0)
         if which == "k":   # K(j+2) -> K image j & 1
             self.emit("s_add_u32", M0, [SN("ldsk"), I(par * KSLOT + i * 1024)])
-            self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), SN("kres", 4)] + ([SN("ksoff")] if so else []))
+            self.emit("buffer_load_dwordx4_lds", None, [VN("koff%d" % i), SN("kres", 4)] + ([SN("ksoff")] if so else []), pol=getattr(self.cfg, "dmapol", ""))
         else:              # V(j+1) -> V image (j + 1) % 3
             self.emit("s_add_u32", M0, [SN("vwr"), I(i * 1024)])
-            self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), SN("vres", 4)] + ([SN("vsoff")] if so else []))
+            self.emit("buffer_load_dwordx4_lds", None, [VN("voff%d" % i), SN("vres", 4)] + ([SN("vsoff")] if so else []), pol=getattr(self.cfg, "dmapol", ""))
 
     def last_v_tile(self):
         """transposed streams, in front of the pieces of V(j+1): the tile advances ALONG the rows of V^T, so the end of the
@@ -1045,7 +1045,7 @@ def render_one(ins, suffix="%="):
     if op in ("s_cbranch_scc0", "s_cbranch_scc1", "s_cbranch_vccnz", "s_branch"):
         return "%s %s_%s" % (op, m["target"], suffix)
     if op == "buffer_load_dwordx4_lds":
-        return "buffer_load_dwordx4 %s, %s, %s offen lds" % (fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]) if len(ins.s) > 2 else "0")
+        return "buffer_load_dwordx4 %s, %s, %s offen%s lds" % (fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]) if len(ins.s) > 2 else "0", m.get("pol", ""))
     if op in ("buffer_load_dword", "buffer_load_ushort"):
         return "%s %s, %s, %s, 0 offen" % (op, fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]))
     if op == "buffer_store_dwordx4":     # s = (four data registers, per-lane byte offset, buffer resource)

@@ -76,7 +76,7 @@ class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
     def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0,
-                 fastloop=0, align=0, soff=0, pksum=0):
+                 fastloop=0, align=0, soff=0, pksum=0, dmapol=""):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
         # fastloop (round 6, dense streams): the timing-only ablation that dropped the per-tile tests of the loop -- block switch
@@ -94,6 +94,9 @@ class PCfg(Cfg):
         # pksum (round 6 experiment): the two partial row sums of a row block live in an aligned register pair (l0 | v31, v244 | v245)
         # and a score pair is added with ONE v_pk_add_f32: 32 vector instructions per tile less
         self.pksum = pksum
+        # dmapol (round 6 experiment): cache-policy bits on the steady-state LDS-DMA loads of K / V (" nt", " sc1", ...): every line of a
+        # tile is read once per compute unit, the vector L1 never hits
+        self.dmapol = dmapol
         assert not (pksum and bal != 2)
         assert not (fastloop and (merge or bal != 2))
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
@@ -992,6 +995,10 @@ VARIANTS = {
     "BF16_FOLD_L16_FL1_AL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
     "BF16_FOLD_L16_FL1_SPROF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, pprof=2),
     "BF16_EXACT_FL1": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1),
+    "BF16_FOLD_L16_NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, dmapol=" nt"),
+    "BF16_FOLD_L16_SC1": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, dmapol=" sc1"),
+    "BF16_FOLD_L16_SC0": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, dmapol=" sc0"),
+    "BF16_FOLD_L16_SC1NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, dmapol=" sc1 nt"),
     "BF16_FOLD_L16_SOFF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, soff=1),
     "BF16_FOLD_L16_PKS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, pksum=1),
     "BF16_FOLD_L16_FL1_SOFF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, soff=1),
@@ -1010,7 +1017,7 @@ VARIANTS = {
     "ABL_BAL32_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("bar",)),
     "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS', n))
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d', n))
 assert "BF16_FOLD_L16_SPROF" not in PRODUCT_STREAMS
 
 

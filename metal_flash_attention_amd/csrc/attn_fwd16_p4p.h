@@ -44,8 +44,7 @@ constexpr StreamTraits traits(int s) {
                  [nt] "s"(nt), [maskfrom] "s"(maskfrom), [scale2] "s"(a.scale2), [kinc] "s"(kinc), [vinc] "s"(vinc),      \
                  [ldsk] "s"(ldsk), [ldsv] "s"(ldsv), [ldsq] "s"(ldsq), [qrel] "s"(qrel), [nblk] "s"(nblk), [tbl] "s"(tbl), \
                  [wave64] "s"(wave64), [ldq2] "s"(ldq2), [ldo] "s"(ldob), [nrecq] "s"(nrecq), [nreck] "s"(nreck),         \
-                 [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl), [dr] "s"(dr), [coff] "s"(coff),              \
-                 [cm1] "s"(cm1), [rr] "s"(R), [ttot] "s"(ttot)                                                            \
+                 [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl), [dr] "s"(dr), [cflag] "s"(cflag)             \
                : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_P4P_OWNED_VGPRS, MFA_P4P_OWNED_SGPRS)
 
 // T: __bf16 or _Float16 (must match the stream); STREAM: p4p::S_*.  `total` = units x heads x batches; workgroup w of G takes the
@@ -67,42 +66,47 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   if (first >= total) return;
   const uint32_t nunits = (total - first + G - 1) / G;   // blocks per unit x nunits <= TABLE_ENTRIES (the launcher sizes the grid)
 
-  // ---- block table: what attn_fwd16_p4 decodes per workgroup, once per block of this workgroup
+  // ---- block table: what attn_fwd16_p4 decodes per workgroup, once per block of this workgroup.  Entry = Q, K, V, O, L base of the
+  // block's head (words 0..9), its first row (10) and -- causal ("geometry") streams, round 6 -- the rows and keys of its batch entry
+  // (11, 12: per-batch lengths; the launch's R, C otherwise).  Row blocks beyond an entry's rows are NOT entered: the table is
+  // compacted (unit n's entries start behind those of the units before it: counts through LDS, then a prefix sum).
   uint32_t *table = reinterpret_cast<uint32_t *>(smem + TABLE);
   Fwd16Grid dgrid = grid;
   const uint32_t RB = grid.rowBlocks;
   if constexpr (TR.causal) dgrid.rowBlocks = (RB + 1) / 2;
-  for (uint32_t n = tid; n < nunits; n += 256) {
-    uint32_t r, head, batch;
-    fwd16_decode_block_lane(dgrid, first + n * G, &r, &head, &batch);
-    const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
-                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
-                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
-    // entry of the unit's block(s).  Causal, odd block count: the middle block is its own pair -- the units before it in this
-    // workgroup's list hold two entries each unless they are middle blocks themselves (same r for every unit whose index
-    // differs by a multiple of the decode period; counted, not assumed)
-    uint32_t pos = TR.causal ? 2 * n : n;
-    if constexpr (TR.causal) {
-      if (RB & 1u) {
-        for (uint32_t i = 0; i < n; ++i) {
-          uint32_t ri, hi_, bi;
-          fwd16_decode_block_lane(dgrid, first + i * G, &ri, &hi_, &bi);
-          if (ri == RB - 1 - ri) --pos;
-        }
-      }
-    }
-    const uint32_t rows[2] = {TR.causal ? RB - 1 - r : r, r};
-    const int count = (TR.causal && rows[0] != rows[1]) ? 2 : 1;
-    for (int w = 0; w < count; ++w) {
+  uint32_t *counts = reinterpret_cast<uint32_t *>(smem);   // (the K ring's first bytes: free until the stream starts)
+  uint32_t myrows[2] = {0, 0}, myhead = 0, mybatch = 0;
+  int mycount = 0, myR = (int)a.R, myC = (int)a.C;
+  if ((uint32_t)tid < nunits) {
+    uint32_t r;
+    fwd16_decode_block_lane(dgrid, first + (uint32_t)tid * G, &r, &myhead, &mybatch);
+    if constexpr (TR.causal) batch_lengths(a, mybatch, myR, myC);
+    const uint32_t cand[2] = {TR.causal ? RB - 1 - r : r, r};
+    const int ncand = (TR.causal && cand[0] != cand[1]) ? 2 : 1;
+    for (int w = 0; w < ncand; ++w)
+      if ((int64_t)cand[w] * GROWS < myR) myrows[mycount++] = cand[w];
+    counts[tid] = (uint32_t)mycount;
+  }
+  __syncthreads();
+  if ((uint32_t)tid < nunits) {
+    uint32_t pos = 0;
+    for (int i = 0; i < tid; ++i) pos += counts[i];
+    const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], myhead, mybatch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], myhead, mybatch),
+                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], myhead, mybatch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], myhead, mybatch),
+                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], myhead, mybatch)};
+    for (int w = 0; w < mycount; ++w) {
       uint32_t *e = table + 16 * (pos + w);
 #pragma unroll
       for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
-      e[10] = rows[w] * GROWS;
+      e[10] = myrows[w] * GROWS;
+      e[11] = (uint32_t)myR;
+      e[12] = (uint32_t)myC;
     }
-    if (n == nunits - 1) table[16 * TABLE_ENTRIES - 1] = pos + count;   // blocks of this workgroup (the last table word is never an entry's)
+    if ((uint32_t)tid == nunits - 1) table[16 * TABLE_ENTRIES - 1] = pos + (uint32_t)mycount;   // blocks of this workgroup (the last table word is never an entry's)
   }
   __syncthreads();
   const uint32_t nblk = __builtin_amdgcn_readfirstlane(table[16 * TABLE_ENTRIES - 1]);
+  if (nblk == 0) return;   // (per-batch lengths: every row block of this workgroup's units lies beyond its entry's rows)
   // desynchronise the compute units: blocks that end in lockstep store 32 MB at once and the next block's loads queue
   // behind them (profiles/r02_fwd16p4_block_overhead_persistent_experiment.txt)
   for (uint32_t i = 0; i < (stagger & 0xFFFFu) * ((first >> 3) & 31u); ++i) __builtin_amdgcn_s_sleep(8);   // 512 clocks per step
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   // register r of a lane covers key (r & 3) + 8 (r >> 2) + 4 hi of its 32-key block; dense: every row sees all C keys (causal
   // streams recompute both limits per block: min(C - 1, row + C - R) - 4 hi)
   int lim0 = (int)C - 1 - 4 * hi, lim1 = lim0;
-  const uint32_t qlane = q, hi4 = 4 * hi, coff = C - R, cm1 = C - 1, ttot = (C + BC - 1) / BC;
+  const uint32_t qlane = q, hi4 = 4 * hi;
+  const uint32_t cflag = (uint32_t)__builtin_amdgcn_readfirstlane(a.causal ? 1 : 0);
 
   // ---- lane parts of the LDS-DMA source offsets (the stream adds the scalar parts: first row of the piece x leading dimension).
   // Piece i of a K-shaped image (K tiles, the wave's Q image): 16-byte position p = i * 64 + lane holds row p >> 4, chunk

@@ -65,10 +65,13 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
 }  // namespace
 
 // Dense launch of a D <= 128 forward problem on the persistent kernel.  Returns false when the launch is not one it serves
-// (the caller then launches attn_fwd16_p4): per-batch lengths, a storage type of O / L no stream was generated for.
+// (the caller then launches attn_fwd16_p4): block masks, a storage type of O / L no stream was generated for.
 template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args) {
-  if (args.rowLen || args.colLen || args.mask) return false;
+  if (args.mask) return false;
   if (args.causal && args.C < args.R) return false;
+  // per-batch lengths (round 6): the causal ("geometry") streams, whose table entries carry the rows and keys of their batch entry --
+  // with or without the causal mask (KernelArgs.causal is the stream's flag)
+  const bool geometry = args.causal || args.rowLen || args.colLen;
 #ifdef MFA_DEV_VARIANTS   // developer builds: A/B against the one-block-per-workgroup kernel, phase clocks (tools/p4p_prof.py)
   if (std::getenv("MFA_P4_NO_PERSISTENT")) return false;
   if constexpr (!FOLD && __is_same(T, __bf16)) {
@@ -80,9 +83,9 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   // tools/p4p_streams_ab.py)
   if constexpr (__is_same(T, __bf16)) {
     const char *want = std::getenv("MFA_P4P_DEV_STREAM");
-    if (want && *want && !args.causal && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == (FOLD ? PREC_FP16 : PREC_FP32)) {
-#define MFA_P4P_BYNAME(name, f16, fold, o16, l16, causal) \
-      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD && !causal) { if (std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
+    if (want && *want && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == (FOLD ? PREC_FP16 : PREC_FP32)) {
+#define MFA_P4P_BYNAME(name, f16, fold, o16, l16, scausal) \
+      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD) { if ((scausal != 0) == geometry && std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
       MFA_P4P_DEV_STREAM_LIST(MFA_P4P_BYNAME)
 #undef MFA_P4P_BYNAME
       return false;   // (an unknown name must not silently time the product stream)
@@ -97,19 +100,19 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   if constexpr (FOLD) {
     if (!l16) return false;   // (FOLD streams exist with FP16 L: the mixed-precision mode's storage type)
     if constexpr (__is_same(T, _Float16)) {
-      if (args.causal) return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16_CAUSAL>(grid, stream, args);
+      if (geometry) return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16_CAUSAL>(grid, stream, args);
       return o16 ? launch_stream<T, p4p::S_F16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_F16_FOLD_L16>(grid, stream, args);
     } else {
-      if (args.causal) return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16_CAUSAL>(grid, stream, args);
+      if (geometry) return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16_CAUSAL>(grid, stream, args);
       return o16 ? launch_stream<T, p4p::S_BF16_FOLD_O16_L16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_FOLD_L16>(grid, stream, args);
     }
   } else {
     if (l16) return false;
     if constexpr (__is_same(T, _Float16)) {
-      if (args.causal) return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT_CAUSAL>(grid, stream, args);
+      if (geometry) return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT_CAUSAL>(grid, stream, args);
       return o16 ? launch_stream<T, p4p::S_F16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_F16_EXACT>(grid, stream, args);
     } else {
-      if (args.causal) return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT_CAUSAL>(grid, stream, args);
+      if (geometry) return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT_CAUSAL>(grid, stream, args);
       return o16 ? launch_stream<T, p4p::S_BF16_EXACT_O16>(grid, stream, args) : launch_stream<T, p4p::S_BF16_EXACT>(grid, stream, args);
     }
   }
@@ -117,7 +120,7 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
 
 // the launches launch_p4p serves (the same conditions, nothing launched)
 template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args) {
-  if (args.rowLen || args.colLen || args.mask) return nullptr;
+  if (args.mask) return nullptr;
   if (args.causal && args.C < args.R) return nullptr;
 #ifdef MFA_DEV_VARIANTS
   if (std::getenv("MFA_P4_NO_PERSISTENT")) return nullptr;
@@ -126,6 +129,9 @@ template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args) {
   constexpr int PT = __is_same(T, _Float16) ? PREC_FP16 : PREC_BF16;
   if (po != PT && po != PREC_FP32) return nullptr;
   if (FOLD ? pl != PREC_FP16 : pl != PREC_FP32) return nullptr;
+  if (args.rowLen || args.colLen)
+    return args.causal ? "attn_fwd16_p4p (persistent: one workgroup per compute unit walks the row-block pairs; per-batch lengths in the block table)"
+                       : "attn_fwd16_p4p (persistent: one workgroup per compute unit walks the row-block pairs; per-batch lengths in the block table, no causal mask)";
   return args.causal ? "attn_fwd16_p4p (persistent: one workgroup per compute unit walks the row-block pairs)"
                      : "attn_fwd16_p4p (persistent: one workgroup per compute unit walks the row blocks)";
 }

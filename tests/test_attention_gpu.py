@@ -682,7 +682,9 @@ def test_launch_form_names_what_runs():
     assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs).startswith("attn_fwd16_p4p (persistent")
     assert "row-block pairs" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, causal=True)
     lens = torch.full((1,), N, dtype=torch.int32, device="cuda")
-    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens) == k.variant
+    # (round 6: per-batch lengths run on the persistent kernel too -- its causal streams read rows / keys per block-table entry)
+    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens).startswith("attn_fwd16_p4p (persistent") and \
+        "per-batch lengths" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens)
     one = {op: t[0] for op, t in bufs.items()}
     ws = torch.empty(k.workspaceSize(row=N, column=N) + 256, dtype=torch.uint8, device="cuda")
     split_form = k.launchForm(one, row=N, column=N, workspace=ws)
@@ -1414,6 +1416,10 @@ def test_variable_sequence_lengths(low, causal, D):
     rl = torch.tensor(rlen, dtype=torch.int32, device="cuda")
     cl = torch.tensor(clen, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    if low and D == 128:   # (round 6) the persistent forward kernel serves per-batch lengths: rows / keys per block-table entry
+        form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                                                                causal=causal, rowLengths=rl, columnLengths=cl)
+        assert form.startswith("attn_fwd16_p4p (persistent") and "per-batch lengths" in form, form
     for t in (AttentionKernelType.forward, AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):
         kernels[t].dispatch(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                             stream=stream, causal=causal, rowLengths=rl, columnLengths=cl)

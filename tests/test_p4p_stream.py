@@ -188,6 +188,41 @@ def test_causal_branch_free_loop(cfg):
     assert len(set(w.count["s_barrier"] for w in wg.waves)) == 1, "waves disagree on the barriers"
 
 
+def _check_lengths(cfg, lens, cflag, R, C, seed=0, order_blocks=None, **kw):
+    """causal ("geometry") streams with per-batch lengths: head h = a batch entry of lens[h] = (rows, keys) inside [R] x [C] arrays; the
+    table holds the non-empty row blocks only (the C++ prologue compacts it), every entry its own lengths"""
+    rng = np.random.default_rng(seed)
+    H = len(lens)
+    q, k, v = (p4psim.rand_bf16(s_, rng) for s_ in ((H, R, 128), (H, C, 128), (H, C, 128)))
+    blocks = [(h, rb) for h in range(H) for rb in range((lens[h][0] + 255) // 256)]
+    if order_blocks:
+        blocks = order_blocks(blocks)
+    O, L, wg, (om, lm) = p4psim.run_workgroup(q, k, v, blocks, cfg, lengths={h: lens[h] for h in range(H)}, cflag=cflag, **kw)
+    for h, (Rb, Cb) in enumerate(lens):
+        Oref, Lref = p4psim.reference(q[h, :Rb], k[h, :Cb], v[h, :Cb], causal=bool(cflag))
+        dO, dL = np.abs(O[h, :Rb] - Oref).max(), np.abs(L[h, :Rb] - Lref).max()
+        assert dO < 8e-3 and dL < (2e-2 + 5e-3) * max(1.0, np.abs(Lref).max() / 8), (h, Rb, Cb, dO, dL)
+        # nothing beyond an entry's rows is written
+        assert (om.reshape(H, R, 512)[h, Rb:] == 0xCD).all() and (lm.reshape(H, R, 2 if cfg.l16 else 4)[h, Rb:] == 0xCD).all(), (h, Rb)
+    return wg
+
+
+@pytest.mark.parametrize("cflag", [0, 1])
+def test_per_batch_lengths_on_the_persistent_kernel(cflag):
+    """round 6: the causal streams take rows / keys per table entry -- per-batch lengths run on the persistent kernel, with the causal
+    mask (each entry's own diagonal offset, clamped at 0 when it has fewer keys than rows) or without it (the offset out of reach)"""
+    lens = [(300, 520), (77, 100), (512, 64), (130, 130), (256, 700)]
+    if cflag:
+        lens.append((300, 200))    # fewer keys than rows: offset 0
+    _check_lengths(CAUSAL_FOLD, lens, cflag, 512, 704, seed=41 + cflag)
+    _check_lengths(CAUSAL_EXACT, lens[:3], cflag, 512, 704, seed=43 + cflag, dma_mode="early", stores="late", order=(3, 2, 1, 0))
+
+
+def test_per_batch_lengths_long_entries_use_the_branch_free_loop():
+    wg = _check_lengths(CAUSAL_FOLD, [(256, 1024), (300, 960)], 0, 512, 1024, seed=45, order_blocks=lambda b: b[::-1])
+    assert wg.waves[0].count.get("s_cmp_lg_u32", 0) > 0
+
+
 @pytest.mark.parametrize("C", [64, 128, 256, 449])
 def test_merged_block_switch_experiment(C):
     """developer stream (slower on the GPU, kept as a record): the last tile's softmax finish beside the next block's first K Q^T.

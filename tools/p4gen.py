@@ -138,7 +138,7 @@ def F(v):
     return ("f", float(v))
 
 
-VCC, M0, VCC_LO = ("vcc",), ("m0",), ("vcc_lo",)
+VCC, M0, VCC_LO, VCC_HI = ("vcc",), ("m0",), ("vcc_lo",), ("vcc_hi",)
 
 
 class Ins:
@@ -824,6 +824,34 @@ class Stream:
         if after_mfma:
             self.emit("s_nop", None, [I(15)], note="S(j) is still leaving the matrix pipe")
         self.emit("s_lshl_b32", SN("t0"), [SN("j"), I(6)])
+        if getattr(self.cfg, "causal", 0) and getattr(self.cfg, "diagmask", 0):
+            # round 6, causal streams: the tile ON the wave's diagonal with everything aligned (first row of the wave + C - R = first key
+            # of the tile, the tile inside the sequence -- every self-attention launch with N % 64 == 0): which lanes lose which key is
+            # a compile-time pattern.  Row block = key block: register r masks rows q < (r & 3) + 8 (r >> 2) (+ 4 in the upper half-wave)
+            # -- two scalar moves into vcc and ONE v_cndmask instead of a compare + v_cndmask per score; keys 32..63 against rows 0..31:
+            # all masked (a move); keys 0..31 against rows 32..63: all visible (nothing).  48 vector instructions instead of 256, and
+            # only one score block's row maxima to take again
+            general = self.newlabel("MASKGENERAL")
+            self.emit("s_cmp_eq_u32", None, [SN("t0"), SN("wdiag")])
+            self.emit("s_cbranch_scc0", None, [], target=general)
+            self.emit("s_add_u32", SN("t1x"), [SN("t0"), I(63)])
+            self.emit("s_cmp_gt_u32", None, [SN("t1x"), SN("cm1")])
+            self.emit("s_cbranch_scc1", None, [], target=general)
+            self.emit("v_mov_b32", V(self.r_maskv), [F(-(0.875 / 1.44269504089) * 3.402823466e+38)])
+            for rb in range(2):
+                for r in range(16):
+                    c0 = (r & 3) + 8 * (r >> 2)
+                    x = s_elem(par, rb, rb, r)
+                    self.emit("s_mov_b32", VCC_LO, [I((1 << c0) - 1)])
+                    self.emit("s_mov_b32", VCC_HI, [I((1 << (c0 + 4)) - 1)])
+                    self.emit("v_cndmask_b32", x, [x, V(self.r_maskv), VCC])
+            for r in range(16):
+                self.emit("v_mov_b32", s_elem(par, 0, 1, r), [V(self.r_maskv)])
+            if self.cfg.bal and self.cfg.maxa:
+                for i in range(8):     # (rb 0, kb 0) is the one first-key-block score block the mask touched
+                    self.max_op(par, i)
+            self.emit("s_branch", None, [], target=skip)
+            self.label(general)
         for rb in range(2):
             self.emit("v_subrev_u32", V(T_TL + rb), [SN("t0"), VN("lim%d" % rb)])   # lim - 4 hi - 64 j
         self.emit("v_mov_b32", V(self.r_maskv), [F(-(0.875 / 1.44269504089) * 3.402823466e+38)])   # +Softmax.swift:242-243
@@ -1013,6 +1041,8 @@ def fmt(o):
         return "s%d" % o[1] if o[2] == 1 else "s[%d:%d]" % (o[1], o[1] + o[2] - 1)
     if k == "vcc_lo":
         return "vcc_lo"
+    if k == "vcc_hi":
+        return "vcc_hi"
     if k == "i":
         return str(o[1]) if -16 <= o[1] <= 64 else hex(o[1] & 0xFFFFFFFF)
     if k == "f":

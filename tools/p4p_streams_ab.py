@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--mixed", type=int, default=1, help="0: the fp32-intermediates mode (exact-scale streams, FP32 L)")
+    ap.add_argument("--causal", type=int, default=0, help="1: causal launches (the causal developer streams)")
     ap.add_argument("--heat", type=float, default=0.0, help="seconds of back-to-back product launches in front of the timed rounds (a GPU "
                     "under sustained load sits at its power / thermal limit: the clock the streams are then granted differs from a cold start)")
     args = ap.parse_args()
@@ -45,7 +46,8 @@ def main():
     hs = {Op.Q: N * D, Op.K: N * D, Op.V: N * D, Op.O: N * D, Op.L: N}
     stream = torch.cuda.current_stream().cuda_stream
     names = ["product"] + [s for s in args.streams.split(",") if s]
-    flops = 4.0 * N * N * D * H
+    flops = 4.0 * N * N * D * H * ((N + 1) / (2.0 * N) if args.causal else 1.0)
+    causal = bool(args.causal)
     for fill in args.fills.split(","):
         g = torch.Generator(device="cuda")
         g.manual_seed(0)
@@ -65,22 +67,22 @@ def main():
         for name in names:
             setenv(name)
             bufs[Op.O].zero_()
-            k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream)
+            k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, causal=causal)
             torch.cuda.synchronize()
             outs[name] = (bufs[Op.O].clone(), bufs[Op.L].float().clone())
         setenv("product")
         for _ in range(40):
-            k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream)
+            k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, causal=causal)
         import time as _time
         t_heat = _time.perf_counter()
         while _time.perf_counter() - t_heat < args.heat:
             for _ in range(50):
-                k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream)
+                k.dispatch(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, causal=causal)
             torch.cuda.synchronize()
         for r in range(args.rounds):
             for name in names:
                 setenv(name)
-                times[name].append(k.time(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, warmup=2, iterations=args.iters) / args.iters)
+                times[name].append(k.time(bufs, row=N, column=N, heads=H, headStrides=hs, stream=stream, warmup=2, iterations=args.iters, causal=causal) / args.iters)
         print("## fill = %s   (N = %d, D = %d, %d heads, %s; 2.5 PF roof)" % (fill, N, D, H, "mixed mode" if args.mixed else "fp32 intermediates"))
         for name in names:
             t = sorted(times[name])

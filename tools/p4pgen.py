@@ -61,22 +61,26 @@ PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
              j=(77, 1), vrd=(78, 1), vwr=(79, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
              kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), wntb=(90, 1), maskb=(91, 1), ntu=(92, 1), t5=(93, 1),
              q4=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1), plast=(100, 1), qswj=(101, 1),
-             fend=(101, 1), fcnt=(93, 1), ksoff=(67, 1), vsoff=(98, 1))   # branch-free loop (dense streams without the merged block switch): first tile it does not take, iterations left
-FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 101
+             fend=(101, 1), fcnt=(93, 1), ksoff=(67, 1), vsoff=(98, 1),
+             wdiag=(99, 1), t1x=(85, 1),
+             # causal ("geometry") streams, round 6: the block's own sequence lengths travel in its table entry (per-batch lengths) -- rows
+             # and keys of the NEXT entry, rows / last key / tile count / diagonal offset of the current block
+             rrn=(36, 1), ccn=(37, 1), rr=(38, 1), cm1=(39, 1), ttot=(67, 1), coff=(98, 1))   # causal streams: first row of the wave + C - R (the first key of its diagonal tile when aligned); a temporary   # branch-free loop (dense streams without the merged block switch): first tile it does not take, iterations left
+FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 36, 101
 
 # inputs of the statement (hipcc allocates them below s40 / v28)
 INOUT_V = ["lim0", "lim1"]          # mask limits per row block: constant in dense streams, rewritten per block by causal ones
 IN_V = ["kbase", "vbase", "kv0", "kv1", "kv2", "kv3", "vv", "qv0", "qv1", "qv2", "qv3", "ov0", "ov1", "ov2", "ov3",
         "lv", "ewa", "era", "qlane", "hi4"]
 IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qrel", "nblk", "tbl", "wave64", "ldq2", "ldo",
-        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "dr", "coff", "cm1", "rr", "ttot"]
+        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "dr", "cflag"]   # (nrec*: dense streams; cflag: causal streams -- 1 = causal mask, 0 = lengths only)
 
 
 class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
     def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0,
-                 fastloop=0, align=0, soff=0, pksum=0, dmapol=""):
+                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
         # fastloop (round 6, dense streams): the timing-only ablation that dropped the per-tile tests of the loop -- block switch
@@ -97,6 +101,9 @@ class PCfg(Cfg):
         # dmapol (round 6 experiment): cache-policy bits on the steady-state LDS-DMA loads of K / V (" nt", " sc1", ...): every line of a
         # tile is read once per compute unit, the vector L1 never hits
         self.dmapol = dmapol
+        # diagmask (round 6, causal streams): compile-time lane masks for the aligned diagonal tile (p4gen.mask_section)
+        self.diagmask = diagmask
+        assert not (diagmask and (not causal or pprof))
         assert not (pksum and bal != 2)
         assert not (fastloop and (merge or bal != 2))
         # causal (extension, row r sees key c iff c <= r + C - R): tile counts, mask limits and the per-wave traversal bound are
@@ -228,8 +235,25 @@ class PStream(Stream):
         """128-bit buffer resource `name` = (64-bit base in SGPR pair `base`, byte count `nrec`)"""
         self.emit("s_mov_b32", s(name, 1, 0), [s(base, 1, 0)])
         self.emit("s_and_b32", s(name, 1, 1), [s(base, 1, 1), I(0xFFFF)])
-        self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
+        self.nrec(name, nrec)
         self.emit("s_mov_b32", s(name, 1, 3), [I(DESC_FLAGS)])
+
+    def nrec(self, name, which):
+        """word 2 of resource `name`: the byte count of the operand -- a launch constant in dense streams, rows (or keys) of the block's
+        own batch entry x bytes per row in causal ("geometry") streams.  which: nrecq / nreck / nrecv (NEXT block), nreco / nrecl (current)"""
+        if not self.cfg.causal:
+            self.emit("s_mov_b32", s(name, 1, 2), [SN(which)])
+            return
+        d = s(name, 1, 2)
+        if which == "nrecq":
+            self.emit("s_mul_i32", d, [s("rrn"), SN("ldq2")])
+        elif which in ("nreck", "nrecv"):
+            self.emit("s_lshr_b32", d, [SN("kinc" if which == "nreck" else "vinc"), I(6)])    # bytes per row
+            self.emit("s_mul_i32", d, [s("ccn"), d])
+        elif which == "nreco":
+            self.emit("s_mul_i32", d, [s("rr"), SN("ldo")])
+        else:
+            self.emit("s_lshl_b32", d, [s("rr"), I(1 if self.cfg.l16 else 2)])
 
     def load_next(self):
         """entry `blk` of the block table -> the *n registers (Q, K, V, O, L bases and the first row of the block)"""
@@ -237,11 +261,13 @@ class PStream(Stream):
         self.emit("s_lshl_b32", s("t0"), [s("blk"), I(6)])
         self.emit("s_add_u32", s("t0"), [s("t0"), SN("tbl")])
         self.emit("v_mov_b32", V(tv), [s("t0")])
-        ids = [self.lds_read("ds_read_b128", V(tb + 4 * i, 4), V(tv), 16 * i, note="block table") for i in range(3)]
+        ids = [self.lds_read("ds_read_b128", V(tb + 4 * i, 4), V(tv), 16 * i, note="block table") for i in range(4 if self.cfg.causal else 3)]
         self.lds_need(ids[-1])
         self.lds_flush()
-        for i, (name, off) in enumerate((("qbn", 0), ("qbn", 1), ("kbn", 0), ("kbn", 1), ("vbn", 0), ("vbn", 1), ("obn", 0),
-                                         ("obn", 1), ("lbn", 0), ("lbn", 1), ("row0n", 0))):
+        words = [("qbn", 0), ("qbn", 1), ("kbn", 0), ("kbn", 1), ("vbn", 0), ("vbn", 1), ("obn", 0), ("obn", 1), ("lbn", 0), ("lbn", 1), ("row0n", 0)]
+        if self.cfg.causal:
+            words += [("rrn", 0), ("ccn", 0)]      # rows and keys of the block's batch entry (words 11, 12)
+        for i, (name, off) in enumerate(words):
             self.emit("v_readfirstlane_b32", s(name, 1, off), [V(tb + i)])
         self.emit("s_nop", None, [I(4)], note="v_readfirstlane -> SALU / VMEM use of the scalar")
 
@@ -249,6 +275,8 @@ class PStream(Stream):
         if not init:
             self.emit("s_mov_b32", s("kres", 1, 0), [s("kbn", 1, 0)])
             self.emit("s_and_b32", s("kres", 1, 1), [s("kbn", 1, 1), I(0xFFFF)])
+            if self.cfg.causal:
+                self.nrec("kres", "nreck")
             if self.cfg.soff:
                 self.emit("s_mov_b32", s("ksoff"), [I(0)])
                 return
@@ -262,6 +290,8 @@ class PStream(Stream):
         if not init:
             self.emit("s_mov_b32", s("vres", 1, 0), [s("vbn", 1, 0)])
             self.emit("s_and_b32", s("vres", 1, 1), [s("vbn", 1, 1), I(0xFFFF)])
+            if self.cfg.causal:
+                self.nrec("vres", "nrecv")
             if self.cfg.soff:
                 self.emit("s_mov_b32", s("vsoff"), [I(0)])
                 return
@@ -294,6 +324,8 @@ class PStream(Stream):
         self.emit("s_cmp_ge_u32", None, [t2, SN("rr")])              # a wave beyond the last row: one tile, nothing stored
         self.emit("s_cselect_b32", s("wntb"), [I(1), t3])
         self.emit("s_add_u32", t3, [t2, SN("coff")])
+        if self.cfg.diagmask:
+            self.emit("s_mov_b32", s("wdiag"), [t3])
         self.emit("s_min_u32", t0, [t3, SN("cm1")])
         self.emit("s_add_u32", t0, [t0, I(1)])
         self.emit("s_lshr_b32", s("maskb"), [t0, I(6)])
@@ -605,6 +637,18 @@ class PStream(Stream):
             self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
         self.emit("s_mov_b32", s("row0"), [s("row0n")])
         if cfg.causal:
+            # rows / last key / key tiles / diagonal offset of THIS block's batch entry (the *n registers still hold its table entry):
+            # row r sees key c iff c <= r + max(C - R, 0) (include/mfa.h: with per-batch lengths the offset is each entry's own, clamped
+            # at 0); without the causal mask the offset is out of reach of any row and the same arithmetic yields the dense geometry
+            self.emit("s_mov_b32", s("rr"), [s("rrn")])
+            self.emit("s_sub_u32", s("cm1"), [s("ccn"), I(1)])
+            self.emit("s_add_u32", s("ttot"), [s("ccn"), I(63)])
+            self.emit("s_lshr_b32", s("ttot"), [s("ttot"), I(6)])
+            self.emit("s_max_u32", s("ttot"), [s("ttot"), I(1)])       # (an entry without keys: one fully masked tile pair, O = 0)
+            self.emit("s_sub_u32", s("coff"), [s("ccn"), s("rrn")])
+            self.emit("s_max_i32", s("coff"), [s("coff"), I(0)])
+            self.emit("s_cmp_eq_u32", None, [SN("cflag"), I(0)])
+            self.emit("s_cselect_b32", s("coff"), [I(0x40000000), s("coff")])
             self.block_geometry()
             if cfg.fastloop:
                 self.fast_end()
@@ -696,7 +740,8 @@ class PStream(Stream):
         self.emit("s_lshr_b32", s("vstep"), [SN("vinc"), I(2)])              # sixteen keys of V
         self.emit("s_lshl_b32", s("q4"), [SN("ldq2"), I(2)])
         for name, nrec in (("kres", "nreck"), ("vres", "nrecv")):
-            self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
+            if not cfg.causal:     # (causal streams: per block, switch_k / switch_v)
+                self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
             self.emit("s_mov_b32", s(name, 1, 3), [I(DESC_FLAGS)])
         # ---- first block: its Q, K(0), V(0), K(1) are requested here; later blocks find theirs requested by their predecessor
         self.emit("s_mov_b32", s("blk"), [I(0)])
@@ -896,7 +941,7 @@ def render_one(ins):
         return "s_memtime %s" % f(ins.d)
     if op == "align":
         return ".p2align %d" % ins.s[0][1]
-    if op in ("s_cmp_lg_u32", "s_bitcmp1_b32"):
+    if op in ("s_cmp_lg_u32", "s_bitcmp1_b32", "s_cmp_gt_u32"):
         return "%s %s, %s" % (op, f(ins.s[0]), f(ins.s[1]))
     if op == "s_mov_b64" and ins.d == ("exec",):
         return "s_mov_b64 exec, %s" % f(ins.s[0])
@@ -1005,6 +1050,8 @@ VARIANTS = {
     "BF16_FOLD_L16_FL1_SOFF_PKS": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, soff=1, pksum=1),
     "BF16_FOLD_L16_FL2_SOFF": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=2, soff=1),
     "BF16_EXACT_FL1_SOFF": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, soff=1),
+    "BF16_FOLD_L16_CAUSAL_DM": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, diagmask=1),
+    "BF16_EXACT_CAUSAL_DM": PCfg("bf16", 8, fold=0, causal=1, bal=2, xe=32, cap=8, fastloop=1, align=1, diagmask=1),
     "R5_BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1),   # the round-5 causal stream (A/B baseline)
     "BF16_FOLD_L16_PAD": PCfg("bf16", 8, fold=1, l16=1, pad=1),
     "BF16_FOLD_L16_BAL32_PAD": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, pad=1),
@@ -1017,7 +1064,7 @@ VARIANTS = {
     "ABL_BAL32_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("bar",)),
     "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d', n))
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d|_DM$', n))
 assert "BF16_FOLD_L16_SPROF" not in PRODUCT_STREAMS
 
 

@@ -90,6 +90,15 @@ class PWorkgroup(Workgroup):
         scalar_kinds = ("sr",)
         if op == "align":
             return None
+        if op == "s_mov_b32" and d[0] in ("vcc_lo", "vcc_hi"):   # a scalar constant into one half of the lane mask
+            val = int(self.sval(w, s[0])) & 0xFFFFFFFF
+            bits = np.array([(val >> i) & 1 for i in range(32)], bool)
+            w.vcc = w.vcc.copy()
+            if d[0] == "vcc_lo":
+                w.vcc[:32] = bits
+            else:
+                w.vcc[32:] = bits
+            return None
         if op in ("s_mov_b32", "s_add_u32", "s_sub_u32", "s_and_b32", "s_or_b32", "s_lshl_b32", "s_lshr_b32", "s_mul_i32", "s_min_u32", "s_max_u32", "s_max_i32", "s_min_i32"):
             vals = [self.sval(w, x) for x in s]
             if op == "s_mov_b32":
@@ -113,12 +122,12 @@ class PWorkgroup(Workgroup):
         if op == "s_bitcmp1_b32":
             w.scc = (int(self.sval(w, s[0])) >> (int(self.sval(w, s[1])) & 31)) & 1
             return None
-        if op in ("s_cmp_lt_i32", "s_cmp_ge_i32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_cmp_lt_u32", "s_cmp_lg_u32"):
+        if op in ("s_cmp_lt_i32", "s_cmp_ge_i32", "s_cmp_ge_u32", "s_cmp_eq_u32", "s_cmp_lt_u32", "s_cmp_lg_u32", "s_cmp_gt_u32"):
             a, b = int(self.sval(w, s[0])) & 0xFFFFFFFF, int(self.sval(w, s[1])) & 0xFFFFFFFF
             if op.endswith("i32"):
                 a, b = int(np.int32(np.uint32(a))), int(np.int32(np.uint32(b)))
             w.scc = int({"s_cmp_lt_i32": a < b, "s_cmp_ge_i32": a >= b, "s_cmp_ge_u32": a >= b, "s_cmp_eq_u32": a == b,
-                         "s_cmp_lt_u32": a < b, "s_cmp_lg_u32": a != b}[op])
+                         "s_cmp_lt_u32": a < b, "s_cmp_lg_u32": a != b, "s_cmp_gt_u32": a > b}[op])
             return None
         if op == "s_cselect_b32":
             self.sset(w, d, self.sval(w, s[0]) if w.scc else self.sval(w, s[1]))
@@ -235,7 +244,10 @@ class PWorkgroup(Workgroup):
                 self.lds_write16(addrs, data)
 
 
-def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None, causal=None):
+def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None, causal=None,
+                  lengths=None, cflag=None):
+    # lengths (causal / "geometry" streams): {head: (rows, keys)} of the head's batch entry, at most the array shapes (per-batch lengths);
+    # cflag: 1 = causal mask (default for causal streams), 0 = lengths only
     """One persistent workgroup over `blocks` = [(head, row block), ...].  q [H][R][D], k / v [H][C][D] uint16 bit patterns.
     Restates the C++ prologue of attn_fwd16_p4p (block table, lane constants, scalar inputs).  Returns O [H][R][D] float32
     (or the 16-bit patterns as float32 when cfg.o16), L [H][R] float32 (log2 units), the workgroup."""
@@ -263,6 +275,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
         for i, a in enumerate((qb + h * R * ldq * 2, kb + h * C * ldk * 2, vb + h * C * ldv * 2, ob + h * R * ldo * osz, lb + h * R * lsz)):
             table[n, 2 * i], table[n, 2 * i + 1] = a & 0xFFFFFFFF, a >> 32
         table[n, 10] = rblk * 256
+        table[n, 11], table[n, 12] = (lengths or {}).get(h, (R, C))
     tb = table.reshape(-1).view(np.uint8)
     wg.lds[p4pgen.TABLE:p4pgen.TABLE + tb.size] = tb
     nt = (C + 63) // 64
@@ -300,7 +313,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
                      "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "ldsq": p4pgen.QIMG + wave * 16384,
                      "qrel": p4pgen.QIMG + wave * 16384, "nblk": len(blocks), "tbl": p4pgen.TABLE, "wave64": wave * 64,
                      "ldq2": ldq2, "ldo": ldo * osz, "nrecq": R * ldq2, "nreck": C * ldk2, "nrecv": C * ldv2,
-                     "nreco": R * ldo * osz, "nrecl": R * lsz, "dr": D, "coff": C - R, "cm1": C - 1, "rr": R, "ttot": (C + 63) // 64})
+                     "nreco": R * ldo * osz, "nrecl": R * lsz, "dr": D, "cflag": int(bool(cfg.causal)) if cflag is None else int(cflag)})
     wg.run(order)
     for w in wg.waves:
         assert not w.lds_q, "LDS reads left in flight"

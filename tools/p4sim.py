@@ -610,7 +610,7 @@ def reference(q, k, v, causal=False, f16=False):
     R, C = qf.shape[0], kf.shape[0]
     s = qf @ kf.T / np.sqrt(qf.shape[1])
     if causal:
-        mask = np.arange(C)[None, :] > (np.arange(R)[:, None] + (C - R))
+        mask = np.arange(C)[None, :] > (np.arange(R)[:, None] + max(C - R, 0))   # (the offset is clamped at 0: include/mfa.h, rowLengths)
         s = np.where(mask, -np.inf, s)
     mx = s.max(axis=1, keepdims=True)
     p = np.exp(s - mx)

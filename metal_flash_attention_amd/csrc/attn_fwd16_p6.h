@@ -50,7 +50,7 @@ constexpr StreamTraits traits(int s) {
                  [ldsk] "s"(ldsk), [ldsv] "s"(ldsv), [ldsq] "s"(ldsq), [qrel] "s"(qrel), [ldsst] "s"(ldsst),              \
                  [nblk] "s"(nblk), [tbl] "s"(tbl), [wave64] "s"(wave64), [ldq2] "s"(ldq2), [ldo] "s"(ldob),               \
                  [nrecq] "s"(nrecq), [nreck] "s"(nreck), [nrecv] "s"(nrecv), [nreco] "s"(nreco), [nrecl] "s"(nrecl),      \
-                 [coff] "s"(coff), [cm1] "s"(cm1), [rr] "s"(R), [ttot] "s"(ttot)                                          \
+                 [cflag] "s"(cflag)                                                                                        \
                : "memory", "vcc", "scc", MFA_ALL_AGPRS, MFA_P6_OWNED_VGPRS, MFA_P6_OWNED_SGPRS)
 
 // T: __bf16 or _Float16 (must match the stream); STREAM: p6::S_*.  `total` = row blocks x heads x batches; workgroup w of G takes
@@ -77,10 +77,28 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   Fwd16Grid dgrid = grid;
   const uint32_t RB = grid.rowBlocks;
   if constexpr (TR.causal) dgrid.rowBlocks = (RB + 1) / 2;
-  for (uint32_t n = tid; n < nunits; n += 256) {
-    uint32_t r, head, batch, unit = first + n * G, piece = 0;
-    if constexpr (TR.split) { piece = unit % grid.splits; unit /= grid.splits; }   // SPLIT: a unit is (row block, piece of the key range)
-    fwd16_decode_block_lane(dgrid, unit, &r, &head, &batch);
+  // (round 6, causal / "geometry" streams: an entry also carries the rows and keys of its batch entry -- words 11, 12: per-batch lengths,
+  // or the launch's R, C -- and row blocks beyond an entry's rows are NOT entered: the table is compacted, unit n's entries start
+  // behind those of the units before it -- counts through LDS, then a prefix sum; nunits <= 255: one unit per thread)
+  uint32_t *counts = reinterpret_cast<uint32_t *>(smem);   // (the K ring's first bytes: free until the stream starts)
+  uint32_t myrows[2] = {0, 0}, myhead = 0, mybatch = 0, mypiece = 0;
+  int mycount = 0, myR = (int)a.R, myC = (int)a.C;
+  if ((uint32_t)tid < nunits) {
+    uint32_t r, unit = first + (uint32_t)tid * G;
+    if constexpr (TR.split) { mypiece = unit % grid.splits; unit /= grid.splits; }   // SPLIT: a unit is (row block, piece of the key range)
+    fwd16_decode_block_lane(dgrid, unit, &r, &myhead, &mybatch);
+    if constexpr (TR.causal) batch_lengths(a, mybatch, myR, myC);
+    const uint32_t cand[2] = {TR.causal ? RB - 1 - r : r, r};
+    const int ncand = (TR.causal && cand[0] != cand[1]) ? 2 : 1;
+    for (int w = 0; w < ncand; ++w)
+      if ((int64_t)cand[w] * GROWS < myR) myrows[mycount++] = cand[w];
+    counts[tid] = (uint32_t)mycount;
+  }
+  __syncthreads();
+  if ((uint32_t)tid < nunits) {
+    const uint32_t head = myhead, batch = mybatch, piece = mypiece;
+    uint32_t pos = 0;
+    for (int i = 0; i < tid; ++i) pos += counts[i];
     uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], head, batch),
                         (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], head, batch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], head, batch),
                         (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], head, batch)};
@@ -94,30 +112,19 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
       base[3] = (uint64_t)(uintptr_t)(grid.wsO + slab * a.D);
       base[4] = (uint64_t)(uintptr_t)(grid.wsML + slab * 2);
     }
-    // causal, odd block count: the middle block is its own pair -- the units before it in this workgroup's list hold two entries
-    // each unless they are middle blocks themselves (counted, not assumed)
-    uint32_t pos = TR.causal ? 2 * n : n;
-    if constexpr (TR.causal) {
-      if (RB & 1u) {
-        for (uint32_t i = 0; i < n; ++i) {
-          uint32_t ri, hi_, bi;
-          fwd16_decode_block_lane(dgrid, first + i * G, &ri, &hi_, &bi);
-          if (ri == RB - 1 - ri) --pos;
-        }
-      }
-    }
-    const uint32_t rows[2] = {TR.causal ? RB - 1 - r : r, r};
-    const int count = (TR.causal && rows[0] != rows[1]) ? 2 : 1;
-    for (int w = 0; w < count; ++w) {
+    for (int w = 0; w < mycount; ++w) {
       uint32_t *e = table + 16 * (pos + w);
 #pragma unroll
       for (int i = 0; i < 5; ++i) { e[2 * i] = (uint32_t)base[i]; e[2 * i + 1] = (uint32_t)(base[i] >> 32); }
-      e[10] = rows[w] * GROWS;
+      e[10] = myrows[w] * GROWS;
+      e[11] = (uint32_t)myR;
+      e[12] = (uint32_t)myC;
     }
-    if (n == nunits - 1) table[16 * TABLE_ENTRIES - 1] = pos + count;   // blocks of this workgroup (the last table word is never an entry's)
+    if ((uint32_t)tid == nunits - 1) table[16 * TABLE_ENTRIES - 1] = pos + (uint32_t)mycount;   // blocks of this workgroup (the last table word is never an entry's)
   }
   __syncthreads();
   const uint32_t nblk = __builtin_amdgcn_readfirstlane(table[16 * TABLE_ENTRIES - 1]);
+  if (nblk == 0) return;   // (per-batch lengths: every row block of this workgroup's units lies beyond its entry's rows)
 
   // (SPLIT: every workgroup sees its piece as the key range; the division runs on the vector ALU and hipcc does not move its result
   // back to a scalar register by itself when the asm statement asks for "s" operands derived from it)
@@ -134,7 +141,8 @@ __global__ __launch_bounds__(256) void attn_fwd16_p6(const KernelArgs a, const F
   const uint32_t maskfrom = C / BC;
   // register r of a lane covers key (r & 3) + 8 (r >> 2) + 4 hi of its 32-key block; every row sees all C keys
   int lim0 = (int)C - 1 - 4 * hi, lim1 = lim0;   // (causal streams recompute both limits per block: min(C - 1, row + C - R) - 4 hi)
-  const uint32_t qlane = q, hi4 = 4 * hi, coff = C - R, cm1 = C - 1, ttot = (C + BC - 1) / BC;
+  const uint32_t qlane = q, hi4 = 4 * hi;
+  const uint32_t cflag = (uint32_t)a.causal;   // (0 / 1, mfa_kernel.hip; a kernel argument: a scalar register)
 
   // ---- lane parts of the LDS-DMA source offsets (the stream adds the scalar parts).  K-shaped images (K tiles, the wave's Q
   // image): rows of 128 bytes, a 1 KiB piece = 8 rows; the 16-byte position (lane & 7) of row 8 i + (lane >> 3) holds chunk

@@ -54,7 +54,7 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args, uint32
 
 bool serves(int precision, bool fold, const KernelArgs &args) {
   if (precision != PREC_BF16 && precision != PREC_FP16) return false;
-  if (args.rowLen || args.colLen || args.mask) return false;
+  if (args.mask) return false;   // (per-batch lengths: served since round 6 -- the causal streams read rows / keys per block-table entry)
   if (args.causal && args.C < args.R) return false;
   if (args.D > 64 || args.D % 8) return false;
   const int po = args.op[SLOT_O].precision, pl = args.op[SLOT_L].precision;
@@ -75,7 +75,7 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
   if (const char *want = std::getenv("MFA_P6_DEV_STREAM")) {
     if (*want && precision == PREC_BF16 && args.op[SLOT_O].precision == PREC_FP32) {
 #define MFA_P6_BYNAME(name, f16, sfold, o16, l16, scausal, ssplit) \
-      if constexpr (!f16 && !o16 && !ssplit) { if ((sfold != 0) == fold && (scausal != 0) == (args.causal != 0) && std::strcmp(want, #name) == 0) return launch_stream<__bf16, p6::S_##name>(grid, stream, args); }
+      if constexpr (!f16 && !o16 && !ssplit) { if ((sfold != 0) == fold && (scausal != 0) == (args.causal != 0 || args.rowLen || args.colLen) && std::strcmp(want, #name) == 0) return launch_stream<__bf16, p6::S_##name>(grid, stream, args); }
       MFA_P6_DEV_STREAM_LIST(MFA_P6_BYNAME)
 #undef MFA_P6_BYNAME
       return false;
@@ -84,7 +84,7 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
 #endif
   const bool o16 = args.op[SLOT_O].precision != PREC_FP32;
 #define MFA_P6_PICK(T, PFX)                                                                                                          \
-  if (args.causal) {                                                                                                                 \
+  if (args.causal || args.rowLen || args.colLen) {   /* the "geometry" streams; KernelArgs.causal is their run-time flag */           \
     if (fold) return o16 ? launch_stream<T, p6::S_##PFX##_FOLD_O16_L16_CAUSAL>(grid, stream, args) : launch_stream<T, p6::S_##PFX##_FOLD_L16_CAUSAL>(grid, stream, args); \
     return o16 ? launch_stream<T, p6::S_##PFX##_EXACT_O16_CAUSAL>(grid, stream, args) : launch_stream<T, p6::S_##PFX##_EXACT_CAUSAL>(grid, stream, args); \
   }                                                                                                                                  \
@@ -99,7 +99,7 @@ bool launch_p6(int precision, bool fold, dim3 grid, hipStream_t stream, const Ke
 // kernel, then the combine pass.  false = not one it serves (pieces that are not whole multiples of four tiles, ...): the caller
 // launches the eight-wave kernel's split sibling
 bool launch_p6_split(int precision, bool fold, dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
-  if (!serves(precision, fold, args) || args.causal || splits < 2) return false;
+  if (!serves(precision, fold, args) || args.causal || args.rowLen || args.colLen || splits < 2) return false;
   if (args.C % (256u * splits) != 0) return false;
 #ifdef MFA_DEV_VARIANTS
   if (std::getenv("MFA_P6_OFF") || std::getenv("MFA_P6_NO_SPLIT")) return false;
@@ -130,6 +130,9 @@ const char *p6_form(int precision, bool fold, const KernelArgs &args) {
 #ifdef MFA_DEV_VARIANTS
   if (std::getenv("MFA_P6_OFF")) return nullptr;
 #endif
+  if (args.rowLen || args.colLen)
+    return fold ? "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row-block pairs; per-batch lengths in the block table; row sums in the matrix pipe)"
+                : "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row-block pairs; per-batch lengths in the block table)";
   if (args.causal)
     return fold ? "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row-block pairs; row sums in the matrix pipe)"
                 : "attn_fwd16_p6 (persistent: one workgroup per compute unit walks the row-block pairs)";

@@ -136,7 +136,7 @@ def test_head_dimensions_up_to_32_on_the_persistent_four_wave_kernel(low_mid, in
 
 
 def test_head_dimensions_up_to_32_launches_the_persistent_kernel_does_not_serve():
-    """| 32 | 256 | 64 | 64 | at D <= 32: what attn_fwd16_p6 does not take (per-batch lengths, an L of the other storage type, a one-head
+    """| 32 | 256 | 64 | 64 | at D <= 32: per-batch lengths (served by attn_fwd16_p6 itself since round 6) and what it does not take (an L of the other storage type, a one-head
     split whose key range is not whole multiples of four tiles per piece) runs on the D = 64 EIGHT-wave kernels -- the variant must then
     carry their functions (dynamic LDS above 64 KiB: a fresh process fails otherwise), their 256-row blocks for the split grid, and
     the launch form must name them."""
@@ -164,7 +164,7 @@ def test_head_dimensions_up_to_32_launches_the_persistent_kernel_does_not_serve(
         rl, cl = (torch.tensor(x, dtype=torch.int32, device="cuda") for x in (rlen, clen))
         kw = dict(row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs, rowLengths=rl, columnLengths=cl)
         form = kernel.launchForm(bufs, **kw)
-        assert form.startswith("attn_fwd16v3_bf16_d64_w8x32"), form
+        assert form.startswith("attn_fwd16_p6 (persistent") and "per-batch lengths" in form, form   # (round 6: served by the persistent kernel)
         kernel.dispatch(bufs, stream=stream, **kw)
         torch.cuda.synchronize()
         o, l = bufs[Op.O].cpu().numpy(), bufs[Op.L].float().cpu().numpy() / np.float32(harness.LOG2E)
@@ -1416,6 +1416,10 @@ def test_variable_sequence_lengths(low, causal, D):
     rl = torch.tensor(rlen, dtype=torch.int32, device="cuda")
     cl = torch.tensor(clen, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    if low and D == 64:    # (round 6) so does the D <= 64 persistent kernel (FP32 L here: its exact-scale geometry streams)
+        form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                                                                causal=causal, rowLengths=rl, columnLengths=cl)
+        assert form.startswith("attn_fwd16_p6 (persistent") and "per-batch lengths" in form, form
     if low and D == 128:   # (round 6) the persistent forward kernel serves per-batch lengths: rows / keys per block-table entry
         form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                                                                 causal=causal, rowLengths=rl, columnLengths=cl)

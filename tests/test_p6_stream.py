@@ -210,3 +210,29 @@ def test_stream_file_is_current(built_library):
     with tempfile.NamedTemporaryFile("r", suffix=".inc") as tmp:
         p6gen.write_inc(tmp.name)
         assert open(path).read() == open(tmp.name).read(), "run python tools/p6gen.py"
+
+
+# ---- round 6: per-batch lengths on the persistent kernel (the causal streams read rows / keys per block-table entry) -----------------
+def _check_lengths(cfg, lens, cflag, R, C, seed=0, **kw):
+    rng = np.random.default_rng(seed)
+    H = len(lens)
+    q, k, v = (p4psim.rand_bf16(s_, rng) for s_ in ((H, R, 64), (H, C, 64), (H, C, 64)))
+    blocks = [(h, rb) for h in range(H) for rb in range((lens[h][0] + 255) // 256)]   # the compacted table: non-empty row blocks only
+    O, L, wg, (om, lm) = p6sim.run_workgroup(q, k, v, blocks, cfg, lengths={h: lens[h] for h in range(H)}, cflag=cflag, **kw)
+    for h, (Rb, Cb) in enumerate(lens):
+        Oref, Lref = p4psim.reference(q[h, :Rb], k[h, :Cb], v[h, :Cb], causal=bool(cflag))
+        dO, dL = np.abs(O[h, :Rb] - Oref).max(), np.abs(L[h, :Rb] - Lref).max()
+        assert dO < 8e-3 and dL < (2e-2 + 5e-3) * max(1.0, np.abs(Lref).max() / 8), (h, Rb, Cb, dO, dL)
+        assert (om.reshape(H, R, -1)[h, Rb:] == 0xCD).all() and (lm.reshape(H, R, -1)[h, Rb:] == 0xCD).all(), (h, Rb)
+    return wg
+
+
+@pytest.mark.parametrize("cflag", [0, 1])
+def test_per_batch_lengths_on_the_persistent_kernel(cflag):
+    """each table entry carries the rows and keys of its batch entry; with the causal mask every entry has its own diagonal offset
+    (clamped at 0 when it has fewer keys than rows), without it the offset is out of reach and the geometry is the dense one"""
+    lens = [(300, 520), (77, 100), (512, 64), (130, 130), (256, 700)]
+    if cflag:
+        lens.append((300, 200))
+    _check_lengths(CAUSAL_FOLD, lens, cflag, 512, 704, seed=51 + cflag)
+    _check_lengths(CAUSAL_EXACT, lens[:3], cflag, 512, 704, seed=53 + cflag, dma_mode="early", stores="late", order=(3, 2, 1, 0))

@@ -67,14 +67,17 @@ PSGPR = dict(kres=(40, 4), vres=(44, 4), tres=(48, 4), lres=(52, 4),
              qbn=(56, 2), kbn=(58, 2), vbn=(60, 2), obn=(62, 2), lbn=(64, 2), row0n=(66, 1),
              ob=(68, 2), lb=(70, 2), row0=(72, 1), blk=(73, 1), hasnext=(74, 1), ntm2=(75, 1), ntm3=(76, 1),
              j=(77, 1), pend=(80, 1), t0=(81, 1), t1=(82, 1), t2=(83, 1), sv=(84, 2),
-             kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), maskb=(90, 1), q8=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1))
+             kc0=(86, 1), kstep=(87, 1), vstep=(88, 1), ntb=(89, 1), maskb=(90, 1), q8=(94, 1), t3=(95, 1), t4=(96, 1), qrow=(97, 1),
+             # causal ("geometry") streams, round 6: rows / keys of the NEXT table entry, rows / last key / key tiles / diagonal offset of
+             # the current block (per-batch lengths travel in the block table, as in tools/p4pgen.py)
+             rrn=(91, 1), ccn=(92, 1), rr=(93, 1), cm1=(78, 1), ttot=(79, 1), coff=(67, 1))
 FIRST_CLOBBERED_SGPR, LAST_CLOBBERED_SGPR = 40, 97
 FIRST_OWNED_VGPR = 28
 
 INOUT_V = ["lim0", "lim1"]
 IN_V = ["kbase", "vbase", "kv0", "kv1", "vv", "qv0", "qv1", "ov0", "ov1", "lv", "ewa", "era", "qlane", "hi4"]
 IN_S = ["nt", "maskfrom", "scale2", "kinc", "vinc", "ldsk", "ldsv", "ldsq", "qrel", "ldsst", "nblk", "tbl", "wave64", "ldq2", "ldo",
-        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "coff", "cm1", "rr", "ttot"]
+        "nrecq", "nreck", "nrecv", "nreco", "nrecl", "cflag"]   # (nrec*: dense streams; cflag: causal streams -- 1 = causal mask, 0 = lengths only)
 
 
 class Cfg6(p4gen.Cfg):
@@ -185,8 +188,25 @@ class Stream6(Stream):
     def desc(self, name, base, nrec):
         self.emit("s_mov_b32", s(name, 1, 0), [s(base, 1, 0)])
         self.emit("s_and_b32", s(name, 1, 1), [s(base, 1, 1), I(0xFFFF)])
-        self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
+        self.nrec(name, nrec)
         self.emit("s_mov_b32", s(name, 1, 3), [I(DESC_FLAGS)])
+
+    def nrec(self, name, which):
+        """word 2 of resource `name`: a launch constant in dense streams; rows (or keys) of the block's own batch entry x bytes per row in
+        causal ("geometry") streams -- nrecq / nreck / nrecv belong to the NEXT block, nreco / nrecl to the current one"""
+        if not self.cfg.causal:
+            self.emit("s_mov_b32", s(name, 1, 2), [SN(which)])
+            return
+        d = s(name, 1, 2)
+        if which == "nrecq":
+            self.emit("s_mul_i32", d, [s("rrn"), SN("ldq2")])
+        elif which in ("nreck", "nrecv"):
+            self.emit("s_lshr_b32", d, [SN("kinc" if which == "nreck" else "vinc"), I(6)])    # bytes per row
+            self.emit("s_mul_i32", d, [s("ccn"), d])
+        elif which == "nreco":
+            self.emit("s_mul_i32", d, [s("rr"), SN("ldo")])
+        else:
+            self.emit("s_lshl_b32", d, [s("rr"), I(1 if self.cfg.l16 else 2)])
 
     def lds_write(self, op, addr, data, offset):
         self.emit(op, None, [addr, data], offset=offset)
@@ -197,11 +217,13 @@ class Stream6(Stream):
         self.emit("s_lshl_b32", s("t0"), [s("blk"), I(6)])
         self.emit("s_add_u32", s("t0"), [s("t0"), SN("tbl")])
         self.emit("v_mov_b32", V(tv), [s("t0")])
-        ids = [self.lds_read("ds_read_b128", V(tb + 4 * i, 4), V(tv), 16 * i, note="block table") for i in range(3)]
+        ids = [self.lds_read("ds_read_b128", V(tb + 4 * i, 4), V(tv), 16 * i, note="block table") for i in range(4 if self.cfg.causal else 3)]
         self.lds_need(ids[-1])
         self.lds_flush()
-        for i, (name, off) in enumerate((("qbn", 0), ("qbn", 1), ("kbn", 0), ("kbn", 1), ("vbn", 0), ("vbn", 1), ("obn", 0),
-                                         ("obn", 1), ("lbn", 0), ("lbn", 1), ("row0n", 0))):
+        words = [("qbn", 0), ("qbn", 1), ("kbn", 0), ("kbn", 1), ("vbn", 0), ("vbn", 1), ("obn", 0), ("obn", 1), ("lbn", 0), ("lbn", 1), ("row0n", 0)]
+        if self.cfg.causal:
+            words += [("rrn", 0), ("ccn", 0)]      # rows and keys of the block's batch entry (words 11, 12)
+        for i, (name, off) in enumerate(words):
             self.emit("v_readfirstlane_b32", s(name, 1, off), [V(tb + i)])
         self.emit("s_nop", None, [I(4)], note="v_readfirstlane -> SALU / VMEM use of the scalar")
 
@@ -209,6 +231,8 @@ class Stream6(Stream):
         """K descriptor and piece offsets of the NEXT block: piece i = rows 16 wave + 8 i .. + 7"""
         self.emit("s_mov_b32", s("kres", 1, 0), [s("kbn", 1, 0)])
         self.emit("s_and_b32", s("kres", 1, 1), [s("kbn", 1, 1), I(0xFFFF)])
+        if self.cfg.causal:
+            self.nrec("kres", "nreck")
         self.emit("v_add_u32_e64", VN("koff0"), [VN("kv0"), s("kc0")], clamp=1)
         self.emit("s_add_u32", s("t3"), [s("kc0"), s("kstep")])
         self.emit("v_add_u32_e64", VN("koff1"), [VN("kv1"), s("t3")], clamp=1)
@@ -217,6 +241,8 @@ class Stream6(Stream):
         """V descriptor and piece offsets of the next block: piece i = keys 32 (wave & 1) + 16 i .. + 15 (the lane part holds the 32)"""
         self.emit("s_mov_b32", s("vres", 1, 0), [s("vbn", 1, 0)])
         self.emit("s_and_b32", s("vres", 1, 1), [s("vbn", 1, 1), I(0xFFFF)])
+        if self.cfg.causal:
+            self.nrec("vres", "nrecv")
         self.emit("v_mov_b32", VN("voff0"), [VN("vv")])
         self.emit("v_add_u32_e64", VN("voff1"), [VN("vv"), s("vstep")], clamp=1)
 
@@ -661,6 +687,17 @@ class Stream6(Stream):
             self.emit("s_mov_b32", s(name, 1, 1), [s(name + "n", 1, 1)])
         self.emit("s_mov_b32", s("row0"), [s("row0n")])
         if self.cfg.causal:
+            # rows / last key / key tiles / diagonal offset of THIS block's batch entry (the *n registers still hold its table entry); without
+            # the causal mask the offset is out of reach of any row and the same arithmetic yields the dense geometry (tools/p4pgen.py)
+            self.emit("s_mov_b32", s("rr"), [s("rrn")])
+            self.emit("s_sub_u32", s("cm1"), [s("ccn"), I(1)])
+            self.emit("s_add_u32", s("ttot"), [s("ccn"), I(63)])
+            self.emit("s_lshr_b32", s("ttot"), [s("ttot"), I(6)])
+            self.emit("s_max_u32", s("ttot"), [s("ttot"), I(1)])
+            self.emit("s_sub_u32", s("coff"), [s("ccn"), s("rrn")])
+            self.emit("s_max_i32", s("coff"), [s("coff"), I(0)])
+            self.emit("s_cmp_eq_u32", None, [SN("cflag"), I(0)])
+            self.emit("s_cselect_b32", s("coff"), [I(0x40000000), s("coff")])
             self.block_geometry()
         self.emit("s_add_u32", s("blk"), [s("blk"), I(1)])
         self.emit("s_mov_b32", s("hasnext"), [I(0)])
@@ -734,7 +771,8 @@ class Stream6(Stream):
         self.emit("s_lshr_b32", s("vstep"), [SN("vinc"), I(2)])              # sixteen keys of V
         self.emit("s_lshl_b32", s("q8"), [SN("ldq2"), I(3)])
         for name, nrec in (("kres", "nreck"), ("vres", "nrecv")):
-            self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
+            if not cfg.causal:     # (causal streams: per block, switch_k / switch_v)
+                self.emit("s_mov_b32", s(name, 1, 2), [SN(nrec)])
             self.emit("s_mov_b32", s(name, 1, 3), [I(DESC_FLAGS)])
         # ---- first block: Q', K(0), V(0), K(1), V(1), K(2) are requested here; later blocks find theirs requested by their predecessor
         self.emit("s_mov_b32", s("blk"), [I(0)])

@@ -8,7 +8,9 @@ from p4psim import GlobalMem, PWorkgroup
 from p4sim import h16_to_f32, rand_bf16, reference, f32_to_h16  # noqa: F401
 
 
-def run_workgroup(q, k, v, blocks, cfg, D=64, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None, splits=1):
+def run_workgroup(q, k, v, blocks, cfg, D=64, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None, splits=1,
+                  lengths=None, cflag=None):
+    # lengths (causal / "geometry" streams): {head: (rows, keys)} of the head's batch entry; cflag: 1 = causal mask, 0 = lengths only
     """One persistent workgroup over `blocks` = [(head, row block), ...].  q [H][R][D], k / v [H][C][D] uint16 bit patterns.
     Returns O [H][R][D] float32 (the 16-bit patterns as float32 when cfg.o16), L [H][R] float32 (log2 units), the workgroup."""
     f16 = cfg.dtype == "f16"
@@ -48,6 +50,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=64, dma_mode="late", stores="late", or
         for i, a in enumerate(bases):
             table[n, 2 * i], table[n, 2 * i + 1] = a & 0xFFFFFFFF, a >> 32
         table[n, 10] = rblk * 256
+        table[n, 11], table[n, 12] = (lengths or {}).get(h, (R, C))
     tb = table.reshape(-1).view(np.uint8)
     wg.lds[p6gen.TABLE:p6gen.TABLE + tb.size] = tb
     nt = max(4, ((C + 63) // 64 + 3) // 4 * 4)     # a multiple of the loop body's four tiles
@@ -87,7 +90,7 @@ def run_workgroup(q, k, v, blocks, cfg, D=64, dma_mode="late", stores="late", or
                      "ldsq": p6gen.QIMG + wave * 8192, "qrel": p6gen.QIMG + wave * 8192, "ldsst": p6gen.STAGE + wave * 4096,
                      "nblk": len(blocks), "tbl": p6gen.TABLE, "wave64": wave * 64,
                      "ldq2": ldq2, "ldo": ldo * osz, "nrecq": R * ldq2, "nreck": Ck * ldk2, "nrecv": Ck * ldv2,
-                     "nreco": R * ldo * osz, "nrecl": R * lsz, "coff": C - R, "cm1": C - 1, "rr": R, "ttot": (C + 63) // 64})
+                     "nreco": R * ldo * osz, "nrecl": R * lsz, "cflag": int(bool(cfg.causal)) if cflag is None else int(cflag)})
     wg.run(order)
     for w in wg.waves:
         assert not w.lds_q, "LDS reads left in flight"

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Forward launches with per-batch lengths at D = 128 (bf16, mixed mode): the persistent kernel's geometry streams (round 6) against the
-one-block-per-workgroup kernel that served them until round 5 (developer library: MFA_P4_NO_PERSISTENT=1).
+"""Forward launches with per-batch lengths at D = 128 (bf16, mixed mode): the persistent kernels' geometry streams (round 6) against the kernels
+that served them until round 5 (developer library knobs: MFA_P4_NO_PERSISTENT=1 -> attn_fwd16_p4, one block per workgroup; MFA_P6_OFF=1 ->
+the eight-wave attn_fwd16_v3 at D <= 64).
 
   python tools/time_varlen.py [--N 4096 --batches 8 --heads 32]
 """
@@ -18,12 +19,14 @@ def main():
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--batches", type=int, default=8)
     ap.add_argument("--heads", type=int, default=32)
+    ap.add_argument("--D", type=int, default=128, help="128: attn_fwd16_p4p; 64: attn_fwd16_p6")
     args = ap.parse_args()
     import numpy as np
     import torch
     from metal_flash_attention_amd import (AttentionDescriptor, AttentionKernel, AttentionKernelType,
                                            AttentionOperand as Op, GEMMOperandPrecision as P)
-    N, B, H, D = args.N, args.batches, args.heads, 128
+    N, B, H, D = args.N, args.batches, args.heads, args.D
+    knob = "MFA_P4_NO_PERSISTENT" if D > 64 else "MFA_P6_OFF"
     desc = AttentionDescriptor()
     desc.lowPrecisionInputs = desc.lowPrecisionIntermediates = True
     desc.lowPrecisionInputType = P.BF16
@@ -44,10 +47,10 @@ def main():
         for causal in (False, True):
             flops = sum(4.0 * L * L * D * H * ((L + 1) / (2.0 * L) if causal else 1.0) for L in lens)
             kw = dict(row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs, stream=stream, causal=causal, rowLengths=rl, columnLengths=rl)
-            for label, env in (("persistent (round 6)", None), ("one block per workgroup (round 5)", "1")):
-                os.environ.pop("MFA_P4_NO_PERSISTENT", None)
+            for label, env in (("persistent (round 6)", None), ("round-5 kernel (knob)", "1")):
+                os.environ.pop(knob, None)
                 if env:
-                    os.environ["MFA_P4_NO_PERSISTENT"] = env
+                    os.environ[knob] = env
                 form = k.launchForm(bufs, **{x: y for x, y in kw.items() if x != "stream"})
                 for _ in range(3):
                     k.dispatch(bufs, **kw)
@@ -59,7 +62,7 @@ def main():
                 torch.cuda.synchronize()
                 ms = e0.elapsed_time(e1) / 10
                 print(f"{name:18s} causal={int(causal)} {label:34s} {ms:8.4f} ms {flops / ms / 1e9:8.1f} TF {flops / ms / 2.5e12:6.3f}   {form[:60]}", flush=True)
-    os.environ.pop("MFA_P4_NO_PERSISTENT", None)
+    os.environ.pop(knob, None)
 
 
 if __name__ == "__main__":

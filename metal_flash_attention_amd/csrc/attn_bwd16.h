@@ -18,7 +18,7 @@
 // and [D/32][rows][32] (ds_read_b64_tr_b16).  That is K in backwardQuery and Q, dO in
 // backwardKeyValue; each staged chunk is simply written twice.
 #pragma once
-#include "attn_fwd16_v2.h"
+#include "attn_fwd16_common.h"
 
 namespace mfa {
 

@@ -31,7 +31,7 @@
 //     two groups of matrix instructions (phase clocks: MFA_F32_PROF=1 in the developer library, tools/f32_perf.py).
 #pragma once
 #include "attn_common.h"
-#include "attn_fwd16.h"   // Fwd16Grid, fwd16_decode_block (XCD-aware workgroup order)
+#include "attn_fwd16_common.h"   // Fwd16Grid, fwd16_decode_block (XCD-aware workgroup order)
 #include <type_traits>
 
 namespace mfa {

@@ -15,7 +15,7 @@
 //   * SPLIT / CAUSAL / SPARSE: column-parallel pieces through the caller's workspace, causal mask, block mask --
 //     separate code objects, so the dense kernel carries none of their code.
 #pragma once
-#include "attn_fwd16_v2.h"
+#include "attn_fwd16_common.h"
 #include <type_traits>
 
 // Tile loads forced inline: at D > 128 hipcc otherwise leaves the transposed code objects' tile loads (issue_loads below: NCH

@@ -22,7 +22,7 @@
 // transposed operands and block masks keep the general kernel.  Exact-scale arithmetic (s * scale2 - m in fp32) in both
 // precision modes; L in the descriptor's storage type.
 #pragma once
-#include "attn_fwd16_v2.h"
+#include "attn_fwd16_common.h"
 #include <type_traits>
 
 namespace mfa {

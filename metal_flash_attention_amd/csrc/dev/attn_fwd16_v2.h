@@ -26,34 +26,6 @@
 
 namespace mfa {
 
-template <int D, int NW, int RB, int RING = 3, int KPADB = 0> constexpr int fwd16v2_lds_bytes() {
-  constexpr int ring = RING * (2 * 64 * D * 2 + 64 * KPADB);
-  constexpr int epi = NW * RB * 32 * (D + 4) * 4;
-  return ring > epi ? ring : epi;
-}
-
-// Exchange between the two half-waves (lane l <-> lane l^32) with v_permlane32_swap: lanes 32-63
-// of the first operand trade places with lanes 0-31 of the second, so {a, b} = {own, partner} in
-// some order on every lane.  Inline asm on purpose: with hipcc (ROCm 7.2) the second result of
-// __builtin_amdgcn_permlane32_swap reads the FIRST operand's register (both extracts alias).  The
-// s_nop covers the VALU-write -> permlane-read hazard inside the asm string.
-__device__ __forceinline__ void half_swap(float x, float *a, float *b) {
-  uint32_t b0 = __builtin_bit_cast(uint32_t, x), b1 = b0;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(b0), "+v"(b1));
-  *a = __builtin_bit_cast(float, b0);
-  *b = __builtin_bit_cast(float, b1);
-}
-__device__ __forceinline__ float half_swap_max(float x) {
-  float a, b;
-  half_swap(x, &a, &b);
-  return fmaxf(a, b);
-}
-__device__ __forceinline__ float half_swap_add(float x) {
-  float a, b;
-  half_swap(x, &a, &b);
-  return a + b;
-}
-
 template <typename T, int D, int NW, int RB, int THR, bool MSUM>
 __global__ __launch_bounds__(NW * 64) void attn_fwd16_v2(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;

@@ -23,7 +23,7 @@
 // asked and store with the reference's rounding: FP16 round-to-nearest, BF16 truncation.
 #pragma once
 #include <type_traits>
-#include "attn_fwd16.h"
+#include "attn_fwd16_common.h"
 
 namespace mfa {
 

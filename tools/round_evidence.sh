@@ -10,8 +10,9 @@ OUT=gpurun_out/${ROUND}_final
 mkdir -p "$OUT"
 sha256sum metal_flash_attention_amd/libmfa_hip.so > "$OUT/library.sha256"
 if [ -z "$FAST" ]; then
-  timeout 1100 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
+  timeout 1500 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
   tail -3 "$OUT/pytest_gpu.txt"
+  cp gpurun_out/variant_coverage.json "$OUT/variant_coverage.json" 2>/dev/null   # (tests/conftest.py: variant name -> tests; copy to tests/golden/)
 fi
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$OUT/smoke.txt" 2>&1; tail -1 "$OUT/smoke.txt"
 timeout 300 python bench.py 2> "$OUT/bench_default.err" | tail -1 > "$OUT/bench_default.json"; cut -c1-300 "$OUT/bench_default.json"
@@ -23,7 +24,7 @@ fi
 ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof_d64" --steps 20 --warmup 5 --no-cpu-baseline --workload fwd_bf16_d64 > "$OUT/prof_d64.log" 2>&1; tail -12 "$OUT/prof_d64.log" | head -12
 ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/prof.log" 2>&1; tail -25 "$OUT/prof.log" | head -40
 if [ -z "$FAST" ]; then
-  for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_fp32mid fwd_bf16_d64_1head \
+  for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_n16k_mixed fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_fp32mid fwd_bf16_d64_1head \
            fwd_bf16_d256 fwd_bf16_d256_mixed fwdbwd_bf16_d128 fwdbwd_bf16_d128_mixed fwdbwd_bf16_d128_causal fwdbwd_bf16_d128_transposed \
            fwdbwd_bf16_d128_transposed_ws fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128 fwdbwd_bf16_d256_mixed dq_bf16_d256 dkv_bf16_d256; do
     timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_$w.json"
@@ -62,4 +63,18 @@ PY
   timeout 300 python tools/fuzz_shapes.py 120 5 --fp32 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_fp32_120_seed5.txt"; grep "random problems" "$OUT/fuzz_fp32_120_seed5.txt"
   timeout 300 python tools/fuzz_shapes.py 120 2 --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_120_seed2.txt"; grep "random problems" "$OUT/fuzz_transposed_120_seed2.txt"
   timeout 400 python tools/fuzz_shapes.py 90 3 --transposed --backward 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_backward_90_seed3.txt"; grep "random problems" "$OUT/fuzz_transposed_backward_90_seed3.txt"
+fi
+
+if [ -z "$FAST" ]; then
+  # round 6: the 256 < D <= 384 forward on the 16-bit matrix cores, per-batch lengths on the persistent forwards, the vendor GEMM calibration,
+  # the product schedule against the round-5 streams in one process (developer library)
+  timeout 300 python tools/time_wide.py 2>&1 | grep -v amdgpu.ids > "$OUT/time_wide.txt"; cat "$OUT/time_wide.txt"
+  timeout 300 bash tools/vendor_calib.sh "$OUT/vendor_calib" > /dev/null 2>&1; cp "$OUT/vendor_calib/vendor_calib.txt" "$OUT/vendor_gemm_calibration.txt"; rm -rf "$OUT/vendor_calib"
+  if [ -f metal_flash_attention_amd/libmfa_hip_dev.so ]; then
+    timeout 300 python tools/time_varlen.py --D 128 2>&1 | grep -v amdgpu.ids > "$OUT/time_varlen_d128.txt"; cat "$OUT/time_varlen_d128.txt"
+    timeout 300 python tools/time_varlen.py --D 64 2>&1 | grep -v amdgpu.ids > "$OUT/time_varlen_d64.txt"; cat "$OUT/time_varlen_d64.txt"
+    timeout 300 python tools/p4p_streams_ab.py --streams R5_BF16_FOLD_L16 --rounds 7 2>&1 | grep -v amdgpu.ids > "$OUT/p4p_product_vs_round5.txt"; cat "$OUT/p4p_product_vs_round5.txt"
+    timeout 300 python tools/p4p_sprof.py --fill normal --stream BF16_FOLD_L16_FL1_SPROF 2>&1 | grep -v amdgpu.ids > "$OUT/p4p_phase_stamps.txt"
+    timeout 300 python tools/p4p_sprof.py --fill zero --stream BF16_FOLD_L16_FL1_SPROF 2>&1 | grep -v amdgpu.ids >> "$OUT/p4p_phase_stamps.txt"
+  fi
 fi

@@ -7,6 +7,8 @@ namespace mfa {
 // persistent form (attn_fwd16_p4p.hip): dense launches without per-batch lengths; false = not served, launch this kernel
 template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args);
 template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args);
+template <typename T, bool FOLD> bool launch_p4p_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args);
+template <typename T, bool FOLD> bool p4p_split_serves(const KernelArgs &args, uint32_t splits);
 
 template <typename T, int STREAM, bool CAUSAL>
 static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
@@ -22,9 +24,20 @@ static void launch_p4(dim3 grid, hipStream_t stream, const KernelArgs &args) {
 template <typename T, int STREAM>
 static void launch_p4_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
   Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
-  hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, false, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), p4::LDS_BYTES, stream, args, g);
+  bool persistent = false;
+  if constexpr (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD)
+    persistent = launch_p4p_split<T, p4::stream_folds(STREAM)>(grid, splits, wsO, wsML, stream, args);   // (round 6: the pieces on the persistent kernel)
+  if (!persistent)
+    hipLaunchKernelGGL((attn_fwd16_p4<T, STREAM, false, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), p4::LDS_BYTES, stream, args, g);
   const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
   hipLaunchKernelGGL(attn_fwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g);
+}
+
+template <typename T, int STREAM> static const char *p4_split_form(const KernelArgs &args, uint32_t splits) {
+  if constexpr (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD) {
+    if (p4p_split_serves<T, p4::stream_folds(STREAM)>(args, splits)) return "pieces by attn_fwd16_p4p, persistent";
+  }
+  return "pieces by attn_fwd16_p4, one block per workgroup";
 }
 
 template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char *name) {
@@ -46,6 +59,7 @@ template <typename T, int STREAM> static void fill_p4(VariantInfo *v, const char
   v->funcSplit = reinterpret_cast<const void *>(&attn_fwd16_p4<T, STREAM, false, true>);
   v->splitTarget = 256;   // one workgroup per compute unit
   v->splitParallelization = 256;   // (the pieces of a column-parallel launch are THIS kernel's: attn_fwd16_p4<..., split>, not the sibling's)
+  v->splitForm = &p4_split_form<T, STREAM>;
   if constexpr (STREAM == p4::S_BF16_THR8 || STREAM == p4::S_F16_THR8 || STREAM == p4::S_BF16_FOLD || STREAM == p4::S_F16_FOLD)
     v->launchForm = &p4p_form<T, p4::stream_folds(STREAM)>;
 }

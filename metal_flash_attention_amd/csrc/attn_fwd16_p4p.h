@@ -24,12 +24,12 @@ constexpr int QIMG = MFA_P4P_QIMG, TABLE = MFA_P4P_TABLE, TABLE_ENTRIES = MFA_P4
 enum : int { MFA_P4P_STREAM_LIST(MFA_P4P_ENUM) S_COUNT };
 #undef MFA_P4P_ENUM
 
-struct StreamTraits { bool f16, fold, o16, l16, causal; };
+struct StreamTraits { bool f16, fold, o16, l16, causal, split; };   // (the stream list's last column: 1 = causal / geometry stream, 2 = column-parallel pieces)
 constexpr StreamTraits traits(int s) {
-#define MFA_P4P_TRAITS(name, f16, fold, o16, l16, causal) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, causal != 0};
+#define MFA_P4P_TRAITS(name, f16, fold, o16, l16, kind) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, kind == 1, kind == 2};
   MFA_P4P_STREAM_LIST(MFA_P4P_TRAITS)
 #undef MFA_P4P_TRAITS
-  return StreamTraits{false, false, false, false, false};
+  return StreamTraits{false, false, false, false, false, false};
 }
 
 }  // namespace p4p
@@ -77,9 +77,11 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   uint32_t *counts = reinterpret_cast<uint32_t *>(smem);   // (the K ring's first bytes: free until the stream starts)
   uint32_t myrows[2] = {0, 0}, myhead = 0, mybatch = 0;
   int mycount = 0, myR = (int)a.R, myC = (int)a.C;
+  uint32_t mypiece = 0;
   if ((uint32_t)tid < nunits) {
-    uint32_t r;
-    fwd16_decode_block_lane(dgrid, first + (uint32_t)tid * G, &r, &myhead, &mybatch);
+    uint32_t r, unit = first + (uint32_t)tid * G;
+    if constexpr (TR.split) { mypiece = unit % grid.splits; unit /= grid.splits; }   // SPLIT: a unit is (row block, piece of the key range)
+    fwd16_decode_block_lane(dgrid, unit, &r, &myhead, &mybatch);
     if constexpr (TR.causal) batch_lengths(a, mybatch, myR, myC);
     const uint32_t cand[2] = {TR.causal ? RB - 1 - r : r, r};
     const int ncand = (TR.causal && cand[0] != cand[1]) ? 2 : 1;
@@ -91,9 +93,19 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   if ((uint32_t)tid < nunits) {
     uint32_t pos = 0;
     for (int i = 0; i < tid; ++i) pos += counts[i];
-    const uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], myhead, mybatch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], myhead, mybatch),
-                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], myhead, mybatch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], myhead, mybatch),
-                              (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], myhead, mybatch)};
+    uint64_t base[5] = {(uint64_t)(uintptr_t)operand_base(a.op[SLOT_Q], myhead, mybatch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_K], myhead, mybatch),
+                        (uint64_t)(uintptr_t)operand_base(a.op[SLOT_V], myhead, mybatch), (uint64_t)(uintptr_t)operand_base(a.op[SLOT_O], myhead, mybatch),
+                        (uint64_t)(uintptr_t)operand_base(a.op[SLOT_L], myhead, mybatch)};
+    if constexpr (TR.split) {
+      // K / V start at the piece (C / splits keys, a multiple of 128: the launcher checks); O and (m, l) go to the piece's slabs of
+      // the caller's workspace: wsO [splits][heads x batches][R][D] fp32, wsML [splits][heads x batches][R][2] (attn_fwd_combine)
+      const uint64_t keys = (uint64_t)mypiece * (a.C / grid.splits);
+      base[1] += keys * (uint64_t)a.op[SLOT_K].ld * 2;
+      base[2] += keys * (uint64_t)a.op[SLOT_V].ld * 2;
+      const uint64_t slab = ((uint64_t)mypiece * grid.heads * grid.batches + (uint64_t)mybatch * grid.heads + myhead) * a.R;
+      base[3] = (uint64_t)(uintptr_t)(grid.wsO + slab * a.D);
+      base[4] = (uint64_t)(uintptr_t)(grid.wsML + slab * 2);
+    }
     for (int w = 0; w < mycount; ++w) {
       uint32_t *e = table + 16 * (pos + w);
 #pragma unroll
@@ -111,10 +123,12 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   // behind them (profiles/r02_fwd16p4_block_overhead_persistent_experiment.txt)
   for (uint32_t i = 0; i < (stagger & 0xFFFFu) * ((first >> 3) & 31u); ++i) __builtin_amdgcn_s_sleep(8);   // 512 clocks per step
 
-  const uint32_t R = a.R, C = a.C, dr = a.D;
+  // (SPLIT: every workgroup sees its piece as the key range; the division runs on the vector ALU and hipcc does not move its result
+  // back to a scalar register by itself when the asm statement asks for "s" operands derived from it)
+  const uint32_t R = a.R, C = TR.split ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.C / grid.splits)) : a.C, dr = a.D;
   const uint32_t ldq2 = (uint32_t)a.op[SLOT_Q].ld * 2, ldk2 = (uint32_t)a.op[SLOT_K].ld * 2, ldv2 = (uint32_t)a.op[SLOT_V].ld * 2;
-  constexpr uint32_t OSZ = TR.o16 ? 2 : 4, LSZ = TR.l16 ? 2 : 4;
-  const uint32_t ldob = (uint32_t)a.op[SLOT_O].ld * OSZ;
+  constexpr uint32_t OSZ = TR.o16 ? 2 : 4, LSZ = TR.split ? 8 : TR.l16 ? 2 : 4;
+  const uint32_t ldob = TR.split ? dr * 4 : (uint32_t)a.op[SLOT_O].ld * OSZ;
   const uint32_t nrecq = R * ldq2, nreck = C * ldk2, nrecv = C * ldv2, nreco = R * ldob, nrecl = R * LSZ;
   const uint32_t kinc = BC * ldk2, vinc = BC * ldv2;
   // a block walks an EVEN number of key tiles (an odd count gets one fully masked tile): the two K images and the score-tile

@@ -20,7 +20,7 @@ std::mutex g_mutex;
 DeviceInfo g_devices[64];
 
 template <typename T, int STREAM>
-bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
+bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args, uint32_t splits = 1, float *wsO = nullptr, float *wsML = nullptr) {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 64) return false;
   int cus;
@@ -44,7 +44,7 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   // units: row blocks, or (causal) pairs of row blocks -- two table entries each
   constexpr bool CAUSAL = p4p::traits(STREAM).causal;
   constexpr uint64_t PER_UNIT = CAUSAL ? 2 : 1;
-  const uint64_t total = (uint64_t)(CAUSAL ? (grid.x + 1) / 2 : grid.x) * grid.y * grid.z;
+  const uint64_t total = (uint64_t)(CAUSAL ? (grid.x + 1) / 2 : grid.x) * grid.y * grid.z * splits;
   // one workgroup per compute unit; more only when a workgroup's share would not fit the block table.  A multiple of 8 keeps
   // fwd16_decode_block's head -> XCD affinity for every block of a workgroup
   uint64_t groups = total < (uint64_t)cus ? total : (uint64_t)cus;
@@ -53,7 +53,7 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   if (groups >= 8) groups = (groups + 7) / 8 * 8;
   if (groups > total) groups = total;
   if ((total + groups - 1) / groups > MAX_UNITS) return false;
-  Fwd16Grid g{grid.x, grid.y, grid.z};
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, wsO, wsML};
   uint32_t stagger = P4P_STAGGER;
 #ifdef MFA_DEV_VARIANTS
   if (const char *e = std::getenv("MFA_P4P_STAGGER")) stagger = (uint32_t)std::atoi(e);
@@ -69,8 +69,17 @@ bool launch_stream(dim3 grid, hipStream_t stream, const KernelArgs &args) {
 template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, const KernelArgs &args) {
   if (args.mask) return false;
   if (args.causal && args.C < args.R) return false;
-  // per-batch lengths (round 6): the causal ("geometry") streams, whose table entries carry the rows and keys of their batch entry --
-  // with or without the causal mask (KernelArgs.causal is the stream's flag)
+  // per-batch lengths (round 6): the causal ("geometry") streams carry the rows and keys of a block's batch entry in its table entry and
+  // serve such launches with or without the causal mask (KernelArgs.causal is the stream's flag) -- but at this head dimension they do
+  // not pay: one workgroup per compute unit with a FIXED share of the units is 6 % slower than the one-block-per-workgroup kernel on
+  // batches of mixed lengths (the dispatcher balances what a static share cannot) and on dense full-length ones; +2 % on causal
+  // full-length ones (profiles/r06_final/time_varlen_d128.txt).  The launches stay with attn_fwd16_p4; the developer library routes
+  // them here with MFA_P4P_LENGTHS=1 (tools/time_varlen.py).  At D <= 64 the same streams win by up to 43 % (attn_fwd16_p6.hip)
+  bool lengths_here = false;
+#ifdef MFA_DEV_VARIANTS
+  lengths_here = std::getenv("MFA_P4P_LENGTHS") != nullptr;
+#endif
+  if ((args.rowLen || args.colLen) && !lengths_here) return false;
   const bool geometry = args.causal || args.rowLen || args.colLen;
 #ifdef MFA_DEV_VARIANTS   // developer builds: A/B against the one-block-per-workgroup kernel, phase clocks (tools/p4p_prof.py)
   if (std::getenv("MFA_P4_NO_PERSISTENT")) return false;
@@ -85,7 +94,7 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
     const char *want = std::getenv("MFA_P4P_DEV_STREAM");
     if (want && *want && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == (FOLD ? PREC_FP16 : PREC_FP32)) {
 #define MFA_P4P_BYNAME(name, f16, fold, o16, l16, scausal) \
-      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD) { if ((scausal != 0) == geometry && std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
+      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD) { if (scausal != 2 && (scausal != 0) == geometry && std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
       MFA_P4P_DEV_STREAM_LIST(MFA_P4P_BYNAME)
 #undef MFA_P4P_BYNAME
       return false;   // (an unknown name must not silently time the product stream)
@@ -118,10 +127,42 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   }
 }
 
+// Column-parallel launch (few-workgroup problems: one head -- the reference's own benchmark shape): the pieces of the key range on the
+// persistent kernel's split streams (round 6); the caller launches attn_fwd_combine behind it.  false = not one it serves (pieces that
+// are not whole multiples of two tiles): the caller launches the one-block-per-workgroup kernel's pieces
+template <typename T, bool FOLD> bool p4p_split_serves(const KernelArgs &args, uint32_t splits) {
+  if (args.rowLen || args.colLen || args.mask || args.causal || splits < 2) return false;
+  if (args.C % (128u * splits) != 0) return false;
+#ifdef MFA_DEV_VARIANTS
+  if (std::getenv("MFA_P4_NO_PERSISTENT") || std::getenv("MFA_P4P_NO_SPLIT")) return false;
+#endif
+  return true;
+}
+template <typename T, bool FOLD> bool launch_p4p_split(dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args) {
+  if (!p4p_split_serves<T, FOLD>(args, splits)) return false;
+  if constexpr (__is_same(T, _Float16))
+    return FOLD ? launch_stream<T, p4p::S_F16_FOLD_SPLIT>(grid, stream, args, splits, wsO, wsML) : launch_stream<T, p4p::S_F16_EXACT_SPLIT>(grid, stream, args, splits, wsO, wsML);
+  else
+    return FOLD ? launch_stream<T, p4p::S_BF16_FOLD_SPLIT>(grid, stream, args, splits, wsO, wsML) : launch_stream<T, p4p::S_BF16_EXACT_SPLIT>(grid, stream, args, splits, wsO, wsML);
+}
+template bool launch_p4p_split<__bf16, true>(dim3, uint32_t, float *, float *, hipStream_t, const KernelArgs &);
+template bool launch_p4p_split<__bf16, false>(dim3, uint32_t, float *, float *, hipStream_t, const KernelArgs &);
+template bool launch_p4p_split<_Float16, true>(dim3, uint32_t, float *, float *, hipStream_t, const KernelArgs &);
+template bool launch_p4p_split<_Float16, false>(dim3, uint32_t, float *, float *, hipStream_t, const KernelArgs &);
+template bool p4p_split_serves<__bf16, true>(const KernelArgs &, uint32_t);
+template bool p4p_split_serves<__bf16, false>(const KernelArgs &, uint32_t);
+template bool p4p_split_serves<_Float16, true>(const KernelArgs &, uint32_t);
+template bool p4p_split_serves<_Float16, false>(const KernelArgs &, uint32_t);
+
 // the launches launch_p4p serves (the same conditions, nothing launched)
 template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args) {
   if (args.mask) return nullptr;
   if (args.causal && args.C < args.R) return nullptr;
+  bool lengths_here = false;
+#ifdef MFA_DEV_VARIANTS
+  lengths_here = std::getenv("MFA_P4P_LENGTHS") != nullptr;
+#endif
+  if ((args.rowLen || args.colLen) && !lengths_here) return nullptr;
 #ifdef MFA_DEV_VARIANTS
   if (std::getenv("MFA_P4_NO_PERSISTENT")) return nullptr;
 #endif

@@ -682,15 +682,16 @@ def test_launch_form_names_what_runs():
     assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs).startswith("attn_fwd16_p4p (persistent")
     assert "row-block pairs" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, causal=True)
     lens = torch.full((1,), N, dtype=torch.int32, device="cuda")
-    # (round 6: per-batch lengths run on the persistent kernel too -- its causal streams read rows / keys per block-table entry)
-    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens).startswith("attn_fwd16_p4p (persistent") and \
-        "per-batch lengths" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens)
+    # (round 6: the persistent kernel's causal streams CAN serve per-batch lengths -- rows / keys per block-table entry -- but at D = 128 a
+    # fixed share of the units per workgroup loses to the dispatcher on mixed lengths: such launches keep the one-block kernel)
+    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens) == k.variant
     one = {op: t[0] for op, t in bufs.items()}
     ws = torch.empty(k.workspaceSize(row=N, column=N) + 256, dtype=torch.uint8, device="cuda")
     split_form = k.launchForm(one, row=N, column=N, workspace=ws)
     # (the pieces of the D = 128 forward split are the variant's OWN kernel, attn_fwd16_p4<..., split>: the text must not name the
     # eight-wave sibling -- round-5 verdict, weak item 7)
-    assert split_form.startswith(k.variant + " column-parallel x") and split_form.endswith("+ combine") and "sibling" not in split_form, split_form
+    # (round 6: and they run on the persistent kernel's split streams when the pieces are whole multiples of two tiles)
+    assert split_form.startswith(k.variant + " column-parallel x") and "+ combine (pieces by attn_fwd16_p4p, persistent)" in split_form and "sibling" not in split_form, split_form
     assert "general kernel" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, leadingDimensions={Op.K: D + 1})
 
 
@@ -1420,10 +1421,6 @@ def test_variable_sequence_lengths(low, causal, D):
         form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                                                                 causal=causal, rowLengths=rl, columnLengths=cl)
         assert form.startswith("attn_fwd16_p6 (persistent") and "per-batch lengths" in form, form
-    if low and D == 128:   # (round 6) the persistent forward kernel serves per-batch lengths: rows / keys per block-table entry
-        form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
-                                                                causal=causal, rowLengths=rl, columnLengths=cl)
-        assert form.startswith("attn_fwd16_p4p (persistent") and "per-batch lengths" in form, form
     for t in (AttentionKernelType.forward, AttentionKernelType.backwardQuery, AttentionKernelType.backwardKeyValue):
         kernels[t].dispatch(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                             stream=stream, causal=causal, rowLengths=rl, columnLengths=cl)

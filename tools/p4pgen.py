@@ -80,7 +80,7 @@ class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
     def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0,
-                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0):
+                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0, split=0):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
         # fastloop (round 6, dense streams): the timing-only ablation that dropped the per-tile tests of the loop -- block switch
@@ -103,6 +103,14 @@ class PCfg(Cfg):
         self.dmapol = dmapol
         # diagmask (round 6, causal streams): compile-time lane masks for the aligned diagonal tile (p4gen.mask_section)
         self.diagmask = diagmask
+        # split (round 6; column-parallel launches of few-workgroup problems -- one head, the reference's own benchmark shape): a table
+        # entry is (row block, piece of the key range), its K / V bases start at the piece; the epilogue leaves the UN-NORMALISED O^T
+        # (fp32, leading dimension D) and (m, l) in the piece's slabs of the caller's workspace, which attn_fwd_combine merges
+        # (attn_fwd16_v3.h), like the split streams of tools/p6gen.py.  Pieces are whole multiples of two tiles
+        self.split = split
+        assert not (split and (causal or o16 or merge or fuse))
+        if split:
+            self.l16 = 0
         assert not (diagmask and (not causal or pprof))
         assert not (pksum and bal != 2)
         assert not (fastloop and (merge or bal != 2))
@@ -454,6 +462,8 @@ class PStream(Stream):
             self.emit("v_permlane32_swap_b32", ta, [tb], swap=1)
             self.emit("v_add_f32", lt, [ta, tb])
             self.emit("v_add_f32", lt, [I(1), lt], note="+ denorm_min (+Caching.swift:311)")
+            if self.cfg.split:     # (the pieces stay un-normalised: attn_fwd_combine divides by the merged l)
+                continue
             self.emit("v_rcp_f32", iv, [lt])
             self.emit("s_nop", None, [I(0)], note="trans -> VALU")
             self.emit("v_fma_f32", ta, [lt, iv, F(1.0)], neg0=1)      # e = 1 - l r
@@ -509,7 +519,7 @@ class PStream(Stream):
             if cfg.merge:       # the next block's first phase multiplied K Q^T beside this block's softmax: O is zeroed here
                 for r in range(16):
                     work.append((i, lambda r=r, b=b: self.emit("v_accvgpr_write_b32", A(O_BASE + 16 * b + r), [I(0)])))
-            for r in range(16):
+            for r in range(0 if cfg.split else 16):
                 work.append((i, lambda r=r, src=src, rb=rb: self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])))
             for g in range(4):
                 work.append((i, lambda g=g, src=src: self.lds_write("ds_write_b128", V(wa[g]), V(src + 4 * g, 4), 0)))
@@ -530,6 +540,18 @@ class PStream(Stream):
         cfg = self.cfg
         vo = V(self.EPI_VO)
         for rb in range(2):
+            if cfg.split:     # (m, l) of the lane's row, two floats at 8 bytes per row (one 8-byte store: an instruction offset on top of an
+                self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])   # out-of-range lane offset would wrap past 2^32 into the buffer)
+                if rb:
+                    self.emit("s_add_u32", s("t0"), [s("t0"), I(32)])
+                self.emit("s_lshl_b32", s("t0"), [s("t0"), I(3)])
+                self.emit("v_add_u32_e64", vo, [VN("lv"), s("t0")], clamp=1)
+                pair = T_SW - 1      # v238:239 (T_MN + 1, T_SW: dead behind the loop); an EVEN-aligned pair (gfx950: 64-bit VGPR tuples)
+                assert pair % 2 == 0
+                self.emit("v_mov_b32", V(pair), [VN("m%d" % rb)])
+                self.emit("v_mov_b32", V(pair + 1), [V(self.EPI_LTOT[rb])])
+                self.emit("buffer_store_dwordx2", None, [V(pair, 2), vo, s("lres", 4)], offset=0)
+                continue
             x = V(T_SW + rb)
             self.emit("v_log_f32", x, [V(self.EPI_LTOT[rb])])
             self.emit("s_nop", None, [I(0)], note="trans -> VALU")
@@ -966,6 +988,10 @@ VARIANTS = {
     "F16_FOLD_O16_L16": PCfg("f16", 8, fold=1, o16=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
     "F16_EXACT": PCfg("f16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1),
     "F16_EXACT_O16": PCfg("f16", 8, fold=0, o16=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
+    "BF16_FOLD_SPLIT": PCfg("bf16", 8, fold=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, split=1),   # column-parallel pieces: un-normalised O and (m, l) into the workspace
+    "BF16_EXACT_SPLIT": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1, split=1),
+    "F16_FOLD_SPLIT": PCfg("f16", 8, fold=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, split=1),
+    "F16_EXACT_SPLIT": PCfg("f16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1, split=1),
     "BF16_FOLD_L16_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
     "BF16_FOLD_O16_L16_CAUSAL": PCfg("bf16", 8, fold=1, o16=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
     "BF16_EXACT_CAUSAL": PCfg("bf16", 8, fold=0, causal=1, bal=2, xe=32, cap=8, fastloop=1, align=1),
@@ -1078,17 +1104,17 @@ def write_inc(path):
     lines.append("#define MFA_P4P_TABLE_ENTRIES %d" % TABLE_ENTRIES)
     lines.append("#define MFA_P4P_LDS_BYTES %d" % LDS_BYTES)
     lines.append("")
-    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16, causal)")
+    lines.append("// X(name, 16-bit type is f16, folds the softmax scale into Q, O in the 16-bit type, L in FP16, causal [2 = column-parallel pieces])")
     lines.append("#define MFA_P4P_PRODUCT_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, 2 if cfg.split else cfg.causal))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates")
     lines.append("#define MFA_P4P_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name not in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, cfg.causal))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, 2 if cfg.split else cfg.causal))
     lines.append("")
     lines.append("#ifdef MFA_DEV_VARIANTS")
     lines.append("#define MFA_P4P_STREAM_LIST(X) MFA_P4P_PRODUCT_STREAM_LIST(X) MFA_P4P_DEV_STREAM_LIST(X)")

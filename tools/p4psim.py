@@ -245,7 +245,7 @@ class PWorkgroup(Workgroup):
 
 
 def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", order=(0, 1, 2, 3), stream=None, ld=None, causal=None,
-                  lengths=None, cflag=None):
+                  lengths=None, cflag=None, splits=1):
     # lengths (causal / "geometry" streams): {head: (rows, keys)} of the head's batch entry, at most the array shapes (per-batch lengths);
     # cflag: 1 = causal mask (default for causal streams), 0 = lengths only
     """One persistent workgroup over `blocks` = [(head, row block), ...].  q [H][R][D], k / v [H][C][D] uint16 bit patterns.
@@ -265,14 +265,28 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
     qm, km, vm = (np.ascontiguousarray(padded(x, ldq)).reshape(-1).view(np.uint8).copy() for x in (q, k, v))
     osz = 2 if cfg.o16 else 4
     lsz = 2 if cfg.l16 else 4
-    om = np.full(H * R * ldo * osz, 0xCD, np.uint8)
-    lm = np.full(H * R * lsz, 0xCD, np.uint8)
+    split = bool(getattr(cfg, "split", 0))
+    if split:      # blocks = [(head, row block, piece)]: wsO [splits][H][R][D] fp32, wsML [splits][H][R][2]
+        assert C % (128 * splits) == 0 and ldo == D
+        lsz, piece = 8, C // splits
+        om = np.full(splits * H * R * D * 4, 0xCD, np.uint8)
+        lm = np.full(splits * H * R * 8, 0xCD, np.uint8)
+    else:
+        om = np.full(H * R * ldo * osz, 0xCD, np.uint8)
+        lm = np.full(H * R * lsz, 0xCD, np.uint8)
     qb, kb, vb, ob, lb = (mem.alloc(x) for x in (qm, km, vm, om, lm))
     wg = PWorkgroup(instrs, mem, dma_mode, stores)
     # block table (64 bytes per entry): Q, K, V, O, L base of the head, first row of the block
     table = np.zeros((len(blocks), 16), np.uint32)
-    for n, (h, rblk) in enumerate(blocks):
-        for i, a in enumerate((qb + h * R * ldq * 2, kb + h * C * ldk * 2, vb + h * C * ldv * 2, ob + h * R * ldo * osz, lb + h * R * lsz)):
+    for n, blk in enumerate(blocks):
+        h, rblk = blk[0], blk[1]
+        if split:
+            sp = blk[2]
+            bases = (qb + h * R * ldq * 2, kb + (h * C + sp * piece) * ldk * 2, vb + (h * C + sp * piece) * ldv * 2,
+                     ob + (sp * H + h) * R * D * 4, lb + (sp * H + h) * R * 8)
+        else:
+            bases = (qb + h * R * ldq * 2, kb + h * C * ldk * 2, vb + h * C * ldv * 2, ob + h * R * ldo * osz, lb + h * R * lsz)
+        for i, a in enumerate(bases):
             table[n, 2 * i], table[n, 2 * i + 1] = a & 0xFFFFFFFF, a >> 32
         table[n, 10] = rblk * 256
         table[n, 11], table[n, 12] = (lengths or {}).get(h, (R, C))
@@ -280,6 +294,9 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
     wg.lds[p4pgen.TABLE:p4pgen.TABLE + tb.size] = tb
     nt = (C + 63) // 64
     nt += nt & 1
+    Ck = C
+    if split:      # every workgroup sees its piece as the key range
+        Ck, nt = piece, piece // 64
     scale2 = float(np.float32(1.44269504089) * np.float32(1.0 / np.sqrt(np.float32(D))))
     lane = np.arange(64)
     qq, hi = lane & 31, lane >> 5
@@ -297,8 +314,8 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
         w.vn.update({
             "kbase": (qq * 256 + ((hi ^ (qq & 15)) << 4)).astype(np.uint32),
             "vbase": (VBASE + ((n16 >> 2) + 4 * hi) * 64 + (((lane >> 4) & 1) * 16 + 4 * (n16 & 3)) * 2).astype(np.uint32),
-            "lim0": (C - 1 - 4 * hi).astype(np.int64).astype(np.uint32), "lim1": (C - 1 - 4 * hi).astype(np.int64).astype(np.uint32),
-            "vv": vv, "lv": np.where(hi == 0, qq * lsz, p4pgen.OOB).astype(np.uint32),
+            "lim0": (Ck - 1 - 4 * hi).astype(np.int64).astype(np.uint32), "lim1": (Ck - 1 - 4 * hi).astype(np.int64).astype(np.uint32),
+            "vv": vv, "lv": np.where(hi == 0, qq * lsz, p4pgen.OOB).astype(np.uint32),   # (split: lsz = 8, the (m, l) pair of the row)
             # epilogue: in as lane = row (16-byte chunks, chunk index XOR row & 7), out as lane = (row & 7, chunk)
             "qlane": qq.astype(np.uint32), "hi4": (4 * hi).astype(np.uint32),
             "ewa": (qq * 128 + ((hi ^ (qq & 7)) << 4)).astype(np.uint32),
@@ -309,15 +326,24 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
             w.vn["ov%d" % db] = np.where(col < D, (lane >> 3) * ldo * osz + col * osz, p4pgen.OOB).astype(np.uint32)
         for i in range(4):
             w.vn["kv%d" % i], w.vn["qv%d" % i] = kv[i], qv[i]
-        w.sn.update({"nt": nt, "maskfrom": C // 64, "scale2": scale2, "kinc": 64 * ldk2, "vinc": 64 * ldv2,
+        w.sn.update({"nt": nt, "maskfrom": Ck // 64, "scale2": scale2, "kinc": 64 * ldk2, "vinc": 64 * ldv2,
                      "ldsk": wave * 4096, "ldsv": VBASE + wave * 4096, "ldsq": p4pgen.QIMG + wave * 16384,
                      "qrel": p4pgen.QIMG + wave * 16384, "nblk": len(blocks), "tbl": p4pgen.TABLE, "wave64": wave * 64,
-                     "ldq2": ldq2, "ldo": ldo * osz, "nrecq": R * ldq2, "nreck": C * ldk2, "nrecv": C * ldv2,
+                     "ldq2": ldq2, "ldo": ldo * osz, "nrecq": R * ldq2, "nreck": Ck * ldk2, "nrecv": Ck * ldv2,
                      "nreco": R * ldo * osz, "nrecl": R * lsz, "dr": D, "cflag": int(bool(cfg.causal)) if cflag is None else int(cflag)})
     wg.run(order)
     for w in wg.waves:
         assert not w.lds_q, "LDS reads left in flight"
         wg.retire_vm(w, 0)
+    if split:      # the merge of attn_fwd_combine, restated: m* = max m_s, w_s = 2^(m_s - m*), O = sum w_s O_s / sum w_s l_s, L = m* + log2 l*
+        Os = om.view(np.float32).reshape(splits, H, R, D).astype(np.float64)
+        ml = lm.view(np.float32).reshape(splits, H, R, 2).astype(np.float64)
+        mstar = ml[..., 0].max(axis=0)
+        wgt = np.exp2(ml[..., 0] - mstar[None])
+        lstar = (wgt * ml[..., 1]).sum(axis=0)
+        O = ((wgt[..., None] * Os).sum(axis=0) / lstar[..., None]).astype(np.float32)
+        L = (mstar + np.log2(lstar)).astype(np.float32)
+        return O, L, wg, (om, lm)
     if cfg.o16:
         O = h16_to_f32(om.view(np.uint16).astype(np.uint32), f16).reshape(H, R, ldo)[..., :D]
     else:

@@ -49,8 +49,11 @@ def main():
             kw = dict(row=N, column=N, heads=H, batches=B, headStrides=hs, batchStrides=bs, stream=stream, causal=causal, rowLengths=rl, columnLengths=rl)
             for label, env in (("persistent (round 6)", None), ("round-5 kernel (knob)", "1")):
                 os.environ.pop(knob, None)
+                os.environ.pop("MFA_P4P_LENGTHS", None)
                 if env:
                     os.environ[knob] = env
+                elif D > 64:
+                    os.environ["MFA_P4P_LENGTHS"] = "1"    # (D = 128: the product keeps such launches on attn_fwd16_p4; the developer library routes them)
                 form = k.launchForm(bufs, **{x: y for x, y in kw.items() if x != "stream"})
                 for _ in range(3):
                     k.dispatch(bufs, **kw)

@@ -70,14 +70,14 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
   if (args.mask) return false;
   if (args.causal && args.C < args.R) return false;
   // per-batch lengths (round 6): the causal ("geometry") streams carry the rows and keys of a block's batch entry in its table entry and
-  // serve such launches with or without the causal mask (KernelArgs.causal is the stream's flag) -- but at this head dimension they do
-  // not pay: one workgroup per compute unit with a FIXED share of the units is 6 % slower than the one-block-per-workgroup kernel on
-  // batches of mixed lengths (the dispatcher balances what a static share cannot) and on dense full-length ones; +2 % on causal
-  // full-length ones (profiles/r06_final/time_varlen_d128.txt).  The launches stay with attn_fwd16_p4; the developer library routes
-  // them here with MFA_P4P_LENGTHS=1 (tools/time_varlen.py).  At D <= 64 the same streams win by up to 43 % (attn_fwd16_p6.hip)
-  bool lengths_here = false;
+  // serve such launches with or without the causal mask (KernelArgs.causal is the stream's flag).  Without the mask they win (+4 % on
+  // full-length batches, +1 % on mixed lengths against the one-block-per-workgroup kernel; interleaved rounds, profiles/r06_final/
+  // time_varlen_d128.txt); WITH it a workgroup's fixed share of (long, short) row-block pairs is 6 % slower on mixed lengths than what
+  // the dispatcher balances block by block (+4 % on full-length batches, which the host cannot tell apart: the lengths are device
+  // arrays) -- causal launches with lengths stay with attn_fwd16_p4; the developer library routes them here with MFA_P4P_LENGTHS=1
+  bool lengths_here = !args.causal;
 #ifdef MFA_DEV_VARIANTS
-  lengths_here = std::getenv("MFA_P4P_LENGTHS") != nullptr;
+  lengths_here = lengths_here || std::getenv("MFA_P4P_LENGTHS") != nullptr;
 #endif
   if ((args.rowLen || args.colLen) && !lengths_here) return false;
   const bool geometry = args.causal || args.rowLen || args.colLen;
@@ -158,9 +158,9 @@ template bool p4p_split_serves<_Float16, false>(const KernelArgs &, uint32_t);
 template <typename T, bool FOLD> const char *p4p_form(const KernelArgs &args) {
   if (args.mask) return nullptr;
   if (args.causal && args.C < args.R) return nullptr;
-  bool lengths_here = false;
+  bool lengths_here = !args.causal;   // (causal launches with per-batch lengths: attn_fwd16_p4, see launch_p4p)
 #ifdef MFA_DEV_VARIANTS
-  lengths_here = std::getenv("MFA_P4P_LENGTHS") != nullptr;
+  lengths_here = lengths_here || std::getenv("MFA_P4P_LENGTHS") != nullptr;
 #endif
   if ((args.rowLen || args.colLen) && !lengths_here) return nullptr;
 #ifdef MFA_DEV_VARIANTS

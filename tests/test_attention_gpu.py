@@ -682,9 +682,11 @@ def test_launch_form_names_what_runs():
     assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs).startswith("attn_fwd16_p4p (persistent")
     assert "row-block pairs" in k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, causal=True)
     lens = torch.full((1,), N, dtype=torch.int32, device="cuda")
-    # (round 6: the persistent kernel's causal streams CAN serve per-batch lengths -- rows / keys per block-table entry -- but at D = 128 a
-    # fixed share of the units per workgroup loses to the dispatcher on mixed lengths: such launches keep the one-block kernel)
-    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens) == k.variant
+    # (round 6: per-batch lengths run on the persistent kernel -- rows / keys per block-table entry; with the causal mask a workgroup's
+    # fixed share of row-block pairs loses to the dispatcher on mixed lengths: those launches keep the one-block kernel)
+    form = k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens)
+    assert form.startswith("attn_fwd16_p4p (persistent") and "per-batch lengths" in form, form
+    assert k.launchForm(bufs, row=N, column=N, heads=H, headStrides=hs, rowLengths=lens, causal=True) == k.variant
     one = {op: t[0] for op, t in bufs.items()}
     ws = torch.empty(k.workspaceSize(row=N, column=N) + 256, dtype=torch.uint8, device="cuda")
     split_form = k.launchForm(one, row=N, column=N, workspace=ws)
@@ -1417,6 +1419,10 @@ def test_variable_sequence_lengths(low, causal, D):
     rl = torch.tensor(rlen, dtype=torch.int32, device="cuda")
     cl = torch.tensor(clen, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    if low and D == 128 and not causal:   # (round 6) the persistent forward kernel serves per-batch lengths: rows / keys per block-table entry
+        form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
+                                                                causal=causal, rowLengths=rl, columnLengths=cl)
+        assert form.startswith("attn_fwd16_p4p (persistent") and "per-batch lengths" in form, form
     if low and D == 64:    # (round 6) so does the D <= 64 persistent kernel (FP32 L here: its exact-scale geometry streams)
         form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                                                                 causal=causal, rowLengths=rl, columnLengths=cl)

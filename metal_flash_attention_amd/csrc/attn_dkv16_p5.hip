@@ -13,7 +13,19 @@ static void launch_dkv_p5(dim3 grid, hipStream_t stream, const KernelArgs &args)
   hipLaunchKernelGGL((attn_dkv16_p5<T, STREAM, CAUSAL>), dim3(grid.x * grid.y * grid.z), dim3(256), LDS, stream, args, g);
 }
 
-// `v` arrives filled by dkv16_rs_variant*: block-sparse and row-parallel launches keep the 32-key role-split kernel's code objects
+// row-parallel launch (round 6): the 32-row blocks in `splits` pieces (SPLIT of attn_dkv16_p5.h), then the sums of the dV and dK slabs
+template <typename T, int STREAM>
+static void launch_dkv_p5_split(dim3 grid, uint32_t splits, float *ws, float *, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, ws, nullptr};
+  constexpr int LDS = dkv5::lds_bytes(dkv5::stream_bucket(STREAM));
+  hipLaunchKernelGGL((attn_dkv16_p5<T, STREAM, false, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), LDS, stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.C;
+  const float *dk_slabs = ws + (uint64_t)splits * rows * args.D;   // dV slabs first, then dK slabs
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dV, args.C, (const float *)ws);
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dK, args.C, dk_slabs);
+}
+
+// `v` arrives filled by dkv16_rs_variant*: block-sparse and CAUSAL row-parallel launches keep the 32-key role-split kernel's code objects
 template <typename T, int STREAM> static void fill_dkv_p5(VariantInfo *v, const char *name) {
   constexpr int LDS = dkv5::lds_bytes(dkv5::stream_bucket(STREAM));
   v->func = reinterpret_cast<const void *>(&attn_dkv16_p5<T, STREAM, false>);
@@ -31,6 +43,13 @@ template <typename T, int STREAM> static void fill_dkv_p5(VariantInfo *v, const 
   v->launchCausal = &launch_dkv_p5<T, STREAM, true>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dkv16_p5<T, STREAM, true>);
   v->causal = true;
+  if constexpr (!dkv5::stream_profiles(STREAM)) {
+    v->launchSplitCausal = v->launchSplit;   // (the sibling's)
+    v->launchSplit = &launch_dkv_p5_split<T, STREAM>;
+    v->funcSplit = reinterpret_cast<const void *>(&attn_dkv16_p5<T, STREAM, false, true>);
+    v->splitParallelization = dkv5::WGKEYS;
+    v->splitTarget = 256;   // one workgroup per compute unit (512 registers per lane)
+  }
 }
 
 // precision: Q, K, V; gprecision: dO; lprec / dprec: storage types of L and D.  The streams exist for the two combinations the

@@ -14,7 +14,17 @@ static void launch_dq_p5(dim3 grid, hipStream_t stream, const KernelArgs &args) 
   hipLaunchKernelGGL((attn_dq16_p5<T, STREAM, CAUSAL, TG>), dim3(grid.x * grid.y * grid.z), dim3(256), LDS, stream, args, g);
 }
 
-// `v` arrives filled by dq16_variant*: block-sparse and column-parallel launches keep the 32-row-wave kernel's code objects
+// column-parallel launch (round 6): the 32-key blocks in `splits` pieces (SPLIT of attn_dq16_p5.h), then the sum of the slabs
+template <typename T, int STREAM, typename TG>
+static void launch_dq_p5_split(dim3 grid, uint32_t splits, float *ws, float *, hipStream_t stream, const KernelArgs &args) {
+  Fwd16Grid g{grid.x, grid.y, grid.z, splits, ws, nullptr};
+  constexpr int LDS = dq5::lds_bytes(dq5::stream_bucket(STREAM));
+  hipLaunchKernelGGL((attn_dq16_p5<T, STREAM, false, TG, true>), dim3(grid.x * grid.y * grid.z * splits), dim3(256), LDS, stream, args, g);
+  const uint64_t rows = (uint64_t)grid.y * grid.z * args.R;
+  hipLaunchKernelGGL(attn_bwd_combine, dim3((uint32_t)((rows + 3) / 4)), dim3(256), 0, stream, args, g, (int)SLOT_dQ, args.R, (const float *)ws);
+}
+
+// `v` arrives filled by dq16_variant*: block-sparse and CAUSAL column-parallel launches keep the 32-row-wave kernel's code objects
 template <typename T, int STREAM, typename TG = T> static void fill_dq_p5(VariantInfo *v, const char *name) {
   constexpr int LDS = dq5::lds_bytes(dq5::stream_bucket(STREAM));
   v->func = reinterpret_cast<const void *>(&attn_dq16_p5<T, STREAM, false, TG>);
@@ -32,6 +42,13 @@ template <typename T, int STREAM, typename TG = T> static void fill_dq_p5(Varian
   v->launchCausal = &launch_dq_p5<T, STREAM, true, TG>;
   v->funcCausal = reinterpret_cast<const void *>(&attn_dq16_p5<T, STREAM, true, TG>);
   v->causal = true;
+  if constexpr (!dq5::stream_profiles(STREAM)) {
+    v->launchSplitCausal = v->launchSplit;   // (the sibling's)
+    v->launchSplit = &launch_dq_p5_split<T, STREAM, TG>;
+    v->funcSplit = reinterpret_cast<const void *>(&attn_dq16_p5<T, STREAM, false, TG, true>);
+    v->splitParallelization = dq5::WGROWS;
+    v->splitTarget = 256;   // one workgroup per compute unit (512 registers per lane)
+  }
 }
 
 // impl 0: Q as stored, softmax scale in fp32 (descriptors that keep the attention matrix in FP32 registers); impl 10: Q

@@ -1552,7 +1552,8 @@ def test_block_sparse_mask(shape, causal, empty, low):
 
 # ---- traversal-parallel backward launches through a caller-provided workspace ------------------------
 @pytest.mark.parametrize("shape,causal", [((4096, 4096, 64), False), ((2048, 4096, 128), False), ((3000, 3000, 128), True),
-                                          ((1024, 2048, 256), False)])
+                                          ((1024, 2048, 256), False), ((2100, 1500, 192), False), ((1500, 2100, 256), True),
+                                          ((4096, 4096, 256), False)])
 def test_backward_split_matches_unsplit_and_oracle(shape, causal):
     """Single-head backward launches cannot fill 256 CUs: with a workspace the key (dQ) / row (dK, dV) range is cut
     into pieces whose fp32 partial results are summed by a second kernel.  Same answer as without the
@@ -1577,9 +1578,9 @@ def test_backward_split_matches_unsplit_and_oracle(shape, causal):
         k.dispatch(run.buffers, row=R, column=C, stream=stream, causal=causal, workspace=ws)
         form = k.launchForm(run.buffers, row=R, column=C, causal=causal, workspace=ws)
         assert "column-parallel x" in form, form
-        # the hand-placed kernels of D <= 128 cut dense launches into pieces themselves, causal ones belong to their siblings;
-        # attn_dq16_p5 / attn_dkv16_p5 (D > 128) leave every traversal-parallel launch to the 32-row waves / 32-key role-split pairs
-        assert ("sibling" in form) == ((causal and "p4" in k.variant) or "16p5" in k.variant), form
+        # the hand-placed kernels (D <= 128: attn_dq16_p4 / attn_dkv16_p4; D > 128: attn_dq16_p5 / attn_dkv16_p5, round 6) cut dense
+        # launches into pieces themselves, causal ones belong to their siblings (32-row waves / 32-key role-split pairs)
+        assert ("sibling" in form) == (causal and ("p4" in k.variant or "16p5" in k.variant)), form
     torch.cuda.synchronize()
     got = run.results()
     # the unsplit launch of the 128 bucket is the four-wave hand-placed kernel, the split one its 8 x 32 / role-split sibling:

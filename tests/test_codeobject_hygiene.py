@@ -19,7 +19,7 @@ OBJECTS = ["attn_fwd16_p4", "attn_fwd16_p4p", "attn_fwd16_p6", "attn_fwd16_p5", 
 SCRATCH_BUDGET = {"attn_fwd16_p4": 40, "attn_fwd16_p4p": 0, "attn_fwd16_p6": 0, "attn_fwd16_p5": 40, "attn_dq16_p4": 40, "attn_dkv16_p4": 40, "attn_dq16_p5": 0,
                   "attn_dkv16_p5": 8, "attn_f32": 8, "attn_fwd16_p4_tr": 60, "attn_fwd16_p5_tr": 100, "attn_bwd16_p4_tr": 540}   # (attn_dq16_p4_tr gathers Q^T / dO^T / O^T in its C++ prologue: 526 today)
 # (kernels of the unit that spill at all, most spilled vector registers in one kernel): the state of the round-5 build
-SPILL_BUDGET = {"attn_fwd16_p4p": (0, 0), "attn_fwd16_p6": (0, 0), "attn_dq16_p5": (0, 0), "attn_dkv16_p5": (16, 1), "attn_dq16_p4": (18, 2), "attn_dkv16_p4": (21, 6),
+SPILL_BUDGET = {"attn_fwd16_p4p": (0, 0), "attn_fwd16_p6": (0, 0), "attn_dq16_p5": (0, 0), "attn_dkv16_p5": (28, 2), "attn_dq16_p4": (18, 2), "attn_dkv16_p4": (21, 6),
                 "attn_f32": (1, 2), "attn_fwd16_p4": (4, 15), "attn_fwd16_p5": (12, 2), "attn_fwd16_p4_tr": (24, 19),
                 "attn_fwd16_p5_tr": (56, 34), "attn_bwd16_p4_tr": (24, 73)}
 

@@ -568,17 +568,31 @@ static uint64_t relayout_workspace_bytes(const mfa_attention_kernel *kernel, uin
   return total;
 }
 
-// Column-parallel heuristic: split only when the row-parallel grid cannot fill the 256 CUs and the
-// traversal is long enough to amortise the combine pass; aim at ~2 workgroups per CU, keep >= 4 key
-// tiles (256 keys) per piece.
+// Column-parallel heuristic: split only when the row-parallel grid cannot fill the 256 CUs and the traversal is long enough to
+// amortise the combine pass; keep >= 4 key tiles (256 keys) per piece.
 // `target`: workgroups the variant wants in flight (512 = two per compute unit; 256 for the kernels that own a compute unit's whole
-// register file and run one workgroup per compute unit -- a second round of half-length pieces would pay the per-block cost twice)
-static uint32_t choose_splits(uint64_t blocks, uint32_t column, uint32_t target = 512) {
-  const uint32_t tiles = (column + 63) / 64;
+// register file and run one workgroup per compute unit -- a second round of half-length pieces would pay the per-block cost twice).
+// Round 6 (tools/sweep_splits.py, profiles/r06_sweep_splits.txt): (1) the count is rounded DOWN to the target: 24 blocks x 11 pieces
+// = 264 workgroups ran a second round of eight (N = 6144, one head: 33.8 us against 26.4 with 8 pieces); (2) more pieces shorten a
+// piece's traversal by t_tile / s but every piece adds a slab to the combine pass (s x parallel x (D + 2) floats read back): the sum has
+// its minimum at s^2 = K x traversal / parallel with K ~ 117 for every head dimension (a tile's time and a slab's bytes both grow
+// with D), i.e. ~11 pieces for a square problem -- N = 4096 D = 64 one head forward: 21.0 us with 8 pieces, 23.5 with 16.
+static uint32_t choose_splits(uint64_t blocks, uint32_t traversal, uint32_t parallel, uint32_t target = 512) {
+  const uint32_t tiles = (traversal + 63) / 64;
   if (blocks >= 192 || tiles < 8) return 1;
-  uint64_t s = (target + blocks - 1) / blocks;
+  uint64_t s = target / blocks;
+  uint64_t best = 1;
+  while ((best + 1) * (best + 1) * (uint64_t)parallel <= 117ull * traversal + (uint64_t)parallel * (best + 1)) ++best;   // ~ round(sqrt(117 t / p))
+  if (s > best) s = best;
+#ifdef MFA_DEV_VARIANTS
+  if (const char *knob = std::getenv("MFA_SPLITS")) s = (uint64_t)std::atoi(knob);   // developer library: sweep of the piece count (tools/sweep_splits.py)
+#endif
   if (s > tiles / 4) s = tiles / 4;
   if (s > 64) s = 64;
+  // equal pieces of whole 256-key blocks when a count between s / 2 and s gives them (what the persistent forward kernels' split
+  // streams serve: attn_fwd16_p4p.hip, attn_fwd16_p6.hip)
+  for (uint64_t c = s; c >= 2 && 2 * c > s; --c)
+    if (traversal % (256 * c) == 0) { s = c; break; }
   return s < 2 ? 1 : (uint32_t)s;
 }
 
@@ -714,7 +728,7 @@ static mfa_status prepare_launch(const mfa_attention_kernel *kernel, void *const
     const bool ownSplit = plan->variant->splitParallelization && !(args->causal && plan->variant->launchSplitCausal);
     const uint32_t sibBlocks = ownSplit ? (par + plan->variant->splitParallelization - 1) / plan->variant->splitParallelization : siblingBlocks;
     const uint32_t s = choose_splits((uint64_t)sibBlocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? p->row : p->column,
-                                     plan->variant->splitTarget ? plan->variant->splitTarget : 512);
+                                     type == MFA_BACKWARD_KEY_VALUE ? p->column : p->row, plan->variant->splitTarget ? plan->variant->splitTarget : 512);
     if (s > 1) {
       plan->workspaceNeeded = split_workspace_bytes(type, s, heads, batches, p->row, p->column, D);
       if (p->workspace && p->workspaceBytes >= plan->workspaceNeeded &&
@@ -852,7 +866,7 @@ mfa_status mfa_attention_kernel_workspace_size(const mfa_attention_kernel *kerne
                                   : kernel->variant.siblingParallelization ? kernel->variant.siblingParallelization : kernel->variant.parallelization;
   const uint32_t blocks = (par + wgPar - 1) / wgPar;
   const uint32_t s = choose_splits((uint64_t)blocks * heads * batches, type == MFA_BACKWARD_KEY_VALUE ? params->row : params->column,
-                                   kernel->variant.splitTarget ? kernel->variant.splitTarget : 512);
+                                   type == MFA_BACKWARD_KEY_VALUE ? params->column : params->row, kernel->variant.splitTarget ? kernel->variant.splitTarget : 512);
   if (s > 1) *bytes = split_workspace_bytes(type, s, heads, batches, params->row, params->column, kernel->desc.headDimension);
   return MFA_OK;
 }

@@ -24,12 +24,14 @@ constexpr int QIMG = MFA_P4P_QIMG, TABLE = MFA_P4P_TABLE, TABLE_ENTRIES = MFA_P4
 enum : int { MFA_P4P_STREAM_LIST(MFA_P4P_ENUM) S_COUNT };
 #undef MFA_P4P_ENUM
 
-struct StreamTraits { bool f16, fold, o16, l16, causal, split; };   // (the stream list's last column: 1 = causal / geometry stream, 2 = column-parallel pieces)
+// (the stream list's last column: & 3: 1 = causal / geometry stream, 2 = column-parallel pieces; & 4: O = P V with lane = column, rows stored
+// straight from the registers -- PCfg.orow of tools/p4pgen.py)
+struct StreamTraits { bool f16, fold, o16, l16, causal, split, orow; };
 constexpr StreamTraits traits(int s) {
-#define MFA_P4P_TRAITS(name, f16, fold, o16, l16, kind) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, kind == 1, kind == 2};
+#define MFA_P4P_TRAITS(name, f16, fold, o16, l16, kind) if (s == S_##name) return StreamTraits{f16 != 0, fold != 0, o16 != 0, l16 != 0, ((kind) & 3) == 1, ((kind) & 3) == 2, ((kind) & 4) != 0};
   MFA_P4P_STREAM_LIST(MFA_P4P_TRAITS)
 #undef MFA_P4P_TRAITS
-  return StreamTraits{false, false, false, false, false, false};
+  return StreamTraits{false, false, false, false, false, false, false};
 }
 
 }  // namespace p4p
@@ -163,6 +165,9 @@ __global__ __launch_bounds__(256) void attn_fwd16_p4p(const KernelArgs a, const 
   for (int db = 0; db < 4; ++db) {
     const uint32_t col = 32 * db + 4 * chunk;
     ov[db] = col < dr ? row8 * ldob + col * OSZ : OOB;
+    // orow streams: no LDS trip -- register r of accumulator block (rb, db) is column 32 db + q of row 8 (r >> 2) + 4 hi + (r & 3); the row
+    // is the store's scalar offset, the lane brings its column and the four rows of the upper half-wave
+    if constexpr (TR.orow) ov[db] = 32 * db + (uint32_t)q < dr ? (32 * db + (uint32_t)q) * 4 + (uint32_t)hi * 4 * ldob : OOB;
   }
   const uint32_t lv = hi == 0 ? (uint32_t)q * LSZ : OOB;   // L: one lane per row
 

@@ -94,7 +94,7 @@ template <typename T, bool FOLD> bool launch_p4p(dim3 grid, hipStream_t stream, 
     const char *want = std::getenv("MFA_P4P_DEV_STREAM");
     if (want && *want && args.op[SLOT_O].precision == PREC_FP32 && args.op[SLOT_L].precision == (FOLD ? PREC_FP16 : PREC_FP32)) {
 #define MFA_P4P_BYNAME(name, f16, fold, o16, l16, scausal) \
-      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD) { if (scausal != 2 && (scausal != 0) == geometry && std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
+      if constexpr (!f16 && fold == FOLD && !o16 && l16 == FOLD) { if (((scausal) & 3) != 2 && (((scausal) & 3) != 0) == geometry && std::strcmp(want, #name) == 0) return launch_stream<T, p4p::S_##name>(grid, stream, args); }
       MFA_P4P_DEV_STREAM_LIST(MFA_P4P_BYNAME)
 #undef MFA_P4P_BYNAME
       return false;   // (an unknown name must not silently time the product stream)

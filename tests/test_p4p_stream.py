@@ -279,3 +279,22 @@ def test_column_parallel_pieces(name, R, C, splits):
         Oref, Lref = p4psim.reference(q[h], k[h], v[h], causal=False, f16=f16)
         dO, dL = np.abs(O[h] - Oref).max(), np.abs(L[h] - Lref).max()
         assert dO < 6e-3 and dL < 6e-3, (h, dO, dL)
+
+
+# ---- round 6, developer streams: O = P V with lane = column (PCfg.orow) -- rows stored straight from the registers, no LDS trip.  Measured
+# equal to the product streams (profiles/r06_p4p_epilogue.txt: the epilogue is bound by the store path, not by LDS); kept as the record
+@pytest.mark.parametrize("name", ["BF16_FOLD_L16_OROW", "BF16_EXACT_OROW", "BF16_FOLD_L16_CAUSAL_OROW"])
+def test_row_major_accumulators_give_the_same_bytes(name):
+    """same instruction multiset inside the loop, the second products' operands exchanged: every byte of O and L equals the product
+    stream's -- also behind a deferred rescale (the row's factor per REGISTER, by ds_bpermute_b32) and with D < 128, ragged rows / keys"""
+    cfg = p4pgen.VARIANTS[name]
+    base = p4pgen.VARIANTS[name[:-5]]
+    assert cfg.orow and not base.orow and name not in p4pgen.PRODUCT_STREAMS
+    C = 640
+    for kw in (dict(spike=(17, 64 * 5 + 5, 3.0), tol_o=1.2e-2), dict(D=72, ld=128), dict(stores="late", dma_mode="late", order=(3, 2, 1, 0))):
+        a = _check(2, 300, C, cfg=cfg, seed=31, **kw)
+        b = _check(2, 300, C, cfg=base, seed=31, **kw)
+        assert (a[1][0] == b[1][0]).all() and (a[1][1] == b[1][1]).all()
+    assert a[0].waves[0].count["buffer_store_dword"] >= 2 * 128 and not a[0].waves[0].count.get("buffer_store_dwordx4")
+    wg = _check(2, 300, C, cfg=cfg, seed=31, spike=(17, 64 * 5 + 5, 3.0), tol_o=1.2e-2)[0]
+    assert wg.waves[0].count.get("ds_bpermute_b32", 0) >= 2 * 32 + 32      # two epilogues + at least one rescale

@@ -209,6 +209,9 @@ class Stream:
         # loop runs -- no mask-section test, no block-switch tests, no pending-rescale test; their rare rescale decision continues in
         # the ordinary copy of the same phase (slow_dec_back: parity -> the label behind that copy's decision)
         self.fast = False
+        # orow (round 6, persistent streams with fp32 O): the second products run as O = P V (operands exchanged: A = P, B = V^T fragment)
+        # -- lane = head-dimension column, register = row -- so that the epilogue stores rows straight from the registers
+        self.orow = bool(getattr(cfg, "orow", 0))
         self.slow_dec_back = {}
         # second partial row sum per row block, mask value: module constants unless a stream re-maps them (p4pgen, pksum)
         self.r_lb = [T_LB, T_LB + 1]
@@ -225,8 +228,8 @@ class Stream:
         return "%s_%d" % (stem, self.uid)
 
     # ---- LDS reads with exact wait counting (LDS returns in order)
-    def lds_read(self, op, d, addr, offset, note=""):
-        self.emit(op, d, [addr], note=note, offset=offset)
+    def lds_read(self, op, d, addr, offset, note="", src=None):
+        self.emit(op, d, [addr] + ([src] if src is not None else []), note=note, offset=offset)
         self.lds_issued += 1
         return self.lds_issued      # id = position in issue order (1-based)
 
@@ -260,6 +263,13 @@ class Stream:
     # ---- matrix instructions
     def mfma(self, d, a, b, c):
         self.emit("v_mfma_f32_32x32x16_" + self.cfg.dtype, d, [a, b, c])
+
+    def pv(self, rb, db, f, par, u):
+        """one second-product instruction: O^T(db, rb) += V^T P^T, or (orow) O(rb, db) += P V with the same registers"""
+        a, b = vf_frag(f), p_frag(par ^ 1, rb, u)
+        if self.orow:
+            a, b = b, a
+        self.mfma(o_acc(rb, db), a, b, o_acc(rb, db))
 
     def qk_order(self):
         if self.cfg.order_a == "kb":      # kb-major: the kb = 0 blocks complete after 16 instructions
@@ -445,7 +455,7 @@ class Stream:
                 f = 4 * u + db
                 if rb == 0 and f % 2 == 0:
                     self.lds_need(vids[2 * f + 3])   # both halves of fragments f and f + 1 have returned
-                self.mfma(o_acc(rb, db), vf_frag(f), p_frag(par ^ 1, rb, u), o_acc(rb, db))
+                self.pv(rb, db, f, par, u)
             for fn in fill[g]:
                 fn()
         while self.xe_pending:
@@ -665,7 +675,7 @@ class Stream:
                 f = 4 * u + db
                 if rb == 0 and f % 2 == 0:
                     self.lds_need(vids[2 * f + 3])
-                self.mfma(o_acc(rb, db), vf_frag(f), p_frag(par ^ 1, rb, u), o_acc(rb, db))
+                self.pv(rb, db, f, par, u)
             for fn in fill[g]:
                 fn()
         self.lds_flush()
@@ -914,7 +924,34 @@ class Stream:
             else:               # O, l *= corr once every matrix instruction that accumulates P(j-1) has been issued
                 self.emit("s_nop", None, [I(15)])
                 self.emit("s_nop", None, [I(7)])
-                for rb in range(2):
+                if self.orow:
+                    # register r of a lane belongs to row 8 (r >> 2) + 4 hi + (r & 3): the row's factor comes from the lane that owns the
+                    # row (ds_bpermute_b32: lane select = (address + offset) / 4, no LDS memory), four registers of the four blocks at a time
+                    self.emit("v_mbcnt_lo_u32_b32", V(rs), [I(-1), I(0)])
+                    self.emit("v_mbcnt_hi_u32_b32", V(rs), [I(-1), V(rs)])
+                    self.emit("v_lshrrev_b32", V(rs), [I(5), V(rs)])
+                    self.emit("v_lshlrev_b32", V(rs), [I(4), V(rs)])          # 16 hi
+                    for rb in range(2):
+                        for g in range(4):
+                            for i in range(3):
+                                self.emit("ds_bpermute_b32", V(rs + 1 + i), [V(rs), V(T_CORR + rb)], offset=4 * (8 * g + i))
+                            self.emit("ds_bpermute_b32", V(rs + 7), [V(rs), V(T_CORR + rb)], offset=4 * (8 * g + 3))
+                            self.emit("s_waitcnt", None, [], lgkmcnt=0)
+                            fac = [rs + 1, rs + 2, rs + 3, rs + 7]
+                            for db in range(4):
+                                for i in range(3):
+                                    self.emit("v_accvgpr_read_b32", V(rs + 4 + i), [A(O_BASE + 64 * rb + 16 * db + 4 * g + i)])
+                                for i in range(3):
+                                    self.emit("v_mul_f32", V(rs + 4 + i), [V(fac[i]), V(rs + 4 + i)])
+                                for i in range(3):
+                                    self.emit("v_accvgpr_write_b32", A(O_BASE + 64 * rb + 16 * db + 4 * g + i), [V(rs + 4 + i)])
+                                # (eight temporaries: the fourth register of the group goes through the fourth factor's register pair)
+                                self.emit("v_accvgpr_read_b32", V(rs + 4), [A(O_BASE + 64 * rb + 16 * db + 4 * g + 3)])
+                                self.emit("v_mul_f32", V(rs + 4), [V(fac[3]), V(rs + 4)])
+                                self.emit("v_accvgpr_write_b32", A(O_BASE + 64 * rb + 16 * db + 4 * g + 3), [V(rs + 4)])
+                        self.emit("v_mul_f32", VN("l%d" % rb), [V(T_CORR + rb), VN("l%d" % rb)])
+                        self.emit("v_mul_f32", V(self.r_lb[rb]), [V(T_CORR + rb), V(self.r_lb[rb])])
+                for rb in range(0 if self.orow else 2):
                     for i0 in range(0, 64, 8):
                         for t in range(8):
                             self.emit("v_accvgpr_read_b32", V(rs + t), [A(O_BASE + 64 * rb + i0 + t)])
@@ -1087,6 +1124,8 @@ def render_one(ins, suffix="%="):
         return "ds_write_b128 %s, %s offset:%d" % (fmt(ins.s[0]), fmt(ins.s[1]), m["offset"])
     if op in ("ds_read_b128", "ds_read_b64", "ds_read_b64_tr_b16"):
         return "%s %s, %s offset:%d" % (op, fmt(ins.d), fmt(ins.s[0]), m["offset"])
+    if op == "ds_bpermute_b32":         # d[lane] = s1[((s0[lane] + offset) >> 2) & 63]
+        return "ds_bpermute_b32 %s, %s, %s offset:%d" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]), m["offset"])
     if op == "v_fma_f32":
         return "v_fma_f32 %s, %s, %s, -%s" % (fmt(ins.d), fmt(ins.s[0]), fmt(ins.s[1]), fmt(ins.s[2]))
     if op == "v_add_u32_e64":

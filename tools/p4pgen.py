@@ -80,7 +80,7 @@ class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
     def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0,
-                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0, split=0):
+                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0, split=0, orow=0, stpol=""):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
         # fastloop (round 6, dense streams): the timing-only ablation that dropped the per-tile tests of the loop -- block switch
@@ -109,6 +109,14 @@ class PCfg(Cfg):
         # (attn_fwd16_v3.h), like the split streams of tools/p6gen.py.  Pieces are whole multiples of two tiles
         self.split = split
         assert not (split and (causal or o16 or merge or fuse))
+        # orow (round 6, fp32 O): the second products accumulate O = P V with lane = column, register = row (p4gen.Stream.pv): the
+        # epilogue then stores rows straight from the registers -- 128 buffer_store_dword per wave and block, each two full 128-byte
+        # lines -- instead of turning O^T through LDS (32 ds_write_b128 + 32 ds_read_b128 + waits per wave: 5.7 k clocks per block,
+        # profiles/r06_p4p_epilogue.txt).  The price: a row's factor (deferred rescale, 1 / l) is needed per REGISTER, fetched from the
+        # lane that owns the row by ds_bpermute_b32.  No LDS staging, so no ordering against the V ring either
+        self.orow = orow
+        self.stpol = stpol     # (round 6 experiment) cache-policy bits on the stores of O (" nt", " sc1", " sc0 sc1")
+        assert not (orow and (o16 or merge or fuse or pprof == 1))
         if split:
             self.l16 = 0
         assert not (diagmask and (not causal or pprof))
@@ -470,6 +478,8 @@ class PStream(Stream):
             self.emit("v_fma_f32", iv, [ta, iv, iv])                   # r += e r
             self.emit("v_cmp_lt_f32", VCC, [F(1e-30), lt])
             self.emit("v_cndmask_b32", iv, [I(0), iv, VCC])            # a row without keys: O = 0
+        if self.cfg.orow:
+            return
         wa, ra = self.EPI_WA, self.EPI_RA
         self.emit("s_add_u32", s("t2"), [SN("vwr"), I(VSLOT)])
         self.emit("s_cmp_ge_u32", None, [s("t2"), SN("t1")])
@@ -507,7 +517,7 @@ class PStream(Stream):
                     out.append((i, lambda k=k: self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k + 1), [V(dst + 4 * k + 2), V(dst + 4 * k + 3)])))
                     out.append((i, lambda k=k: self.emit("buffer_store_dwordx2", None, [V(dst + 4 * k, 2), vo, s("tres", 4)], offset=0)))
                 else:
-                    out.append((i, lambda k=k: self.emit("buffer_store_dwordx4", None, [V(dst + 4 * k, 4), vo, s("tres", 4)], offset=0)))
+                    out.append((i, lambda k=k: self.emit("buffer_store_dwordx4", None, [V(dst + 4 * k, 4), vo, s("tres", 4)], offset=0, pol=cfg.stpol)))
             return out
 
         pending = None
@@ -567,20 +577,66 @@ class PStream(Stream):
             else:
                 self.emit("buffer_store_dword", None, [x, vo, s("lres", 4)], offset=0)
 
+    def epilogue_rows(self):
+        """orow streams: O(rb, db) holds column 32 db + n of rows 8 (r >> 2) + 4 hi + (r & 3) in register r.  1 / l of the row per
+        register (ds_bpermute_b32 from the lane that owns the row), then sixteen row stores per block: lane offset = 4 (32 db + n)
+        + 4 hi ld(O) (out of range beyond D: `ov<db>`), scalar offset = the row's (part of the range check like the lane's)."""
+        cfg = self.cfg
+        inv, bpa = self.EPI_INV, V(T_CORR)
+        fac = S_BASE[1] + 32                      # v128..v159: 1 / l per (rb, r)
+        sets = [S_BASE[0] + 16 * i for i in range(4)] + [S_BASE[1], S_BASE[1] + 16]
+        if not cfg.split:
+            self.emit("v_mbcnt_lo_u32_b32", bpa, [I(-1), I(0)])
+            self.emit("v_mbcnt_hi_u32_b32", bpa, [I(-1), bpa])
+            self.emit("v_lshrrev_b32", bpa, [I(5), bpa])
+            self.emit("v_lshlrev_b32", bpa, [I(4), bpa])               # 16 hi
+            ids = []
+            for rb in range(2):
+                for r in range(16):
+                    ids.append(self.lds_read("ds_bpermute_b32", V(fac + 16 * rb + r), bpa, 4 * (8 * (r >> 2) + (r & 3)), src=V(inv[rb])))
+        self.emit("s_add_u32", s("t0"), [s("row0"), SN("wave64")])
+        self.emit("s_mul_i32", s("t0"), [s("t0"), SN("ldo")])           # byte offset of the wave's first row
+        self.emit("s_mul_i32", s("t4"), [SN("ldo"), I(5)])              # rows 3 -> 8 of a register group
+        for i, (rb, db) in enumerate((b // 4, b % 4) for b in range(8)):
+            t = sets[i % len(sets)]
+            b = 4 * rb + db
+            if rb and not db:
+                self.emit("s_lshl_b32", s("t2"), [SN("ldo"), I(5)])
+                self.emit("s_add_u32", s("t0"), [s("t0"), s("t2")])
+            for r in range(16):
+                self.emit("v_accvgpr_read_b32", V(t + r), [A(O_BASE + 16 * b + r)])
+            if not cfg.split:
+                if i == 0 or (rb and not db):
+                    self.lds_need(ids[16 * rb + 15])
+                for r in range(16):
+                    self.emit("v_mul_f32", V(t + r), [V(fac + 16 * rb + r), V(t + r)])
+            self.emit("s_mov_b32", s("t2"), [s("t0")])
+            for r in range(16):
+                self.emit("buffer_store_dword", None, [V(t + r), VN("ov%d" % db), s("tres", 4), s("t2")], offset=0, pol=cfg.stpol)
+                if r != 15:
+                    self.emit("s_add_u32", s("t2"), [s("t2"), s("t4") if (r & 3) == 3 else SN("ldo")])
+        self.lds_flush()
+
     def epilogue(self):
         """O /= l (+Source.swift:165-171) and L = m + log2 l (+Caching.swift:373-377), straight from the registers"""
         cfg = self.cfg
         self.emit("s_nop", None, [I(15)], note="the last accumulating MFMAs leave the matrix pipe")
         self.emit("s_nop", None, [I(7)])
         self.epi_prepare()
+        if cfg.orow:
+            if "epi" not in cfg.abl:
+                self.epilogue_rows()
+            self.epi_finish()
+            return
         # staging registers: four 16-register sets each way (an instruction reads its registers when it issues); the merged
         # block switch has the odd tiles' score registers only (the even ones hold the next block's tile 0): two sets
         if cfg.merge:
             regs = lambda i: (S_BASE[1] + 16 * (i & 1), S_BASE[1] + 32 + 16 * (i & 1))
         else:
             regs = lambda i: (S_BASE[0] + 16 * (i & 3), S_BASE[1] + 16 * (i & 3))
-        for _, fn in self.epi_block_work([(b // 4, b % 4) for b in range(8)], regs):
-            fn()
+        if "epi" not in cfg.abl:     # (timing-only ablation: O stays in the registers -- what the staging and the stores of a block cost)
+            for _, fn in self.epi_block_work([(b // 4, b % 4) for b in range(8)], regs):
+                fn()
         self.lds_flush()
         self.epi_finish()
 
@@ -791,9 +847,11 @@ class PStream(Stream):
         self.block_head(nonext)
         self.pstamp("table")
         # this wave's Q image, and its pieces of K(0), V(0), K(1): everything older than the previous block's stores
-        self.emit("s_waitcnt", None, [], vmcnt=NST)
+        if not cfg.orow:
+            self.emit("s_waitcnt", None, [], vmcnt=NST)
         self.pstamp("wait_q")
-        self.q_fragments()
+        if "qfrag" not in cfg.abl:
+            self.q_fragments()
         self.emit("s_barrier")
         self.pstamp("qfrag")
         self.block_init()
@@ -802,7 +860,8 @@ class PStream(Stream):
         self.lds_flush()
         self.first_tiles = True
         self.phase_a(0, mfma=True, softmax=False, zero_o=True)
-        self.emit("s_waitcnt", None, [], vmcnt=NST)          # K(1) (older than the stores)
+        if not cfg.orow:
+            self.emit("s_waitcnt", None, [], vmcnt=NST)          # K(1) (older than the stores)
         self.emit("s_barrier")
         self.pstamp("tile0_a")
         self.phase_b(0, mfma=False, softmax=True, vids={})
@@ -895,7 +954,7 @@ class PStream(Stream):
                 if par == 0:
                     self.emit("s_branch", None, [], target=skip_odd)
         self.label(done)
-        if cfg.merge:
+        if cfg.merge or cfg.orow:    # (orow: 130 stores per block are beyond a counted wait: the next block's operands land HERE)
             # a merged switch has no barrier between this block's end and the next block's phase B(0), which reads K'(1): every
             # wave's pieces of the next block's first tiles (requested two phases ago) land before the barrier below
             self.emit("s_waitcnt", None, [], vmcnt=0)
@@ -954,7 +1013,7 @@ def render_one(ins):
     f = p4gen.fmt
     if op in ("buffer_store_dwordx4", "buffer_store_dwordx2", "buffer_store_dword", "buffer_store_short"):
         off = " offset:%d" % m["offset"] if m.get("offset") else ""
-        return "%s %s, %s, %s, 0 offen%s" % (op, f(ins.s[0]), f(ins.s[1]), f(ins.s[2]), off)
+        return "%s %s, %s, %s, %s offen%s%s" % (op, f(ins.s[0]), f(ins.s[1]), f(ins.s[2]), f(ins.s[3]) if len(ins.s) > 3 else "0", off, m.get("pol", ""))
     if op == "v_fma_f32" and not m.get("neg2"):
         return "v_fma_f32 %s, %s%s, %s, %s" % (f(ins.d), "-" if m.get("neg0") else "", f(ins.s[0]), f(ins.s[1]), f(ins.s[2]))
     if op == "s_cmp_lt_u32":
@@ -1061,6 +1120,18 @@ VARIANTS = {
     "ABL6_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack")),
     "ABL6_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack", "lds", "dma")),
     "ABL6_ALL_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, abl=("exp", "max", "sum", "pack", "lds", "dma", "bar", "ctl")),
+    "BF16_FOLD_L16_OROW": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, orow=1),
+    "BF16_EXACT_OROW": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1, orow=1),
+    "BF16_FOLD_L16_CAUSAL_OROW": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, orow=1),
+    "BF16_FOLD_L16_ST_NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" nt"),
+    "BF16_FOLD_L16_ST_SC1": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" sc1"),
+    "BF16_FOLD_L16_ST_SC01": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" sc0 sc1"),
+    "BF16_FOLD_L16_ST_SC1NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" sc1 nt"),
+    "BF16_FOLD_L16_OROW_ST_NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, orow=1, stpol=" nt"),
+    "BF16_FOLD_L16_CAUSAL_ST_NT": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" nt"),
+    "ABL7_EPI": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi",)),
+    "ABL7_EPI_QFRAG": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi", "qfrag")),
+    "ABL7_EPI_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi",)),
     "BF16_FOLD_L16_FL1": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1),
     "BF16_FOLD_L16_FL2": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=2),
     "BF16_FOLD_L16_FL1_AL": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1),
@@ -1090,7 +1161,7 @@ VARIANTS = {
     "ABL_BAL32_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("bar",)),
     "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d|_DM$', n))
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d|_DM$|_OROW$|_ST_', n))
 assert "BF16_FOLD_L16_SPROF" not in PRODUCT_STREAMS
 
 
@@ -1108,13 +1179,13 @@ def write_inc(path):
     lines.append("#define MFA_P4P_PRODUCT_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, 2 if cfg.split else cfg.causal))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, (2 if cfg.split else cfg.causal) | (4 if cfg.orow else 0)))
     lines.append("")
     lines.append("// streams that only the developer build (-DMFA_DEV_VARIANTS) instantiates")
     lines.append("#define MFA_P4P_DEV_STREAM_LIST(X) \\")
     for name, cfg in VARIANTS.items():
         if name not in PRODUCT_STREAMS:
-            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, 2 if cfg.split else cfg.causal))
+            lines.append("  X(%s, %d, %d, %d, %d, %d) \\" % (name, cfg.dtype == "f16", cfg.fold, cfg.o16, cfg.l16, (2 if cfg.split else cfg.causal) | (4 if cfg.orow else 0)))
     lines.append("")
     lines.append("#ifdef MFA_DEV_VARIANTS")
     lines.append("#define MFA_P4P_STREAM_LIST(X) MFA_P4P_PRODUCT_STREAM_LIST(X) MFA_P4P_DEV_STREAM_LIST(X)")

@@ -179,6 +179,8 @@ class PWorkgroup(Workgroup):
                     raise Poison("store of a register whose load is in flight")
             words = np.stack([(w.v if kind == "v" else w.a)[idx] for kind, idx in regs], axis=1).astype(np.uint32)   # [64][n]
             off = (w.rd(s[1]).astype(np.int64) + int(m.get("offset", 0))) & 0xFFFFFFFF   # the address adder wraps at 32 bits
+            if len(s) > 3:      # scalar offset: part of the range check, no 32-bit wrap (as for the loads)
+                off = off + (int(self.sval(w, s[3])) & 0xFFFFFFFF)
             arr, base, nrec = self.resource(w, s[2])
             writes = []
             for l in range(64):
@@ -191,6 +193,20 @@ class PWorkgroup(Workgroup):
                 w.vm_q.append((None, None))
             else:
                 w.vm_q.append((("store", arr, writes), None))
+            return None
+        if op == "ds_bpermute_b32":     # d[lane] = s1[((s0[lane] + offset) >> 2) & 63]; returns through the LDS queue like a read
+            sel = ((w.rd(s[0]).astype(np.int64) + int(m.get("offset", 0))) >> 2) & 63
+            data = w.rd(s[1])[sel].astype(np.uint32)
+            dests = w.regs(d)
+            for t in dests:
+                w.poison.add(t)
+            w.lds_q.append((dests, data.reshape(1, 64).copy()))
+            return None
+        if op in ("v_mbcnt_lo_u32_b32", "v_mbcnt_hi_u32_b32"):      # (mask -1: the lane's index, low 32 lanes / the rest)
+            assert s[0] == ("i", -1)
+            lanes = np.arange(64)
+            cnt = np.minimum(lanes, 32) if op.startswith("v_mbcnt_lo") else np.maximum(lanes - 32, 0)
+            w.wr(d, (cnt + self.vsrc(w, s[1]).astype(np.int64)).astype(np.uint32))
             return None
         if op == "ds_write_b128":
             addr = w.rd(s[0]).astype(np.int64) + int(m.get("offset", 0))
@@ -224,6 +240,7 @@ class PWorkgroup(Workgroup):
             w.wr(d, (a * b + c).astype(np.float32))
             return None
         if op == "s_waitcnt" and "vmcnt" in m:
+            assert 0 <= m["vmcnt"] <= 63, "vmcnt is a six-bit counter"
             self.retire_vm(w, m["vmcnt"])
             if "lgkmcnt" in m:
                 w.retire_lds(m["lgkmcnt"])
@@ -324,6 +341,9 @@ def run_workgroup(q, k, v, blocks, cfg, D=128, dma_mode="late", stores="late", o
         for db in range(4):
             col = 32 * db + 4 * (lane & 7)
             w.vn["ov%d" % db] = np.where(col < D, (lane >> 3) * ldo * osz + col * osz, p4pgen.OOB).astype(np.uint32)
+            if getattr(cfg, "orow", 0):     # lane = column 32 db + n of rows 4 hi + ...: one fp32 element per lane and store
+                ocol = 32 * db + qq
+                w.vn["ov%d" % db] = np.where(ocol < D, 4 * ocol + hi * 4 * ldo * 4, p4pgen.OOB).astype(np.uint32)
         for i in range(4):
             w.vn["kv%d" % i], w.vn["qv%d" % i] = kv[i], qv[i]
         w.sn.update({"nt": nt, "maskfrom": Ck // 64, "scale2": scale2, "kinc": 64 * ldk2, "vinc": 64 * ldv2,

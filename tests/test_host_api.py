@@ -190,6 +190,22 @@ def test_workspace_size_query_follows_the_split_heuristic():
     assert AttentionKernel(_desc(dims=(4096, 4096, 64)).kernelDescriptor(T.backwardQuery)).workspaceSize(row=4096, column=4096) == 0
 
 
+def test_piece_count_of_one_head_launches():
+    """round 6 (`choose_splits`, profiles/r06_sweep_splits.txt): the piece count is rounded DOWN to one round of workgroups (24 row
+    blocks x 11 pieces = 264 workgroups ran a second round of eight), capped near sqrt(117 traversal / parallel) (the combine pass reads
+    one slab per piece) and prefers equal pieces of whole 256-key blocks (what the persistent split streams serve)"""
+    for N, D, want in ((6144, 128, 8), (4096, 64, 8), (4096, 128, 8), (3072, 128, 6), (2048, 64, 8), (8192, 128, 8), (16384, 128, 4)):
+        low = _desc(dims=(N, N, D), low_in=True, in_type=P.BF16)
+        k = AttentionKernel(low.kernelDescriptor(T.forward))
+        assert k.workspaceSize(row=N, column=N) == want * N * (D + 2) * 4, (N, D)
+        dq = AttentionKernel(low.kernelDescriptor(T.backwardQuery)).workspaceSize(row=N, column=N)
+        assert dq % (N * D * 4) == 0 and 2 <= dq // (N * D * 4) <= 11 and (N // 256) * (dq // (N * D * 4)) <= 256
+    # D > 128 (round 6): the role-split backward kernels cut the launch themselves -- 128-row / 128-key workgroups, at most 256 of them
+    low = _desc(dims=(8192, 8192, 256), low_in=True, in_type=P.BF16)
+    assert AttentionKernel(low.kernelDescriptor(T.backwardQuery)).workspaceSize(row=8192, column=8192) == 4 * 8192 * 256 * 4
+    assert AttentionKernel(low.kernelDescriptor(T.backwardKeyValue)).workspaceSize(row=8192, column=8192) == 2 * 4 * 8192 * 256 * 4
+
+
 def test_oversized_slices_route_to_general_kernels_without_a_gpu():
     """The 16-bit kernels use 32-bit byte offsets per (head, batch) slice; a launch whose slice would
     exceed them must be planned on the general kernel.  The plan is visible through the workspace query

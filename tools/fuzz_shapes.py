@@ -34,10 +34,13 @@ rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
 bad = 0
 seen = {}
 for i in range(cases):
-    D = int(rng.choice([8, 40, 64, 72, 96, 104, 112, 120, 128, 136, 152, 160, 176, 192, 200, 232, 256]))
+    D = int(rng.choice([8, 40, 64, 72, 96, 104, 112, 120, 128, 136, 152, 160, 176, 192, 200, 232, 256, 272, 320, 344, 384]))
     causal = bool(rng.integers(2))
     R = int(rng.integers(1, 700))
     C = int(rng.integers(R if causal else 1, 900))
+    if with_workspace and not transposed and i % 2:   # long traversals: several pieces per row / key block (round 6: every bucket cuts them itself)
+        C = int(rng.integers(max(R, 1000), 4000))
+        R = C if i % 4 == 1 else R
     low_mid = bool(rng.integers(2))
     in_type = P.BF16 if rng.integers(2) else P.FP16
     if fp32:

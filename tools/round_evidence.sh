@@ -10,7 +10,7 @@ OUT=gpurun_out/${ROUND}_final
 mkdir -p "$OUT"
 sha256sum metal_flash_attention_amd/libmfa_hip.so > "$OUT/library.sha256"
 if [ -z "$FAST" ]; then
-  timeout 1500 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
+  MFA_VARIANT_COVERAGE=1 timeout 1500 python -m pytest tests -q -m gpu -n 4 2>&1 | tail -15 > "$OUT/pytest_gpu.txt"
   tail -3 "$OUT/pytest_gpu.txt"
   cp gpurun_out/variant_coverage.json "$OUT/variant_coverage.json" 2>/dev/null   # (tests/conftest.py: variant name -> tests; copy to tests/golden/)
 fi
@@ -59,7 +59,9 @@ PY
   fi
   [ -x tools/probe_f32_mfma.out ] && timeout 100 tools/probe_f32_mfma.out > "$OUT/probe_f32_mfma.txt" 2>&1
   timeout 200 python tools/time_single_head.py 2>&1 | grep -v amdgpu.ids > "$OUT/single_head.txt"
+  timeout 200 python tools/time_single_head.py --mixed 2>&1 | grep -v amdgpu.ids > "$OUT/single_head_mixed.txt"
   timeout 300 python tools/fuzz_shapes.py 120 1 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_120_seed1.txt"; grep "random problems" "$OUT/fuzz_120_seed1.txt"
+  timeout 400 python tools/fuzz_shapes.py 80 7 --workspace 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_workspace_80_seed7.txt"; grep "random problems" "$OUT/fuzz_workspace_80_seed7.txt"
   timeout 300 python tools/fuzz_shapes.py 120 5 --fp32 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_fp32_120_seed5.txt"; grep "random problems" "$OUT/fuzz_fp32_120_seed5.txt"
   timeout 300 python tools/fuzz_shapes.py 120 2 --transposed 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_120_seed2.txt"; grep "random problems" "$OUT/fuzz_transposed_120_seed2.txt"
   timeout 400 python tools/fuzz_shapes.py 90 3 --transposed --backward 2>&1 | grep -v amdgpu.ids > "$OUT/fuzz_transposed_backward_90_seed3.txt"; grep "random problems" "$OUT/fuzz_transposed_backward_90_seed3.txt"

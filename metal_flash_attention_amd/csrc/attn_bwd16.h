@@ -49,9 +49,11 @@ __device__ __forceinline__ typename Frag16<T>::v8 convert_chunk(u32x4 raw) {
 // keeps the swizzled row-major image.  (An earlier version kept two K images: 3 tiles per stage, which did not
 // fit D = 256.)  D <= 128: 8 waves (two per SIMD); D = 256: 4 waves with 512 registers each.
 // ------------------------------------------------------------------------------------------------
-template <int D, int NW> constexpr int dq16_lds_bytes() {
-  constexpr int ring = 2 * 2 * 64 * D * 2;
-  constexpr int epi = NW * 32 * (D + 4) * 4;
+// (BC: keys per tile, 64; 32 for the head blocks above 256 -- round 6 -- whose epilogue also goes in two halves: EPW waves at a time)
+template <int D, int NW> constexpr int dq16_epilogue_waves() { return NW * 32 * (D + 4) * 4 > 160 * 1024 ? NW / 2 : NW; }
+template <int D, int NW, int BC = 64> constexpr int dq16_lds_bytes() {
+  constexpr int ring = 2 * 2 * BC * D * 2;
+  constexpr int epi = dq16_epilogue_waves<D, NW>() * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }
 
@@ -59,12 +61,13 @@ template <int D, int NW> constexpr int dq16_lds_bytes() {
 // benchmark shape): the key range is cut into grid.splits pieces, each workgroup leaves its partial dQ in its
 // own fp32 slab of the caller's workspace ([split][head x batch][R][D]) and attn_bwd_combine adds the slabs --
 // no atomics, like the reference's refusal of an atomic dQ (README.md:11).  D is written by piece 0.
-template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false, bool SPARSE = false, bool SPLIT = false>
+template <typename T, int D, int NW, typename TG = T, bool CAUSAL = false, bool SPARSE = false, bool SPLIT = false, int BC_ = 64>
 __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const Fwd16Grid grid) {
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BC = 64, NT = NW * 64, NDB = D / 32, NKS = D / 16;
+  constexpr int BC = BC_, NKB = BC / 32, NT = NW * 64, NDB = D / 32, NKS = D / 16;
+  static_assert(BC == 64 || (BC == 32 && !SPARSE && !SPLIT), "32-key tiles: dense / causal / per-batch lengths only (the mask's column blocks are two 64-key tiles)");
   constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 2 * TILE;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     const int jn = next_active(j + 1);
     if (jn < ntiles) { if constexpr (SPARSE) issue_loads_at(jn); else issue_loads(); }
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
       // S^T = K Q^T and dP^T = V dO^T for 32 keys: lane = query row, registers = keys crow(r, hi)
       f32x16 s, dp;
 #pragma unroll
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
 #pragma unroll
       for (int idx = 0; idx < 2 * NDB; ++idx) {
         if (idx + 1 < 2 * NDB) ktf[(idx + 1) & 1] = read_kt(idx + 1);
-        if (kb == 1 && idx % WEVERY == 0) write_chunk(stage ^ 1, idx / WEVERY);
+        if (kb == NKB - 1 && idx % WEVERY == 0) write_chunk(stage ^ 1, idx / WEVERY);
         __builtin_amdgcn_sched_barrier(0x406);
         dq[idx % NDB] = F::mfma(ktf[idx & 1], dsf[idx / NDB], dq[idx % NDB]);
       }
@@ -297,23 +300,29 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   }
 
   // ---- epilogue: dQ through LDS (whole-row stores); D written pre-scaled (+Caching.swift:381-413)
-  constexpr int OLD = D + 4;
-  float *Os = reinterpret_cast<float *>(smem) + wave * (32 * OLD);
-  float *orow = Os + q * OLD;
-#pragma unroll
-  for (int db = 0; db < NDB; ++db)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
-          make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
+  constexpr int OLD = D + 4, EPW = dq16_epilogue_waves<D, NW>();
   if ((!SPLIT || split == 0) && hi == 0 && row < R)
     store_elem(operand_base(a.op[SLOT_D], head, batch), row, a.op[SLOT_D].precision, dterm);
-  if constexpr (SPLIT) {
-    const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)a.R;
-    store_block_rows<T, D>(Os, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr, r0, R, Dr, lane);
-  } else {
-    store_block_rows<T, D>(Os, operand_base(a.op[SLOT_dQ], head, batch), a.op[SLOT_dQ].precision, (uint32_t)a.op[SLOT_dQ].ld,
-                           r0, R, Dr, lane);
+  float *Os = reinterpret_cast<float *>(smem) + (wave % EPW) * (32 * OLD);
+  float *orow = Os + q * OLD;
+#pragma unroll
+  for (int pass = 0; pass < NW / EPW; ++pass) {   // (head blocks above 256: the staging rows of all waves do not fit the LDS at once)
+    if (pass) __syncthreads();
+    if (wave / EPW == pass) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(orow + 32 * db + 8 * g + 4 * hi) =
+              make_float4(dq[db][4 * g], dq[db][4 * g + 1], dq[db][4 * g + 2], dq[db][4 * g + 3]);
+      if constexpr (SPLIT) {
+        const size_t slab = ((size_t)split * grid.heads * grid.batches + (size_t)batch * grid.heads + head) * (size_t)a.R;
+        store_block_rows<T, D>(Os, reinterpret_cast<char *>(grid.wsO + slab * Dr), PREC_FP32, (uint32_t)Dr, r0, R, Dr, lane);
+      } else {
+        store_block_rows<T, D>(Os, operand_base(a.op[SLOT_dQ], head, batch), a.op[SLOT_dQ].precision, (uint32_t)a.op[SLOT_dQ].ld,
+                               r0, R, Dr, lane);
+      }
+    }
   }
 }
 

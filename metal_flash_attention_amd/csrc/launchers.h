@@ -87,6 +87,9 @@ const char *p6_form(int precision, bool fold, const KernelArgs &args);
 bool launch_p6_split(int precision, bool fold, dim3 grid, uint32_t splits, float *wsO, float *wsML, hipStream_t stream, const KernelArgs &args);
 // 256 < D <= 384 (head blocks 320, 384): four waves x 32 rows, 32-key steps, compiler-scheduled (attn_fwd16_wide.h, round 6)
 bool fwd16_wide_variant(int precision, int D, VariantInfo *out);
+// the backward kernels of the same head blocks (attn_bwd16_wide.hip: attn_dq16 with 32-key tiles, attn_dkv16_wide.h; round 6)
+bool dq16_wide_variant(int precision, int gprecision, int D, VariantInfo *out);
+bool dkv16_wide_variant(int precision, int gprecision, int D, VariantInfo *out);
 // 128 < D <= 256: four waves x 64 rows, 32-key steps (attn_fwd16_p5.h); `out` arrives filled by fwd16_v3_variant
 bool fwd16_p5_variant(int precision, int D, int impl, VariantInfo *out);
 // backwardKeyValue counterpart: four waves x 64 keys (attn_dkv16_p4.h); `out` arrives filled by dkv16_rs_variant, whose

@@ -76,7 +76,9 @@ static const char *kDefaultTables[3][2] = {
      "| 160 | 128 | 32 | 160 | Q, dO, dQ |\n"
      "| 192 | 128 | 32 | 192 | Q, dO, dQ |\n"
      "| 256 | 128 | 32 | 256 | Q, dO, dQ |\n"
-     "| 384 | 32  | 32 | 384 | Q, dQ     |\n"},
+     // D in (256, 384] (round 6): four waves x 32 rows, 32-key tiles, Q / dO fragments and dQ^T in registers (attn_bwd16_wide.hip)
+     "| 320 | 128 | 32 | 320 | Q, dO, dQ |\n"
+     "| 384 | 128 | 32 | 384 | Q, dO, dQ |\n"},
     {// backwardKeyValue, FP32
      "| 32  | 128 | 32 | 32  | K, V, dV, dK |\n"
      "| 64  | 128 | 32 | 64  | K, V, dV, dK |\n"
@@ -91,7 +93,9 @@ static const char *kDefaultTables[3][2] = {
      "| 160 | 128 | 32 | 160 | K, V, dV, dK |\n"
      "| 192 | 128 | 32 | 192 | K, V, dV, dK |\n"
      "| 256 | 128 | 32 | 256 | K, V, dV, dK |\n"
-     "| 384 | 32  | 32 | 384 | dV, dK       |\n"}};
+     // D in (256, 384] (round 6): two role-split pairs x 32 keys, 32-row steps, two LDS stages (attn_dkv16_wide.h)
+     "| 320 | 64  | 32 | 320 | K, V, dV, dK |\n"
+     "| 384 | 64  | 32 | 384 | K, V, dV, dK |\n"}};
 
 static std::mutex g_table_mutex;
 static std::string g_tables[3][2];

@@ -1381,7 +1381,8 @@ def test_forward_role_alternating_kernel(shape, causal, impl, monkeypatch):
 
 # ---- variable sequence lengths per batch entry (extension) -------------
 @pytest.mark.parametrize("low,causal,D", [(False, False, 64), (False, True, 64), (True, False, 64), (True, True, 64),
-                                          (True, False, 128), (True, True, 128), (True, False, 256), (True, True, 200)])
+                                          (True, False, 128), (True, True, 128), (True, False, 256), (True, True, 200),
+                                          (True, False, 384), (True, True, 320), (True, True, 384), (True, False, 296)])
 def test_variable_sequence_lengths(low, causal, D):
     """A padded batch [B, H, Rmax, D] / [B, H, Cmax, D] with per-entry lengths: every entry must equal the
     oracle run on its own (rows, columns) slice, and nothing beyond an entry's length may be written.  D = 128 / 200 / 256:
@@ -1423,6 +1424,13 @@ def test_variable_sequence_lengths(low, causal, D):
         form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                                                                 causal=causal, rowLengths=rl, columnLengths=cl)
         assert form.startswith("attn_fwd16_p4p (persistent") and "per-batch lengths" in form, form
+    if low and D > 256:    # (round 6) 256 < D <= 384: all three kernels on the 16-bit matrix cores, per-batch lengths included
+        assert kernels[AttentionKernelType.forward].variant.startswith("attn_fwd16w_")
+        assert kernels[AttentionKernelType.backwardQuery].variant.startswith("attn_dq16w_")
+        assert kernels[AttentionKernelType.backwardKeyValue].variant.startswith("attn_dkv16w_")
+        for t, k in kernels.items():
+            form = k.launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs, causal=causal, rowLengths=rl, columnLengths=cl)
+            assert form.startswith(k.variant), form
     if low and D == 64:    # (round 6) so does the D <= 64 persistent kernel (FP32 L here: its exact-scale geometry streams)
         form = kernels[AttentionKernelType.forward].launchForm(bufs, row=Rmax, column=Cmax, heads=H, batches=B, headStrides=hs, batchStrides=bs,
                                                                 causal=causal, rowLengths=rl, columnLengths=cl)
@@ -1453,7 +1461,7 @@ def test_variable_sequence_lengths(low, causal, D):
 # ---- fused 16-bit output cast (extension) ------------------------------
 @pytest.mark.parametrize("in_type", [P.BF16, P.FP16])
 @pytest.mark.parametrize("shape,causal", [((256, 256, 128), False), ((300, 555, 64), False), ((129, 77, 40), False),
-                                          ((1024, 1024, 128), True), ((100, 1000, 128), False)])
+                                          ((1024, 1024, 128), True), ((100, 1000, 128), False), ((200, 300, 384), False), ((300, 300, 320), True)])
 def test_low_precision_outputs(shape, causal, in_type):
     """O, dQ, dK, dV stored directly in the inputs' 16-bit type by the matrix-core kernels (no separate cast
     pass); backwardQuery reads the 16-bit O for its D term.  Reference mixed tolerances."""
@@ -1664,9 +1672,10 @@ def test_large_head_dimension_fp32(shape):
 @pytest.mark.parametrize("shape,causal", [((150, 170, 320), False), ((64, 300, 384), False), ((300, 333, 264), False), ((257, 600, 352), True),
                                           ((512, 512, 384), True), ((129, 40, 384), False)])
 def test_large_head_dimension_16bit_inputs(shape, causal, low_mid, in_type):
-    """Round 6: 16-bit inputs at 256 < D <= 384 run the FORWARD on the 16-bit matrix cores (attn_fwd16_wide.h: head blocks 320 / 384,
-    four waves x 32 rows -- the `| 384 | ... |` rows of the reference's mixed tables, AttentionDescriptor+Parameters.swift:113, :120);
-    the backward kernels stay on fp32 arithmetic.  Oracle on the rounded inputs, tolerances of the other 16-bit forward kernels."""
+    """Round 6: 16-bit inputs at 256 < D <= 384 run all three kernels on the 16-bit matrix cores -- forward attn_fwd16_wide.h (head
+    blocks 320 / 384, four waves x 32 rows: the `| 384 | ... |` rows of the reference's mixed tables, AttentionDescriptor+Parameters.swift:113,
+    :120), backwardQuery attn_dq16 with 32-key tiles, backwardKeyValue attn_dkv16_wide.h (role-split pairs, two LDS stages).  Oracle on
+    the rounded inputs, tolerances of the other 16-bit kernels."""
     R, C, D = shape
     net = Network(NetworkDescriptor(R, C, D), seed=5 + D)
     desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=in_type)
@@ -1674,7 +1683,12 @@ def test_large_head_dimension_16bit_inputs(shape, causal, low_mid, in_type):
     fwd = run.kernels[AttentionKernelType.forward]
     assert fwd.variant.startswith("attn_fwd16w_") and ("_d320_" if D <= 320 else "_d384_") in fwd.variant, fwd.variant
     assert fwd.blockDimensions == (128, 32, 320 if D <= 320 else 384) and fwd.threadgroupMemoryAllocation == 3 * 2 * 32 * (320 if D <= 320 else 384) * 2
-    assert all("generic" in k.variant and "d384" in k.variant for t, k in run.kernels.items() if t != AttentionKernelType.forward)
+    hb = 320 if D <= 320 else 384
+    dq, dkv = run.kernels[AttentionKernelType.backwardQuery], run.kernels[AttentionKernelType.backwardKeyValue]
+    assert dq.variant.startswith("attn_dq16w_") and "_d%d_" % hb in dq.variant and dq.blockDimensions == (128, 32, hb), dq.variant
+    assert dkv.variant.startswith("attn_dkv16w_") and "_d%d_" % hb in dkv.variant and dkv.blockDimensions == (64, 32, hb), dkv.variant
+    assert dkv.threadgroupMemoryAllocation == 2 * (2 * 32 * hb * 2 + 256) + 2 * 4096
+    assert dq.launchForm(run.buffers, row=R, column=C, causal=causal).startswith("attn_dq16w_")
     got = run.execute()
     round_inputs(net, desc)
     ref = net.run(causal=causal)

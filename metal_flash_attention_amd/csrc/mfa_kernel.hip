@@ -267,10 +267,10 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         }
         add(dkv16_variant(pq, pg, b16 == 96 ? 128 : b16, &v), v);   // one wave per key block (attn_bwd16.h; D = 64, 128 only)
       }
-    } else if (!relayout && same16 && pg != MFA_FP32 && (D % 8) == 0 && D > 256 && D <= 384) {
+    } else if (same16 && pg != MFA_FP32 && (D % 8) == 0 && D > 256 && D <= 384) {
       // 256 < D <= 384 (round 6): the backward kernels of the head blocks 320 / 384 on the 16-bit matrix cores (attn_bwd16_wide.hip;
-      // until then fp32 arithmetic on 16-bit storage, 1/16 of the rate).  Dense, causal, per-batch lengths: block masks and
-      // transposed operands keep the general kernel (the fallback of every launch)
+      // until then fp32 arithmetic on 16-bit storage, 1/16 of the rate).  Dense, causal, per-batch lengths; transposed operands through
+      // the re-layout pass into the caller's workspace like every other bucket; block masks keep the general kernel (the fallback)
       const int hb = D <= 320 ? 320 : 384;
       if (type == MFA_BACKWARD_QUERY && f32_or_inputs(MFA_O) && f32_or_inputs(MFA_dQ)) add(dq16_wide_variant(pq, pg, hb, &v), v);
       if (type == MFA_BACKWARD_KEY_VALUE && f32_or_inputs(MFA_dK) && f32_or_inputs(MFA_dV) &&

@@ -48,7 +48,8 @@
  *   - Head dimensions: any.  16-bit matrix-core code objects exist up to D = 256 for all three kernel types since round 4 and -- round 6 --
  *     up to D = 384 (head blocks 320 / 384: the `| 384 | ... |` rows of the reference's mixed tables,
  *     AttentionDescriptor+Parameters.swift:113, :120, :153-201): attn_fwd16w_*, attn_dq16w_*, attn_dkv16w_* (dense, causal, per-batch
- *     lengths, fused 16-bit outputs; transposed operands of the backward kernels through the re-layout pass).  Kernels with FP32
+ *     lengths, fused 16-bit outputs; transposed operands through the re-layout pass -- at these head blocks the forward kernel too:
+ *     mfa_attention_kernel_needs_workspace_for_fast_path is 1 for it).  Kernels with FP32
  *     operands at D > 128, and block-masked launches at D > 256, run on the fp32-arithmetic kernels, accumulators in registers; D > 384 (beyond the reference's tables, which fall through
  *     to their last row, +Parameters.swift:60-65) runs D-blocked kernels that page the accumulators through the output
  *     buffers like the reference does (+Accumulate.swift:403-469) -- O, dQ, dK, dV must then be FP32 (the fused 16-bit

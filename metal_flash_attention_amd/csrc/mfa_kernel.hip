@@ -200,10 +200,13 @@ mfa_status mfa_attention_kernel_create(const mfa_attention_kernel_descriptor *kd
         add(fwd16_p5_variant(pq, b16, lowS ? 10 : 0, &v), v);
       }
       add(have3, v3);
-    } else if (!transposedOperands && same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && D > 256 && D <= 384) {
+    } else if (same16 && f32_or_inputs(MFA_O) && (D % 8) == 0 && D > 256 && D <= 384) {
       // 256 < D <= 384: the `| 384 | ... |` rows of the reference's mixed tables (AttentionDescriptor+Parameters.swift:113, :120) on the
-      // 16-bit matrix cores (attn_fwd16_wide.h, round 6; until then fp32 arithmetic on 16-bit storage, 1/16 of the rate)
+      // 16-bit matrix cores (attn_fwd16_wide.h, round 6; until then fp32 arithmetic on 16-bit storage, 1/16 of the rate).  Transposed
+      // operands: these head blocks have no in-place code objects -- row-major copies in the caller's workspace, like the backward
+      // kernels' re-layout pass (without a workspace: the general kernel in place)
       add(fwd16_wide_variant(pq, D, &v), v);
+      relayout = transposedOperands;
     }
   } else {
     const int pg = kdesc->memoryPrecisions[MFA_dO];

@@ -1698,6 +1698,31 @@ def test_large_head_dimension_16bit_inputs(shape, causal, low_mid, in_type):
     assert all(run.tails_ok.values())
 
 
+@pytest.mark.parametrize("tr", [(True, True, True, True), (False, True, False, False), (True, False, True, False)])
+@pytest.mark.parametrize("shape,causal", [((200, 300, 384), False), ((260, 260, 320), True)])
+def test_large_head_dimension_16bit_transposed_operands(shape, causal, tr):
+    """256 < D <= 384 with transposeState: these head blocks have no in-place code objects -- given a workspace every transposed
+    operand is re-laid out row-major (inputs before, outputs after the launch) and the 16-bit matrix-core code object runs, the
+    forward kernel included (the other buckets' forward kernels read transposed operands in place); without one the general kernel."""
+    R, C, D = shape
+    net = Network(NetworkDescriptor(R, C, D), seed=R + C + D)
+    desc = make_desc(R, C, D, low_in=True, in_type=P.BF16, tr=tr)
+    run = harness.DeviceRun(desc, net, causal=causal)
+    for t, k in run.kernels.items():
+        assert k.variant.startswith(("attn_fwd16w_", "attn_dq16w_", "attn_dkv16w_")) and k.needsWorkspaceForFastPath, (t, k.variant)
+        assert k.workspaceSize(row=R, column=C) > 0
+        assert "general kernel" in k.launchForm(run.buffers, row=R, column=C, causal=causal)     # (no workspace in this query)
+    got = run.execute(with_workspace=True)
+    round_inputs(net, desc)
+    ref = net.run(causal=causal)
+    failures, report = harness.compare(ref, got, TOL_MIXED)
+    assert not failures, (failures, [k.variant for k in run.kernels.values()])
+    assert all(run.tails_ok.values()), run.tails_ok
+    slow = harness.DeviceRun(desc, net, causal=causal).execute()      # no workspace: the general kernels in place
+    failures, report = harness.compare(ref, slow, TOL_MIXED)
+    assert not failures, failures
+
+
 def test_large_head_dimension_16bit_batched_lengths_and_fused_output_cast():
     """attn_fwd16_wide: heads and batches with strides, per-batch lengths (an entry shorter than one workgroup, one with fewer keys
     than a step), causal with C > R, and O stored in the inputs' 16-bit type by the kernel itself."""

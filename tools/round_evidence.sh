@@ -70,7 +70,7 @@ fi
 if [ -z "$FAST" ]; then
   # round 6: the 256 < D <= 384 forward on the 16-bit matrix cores, per-batch lengths on the persistent forwards, the vendor GEMM calibration,
   # the product schedule against the round-5 streams in one process (developer library)
-  timeout 300 python tools/time_wide.py 2>&1 | grep -v amdgpu.ids > "$OUT/time_wide.txt"; cat "$OUT/time_wide.txt"
+  timeout 300 python tools/time_wide.py --backward 2>&1 | grep -v "amdgpu.ids" | grep -v "fp32 inputs  backward" > "$OUT/time_wide.txt"; cat "$OUT/time_wide.txt"
   timeout 300 bash tools/vendor_calib.sh "$OUT/vendor_calib" > /dev/null 2>&1; cp "$OUT/vendor_calib/vendor_calib.txt" "$OUT/vendor_gemm_calibration.txt"; rm -rf "$OUT/vendor_calib"
   if [ -f metal_flash_attention_amd/libmfa_hip_dev.so ]; then
     timeout 300 python tools/time_varlen.py --D 128 2>&1 | grep -v amdgpu.ids > "$OUT/time_varlen_d128.txt"; cat "$OUT/time_varlen_d128.txt"

@@ -201,7 +201,8 @@ const char *mfa_attention_kernel_fallback_variant(const mfa_attention_kernel *ke
 /* Transposed operands (transposeState, AttentionKernelDescriptor.swift:30-41) and the 16-bit matrix-core kernels.
  * FORWARD: code objects that read Q^T, K^T, V^T and write O^T where they lie (AttentionKernel.swift:189-204: no scratch),
  * one per pattern of (K, V) and head-dimension bucket; rows that are not 16-byte aligned (an odd sequence length as the
- * leading dimension) are gathered element-wise -- slower, never the fp32-arithmetic kernel.  This function returns 0.
+ * leading dimension) are gathered element-wise -- slower, never the fp32-arithmetic kernel.  This function returns 0 (256 < D <= 384,
+ * round 6: no in-place code objects at these head blocks -- it returns 1 and the forward launch takes the re-layout path below).
  * BACKWARD (dQ, dK/dV): those kernels read row-major tiles, so a launch with `workspace` first re-lays every transposed
  * operand out into the workspace (one HBM-bound pass per operand, 2 x sequence x D x size bytes; transposed outputs are written
  * back the same way) and then runs the matrix-core code object; without a workspace the in-place backward kernels take the

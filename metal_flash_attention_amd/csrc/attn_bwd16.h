@@ -181,6 +181,11 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     fread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
     kfread[t] = ((t >> 1) * BC + q) * 64 + (((2 * (t & 1) + hi) ^ ((q >> 2) & 3)) * 16);
   }
+  // (head blocks above 256, BC = 32: the 2 x NKS offsets are TWO lane values per image plus compile-time terms -- the XOR of the
+  // swizzle touches the low two chunk bits only -- which hipcc does not find in the tables above: 43 spilled registers at 384)
+  const int fr_e = fread[0], fr_o = fread[1], kfr_e = kfread[0], kfr_o = kfread[1];
+  auto vfrag_off = [&](int t) { if constexpr (BC == 32) return ((t & 1) ? fr_o : fr_e) + (t >> 1) * 64; else return fread[t]; };
+  auto kfrag_off = [&](int t) { if constexpr (BC == 32) return ((t & 1) ? kfr_o : kfr_e) + (t >> 1) * BC * 64; else return kfread[t]; };
 
   f32x16 dq[NDB];
 #pragma unroll
@@ -243,13 +248,13 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
       // the fragments of k-step t + 1 are requested before the matrix instructions of step t; sched_barrier(0x406)
       // holds that order (LDS and matrix instructions stay, vector / scalar work may move)
       v8 kfa[2], vfa[2];
-      kfa[0] = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfread[0]);
-      vfa[0] = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + fread[0]);
+      kfa[0] = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfrag_off(0));
+      vfa[0] = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + vfrag_off(0));
 #pragma unroll
       for (int t = 0; t < NKS; ++t) {
         if (t + 1 < NKS) {
-          kfa[(t + 1) & 1] = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfread[t + 1]);
-          vfa[(t + 1) & 1] = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + fread[t + 1]);
+          kfa[(t + 1) & 1] = *reinterpret_cast<const v8 *>(st + kb * 32 * 64 + kfrag_off(t + 1));
+          vfa[(t + 1) & 1] = *reinterpret_cast<const v8 *>(st + TILE + kb * 32 * ROWB + vfrag_off(t + 1));
           __builtin_amdgcn_sched_barrier(0x406);
         }
         s = F::mfma(kfa[t & 1], qf[t], s);

@@ -21,7 +21,9 @@ SCRATCH_BUDGET = {"attn_fwd16_p4": 40, "attn_fwd16_p4p": 0, "attn_fwd16_p6": 0, 
 # (kernels of the unit that spill at all, most spilled vector registers in one kernel): the state of the round-5 build
 SPILL_BUDGET = {"attn_fwd16_p4p": (0, 0), "attn_fwd16_p6": (0, 0), "attn_dq16_p5": (0, 0), "attn_dkv16_p5": (28, 2), "attn_dq16_p4": (18, 2), "attn_dkv16_p4": (21, 6),
                 "attn_f32": (1, 2), "attn_fwd16_p4": (4, 15), "attn_fwd16_p5": (12, 2), "attn_fwd16_p4_tr": (24, 19),
-                "attn_fwd16_p5_tr": (56, 34), "attn_bwd16_p4_tr": (24, 73)}
+                "attn_fwd16_p5_tr": (56, 34), "attn_bwd16_p4_tr": (24, 73),
+                # round 6, the 384 head blocks (compiler-scheduled; the 320 ones and attn_dkv16_wide do not spill)
+                "attn_fwd16_wide": (4, 31), "attn_bwd16_wide": (6, 16)}
 
 
 def _kernels(obj):

@@ -24,12 +24,14 @@ def _rounded(net, precisions):
 
 @pytest.mark.parametrize("low_mid", [False, True])
 @pytest.mark.parametrize("rows", ["default", "rs", "w4"])
-@pytest.mark.parametrize("D", [64, 96, 128, 160, 192, 256])
+@pytest.mark.parametrize("D", [64, 96, 128, 160, 192, 256, 320, 384])
 @pytest.mark.parametrize("grad", [P.FP16, P.BF16])
 def test_fp16_inputs_with_either_gradient_type(D, rows, low_mid, grad):
     """FP16 Q / K / V with dO stored in FP16 (descriptor override) or BF16 (the reference's mix), every backward code-object family"""
     if rows == "w4" and (D not in (64, 128) or low_mid):
         pytest.skip("the one-wave-per-key-block kernel exists for the 64 and 128 buckets, FP32 intermediates")
+    if D > 256 and rows != "default":
+        pytest.skip("one backward code-object family above 256 (attn_bwd16_wide.hip)")
     R, C = 200, 328
     net = Network(NetworkDescriptor(R, C, D), seed=3 * R + C + D)
     desc = make_desc(R, C, D, low_in=True, low_mid=low_mid, in_type=P.FP16)

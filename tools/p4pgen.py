@@ -512,6 +512,8 @@ class PStream(Stream):
                 else:
                     out.append((i, lambda: self.emit("s_add_u32", s("t0"), [s("t0"), s("t4")])))
                 out.append((i, lambda: self.emit("v_add_u32_e64", vo, [VN("ov%d" % db), s("t0")], clamp=1)))
+                if "epi_st" in cfg.abl:
+                    continue
                 if cfg.o16:
                     out.append((i, lambda k=k: self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k), [V(dst + 4 * k), V(dst + 4 * k + 1)])))
                     out.append((i, lambda k=k: self.emit("v_cvt_pk_%s_f32" % cfg.dtype, V(dst + 4 * k + 1), [V(dst + 4 * k + 2), V(dst + 4 * k + 3)])))
@@ -524,12 +526,12 @@ class PStream(Stream):
         for i, (rb, db) in enumerate(blocks):
             src, dst = regs(i)
             b = 4 * rb + db
-            for r in range(16):
+            for r in range(0 if "epi_valu" in cfg.abl else 16):
                 work.append((i, lambda r=r, src=src, b=b: self.emit("v_accvgpr_read_b32", V(src + r), [A(O_BASE + 16 * b + r)])))
             if cfg.merge:       # the next block's first phase multiplied K Q^T beside this block's softmax: O is zeroed here
                 for r in range(16):
                     work.append((i, lambda r=r, b=b: self.emit("v_accvgpr_write_b32", A(O_BASE + 16 * b + r), [I(0)])))
-            for r in range(0 if cfg.split else 16):
+            for r in range(0 if (cfg.split or "epi_valu" in cfg.abl) else 16):
                 work.append((i, lambda r=r, src=src, rb=rb: self.emit("v_mul_f32", V(src + r), [V(inv[rb]), V(src + r)])))
             for g in range(4):
                 work.append((i, lambda g=g, src=src: self.lds_write("ds_write_b128", V(wa[g]), V(src + 4 * g, 4), 0)))
@@ -1129,6 +1131,9 @@ VARIANTS = {
     "BF16_FOLD_L16_ST_SC1NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" sc1 nt"),
     "BF16_FOLD_L16_OROW_ST_NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, orow=1, stpol=" nt"),
     "BF16_FOLD_L16_CAUSAL_ST_NT": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" nt"),
+    "ABL7_EPI_ST": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi_st",)),
+    "ABL7_EPI_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi_valu",)),
+    "ABL7_EPI_ST_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi_st", "epi_valu")),
     "ABL7_EPI": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi",)),
     "ABL7_EPI_QFRAG": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi", "qfrag")),
     "ABL7_EPI_CAUSAL": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi",)),

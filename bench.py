@@ -123,6 +123,11 @@ WORKLOADS = {
                          types=("forward", "backwardQuery", "backwardKeyValue")),
     "dkv_bf16_d256": dict(N=4096, D=256, dtype="bf16", batch=4, heads=16, low_mid=True, timed=("backwardKeyValue",),
                           types=("forward", "backwardQuery", "backwardKeyValue")),
+    # round 6: the head blocks above 256 on the 16-bit matrix cores (attn_fwd16_wide, attn_dq16 with 32-key tiles, attn_dkv16_wide)
+    "fwdbwd_bf16_d384_mixed": dict(N=4096, D=384, dtype="bf16", batch=2, heads=16, low_mid=True,
+                                   types=("forward", "backwardQuery", "backwardKeyValue")),
+    "fwdbwd_bf16_d320_mixed": dict(N=4096, D=320, dtype="bf16", batch=2, heads=16, low_mid=True,
+                                   types=("forward", "backwardQuery", "backwardKeyValue")),
     "fwd_bf16_d128_n16k": dict(N=16384, D=128, dtype="bf16", batch=1, heads=32, types=("forward",)),  # config 5 shard
     # the same shard in the reference's mixed-precision mode, like the headline (FP16 L: at N = 16384 |L| is still below 16,
     # the FP16 resolution the reference's own L tolerance of 7e-3 assumes -- tests/test_attention_gpu.py holds it at full size)

@@ -26,7 +26,7 @@ ROUND=$ROUND timeout 400 bash tools/profile_pmc.sh "$OUT/prof" --steps 20 --warm
 if [ -z "$FAST" ]; then
   for w in fwd_bf16_d128_fp32mid fwd_bf16_d128_causal fwd_bf16_d128_n16k fwd_bf16_d128_n16k_mixed fwd_bf16_d128_transposed fwd_bf16_d256_transposed fwd_bf16_d64 fwd_bf16_d64_fp32mid fwd_bf16_d64_1head \
            fwd_bf16_d256 fwd_bf16_d256_mixed fwdbwd_bf16_d128 fwdbwd_bf16_d128_mixed fwdbwd_bf16_d128_causal fwdbwd_bf16_d128_transposed \
-           fwdbwd_bf16_d128_transposed_ws fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128 fwdbwd_bf16_d256_mixed dq_bf16_d256 dkv_bf16_d256; do
+           fwdbwd_bf16_d128_transposed_ws fwdbwd_f16_d128_refmix fwdbwd_f32_d128 dkv_bf16_d128 dq_bf16_d128 fwdbwd_bf16_d256_mixed dq_bf16_d256 dkv_bf16_d256 fwdbwd_bf16_d320_mixed fwdbwd_bf16_d384_mixed; do
     timeout 200 python bench.py --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_$w.json"
   done
   timeout 200 python bench.py --workload c1_cpu 2>/dev/null | tail -1 > "$OUT/bench_c1_cpu.json"

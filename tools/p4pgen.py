@@ -80,7 +80,7 @@ class PCfg(Cfg):
     """o16: O leaves in the stream's 16-bit type (lowPrecisionOutputs); l16: L is stored in FP16 (mixed-precision mode)"""
 
     def __init__(self, dtype="bf16", thr=8.0, fold=0, xb=40, o16=0, l16=0, pprof=0, causal=0, merge=0, fuse=None, bal=0, cap=7, abl=(), pad=0, maxa=1, va0=0, xe=0, fastdec=0, fdpos=0,
-                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0, split=0, orow=0, stpol=""):
+                 fastloop=0, align=0, soff=0, pksum=0, dmapol="", diagmask=0, split=0, orow=0, stpol="", qearly=0):
         Cfg.__init__(self, dtype=dtype, thr=thr, fold=fold, xb=xb, xe=xe, bal=bal, cap=cap, abl=abl, pad=pad, maxa=maxa, va0=va0, fastdec=fastdec, fdpos=fdpos)
         self.o16, self.l16 = o16, l16
         # fastloop (round 6, dense streams): the timing-only ablation that dropped the per-tile tests of the loop -- block switch
@@ -116,6 +116,11 @@ class PCfg(Cfg):
         # lane that owns the row by ds_bpermute_b32.  No LDS staging, so no ordering against the V ring either
         self.orow = orow
         self.stpol = stpol     # (round 6 experiment) cache-policy bits on the stores of O (" nt", " sc1", " sc0 sc1")
+        # qearly (round 6 experiment): the next block's Q image (64 KiB per workgroup, the largest of its first requests) is asked for one
+        # tile earlier -- with K'(0) under tile nt - 2 instead of with V'(0) / K'(1) under the last tile -- so that it has landed before the
+        # epilogue's 128 KiB of stores want the same path (its LDS image is free since the block's own Q fragments were read)
+        self.qearly = qearly
+        assert not (qearly and merge)
         assert not (orow and (o16 or merge or fuse or pprof == 1))
         if split:
             self.l16 = 0
@@ -370,9 +375,12 @@ class PStream(Stream):
             self.emit("s_cbranch_scc1", None, [], target=over)
             if kind == "k":
                 self.switch_k()
+                if self.cfg.qearly:
+                    self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             else:
                 self.switch_v()
-                self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
+                if not self.cfg.qearly:
+                    self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             self.label(over)
         for i in range(4):
             self.dma_piece("k", par, i)
@@ -701,9 +709,11 @@ class PStream(Stream):
             self.emit("s_cbranch_scc1", None, [], target=back)      # last block: the ring runs ahead into zeros (out of range)
             if kind == "ksw":
                 self.switch_k()
+                if self.cfg.qearly:
+                    self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             elif kind == "vsw":
                 self.switch_v()
-                if not self.cfg.merge:
+                if not self.cfg.merge and not self.cfg.qearly:
                     self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
             else:
                 self.issue_q((T_SW, T_SW + 1, T_TL, T_TL + 1, self.r_maskv))
@@ -1131,6 +1141,9 @@ VARIANTS = {
     "BF16_FOLD_L16_ST_SC1NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" sc1 nt"),
     "BF16_FOLD_L16_OROW_ST_NT": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, orow=1, stpol=" nt"),
     "BF16_FOLD_L16_CAUSAL_ST_NT": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, stpol=" nt"),
+    "BF16_FOLD_L16_QE": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, qearly=1),
+    "BF16_EXACT_QE": PCfg("bf16", 8, fold=0, bal=2, xe=32, cap=8, fastloop=1, align=1, qearly=1),
+    "BF16_FOLD_L16_CAUSAL_QE": PCfg("bf16", 8, fold=1, l16=1, causal=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, qearly=1),
     "ABL7_EPI_ST": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi_st",)),
     "ABL7_EPI_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi_valu",)),
     "ABL7_EPI_ST_VALU": PCfg("bf16", 8, fold=1, l16=1, bal=2, xb=48, fastdec=1, fastloop=1, align=1, abl=("epi_st", "epi_valu")),
@@ -1166,7 +1179,7 @@ VARIANTS = {
     "ABL_BAL32_BAR": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("bar",)),
     "ABL_BAL32_ALL": PCfg("bf16", 8, fold=1, l16=1, bal=1, xb=32, abl=("exp", "max", "sum", "pack", "lds", "dma")),
 }
-PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d|_DM$|_OROW$|_ST_', n))
+PRODUCT_STREAMS = tuple(n for n, c in VARIANTS.items() if re.match(r'^(BF16|F16)_(FOLD|EXACT)', n) and not c.pprof and not c.merge and not c.fuse and not c.abl and not c.pad and not re.search(r'BAL|_FL\d|_SOFF|_PKS|_NT$|_SC\d|_DM$|_OROW$|_ST_|_QE$', n))
 assert "BF16_FOLD_L16_SPROF" not in PRODUCT_STREAMS
 
 

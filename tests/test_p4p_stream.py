@@ -262,7 +262,7 @@ def test_stores_per_block_match_the_wait():
 
 # ---- round 6: column-parallel pieces on the persistent kernel (split streams) --------------------------------------------------------
 @pytest.mark.parametrize("name", ["BF16_FOLD_SPLIT", "BF16_EXACT_SPLIT", "F16_FOLD_SPLIT", "F16_EXACT_SPLIT"])
-@pytest.mark.parametrize("R,C,splits", [(256, 1024, 4), (512, 512, 2), (300, 2048, 2), (256, 256, 2)])
+@pytest.mark.parametrize("R,C,splits", [(256, 1024, 4), (512, 512, 2), (300, 1280, 2), (256, 256, 2)])
 def test_column_parallel_pieces(name, R, C, splits):
     """split streams: a table entry is (row block, piece of the key range: whole multiples of two tiles); the un-normalised O^T and (m, l)
     of every piece land in the workspace slabs and the merge of attn_fwd_combine (restated in tools/p4psim.py) gives the attention of
@@ -290,11 +290,13 @@ def test_row_major_accumulators_give_the_same_bytes(name):
     cfg = p4pgen.VARIANTS[name]
     base = p4pgen.VARIANTS[name[:-5]]
     assert cfg.orow and not base.orow and name not in p4pgen.PRODUCT_STREAMS
-    C = 640
-    for kw in (dict(spike=(17, 64 * 5 + 5, 3.0), tol_o=1.2e-2), dict(D=72, ld=128), dict(stores="late", dma_mode="late", order=(3, 2, 1, 0))):
-        a = _check(2, 300, C, cfg=cfg, seed=31, **kw)
-        b = _check(2, 300, C, cfg=base, seed=31, **kw)
+    C = 448
+    for kw in (dict(spike=(17, 64 * 3 + 5, 3.0), tol_o=1.2e-2, stores="late", dma_mode="late", order=(3, 2, 1, 0)), dict(D=72, ld=128, R=300)):
+        R = kw.pop("R", 256)
+        a = _check(2, R, C, cfg=cfg, seed=31, **kw)
+        b = _check(2, R, C, cfg=base, seed=31, **kw)
         assert (a[1][0] == b[1][0]).all() and (a[1][1] == b[1][1]).all()
-    assert a[0].waves[0].count["buffer_store_dword"] >= 2 * 128 and not a[0].waves[0].count.get("buffer_store_dwordx4")
-    wg = _check(2, 300, C, cfg=cfg, seed=31, spike=(17, 64 * 5 + 5, 3.0), tol_o=1.2e-2)[0]
+        if "spike" in kw:
+            wg = a[0]
+    assert wg.waves[0].count["buffer_store_dword"] >= 2 * 128 and not wg.waves[0].count.get("buffer_store_dwordx4")
     assert wg.waves[0].count.get("ds_bpermute_b32", 0) >= 2 * 32 + 32      # two epilogues + at least one rescale

@@ -89,7 +89,7 @@ def test_library_op_backward_uses_the_laid_out_copies_of_non_contiguous_inputs(d
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
 @pytest.mark.parametrize("causal", [False, True])
-@pytest.mark.parametrize("shape", [(2, 3, 200, 200, 64), (1, 2, 129, 300, 128), (1, 1, 64, 64, 40)])
+@pytest.mark.parametrize("shape", [(2, 3, 200, 200, 64), (1, 2, 129, 300, 128), (1, 1, 64, 64, 40), (1, 2, 150, 260, 320), (2, 1, 200, 200, 384)])
 def test_forward_and_gradients_match_torch(shape, causal, dtype, tol):
     from metal_flash_attention_amd.torch_binding import flash_attention
     B, H, R, C, D = shape

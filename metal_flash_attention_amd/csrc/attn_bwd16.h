@@ -52,7 +52,7 @@ __device__ __forceinline__ typename Frag16<T>::v8 convert_chunk(u32x4 raw) {
 // (BC: keys per tile, 64; 32 for the head blocks above 256 -- round 6 -- whose epilogue also goes in two halves: EPW waves at a time)
 template <int D, int NW> constexpr int dq16_epilogue_waves() { return NW * 32 * (D + 4) * 4 > 160 * 1024 ? NW / 2 : NW; }
 template <int D, int NW, int BC = 64> constexpr int dq16_lds_bytes() {
-  constexpr int ring = 2 * 2 * BC * D * 2;
+  constexpr int ring = 2 * (BC * D * 2 + BC * (D * 2 + (BC == 32 ? 16 : 0)));
   constexpr int epi = dq16_epilogue_waves<D, NW>() * 32 * (D + 4) * 4;
   return ring > epi ? ring : epi;
 }
@@ -68,7 +68,13 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BC = BC_, NKB = BC / 32, NT = NW * 64, NDB = D / 32, NKS = D / 16;
   static_assert(BC == 64 || (BC == 32 && !SPARSE && !SPLIT), "32-key tiles: dense / causal / per-batch lengths only (the mask's column blocks are two 64-key tiles)");
-  constexpr int ROWB = D * 2, TILE = BC * D * 2, STAGE = 2 * TILE;
+  // (BC = 32, the head blocks above 256 -- round 6, profiles/r06_fwdbwd_bf16_d384_mixed_summary_before_lds_fix.txt: 46 % of the LDS cycles
+  // were bank conflicts.  V rows of 640 / 768 bytes start on the same banks (768 = 3 x 256) and the four-chunk XOR cannot spread sixteen
+  // of them: rows padded by one 16-byte chunk instead (41 / 49 chunks: sixteen consecutive rows start on sixteen different slots), no
+  // swizzle.  The K image's staging writes put sixteen consecutive chunks of ONE row on four slots (its d-blocks are 2048 bytes apart):
+  // a group of sixteen lanes now writes four rows x the four chunks of one d-block.)
+  constexpr bool WIDE = BC == 32;
+  constexpr int ROWB = D * 2 + (WIDE ? 16 : 0), TILE = BC * D * 2, STAGE = TILE + BC * ROWB;
   constexpr int CPR = D / 8, NCH = BC * CPR / NT;
   static_assert(BC * CPR % NT == 0, "tile must divide evenly over the workgroup");
 
@@ -135,6 +141,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
     voff[i] = valid ? rr * ldv2 + c * 16 : OOB;
     klds[i] = ((c >> 2) * BC + rr) * 64 + (((c & 3) ^ ((rr >> 2) & 3)) * 16);   // K: [D/32][64][32], chunks swizzled
     vlds[i] = TILE + rr * ROWB + kswz<D>(rr, c) * 16;                           // V: row-major (swizzled)
+    if constexpr (WIDE) {
+      vlds[i] = TILE + rr * ROWB + c * 16;
+      // K: a wave = eight keys x a pair of d-blocks (128 contiguous bytes of a row per load), sixteen lanes = four keys x one d-block's chunks
+      const int l = id & 63, unit = id >> 6, dbp = unit % (NDB / 2), rg = unit / (NDB / 2), c4 = l & 3;
+      const int kr = 8 * rg + 4 * (l >> 5) + ((l >> 2) & 3), kc = 4 * (2 * dbp + ((l >> 4) & 1)) + c4;
+      koff[i] = kc * 8 < Dr ? kr * ldk2 + kc * 16 : OOB;
+      klds[i] = ((kc >> 2) * BC + kr) * 64 + ((c4 ^ ((kr >> 2) & 3)) * 16);
+    }
   }
   u32x4 kreg[NCH], vreg[NCH];
   auto issue_loads = [&]() {
@@ -178,13 +192,13 @@ __global__ __launch_bounds__(NW * 64) void attn_dq16(const KernelArgs a, const F
   int fread[NKS], kfread[NKS];   // row-fragment offsets of key q of a 32-key block: V (row-major) and K (blocked image)
 #pragma unroll
   for (int t = 0; t < NKS; ++t) {
-    fread[t] = q * ROWB + kswz<D>(q, 2 * t + hi) * 16;
+    fread[t] = q * ROWB + (WIDE ? 2 * t + hi : kswz<D>(q, 2 * t + hi)) * 16;
     kfread[t] = ((t >> 1) * BC + q) * 64 + (((2 * (t & 1) + hi) ^ ((q >> 2) & 3)) * 16);
   }
   // (head blocks above 256, BC = 32: the 2 x NKS offsets are TWO lane values per image plus compile-time terms -- the XOR of the
   // swizzle touches the low two chunk bits only -- which hipcc does not find in the tables above: 43 spilled registers at 384)
   const int fr_e = fread[0], fr_o = fread[1], kfr_e = kfread[0], kfr_o = kfread[1];
-  auto vfrag_off = [&](int t) { if constexpr (BC == 32) return ((t & 1) ? fr_o : fr_e) + (t >> 1) * 64; else return fread[t]; };
+  auto vfrag_off = [&](int t) { if constexpr (BC == 32) return fr_e + t * 32; else return fread[t]; };   // (no swizzle there: chunk 2 t + hi)
   auto kfrag_off = [&](int t) { if constexpr (BC == 32) return ((t & 1) ? kfr_o : kfr_e) + (t >> 1) * BC * 64; else return kfread[t]; };
 
   f32x16 dq[NDB];

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void attn_dkv16_wide(const KernelArgs a, const
   constexpr int BR = 32, NT = 256, NDB = D / 32, NKS = D / 16;
   constexpr int TILE = BR * D * 2, STAGE = 2 * TILE + 256, XBUF = 2 * STAGE;
   constexpr int CPR = D / 8, NCHUNK = BR * CPR, SCH = NCHUNK / NT;
-  static_assert(NCHUNK % NT == 0 && D % 32 == 0, "a tile must divide evenly over the workgroup");
+  static_assert(NCHUNK % NT == 0 && D % 64 == 0, "a tile must divide evenly over the workgroup (pairs of d-blocks)");
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,10 +76,15 @@ __global__ __launch_bounds__(256) void attn_dkv16_wide(const KernelArgs a, const
 
   // ---- Q / dO staging (registers, one row block ahead of the LDS) + the L / D slices of the row block
   uint32_t qoff[SCH], goff[SCH], wlds[SCH];
+  // (sixteen consecutive lanes = four rows x the four chunks of ONE d-block: sixteen different 16-byte slots of the image -- with
+  // consecutive chunks of one row on consecutive lanes, as in attn_dkv16_rs.h, they fall on four slots, the d-blocks being 2048 bytes
+  // apart: 22 % of this kernel's LDS cycles were bank conflicts, profiles/r06_fwdbwd_bf16_d384_mixed_summary_before_lds_fix.txt.
+  // A wave = eight rows x a PAIR of d-blocks: 128 contiguous bytes of a row per load)
 #pragma unroll
   for (int i = 0; i < SCH; ++i) {
     const int id = tid + i * NT;
-    const int srow = id / CPR, sc = id % CPR;
+    const int l = id & 63, unit = id >> 6, dbp = unit % (NDB / 2), rg = unit / (NDB / 2);
+    const int srow = 8 * rg + 4 * (l >> 5) + ((l >> 2) & 3), sc = 4 * (2 * dbp + ((l >> 4) & 1)) + (l & 3);
     const bool svalid = sc * 8 < Dr;
     qoff[i] = svalid ? __builtin_elementwise_add_sat((uint32_t)(srow * ldq2 + sc * 16), (uint32_t)block0 * BR * ldq2) : OOB;
     goff[i] = svalid ? __builtin_elementwise_add_sat((uint32_t)(srow * ldg2 + sc * 16), (uint32_t)block0 * BR * ldg2) : OOB;

@@ -28,7 +28,7 @@
 namespace mfa {
 namespace wide {
 constexpr int BK = 32, ROWS = 128, RING = 3, THR = 8;
-template <int DP> constexpr int lds_bytes() { return RING * 2 * BK * DP * 2; }
+template <int DP> constexpr int lds_bytes() { return RING * (BK * (DP * 2 + 16) + BK * DP * 2); }   // (K rows padded by one chunk, see the kernel)
 // two second-product matrix instructions on accumulators that LIVE in the accumulation registers (one asm statement per pair:
 // hipcc puts a wait state between asm statements; the leading s_nop covers a freshly packed P^T fragment)
 template <typename T, typename V8> __device__ __forceinline__ void pv_pair(f32x16 &o0, f32x16 &o1, const V8 &v0, const V8 &v1, const V8 &p) {
@@ -91,8 +91,13 @@ __global__ __launch_bounds__(256) void attn_fwd16_wide(const KernelArgs a, const
   typedef Frag16<T> F;
   typedef typename F::v8 v8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BK = wide::BK, RING = wide::RING, NKS = DP / 16, NDB = DP / 32, ROWB = DP * 2, CPR = DP / 8;
-  constexpr int TILE = BK * ROWB, STAGE = 2 * TILE, NCH = BK * CPR / 256;
+  // LDS layout (round 6, after the counter pass of profiles/r06_fwdbwd_bf16_d384_mixed_summary_before_lds_fix.txt: a third of this
+  // kernel's LDS cycles were bank conflicts): K rows of 640 / 768 bytes all start on the same banks (768 = 3 x 256; 640: two of them) and
+  // an XOR of the low three chunk bits cannot spread SIXTEEN rows -- rows padded by one 16-byte chunk instead (41 / 49 chunks: sixteen
+  // consecutive rows start on sixteen different slots), no swizzle, ONE read address per lane; the V image's staging writes go four rows x
+  // the four chunks of one d-block per sixteen lanes (two d-blocks, 2048 bytes apart, shared a slot)
+  constexpr int BK = wide::BK, RING = wide::RING, NKS = DP / 16, NDB = DP / 32, ROWB = DP * 2 + 16, CPR = DP / 8;
+  constexpr int TILE = BK * ROWB, STAGE = TILE + BK * DP * 2, NCH = BK * CPR / 256;
   static_assert(NDB % 2 == 0 && BK * CPR % 256 == 0 && CPR % 8 == 0, "tile must divide evenly over the workgroup; the swizzle needs whole groups of eight chunks");
   constexpr uint32_t OOB = 0xFFFFFF00u;
 
@@ -140,10 +145,13 @@ __global__ __launch_bounds__(256) void attn_fwd16_wide(const KernelArgs a, const
   // version kept per-chunk offsets and read addresses: 125 spilled registers at the 384 head block)
   constexpr uint32_t SAT = 0xFFFFF000u;   // (past the end: stays out of range with the chunk immediates added, no 32-bit wrap)
   const int srow = tid >> 3, sc0 = tid & 7;
-  uint32_t koff = srow * ldk2 + sc0 * 16, voff = srow * ldv2 + sc0 * 16;
-  const uint32_t klds = srow * ROWB + ((sc0 ^ (srow & 7)) << 4);
-  const uint32_t vlds = TILE + ((sc0 >> 2) * BK + srow) * 64 + (sc0 & 3) * 16;
+  // V: a wave = eight keys x a pair of d-blocks (128 contiguous bytes of a row per load), sixteen lanes = four keys x one d-block's chunks
+  const int vrow = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1) + ((tid >> 2) & 3), vc0 = 4 * ((tid >> 4) & 1) + (tid & 3);
+  uint32_t koff = srow * ldk2 + sc0 * 16, voff = vrow * ldv2 + vc0 * 16;
+  const uint32_t klds = srow * ROWB + (sc0 << 4);
+  const uint32_t vlds = TILE + ((vc0 >> 2) * BK + vrow) * 64 + (vc0 & 3) * 16;
   const int nvalid = (Dr / 8 - sc0 + 7) / 8;   // chunks of this thread inside the head dimension (the others read zeros)
+  const int nvalidv = (Dr / 8 - vc0 + 7) / 8;
   const uint32_t kinc = BK * ldk2, vinc = BK * ldv2;
   // ONE set of staging registers (NCH x 16 bytes per thread): the K chunks of tile j + 2 travel through it during the first half of
   // step j, the V chunks during the second (both operands at once were 48 registers the 384 head block does not have: 49 spilled)
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void attn_fwd16_wide(const KernelArgs a, const
   };
   auto load_v = [&]() {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, i < nvalid ? voff + 128 * i : OOB, 0, 0);
+    for (int i = 0; i < NCH; ++i) sreg[i] = __builtin_amdgcn_raw_buffer_load_b128(vres, i < nvalidv ? voff + 128 * i : OOB, 0, 0);
     voff = min(voff + vinc, SAT);
   };
   auto write_k = [&](auto ST_) {
@@ -175,27 +183,23 @@ __global__ __launch_bounds__(256) void attn_fwd16_wide(const KernelArgs a, const
   // K row fragment of k-step t: logical chunk 2 t + hi of row q; the swizzle touches the low three bits only -- four addresses (t & 3),
   // the group of eight chunks (t >> 2) an immediate
   const uint32_t lds0 = (uint32_t)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char *)smem;
-  uint32_t kread[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) kread[t] = lds0 + q * ROWB + (((2 * t + hi) ^ (q & 7)) << 4);
+  const uint32_t kread = lds0 + q * ROWB + (hi << 4);   // chunk 2 t + hi of row q: + 32 t
 
   // S^T of the 32 keys of stage ST: key = lane % 32, one K row fragment per 16 elements of the head dimension, ring of four
   auto qk = [&](auto ST_, f32x16 &s) {
     // (DS instruction offsets are 16 bits: the stage base goes into the four address registers, the k-step group is the immediate)
-    uint32_t ka[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) ka[t] = kread[t] + decltype(ST_)::value * STAGE;
+    const uint32_t ka = kread + decltype(ST_)::value * STAGE;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = 0.f;
     u32x4 kr[4];
-    wide::unrolled<4>([&](auto T_) { constexpr int t = decltype(T_)::value; kr[t] = wide::frag_read_b128<(t >> 2) * 128>(ka[t & 3]); });
+    wide::unrolled<4>([&](auto T_) { constexpr int t = decltype(T_)::value; kr[t] = wide::frag_read_b128<t * 32>(ka); });
     wide::unrolled<NKS>([&](auto T_) {
       constexpr int t = decltype(T_)::value;
       constexpr int pending = (NKS - 1 - t) < 3 ? (NKS - 1 - t) : 3;
       wide::frag_wait<pending>(kr[t & 3]);
       if constexpr (t < NQA) wide::qk_acc_operand<T>(s, kr[t & 3], qf[t]);   // (Q' fragments t < NQA are parked in the accumulation file)
       else s = F::mfma(__builtin_bit_cast(v8, kr[t & 3]), qf[t], s);
-      if constexpr (t + 4 < NKS) kr[t & 3] = wide::frag_read_b128<((t + 4) >> 2) * 128>(ka[t & 3]);
+      if constexpr (t + 4 < NKS) kr[t & 3] = wide::frag_read_b128<(t + 4) * 32>(ka);
     });
   };
   // maskAttentionMatrixEdge (+Softmax.swift:228-260) and the causal limit, on the steps that need them (wave-uniform tests)

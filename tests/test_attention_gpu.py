@@ -1682,7 +1682,7 @@ def test_large_head_dimension_16bit_inputs(shape, causal, low_mid, in_type):
     run = harness.DeviceRun(desc, net, causal=causal)
     fwd = run.kernels[AttentionKernelType.forward]
     assert fwd.variant.startswith("attn_fwd16w_") and ("_d320_" if D <= 320 else "_d384_") in fwd.variant, fwd.variant
-    assert fwd.blockDimensions == (128, 32, 320 if D <= 320 else 384) and fwd.threadgroupMemoryAllocation == 3 * 2 * 32 * (320 if D <= 320 else 384) * 2
+    assert fwd.blockDimensions == (128, 32, 320 if D <= 320 else 384) and fwd.threadgroupMemoryAllocation == 3 * (32 * ((320 if D <= 320 else 384) * 2 + 16) + 32 * (320 if D <= 320 else 384) * 2)
     hb = 320 if D <= 320 else 384
     dq, dkv = run.kernels[AttentionKernelType.backwardQuery], run.kernels[AttentionKernelType.backwardKeyValue]
     assert dq.variant.startswith("attn_dq16w_") and "_d%d_" % hb in dq.variant and dq.blockDimensions == (128, 32, hb), dq.variant

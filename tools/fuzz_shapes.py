@@ -67,6 +67,11 @@ for i in range(cases):
     tol = TOL_MIXED_SHORT if C <= 20 else TOL_MIXED
     if fp32:
         tol = {k: (2e-5 if max(R, C) <= 777 else 5e-5) for k in TOL_MIXED}
+    if not fp32 and low_mid and backward:
+        # D is STORED in BF16 in the reference's mixed mode (AttentionDescriptor+Precisions.swift:82-83), truncated like its software bfloat: one
+        # unit in the last place is up to 2^-7 |D| -- above the reference's absolute 1e-1 once |D| > 13 (a causal row that sees ONE key at a wide
+        # head: |dO . V| ~ sqrt(D)); the bound follows the storage format there
+        tol = dict(tol, D=max(tol["D"], 2.0 ** -7 * float(np.abs(ref["D"]).max())))
     if not backward:
         tol = {k: v for k, v in tol.items() if k in ("O", "L")}
     failures, report = harness.compare(ref, got, tol)
